@@ -1,0 +1,204 @@
+"""PyTorch-CPU restatement (second, independent oracle) of the Deep Sentiment training step.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py); also the ``cpu_baseline`` ("port") leg of
+bench.py.  PARITY: pinned for SAME-conv / BN moving stats / shapes / variable count by the
+reference's known answers; **parity unpinned** for LSTM, head, CE, Adam (cross-checked against
+oracle/tf_semantics.py only).
+
+Uses stock torch CPU ops + autograd for the backward pass, so it shares no code with either
+the NumPy oracle or the HIP product path.  Parameters live in a flat dict keyed by the
+reference's TF variable names (weights HWIO, like the TF checkpoint).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import tf_semantics as S
+
+
+def _same_pad_nchw(x, k, s, value):
+    h, w = x.shape[2], x.shape[3]
+    _, pt, pb = S.same_pad(h, k, s)
+    _, pl, pr = S.same_pad(w, k, s)
+    if pt or pb or pl or pr:
+        x = F.pad(x, (pl, pr, pt, pb), value=value)
+    return x
+
+
+def conv2d_same(x, w_hwio, stride):
+    """x NCHW, w HWIO.  TF SAME zero padding (extra bottom/right), cross-correlation."""
+    k = w_hwio.shape[0]
+    return F.conv2d(_same_pad_nchw(x, k, stride, 0.0), w_hwio.permute(3, 2, 0, 1), stride=stride)
+
+
+def max_pool_same(x, k, s):
+    return F.max_pool2d(_same_pad_nchw(x, k, s, float("-inf")), k, s)
+
+
+def batch_norm_train(z, beta, eps=S.BN_EPS):
+    mean = z.mean(dim=(0, 2, 3))
+    var = ((z - mean[None, :, None, None]) ** 2).mean(dim=(0, 2, 3))
+    y = (z - mean[None, :, None, None]) * torch.rsqrt(var + eps)[None, :, None, None] + beta[None, :, None, None]
+    return y, mean, var
+
+
+def batch_norm_infer(z, beta, mm, mv, eps=S.BN_EPS):
+    return (z - mm[None, :, None, None]) * torch.rsqrt(mv + eps)[None, :, None, None] + beta[None, :, None, None]
+
+
+class DeepSentimentRef:
+    """mode in {'joint','image','text'}: DeepSentiment (im_text_rnn_model.py:38-105),
+    ImageModel (im_model.py:139-164), TextModel (text_embedding.py:37-86)."""
+
+    def __init__(self, params, embedding=None, mode="joint", dtype=torch.float32,
+                 trainable_bn_beta=True, is_training=True):
+        self.mode = mode
+        self.dtype = dtype
+        self.is_training = is_training
+        self.p = {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in params.items()}
+        self.embedding = None if embedding is None else torch.tensor(np.asarray(embedding), dtype=dtype)
+        self.trainable = []
+        for name in self.p:
+            if self._is_trainable(name, trainable_bn_beta):
+                self.p[name].requires_grad_(True)
+                self.trainable.append(name)
+        self.adam_m = {n: torch.zeros_like(self.p[n]) for n in self.trainable}
+        self.adam_v = {n: torch.zeros_like(self.p[n]) for n in self.trainable}
+        self.step = 0
+        self.bn_batch_stats = {}
+
+    @staticmethod
+    def _is_trainable(name, trainable_bn_beta):
+        if name.endswith("moving_mean") or name.endswith("moving_variance"):
+            return False
+        if name.startswith("InceptionV1/"):
+            if name.endswith("BatchNorm/beta"):
+                return trainable_bn_beta            # beta trainable everywhere
+            if "/Logits/" in name:
+                return True                         # inception_v1.py:302-303 (outside the frozen scope)
+            return any(("/%s/" % b) in name for b in S.TRAINABLE_BLOCKS)   # :229-231
+        return True                                 # Text/rnn/*, W_fc, b_fc, W_softmax, b_softmax
+
+    # -- towers -------------------------------------------------------------------------------
+    def _cbr(self, x, scope, stride=1):
+        z = conv2d_same(x, self.p[scope + "/weights"], stride)
+        beta = self.p[scope + "/BatchNorm/beta"]
+        if self.is_training:
+            y, mean, var = batch_norm_train(z, beta)
+            self.bn_batch_stats[scope] = (mean.detach(), var.detach())
+        else:
+            y = batch_norm_infer(z, beta, self.p[scope + "/BatchNorm/moving_mean"],
+                                 self.p[scope + "/BatchNorm/moving_variance"])
+        return torch.relu(y)
+
+    def image_tower(self, images_nhwc, dropout_mask=None):
+        net = images_nhwc.permute(0, 3, 1, 2)
+        for item in S.INCEPTION_V1:
+            kind, name = item[0], item[1]
+            if kind == "conv":
+                net = self._cbr(net, "InceptionV1/" + name, item[3])
+            elif kind == "maxpool":
+                net = max_pool_same(net, item[2], item[3])
+            else:
+                pre = "InceptionV1/%s/" % name
+                nm = [n for (n, _, _, _) in S.mixed_conv_names(name)]
+                b0 = self._cbr(net, pre + nm[0])
+                b1 = self._cbr(self._cbr(net, pre + nm[1]), pre + nm[2])
+                b2 = self._cbr(self._cbr(net, pre + nm[3]), pre + nm[4])
+                b3 = self._cbr(max_pool_same(net, 3, 1), pre + nm[5])
+                net = torch.cat([b0, b1, b2, b3], dim=1)
+        self.last_mixed_5c = net
+        pooled = F.avg_pool2d(net, 7, 1)
+        assert pooled.shape[2] == 1 and pooled.shape[3] == 1
+        pooled = pooled[:, :, 0, 0]
+        if dropout_mask is not None and self.is_training:
+            pooled = pooled * dropout_mask / S.DROPOUT_KEEP
+        w = self.p["InceptionV1/Logits/Conv2d_0c_1x1/weights"]
+        return pooled @ w.reshape(w.shape[2], w.shape[3]) + self.p["InceptionV1/Logits/Conv2d_0c_1x1/biases"]
+
+    def text_tower(self, texts, seq_lens):
+        x = self.embedding[texts]                                   # [B,T,D]
+        kernel = self.p["Text/rnn/basic_lstm_cell/kernel"]
+        bias = self.p["Text/rnn/basic_lstm_cell/bias"]
+        b, t, _ = x.shape
+        hsz = kernel.shape[1] // 4
+        c = torch.zeros(b, hsz, dtype=self.dtype)
+        h = torch.zeros(b, hsz, dtype=self.dtype)
+        outs = []
+        for s in range(t):
+            z = torch.cat([x[:, s, :], h], dim=1) @ kernel + bias
+            i, j, f, o = torch.split(z, hsz, dim=1)
+            c_new = c * torch.sigmoid(f + S.FORGET_BIAS) + torch.sigmoid(i) * torch.tanh(j)
+            h_new = torch.tanh(c_new) * torch.sigmoid(o)
+            live = (s < seq_lens)[:, None]
+            outs.append(torch.where(live, h_new, torch.zeros_like(h_new)))
+            c = torch.where(live, c_new, c)
+            h = torch.where(live, h_new, h)
+        outs = torch.stack(outs, dim=1)
+        return outs[torch.arange(b), seq_lens - 1]                  # gather_nd, :92
+
+    def forward(self, batch, dropout_mask=None):
+        g = lambda k: torch.as_tensor(batch[k])
+        if self.mode == "image":
+            return self.image_tower(g("images").to(self.dtype), dropout_mask)
+        tx = self.text_tower(g("texts"), g("seq_lens"))
+        if self.mode == "text":
+            self.features = tx
+            return tx @ self.p["W_softmax"] + self.p["b_softmax"]
+        im = self.image_tower(g("images").to(self.dtype), dropout_mask)
+        concat = torch.cat([im, tx], dim=1)
+        self.features = concat
+        dense = torch.relu(concat @ self.p["W_fc"] + self.p["b_fc"])
+        return dense @ self.p["W_softmax"] + self.p["b_softmax"]
+
+    # -- loss / step ---------------------------------------------------------------------------
+    def loss(self, logits, labels):
+        ce = F.cross_entropy(logits, torch.as_tensor(labels), reduction="mean")
+        reg = torch.zeros((), dtype=self.dtype)
+        if self.mode != "text":                                     # text-only graph has no slim conv
+            for name, w in self.p.items():
+                if name.startswith("InceptionV1/") and name.endswith("/weights"):
+                    reg = reg + S.WEIGHT_DECAY * 0.5 * (w * w).sum()
+        return ce + reg, ce
+
+    def train_step(self, batch, lr, dropout_mask=None):
+        """One slim train_step: fwd, total loss, grads of all trainables, BN moving-average
+        updates, TF-Adam.  Returns dict(loss, ce, logits, grads)."""
+        for n in self.trainable:
+            self.p[n].grad = None
+        logits = self.forward(batch, dropout_mask)
+        total, ce = self.loss(logits, batch["labels"])
+        total.backward()
+        grads = {n: self.p[n].grad.detach().clone() for n in self.trainable if self.p[n].grad is not None}
+        self.step += 1
+        t = self.step
+        lr_t = lr * math.sqrt(1 - S.ADAM_B2 ** t) / (1 - S.ADAM_B1 ** t)
+        with torch.no_grad():
+            for scope, (mean, var) in self.bn_batch_stats.items():
+                mm = self.p[scope + "/BatchNorm/moving_mean"]
+                mv = self.p[scope + "/BatchNorm/moving_variance"]
+                mm.mul_(S.BN_DECAY).add_((1 - S.BN_DECAY) * mean)
+                mv.mul_(S.BN_DECAY).add_((1 - S.BN_DECAY) * var)
+            for n, g in grads.items():
+                m, v = self.adam_m[n], self.adam_v[n]
+                m.mul_(S.ADAM_B1).add_((1 - S.ADAM_B1) * g)
+                v.mul_(S.ADAM_B2).add_((1 - S.ADAM_B2) * g * g)
+                self.p[n].sub_(lr_t * m / (v.sqrt() + S.ADAM_EPS))
+        return dict(loss=float(total.detach()), ce=float(ce.detach()), logits=logits.detach(), grads=grads)
+
+
+def make_params(mode, rng, num_classes=15, im_features_size=256, embed_dim=300, rnn_size=512,
+                fc_size=512, dtype=np.float32):
+    """Random-init parameter dict with the reference's variable names/initialisers."""
+    p = {}
+    if mode in ("joint", "image"):
+        p.update(S.init_inception_params(rng, im_features_size if mode == "joint" else num_classes, dtype))
+    if mode in ("joint", "text"):
+        p.update(S.init_text_params(rng, embed_dim, rnn_size, dtype))
+    if mode == "joint":
+        p.update(S.init_joint_head(rng, im_features_size + rnn_size, fc_size, num_classes, dtype))
+    if mode == "text":
+        p.update(S.init_text_head(rng, rnn_size, num_classes, dtype))
+    return p
