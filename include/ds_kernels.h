@@ -1,0 +1,173 @@
+/*
+ * ds_kernels.h -- C ABI of libds_kernels.so, the MI355X (gfx950) kernel library behind the
+ * Deep Sentiment training path.
+ *
+ * The reference (anthonyhu/tumblr-emotions) has no FFI/plugin layer: its hot path sits
+ * directly behind Python calls into TensorFlow 1.x.  Each entry point below
+ * therefore names the TensorFlow op call site (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors); the library
+ *     never allocates, frees or synchronises;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) and returns immediately;
+ *   - return 0 on success, negative DS_ERR_* otherwise; ds_last_error() gives the text;
+ *   - activations NHWC fp32, conv weights HWIO fp32 (TensorFlow layout, never re-packed),
+ *     matrices row-major, ids/labels/seq_len int64 (as the reference's TFRecord schema,
+ *     datasets/convert_to_dataset.py:148-161).
+ */
+#ifndef DS_KERNELS_H
+#define DS_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DS_OK 0
+#define DS_ERR_ARG (-1)
+#define DS_ERR_LAUNCH (-2)
+#define DS_ERR_WORKSPACE (-3)
+
+/* epilogue flags of ds_conv_igemm */
+#define DS_EPI_BIAS 1      /* z += bias[col]                       (BiasAdd)                        */
+#define DS_EPI_RELU 2      /* z = max(z, 0)                        (tf.nn.relu)                     */
+#define DS_EPI_ACCUM 4     /* z += previous contents of z          (AddN of two gradient paths)     */
+#define DS_EPI_STATS 8     /* emit per-column sum / sum-of-squares partials for BatchNorm           */
+#define DS_EPI_MASK 16     /* z *= (mask[row*ldmask+col] > 0)      (ReluGrad)                       */
+
+int ds_version(void);
+const char *ds_last_error(void);
+
+/* Implicit-GEMM convolution / matrix multiply on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *   z[m, co] = sum_{tap, ci} x[pixel(m) + tap, ci] * w[tap', ci|co ...]
+ * One kernel serves
+ *   - Conv2D forward, SAME padding      image_model/inception_v1.py:63-250 (slim.conv2d)
+ *   - Conv2DBackpropInput (dgrad)       implied by create_train_op, im_text_rnn_model.py:135
+ *   - MatMul (+BiasAdd, +Relu)          im_text_rnn_model.py:99-105, text_embedding.py:86,
+ *                                       BasicLSTMCell's [x,h]*kernel, im_text_rnn_model.py:89-90
+ * Weights are read in place from the TF HWIO tensor through (tap, n, k) strides; `flip`
+ * reverses the tap order (dgrad).  A plain GEMM is the case N=M, H=W=OH=OW=KH=KW=1.        */
+typedef struct ds_conv_desc {
+    int32_t N, H, W;          /* input images and spatial size                                      */
+    int32_t Cin;              /* reduction channels per tap                                         */
+    int32_t ldx;              /* input pixel stride in floats (>= Cin; x points at channel offset)  */
+    int32_t KH, KW, stride;
+    int32_t pad_t, pad_l;     /* TF SAME "before" pads (extra goes bottom/right)                    */
+    int32_t OH, OW;
+    int32_t Cout;             /* output channels                                                    */
+    int32_t ldz;              /* output pixel stride in floats                                      */
+    int64_t w_tap_stride;     /* floats between consecutive taps in w                               */
+    int32_t w_n_stride;       /* floats between consecutive output channels in w                    */
+    int32_t w_k_stride;       /* floats between consecutive reduction channels in w (one of the two is 1) */
+    int32_t flip;             /* 1: use tap (KH*KW-1-tap)                                           */
+    int32_t fold_cin;         /* >0: KW is folded into Cin (stem conv): real channels per pixel     */
+    int32_t flags;            /* DS_EPI_*                                                           */
+    int32_t ldmask;           /* row stride of the DS_EPI_MASK source                               */
+} ds_conv_desc;
+
+/* Number of row-tile blocks (P) the launch for `d` will use = number of stats partials.   */
+int ds_conv_igemm_partials(const ds_conv_desc *d);
+/* stats (DS_EPI_STATS): float[P][2][Cout] partial column sums / sums of squares.          */
+int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float *w, float *z, const float *bias,
+                  const float *mask, float *stats, void *stream);
+
+/* Conv2DBackpropFilter / MatMul-transposed (wgrad), split over pixels.
+ *   dw[tap, ci, co] = sum_m x[pixel(m)+tap, ci] * dz[m, co]
+ * only reached for the trainable scope image_model/inception_v1.py:229-250,302-303 and the
+ * tf.get_variable weights im_text_rnn_model.py:89,98-104.  `ws` holds split partials.      */
+size_t ds_conv_wgrad_workspace(const ds_conv_desc *d);
+int ds_conv_wgrad(const ds_conv_desc *d, const float *x, const float *dz, int32_t lddz, float *dw,
+                  void *ws, size_t ws_bytes, void *stream);
+
+/* slim.batch_norm train mode (center, no scale), slim/nets/inception_utils.py:48-70.
+ * finalize: partials -> mean, rstd, scale=rstd, shift=beta-mean*rstd, moving stats update. */
+int ds_bn_finalize(const float *stats, int32_t P, int64_t count, int32_t C, const float *beta, float eps,
+                   float decay, float *mean, float *rstd, float *shift, float *moving_mean,
+                   float *moving_var, void *stream);
+
+/* y = relu(z*rstd + shift) scattered to up to 4 channel segments (branch outputs written
+ * straight into the concat buffer: replaces tf.concat, inception_v1.py:96 ... :248).       */
+typedef struct ds_segments {
+    int32_t nseg;
+    int32_t c_begin[4];       /* first channel of the segment in the [M,C] source/gradient           */
+    int32_t c_end[4];
+    int32_t ld[4];            /* pixel stride of the destination                                     */
+    float *ptr[4];            /* destination (already offset to its first channel)                   */
+} ds_segments;
+int ds_bn_apply_relu(const float *z, int64_t M, int32_t C, const float *rstd, const float *shift,
+                     const ds_segments *dst, void *stream);
+
+/* BatchNorm(train)+ReLU backward: g = dy*(y>0); dbeta = sum g; dz = rstd*(g - mean(g) - xhat*mean(g*xhat)).
+ * dy is gathered from the same segments the forward scattered to.                          */
+int ds_bn_bwd_partials(int64_t M, int32_t C);
+int ds_bn_bwd_reduce(const float *z, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
+                     const float *rstd, const float *shift, float *partials, void *stream);
+int ds_bn_bwd_finalize(const float *partials, int32_t P, int64_t M, int32_t C, float *dbeta, float *coef,
+                       void *stream);
+int ds_bn_bwd_apply(const float *z, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
+                    const float *rstd, const float *shift, const float *coef, float *dz, void *stream);
+
+/* slim.max_pool2d SAME/VALID (inception_v1.py:67,79,94,118,208) with arg-max record, and MaxPoolGrad. */
+int ds_maxpool_fwd(const float *x, float *y, uint8_t *argmax, int32_t N, int32_t H, int32_t W, int32_t C,
+                   int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW,
+                   void *stream);
+int ds_maxpool_bwd(const float *dy, const uint8_t *argmax, float *dx, int32_t accumulate, int32_t N,
+                   int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
+                   int32_t OH, int32_t OW, void *stream);
+
+/* slim.avg_pool2d 7x7 VALID + slim.dropout (inception_v1.py:299-301).  mask_in==NULL: draw
+ * Bernoulli(keep) from a counter-based generator keyed by (seed, element); the mask used is
+ * written to mask_out (needed by the backward).  keep>=1 disables dropout.                 */
+int ds_avgpool_dropout_fwd(const float *x, int32_t N, int32_t HW, int32_t C, float keep, uint64_t seed,
+                           const float *mask_in, float *mask_out, float *out, void *stream);
+int ds_avgpool_dropout_bwd(const float *dout, const float *mask, int32_t N, int32_t HW, int32_t C,
+                           float keep, float *dx, void *stream);
+
+/* tf.nn.embedding_lookup (im_text_rnn_model.py:85): out row (b,t) <- table[ids[b,t]].
+ * time_major!=0 writes row t*B+b (the layout the LSTM consumes), else b*T+t.               */
+int ds_gather_rows(const float *table, const int64_t *ids, float *out, int32_t B, int32_t T, int32_t D,
+                   int64_t table_rows, int32_t time_major, void *stream);
+
+/* BasicLSTMCell gate math + dynamic_rnn length masking (im_text_rnn_model.py:89-90).
+ * gates [B,4H] holds the pre-activations (i,j,f,o) on entry and the activations
+ * (sigmoid i, tanh j, sigmoid(f+forget_bias), sigmoid o) on exit.                          */
+int ds_lstm_cell_fwd(float *gates, const float *c_prev, const float *h_prev, const int64_t *seq_len,
+                     int32_t t, int32_t B, int32_t H, float forget_bias, float *c_out, float *h_out,
+                     void *stream);
+/* one BPTT step: consumes dh (grad wrt h_t), dc (grad wrt c_t); writes dgates [B,4H],
+ * dc_prev, and dh_carry (= dh for rows with t >= seq_len, else 0; the recurrent dgrad GEMM
+ * then accumulates dgates*Wh^T onto it).                                                   */
+int ds_lstm_cell_bwd(const float *acts, const float *c_t, const float *c_prev, const float *dh,
+                     const float *dc, const int64_t *seq_len, int32_t t, int32_t B, int32_t H,
+                     float *dgates, float *dc_prev, float *dh_carry, void *stream);
+
+/* slim.losses.softmax_cross_entropy + its gradient (im_text_rnn_model.py:124-125):
+ * loss[0] = mean_b(logsumexp(z_b) - z_b[y_b]); dlogits = (softmax - onehot) * grad_scale / B;
+ * grad_scale_dev (nullable) is a device scalar multiplied in (autograd's upstream gradient);
+ * loss / dlogits may each be NULL. */
+int ds_softmax_ce(const float *logits, const int64_t *labels, int32_t B, int32_t C, float grad_scale,
+                  const float *grad_scale_dev, float *loss, float *dlogits, void *stream);
+
+/* tf.train.AdamOptimizer.apply_gradients over one flat parameter buffer
+ * (im_text_rnn_model.py:134-135).  g_eff = g*grad_scale + (i < n_wd ? wd*theta : 0): the first
+ * n_wd entries are the slim conv `weights` that carry the L2 regulariser
+ * (slim/nets/inception_utils.py:63-64).  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the host. */
+int ds_adam_tf(float *theta, const float *g, float *m, float *v, int64_t n, int64_t n_wd, float wd,
+               float grad_scale, float lr_t, float beta1, float beta2, float eps, void *stream);
+
+/* small helpers (deterministic two-stage reductions; scratch is caller-provided) */
+/* out[0] = sum x^2 (= 2*tf.nn.l2_loss); scratch >= 256 floats                                */
+int ds_sumsq(const float *x, int64_t n, float *scratch, float *out, void *stream);
+/* BiasAddGrad: out[c] = sum_m x[m*ld + c]; scratch >= 64*C floats                            */
+int ds_colsum(const float *x, int64_t M, int32_t C, int32_t ld, float *scratch, float *out, void *stream);
+int ds_copy2d(const float *src, int32_t lds, float *dst, int32_t ldd, int64_t rows, int32_t cols,
+              void *stream);
+int ds_pad_channels(const float *src, int32_t cs, float *dst, int32_t cd, int64_t pixels, void *stream);
+int ds_fill(float *dst, int64_t n, float value, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DS_KERNELS_H */

@@ -1,0 +1,342 @@
+"""Per-kernel parity: every entry point of the C ABI against the NumPy oracle (fp64) on seeded inputs.
+
+Tolerance: the path computes in fp32 (exact fp32 MFMA = k-ordered fmaf chain); against an fp64
+oracle the bound used is |err| <= 2e-4 * max|ref| unless stated (north-star gate on logits is 1e-3).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf_semantics as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from tumblr_emotions_amd import ops
+    return ops
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda")
+
+
+def close(got, ref, tol=2e-4):
+    got = got.detach().cpu().numpy().astype(np.float64)
+    scale = max(1e-6, np.abs(ref).max())
+    err = np.abs(got - ref).max()
+    assert err <= tol * scale, "max err %.3e vs scale %.3e" % (err, scale)
+
+
+CONV_CASES = [
+    # (N, H, W, Cin, Cout, k, stride)
+    (2, 9, 9, 16, 32, 1, 1),
+    (3, 14, 14, 24, 64, 3, 1),       # Cin not a multiple of the 16-wide K tile
+    (2, 28, 28, 96, 128, 3, 1),
+    (4, 7, 7, 832, 624, 1, 1),       # fused Mixed_5c 1x1: several column tiles
+    (2, 13, 11, 48, 176, 3, 1),      # ragged spatial size, Cout not a multiple of 32*k
+    (1, 8, 8, 8, 200, 1, 1),
+    (2, 10, 10, 20, 12, 3, 2),       # stride 2 SAME (pad goes bottom/right)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_with_stats(case):
+    ops = _ops()
+    N, H, W, Ci, Co, k, s = case
+    rng = np.random.RandomState(1)
+    x = rng.normal(size=(N, H, W, Ci))
+    w = rng.normal(size=(k, k, Ci, Co)) * 0.1
+    ref = S.conv2d_same(x, w, s)
+    xd, wd = dev(x), dev(w)
+    plan = ops.ConvPlan(N, H, W, Ci, Ci, k, k, s, Co, Co, Ci * Co, 1, Co, flags=ops.DS_EPI_STATS)
+    M = plan.M
+    z = torch.empty(M, Co, device="cuda")
+    stats = torch.zeros(plan.partials, 2, Co, device="cuda")
+    plan.run(ops._p(xd), ops._p(wd), ops._p(z), stats=ops._p(stats))
+    torch.cuda.synchronize()
+    close(z, ref.reshape(M, Co))
+    close(stats[:, 0, :].sum(0), ref.reshape(M, Co).sum(0), 1e-3)
+    close(stats[:, 1, :].sum(0), (ref.reshape(M, Co) ** 2).sum(0), 1e-3)
+
+
+def test_conv_stem_7x7_stride2_folded():
+    """Conv2d_1a_7x7 (inception_v1.py:63): Cin=3 padded to 4, KW folded into the channel axis."""
+    ops = _ops()
+    N, H = 2, 32
+    rng = np.random.RandomState(2)
+    x = rng.uniform(-1, 1, size=(N, H, H, 3))
+    w = rng.normal(size=(7, 7, 3, 64)) * 0.1
+    ref = S.conv2d_same(x, w, 2)
+    x4 = torch.zeros(N, H, H, 4, device="cuda")
+    ops.pad_channels(dev(x), 3, x4, 4, N * H * H)
+    w4 = np.zeros((7, 7, 4, 64))
+    w4[:, :, :3, :] = w
+    wd = dev(w4)
+    plan = ops.ConvPlan(N, H, H, 28, 4, 7, 1, 2, 64, 64, 28 * 64, 1, 64, fold_cin=4)
+    assert (plan.d.OH, plan.d.OW, plan.d.pad_t, plan.d.pad_l) == (16, 16, 2, 2)
+    z = torch.empty(plan.M, 64, device="cuda")
+    plan.run(ops._p(x4), ops._p(wd), ops._p(z))
+    torch.cuda.synchronize()
+    close(z, ref.reshape(-1, 64))
+
+
+@pytest.mark.parametrize("case", [(2, 14, 14, 24, 64, 3), (2, 7, 7, 192, 384, 3), (3, 9, 9, 32, 176, 1)])
+def test_conv_dgrad_reads_hwio_weights_in_place(case):
+    ops = _ops()
+    N, H, W, Ci, Co, k = case
+    rng = np.random.RandomState(3)
+    w = rng.normal(size=(k, k, Ci, Co)) * 0.1
+    dy = rng.normal(size=(N, H, W, Co))
+    ref = S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1)
+    # dgrad as a forward conv: reduction over Co, outputs Ci, taps flipped, weights untouched
+    plan = ops.ConvPlan(N, H, W, Co, Co, k, k, 1, Ci, Ci, Ci * Co, Co, 1, flip=1)
+    dx = torch.empty(plan.M, Ci, device="cuda")
+    plan.run(ops._p(dev(dy)), ops._p(dev(w)), ops._p(dx))
+    torch.cuda.synchronize()
+    close(dx, ref.reshape(-1, Ci))
+
+
+@pytest.mark.parametrize("case", [(2, 7, 7, 48, 128, 3), (4, 7, 7, 832, 624, 1), (2, 5, 5, 12, 15, 3)])
+def test_conv_wgrad(case):
+    ops = _ops()
+    N, H, W, Ci, Co, k = case
+    rng = np.random.RandomState(4)
+    x = rng.normal(size=(N, H, W, Ci))
+    dy = rng.normal(size=(N, H, W, Co))
+    ref = S.conv2d_same_bwd_filter(x, dy, (k, k, Ci, Co), 1)
+    plan = ops.WgradPlan(N, H, W, Ci, Ci, k, k, 1, Co, Co)
+    ws = torch.empty(max(plan.ws_bytes // 4, 1), device="cuda")
+    dw = torch.empty(k, k, Ci, Co, device="cuda")
+    plan.run(ops._p(dev(x)), ops._p(dev(dy)), ops._p(dw), ops._p(ws), plan.ws_bytes)
+    torch.cuda.synchronize()
+    close(dw, ref, 3e-4)
+
+
+def test_gemm_variants_bias_relu_accum_mask_and_unaligned():
+    ops = _ops()
+    rng = np.random.RandomState(5)
+    M, K, N = 37, 52, 15                      # 15 classes: rows are not 16-byte aligned
+    a, w, b = rng.normal(size=(M, K)), rng.normal(size=(K, N)), rng.normal(size=N)
+    ad, wd, bd = dev(a), dev(w), dev(b)
+    out = torch.empty(M, N, device="cuda")
+    ops.gemm_plan(M, K, N, K, N, N, flags=ops.DS_EPI_BIAS).run(ops._p(ad), ops._p(wd), ops._p(out), bias=ops._p(bd))
+    close(out, a @ w + b)
+    # transposed weights: dX = dY * W^T with W [K,N] read in place, ReluGrad mask fused
+    dy = rng.normal(size=(M, N))
+    act = rng.normal(size=(M, K))
+    dx = torch.empty(M, K, device="cuda")
+    ops.gemm_plan(M, N, K, N, K, N, transposed_w=True, flags=ops.DS_EPI_MASK, ldmask=K).run(
+        ops._p(dev(dy)), ops._p(wd), ops._p(dx), mask=ops._p(dev(act)))
+    close(dx, (dy @ w.T) * (act > 0))
+    # accumulate + relu with a strided output (ldc > N) and strided input (lda > K)
+    big_a = rng.normal(size=(M, K + 12))
+    prev = rng.normal(size=(M, N + 5))
+    pd = dev(prev)
+    ops.gemm_plan(M, K, N, K + 12, N + 5, N, flags=ops.DS_EPI_ACCUM | ops.DS_EPI_RELU).run(
+        ops._p(dev(big_a)), ops._p(wd), ops._p(pd))
+    exp = prev.copy()
+    exp[:, :N] = np.maximum(prev[:, :N] + big_a[:, :K] @ w, 0)
+    torch.cuda.synchronize()
+    close(pd, exp)
+
+
+def test_gemm_lstm_shape():
+    ops = _ops()
+    rng = np.random.RandomState(6)
+    B, H = 64, 128
+    h, kern = rng.normal(size=(B, H)), rng.normal(size=(40 + H, 4 * H)) * 0.1
+    kd = dev(kern)
+    wh_ptr = C.c_void_p(kd.data_ptr() + 40 * 4 * H * 4)            # rows [D:, :] of the TF kernel
+    gates = rng.normal(size=(B, 4 * H))
+    gd = dev(gates)
+    ops.gemm_plan(B, H, 4 * H, H, 4 * H, 4 * H, flags=ops.DS_EPI_ACCUM).run(ops._p(dev(h)), wh_ptr, ops._p(gd))
+    close(gd, gates + h @ kern[40:])
+    dg = rng.normal(size=(B, 4 * H))
+    dh = torch.zeros(B, H, device="cuda")
+    ops.gemm_plan(B, 4 * H, H, 4 * H, H, 4 * H, transposed_w=True).run(ops._p(dev(dg)), wh_ptr, ops._p(dh))
+    torch.cuda.synchronize()
+    close(dh, dg @ kern[40:].T)
+
+
+def test_batch_norm_forward_backward_with_segments():
+    ops = _ops()
+    rng = np.random.RandomState(7)
+    M, Cc = 1000, 176                                       # fused 1x1 of Mixed_3b: 64 | 96 | 16
+    z = rng.normal(0.5, 2.0, size=(M, Cc))
+    beta = rng.normal(size=Cc) * 0.3
+    y_ref, mean, var, xhat, rstd = S.batch_norm_train(z, beta)
+    y_ref = S.relu(y_ref)
+    zd, bd = dev(z), dev(beta)
+    # forward statistics through the conv epilogue path is covered elsewhere; here feed exact partials
+    stats = torch.stack([zd.sum(0), (zd * zd).sum(0)]).reshape(1, 2, Cc).contiguous()
+    mean_d, rstd_d, shift_d = (torch.empty(Cc, device="cuda") for _ in range(3))
+    mm, mv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    ops.bn_finalize(stats, 1, M, Cc, bd, S.BN_EPS, S.BN_DECAY, mean_d, rstd_d, shift_d, mm, mv)
+    close(mean_d, mean, 1e-4)
+    close(rstd_d, rstd, 1e-4)
+    close(mm, 0.0003 * mean, 1e-3)
+    close(mv, 0.9997 + 0.0003 * var, 1e-5)
+    concat = torch.zeros(M, 256, device="cuda")
+    r1 = torch.zeros(M, 96, device="cuda")
+    r2 = torch.zeros(M, 16, device="cuda")
+    segs = ops.make_segments([(0, 64, concat.data_ptr(), 256), (64, 160, r1.data_ptr(), 96),
+                              (160, 176, r2.data_ptr(), 16)])
+    ops.bn_apply_relu(zd, M, Cc, rstd_d, shift_d, segs)
+    close(concat[:, :64], y_ref[:, :64])
+    close(r1, y_ref[:, 64:160])
+    close(r2, y_ref[:, 160:])
+    assert float(concat[:, 64:].abs().max()) == 0.0
+    # backward
+    dy = rng.normal(size=(M, Cc))
+    g = dy * (y_ref > 0)
+    dz_ref, dbeta_ref = S.batch_norm_train_bwd(g, xhat, rstd)
+    dyc, dr1, dr2 = dev(np.pad(dy[:, :64], ((0, 0), (0, 192)))), dev(dy[:, 64:160]), dev(dy[:, 160:])
+    dsegs = ops.make_segments([(0, 64, dyc.data_ptr(), 256), (64, 160, dr1.data_ptr(), 96),
+                               (160, 176, dr2.data_ptr(), 16)])
+    P = ops.bn_bwd_partials(M, Cc)
+    part = torch.empty(P, 2, Cc, device="cuda")
+    dbeta, coef = torch.empty(Cc, device="cuda"), torch.empty(2, Cc, device="cuda")
+    ops.bn_bwd_reduce(zd, dsegs, M, Cc, mean_d, rstd_d, shift_d, part)
+    ops.bn_bwd_finalize(part, P, M, Cc, dbeta, coef)
+    ops.bn_bwd_apply(zd, dsegs, M, Cc, mean_d, rstd_d, shift_d, coef, zd)        # in place over z
+    torch.cuda.synchronize()
+    close(dbeta, dbeta_ref, 1e-4)
+    close(zd, dz_ref, 3e-4)
+
+
+@pytest.mark.parametrize("case", [(3, 2, 9, "SAME"), (3, 1, 7, "SAME"), (2, 2, 14, "VALID"), (3, 2, 112, "SAME")])
+def test_max_pool_forward_backward(case):
+    ops = _ops()
+    k, s, H, mode = case
+    rng = np.random.RandomState(8)
+    N, Cc = 2, 24
+    x = rng.normal(size=(N, H, H, Cc))
+    ref = S.max_pool(x, k, s, mode)
+    OH = ref.shape[1]
+    xd = dev(x)
+    y = torch.empty(N, OH, OH, Cc, device="cuda")
+    am = torch.empty(N, OH, OH, Cc, dtype=torch.uint8, device="cuda")
+    ops.maxpool_fwd(xd, y, am, N, H, H, Cc, k, s, mode)
+    close(y, ref, 1e-6)
+    dy = rng.normal(size=ref.shape)
+    dx_ref = S.max_pool_bwd(x, dy, k, s, mode)
+    base = rng.normal(size=x.shape)
+    dx = dev(base)
+    ops.maxpool_bwd(dev(dy), am, dx, True, N, H, H, Cc, k, s, mode)
+    torch.cuda.synchronize()
+    close(dx, base + dx_ref, 1e-6)
+
+
+def test_avgpool_dropout():
+    ops = _ops()
+    rng = np.random.RandomState(9)
+    N, HW, Cc = 5, 49, 1024
+    x = rng.normal(size=(N, HW, Cc))
+    mask = (rng.uniform(size=(N, Cc)) < 0.8).astype(np.float64)
+    ref = x.mean(1) * mask / 0.8
+    out, mo = torch.empty(N, Cc, device="cuda"), torch.empty(N, Cc, device="cuda")
+    ops.avgpool_dropout_fwd(dev(x), N, HW, Cc, 0.8, 0, dev(mask), mo, out)
+    close(out, ref)
+    close(mo, mask, 0)
+    # generated mask: Bernoulli(0.8), reproducible per seed, different across seeds
+    m1, m2, m3 = (torch.empty(N, Cc, device="cuda") for _ in range(3))
+    ops.avgpool_dropout_fwd(dev(x), N, HW, Cc, 0.8, 123, None, m1, out)
+    ops.avgpool_dropout_fwd(dev(x), N, HW, Cc, 0.8, 123, None, m2, out)
+    ops.avgpool_dropout_fwd(dev(x), N, HW, Cc, 0.8, 124, None, m3, out)
+    assert torch.equal(m1, m2) and not torch.equal(m1, m3)
+    assert abs(float(m1.mean()) - 0.8) < 0.03
+    close(out, x.mean(1) * m1.cpu().numpy() / 0.8)
+    d = rng.normal(size=(N, Cc))
+    dx = torch.empty(N, HW, Cc, device="cuda")
+    ops.avgpool_dropout_bwd(dev(d), dev(mask), N, HW, Cc, 0.8, dx)
+    torch.cuda.synchronize()
+    close(dx, np.broadcast_to((d * mask / 0.8 / HW)[:, None, :], (N, HW, Cc)))
+
+
+@pytest.mark.parametrize("D", [300, 50, 7])
+def test_gather_rows_is_bit_exact(D):
+    ops = _ops()
+    rng = np.random.RandomState(10)
+    B, T, V = 6, 9, 100
+    table = rng.normal(size=(V + 1, D)).astype(np.float32)
+    table[V] = 0
+    ids = rng.randint(0, V + 1, size=(B, T)).astype(np.int64)
+    td = dev(table)
+    out = torch.empty(T, B, D, device="cuda")
+    ops.gather_rows(td, dev(ids, torch.int64), out, B, T, D, True)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), table[ids].transpose(1, 0, 2))      # bit exact
+    out2 = torch.empty(B, T, D, device="cuda")
+    ops.gather_rows(td, dev(ids, torch.int64), out2, B, T, D, False)
+    torch.cuda.synchronize()
+    assert np.array_equal(out2.cpu().numpy(), table[ids])
+
+
+def test_lstm_cell_forward_backward():
+    ops = _ops()
+    rng = np.random.RandomState(11)
+    B, H, t = 7, 24, 3
+    pre = rng.normal(size=(B, 4 * H))
+    c0, h0 = rng.normal(size=(B, H)), rng.normal(size=(B, H))
+    seq = np.array([5, 1, 4, 3, 9, 2, 4])
+    i, j, f, o = np.split(pre, 4, axis=1)
+    si, tj, sf, so = S.sigmoid(i), np.tanh(j), S.sigmoid(f + 1.0), S.sigmoid(o)
+    live = (t < seq)[:, None]
+    cn = c0 * sf + si * tj
+    hn = np.tanh(cn) * so
+    g = dev(pre)
+    cd, hd = torch.empty(B, H, device="cuda"), torch.empty(B, H, device="cuda")
+    sd = dev(seq, torch.int64)
+    ops.lstm_cell_fwd(g, dev(c0), dev(h0), sd, t, B, H, 1.0, cd, hd)
+    close(cd, np.where(live, cn, c0), 1e-5)
+    close(hd, np.where(live, hn, h0), 1e-5)
+    close(g, np.concatenate([si, tj, sf, so], 1), 1e-5)
+    dh, dc = rng.normal(size=(B, H)), rng.normal(size=(B, H))
+    tc = np.tanh(cn)
+    dct = dc + dh * so * (1 - tc ** 2)
+    ref_dg = np.where(live, np.concatenate([dct * tj * si * (1 - si), dct * si * (1 - tj ** 2),
+                                            dct * c0 * sf * (1 - sf), dh * tc * so * (1 - so)], 1), 0)
+    dg = torch.empty(B, 4 * H, device="cuda")
+    dcp, dhc = torch.empty(B, H, device="cuda"), torch.empty(B, H, device="cuda")
+    ops.lstm_cell_bwd(g, cd, dev(c0), dev(dh), dev(dc), sd, t, B, H, dg, dcp, dhc)
+    torch.cuda.synchronize()
+    close(dg, ref_dg, 1e-5)
+    close(dcp, np.where(live, dct * sf, dc), 1e-5)
+    close(dhc, np.where(live, 0, dh), 1e-6)
+
+
+def test_softmax_ce_and_adam_and_reductions():
+    ops = _ops()
+    rng = np.random.RandomState(12)
+    B, Cc = 300, 15
+    z = rng.normal(size=(B, Cc)) * 3
+    y = rng.randint(0, Cc, size=B)
+    loss, dl = torch.empty(1, device="cuda"), torch.empty(B, Cc, device="cuda")
+    up = torch.full((1,), 0.5, device="cuda")
+    ops.softmax_ce(dev(z), dev(y, torch.int64), B, Cc, 1.0, up, loss, dl)
+    close(loss, np.array([S.softmax_cross_entropy(z, y)]), 1e-5)
+    close(dl, 0.5 * S.softmax_cross_entropy_grad(z, y), 1e-5)
+    # TF Adam, three steps, weight decay on the first 40 entries, averaged gradients (grad_scale)
+    n, nwd = 1003, 40
+    w = rng.normal(size=n)
+    m, v = np.zeros(n), np.zeros(n)
+    wd_, md, vd = dev(w), dev(m), dev(v)
+    for t in range(1, 4):
+        gr = rng.normal(size=n) * 1e-3
+        ge = gr * 0.5
+        ge[:nwd] += S.WEIGHT_DECAY * w[:nwd]
+        w, m, v = S.adam_step(w, ge, m, v, t, 1e-3)
+        lr_t = 1e-3 * np.sqrt(1 - S.ADAM_B2 ** t) / (1 - S.ADAM_B1 ** t)
+        ops.adam_tf(wd_, dev(gr), md, vd, n, nwd, S.WEIGHT_DECAY, 0.5, lr_t, S.ADAM_B1, S.ADAM_B2, S.ADAM_EPS)
+    close(wd_, w, 1e-5)
+    x = rng.normal(size=(777, 130))
+    scratch, out = torch.empty(64 * 130, device="cuda"), torch.empty(130, device="cuda")
+    ops.colsum(dev(x), 777, 130, 130, scratch, out)
+    close(out, x.sum(0), 1e-5)
+    ss = torch.empty(1, device="cuda")
+    ops.sumsq(dev(x), x.size, scratch, ss)
+    torch.cuda.synchronize()
+    close(ss, np.array([(x ** 2).sum()]), 1e-5)

@@ -1,0 +1,88 @@
+"""ctypes binding of libds_kernels.so (the C ABI declared in include/ds_kernels.h).
+
+The library is the product: there is NO CPU or PyTorch fallback.  If the shared object is
+missing or a call fails, a RuntimeError is raised immediately.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libds_kernels.so")
+
+DS_EPI_BIAS, DS_EPI_RELU, DS_EPI_ACCUM, DS_EPI_STATS, DS_EPI_MASK = 1, 2, 4, 8, 16
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("ldx", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
+        ("OH", C.c_int32), ("OW", C.c_int32), ("Cout", C.c_int32), ("ldz", C.c_int32),
+        ("w_tap_stride", C.c_int64), ("w_n_stride", C.c_int32), ("w_k_stride", C.c_int32),
+        ("flip", C.c_int32), ("fold_cin", C.c_int32), ("flags", C.c_int32), ("ldmask", C.c_int32),
+    ]
+
+
+class Segments(C.Structure):
+    _fields_ = [("nseg", C.c_int32), ("c_begin", C.c_int32 * 4), ("c_end", C.c_int32 * 4),
+                ("ld", C.c_int32 * 4), ("ptr", C.c_void_p * 4)]
+
+
+_P = C.c_void_p
+_i32, _i64, _f32, _u64 = C.c_int32, C.c_int64, C.c_float, C.c_uint64
+_CD = C.POINTER(ConvDesc)
+_SG = C.POINTER(Segments)
+
+# name -> (restype, argtypes); mirrors include/ds_kernels.h one to one
+SIGNATURES = {
+    "ds_version": (C.c_int, []),
+    "ds_last_error": (C.c_char_p, []),
+    "ds_conv_igemm_partials": (C.c_int, [_CD]),
+    "ds_conv_igemm": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _P]),
+    "ds_conv_wgrad_workspace": (C.c_size_t, [_CD]),
+    "ds_conv_wgrad": (C.c_int, [_CD, _P, _P, _i32, _P, _P, C.c_size_t, _P]),
+    "ds_bn_finalize": (C.c_int, [_P, _i32, _i64, _i32, _P, _f32, _f32, _P, _P, _P, _P, _P, _P]),
+    "ds_bn_apply_relu": (C.c_int, [_P, _i64, _i32, _P, _P, _SG, _P]),
+    "ds_bn_bwd_partials": (C.c_int, [_i64, _i32]),
+    "ds_bn_bwd_reduce": (C.c_int, [_P, _SG, _i64, _i32, _P, _P, _P, _P, _P]),
+    "ds_bn_bwd_finalize": (C.c_int, [_P, _i32, _i64, _i32, _P, _P, _P]),
+    "ds_bn_bwd_apply": (C.c_int, [_P, _SG, _i64, _i32, _P, _P, _P, _P, _P, _P]),
+    "ds_maxpool_fwd": (C.c_int, [_P, _P, _P] + [_i32] * 10 + [_P]),
+    "ds_maxpool_bwd": (C.c_int, [_P, _P, _P] + [_i32] * 11 + [_P]),
+    "ds_avgpool_dropout_fwd": (C.c_int, [_P, _i32, _i32, _i32, _f32, _u64, _P, _P, _P, _P]),
+    "ds_avgpool_dropout_bwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _f32, _P, _P]),
+    "ds_gather_rows": (C.c_int, [_P, _P, _P, _i32, _i32, _i32, _i64, _i32, _P]),
+    "ds_lstm_cell_fwd": (C.c_int, [_P, _P, _P, _P, _i32, _i32, _i32, _f32, _P, _P, _P]),
+    "ds_lstm_cell_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _P, _P, _P, _P]),
+    "ds_softmax_ce": (C.c_int, [_P, _P, _i32, _i32, _f32, _P, _P, _P, _P]),
+    "ds_adam_tf": (C.c_int, [_P, _P, _P, _P, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _P]),
+    "ds_sumsq": (C.c_int, [_P, _i64, _P, _P, _P]),
+    "ds_colsum": (C.c_int, [_P, _i64, _i32, _i32, _P, _P, _P]),
+    "ds_copy2d": (C.c_int, [_P, _i32, _P, _i32, _i64, _i32, _P]),
+    "ds_pad_channels": (C.c_int, [_P, _i32, _P, _i32, _i64, _P]),
+    "ds_fill": (C.c_int, [_P, _i64, _f32, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared object once; raise loudly if it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "tumblr_emotions_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C tumblr_emotions_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, load().ds_last_error().decode()))

@@ -1,0 +1,286 @@
+// BatchNorm (train mode, beta only) + ReLU, forward and backward.  HBM-bound streaming kernels.
+//
+// Restates slim.batch_norm(center=True, scale=False, decay=0.9997, epsilon=1e-3) as configured by
+// slim/nets/inception_utils.py:48-70, applied after every slim.conv2d of
+// image_model/inception_v1.py:63-250, followed by tf.nn.relu (inception_utils.py:68).
+//   forward : mean/var come from the conv kernel's column-statistics partials (ds_bn_finalize),
+//             y = relu(z*rstd + (beta - mean*rstd)) is scattered straight into the channel slices
+//             of the Inception concat buffer (replaces tf.concat, inception_v1.py:96..248).
+//   backward: g = dy*(y>0); dbeta = sum(g); dz = rstd*(g - mean(g) - xhat*mean(g*xhat)).
+// All kernels move 16 B per lane per access and use a fixed (deterministic) reduction order.
+#include "ds_common.h"
+
+namespace {
+
+struct SegDev {
+    int nseg;
+    int c_begin[4], c_end[4], ld[4];
+    float *ptr[4];
+};
+
+SegDev to_dev(const ds_segments *s) {
+    SegDev o;
+    o.nseg = s->nseg;
+    for (int i = 0; i < 4; ++i) {
+        o.c_begin[i] = s->c_begin[i];
+        o.c_end[i] = s->c_end[i];
+        o.ld[i] = s->ld[i];
+        o.ptr[i] = s->ptr[i];
+    }
+    return o;
+}
+
+__device__ __forceinline__ float *seg_addr(const SegDev &sg, int64_t row, int c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < sg.nseg && c >= sg.c_begin[i] && c < sg.c_end[i])
+            return sg.ptr[i] + row * sg.ld[i] + (c - sg.c_begin[i]);
+    return nullptr;
+}
+
+// ---- forward ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *stats, int P, double inv_count, int C,
+                                                          const float *beta, float eps, float decay, float *mean,
+                                                          float *rstd, float *shift, float *mm, float *mv) {
+    // 16 channels x 16 partial-lanes per workgroup; partials are combined in double
+    __shared__ double sh[2][16][16];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int p = pl; p < P; p += 16) {
+            s += (double)stats[(int64_t)p * 2 * C + c];
+            q += (double)stats[(int64_t)p * 2 * C + C + c];
+        }
+    sh[0][pl][cl] = s;
+    sh[1][pl][cl] = q;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        s = q = 0.0;
+        for (int k = 0; k < 16; ++k) {
+            s += sh[0][k][cl];
+            q += sh[1][k][cl];
+        }
+        const double mu = s * inv_count;
+        double var = q * inv_count - mu * mu;          // biased variance (A3)
+        if (var < 0.0) var = 0.0;
+        const float r = (float)(1.0 / sqrt(var + (double)eps));
+        mean[c] = (float)mu;
+        rstd[c] = r;
+        shift[c] = beta[c] - (float)mu * r;
+        if (mm) mm[c] = decay * mm[c] + (1.f - decay) * (float)mu;     // assign_moving_average
+        if (mv) mv[c] = decay * mv[c] + (1.f - decay) * (float)var;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *z, int64_t M, int C, const float *rstd,
+                                                            const float *shift, SegDev dst) {
+    const int C4 = C >> 2;
+    const int64_t total = M * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / C4;
+        const int c = (int)(i - row * C4) * 4;
+        const float4 v = *reinterpret_cast<const float4 *>(z + row * C + c);
+        const float4 r = *reinterpret_cast<const float4 *>(rstd + c);
+        const float4 s = *reinterpret_cast<const float4 *>(shift + c);
+        float4 y;
+        y.x = fmaxf(v.x * r.x + s.x, 0.f);
+        y.y = fmaxf(v.y * r.y + s.y, 0.f);
+        y.z = fmaxf(v.z * r.z + s.z, 0.f);
+        y.w = fmaxf(v.w * r.w + s.w, 0.f);
+        float *o = seg_addr(dst, row, c);
+        if (o) *reinterpret_cast<float4 *>(o) = y;
+    }
+}
+
+// ---- backward -----------------------------------------------------------------------------------
+// Each workgroup owns a contiguous block of rows; a thread owns one float4 column group and strides
+// over the rows, so every wave reads whole contiguous rows (coalesced) and the per-channel sums stay
+// in registers until one LDS combine at the end.
+// rows per workgroup: 512 for the big maps, fewer on the 14x14 / 7x7 maps so the grid still
+// covers the chip (>= ~2000 workgroups where the tensor allows it)
+int bwd_rows_per_block(int64_t M) {
+    int64_t r = (M + 2047) / 2048;
+    r = (r + 7) / 8 * 8;
+    if (r < 16) r = 16;
+    if (r > 512) r = 512;
+    return (int)r;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *z, SegDev dy, int64_t M, int C,
+                                                            const float *mean, const float *rstd,
+                                                            const float *shift, float *partials, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // [RG][C4][8]
+    const int C4 = C >> 2;
+    const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
+    const int tid = threadIdx.x;
+    const int cg = tid % C4, rg = tid / C4;
+    const bool active = tid < RG * C4;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const int c = cg * 4;
+        const float4 r = *reinterpret_cast<const float4 *>(rstd + c);
+        const float4 s = *reinterpret_cast<const float4 *>(shift + c);
+        const float4 mu = *reinterpret_cast<const float4 *>(mean + c);
+        const float rr[4] = {r.x, r.y, r.z, r.w}, ss[4] = {s.x, s.y, s.z, s.w}, mm[4] = {mu.x, mu.y, mu.z, mu.w};
+        for (int64_t row = r0 + rg; row < r1; row += RG) {
+            const float4 zv = *reinterpret_cast<const float4 *>(z + row * C + c);
+            const float4 dv = *reinterpret_cast<const float4 *>(seg_addr(dy, row, c));
+            const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float g = (zz[j] * rr[j] + ss[j] > 0.f) ? dd[j] : 0.f;
+                sg[j] += g;
+                sx[j] += g * ((zz[j] - mm[j]) * rr[j]);
+            }
+        }
+        float *o = sh + ((int64_t)rg * C4 + cg) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = sg[j];
+            o[4 + j] = sx[j];
+        }
+    }
+    __syncthreads();
+    if (tid < C4) {
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int g = 0; g < RG; ++g)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += sh[((int64_t)g * C4 + tid) * 8 + j];
+        float *o = partials + (int64_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[tid * 4 + j] = a[j];
+            o[C + tid * 4 + j] = a[4 + j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *partials, int P, double inv_count, int C,
+                                                              float *dbeta, float *coef) {
+    __shared__ double sh[2][16][16];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int p = pl; p < P; p += 16) {
+            s += (double)partials[(int64_t)p * 2 * C + c];
+            q += (double)partials[(int64_t)p * 2 * C + C + c];
+        }
+    sh[0][pl][cl] = s;
+    sh[1][pl][cl] = q;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        s = q = 0.0;
+        for (int k = 0; k < 16; ++k) {
+            s += sh[0][k][cl];
+            q += sh[1][k][cl];
+        }
+        dbeta[c] = (float)s;
+        if (coef) {
+            coef[c] = (float)(s * inv_count);          // mean(g)
+            coef[C + c] = (float)(q * inv_count);      // mean(g*xhat)
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, SegDev dy, int64_t M, int C,
+                                                           const float *mean, const float *rstd, const float *shift,
+                                                           const float *coef, float *dz) {
+    const int C4 = C >> 2;
+    const int64_t total = M * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / C4;
+        const int c = (int)(i - row * C4) * 4;
+        const float4 zv = *reinterpret_cast<const float4 *>(z + row * C + c);
+        const float4 dv = *reinterpret_cast<const float4 *>(seg_addr(dy, row, c));
+        const float4 r = *reinterpret_cast<const float4 *>(rstd + c);
+        const float4 s = *reinterpret_cast<const float4 *>(shift + c);
+        const float4 mu = *reinterpret_cast<const float4 *>(mean + c);
+        const float4 k1 = *reinterpret_cast<const float4 *>(coef + c);
+        const float4 k2 = *reinterpret_cast<const float4 *>(coef + C + c);
+        const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+        const float rr[4] = {r.x, r.y, r.z, r.w}, ss[4] = {s.x, s.y, s.z, s.w}, mm[4] = {mu.x, mu.y, mu.z, mu.w};
+        const float a1[4] = {k1.x, k1.y, k1.z, k1.w}, a2[4] = {k2.x, k2.y, k2.z, k2.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float g = (zz[j] * rr[j] + ss[j] > 0.f) ? dd[j] : 0.f;
+            const float xh = (zz[j] - mm[j]) * rr[j];
+            o[j] = rr[j] * (g - a1[j] - xh * a2[j]);
+        }
+        *reinterpret_cast<float4 *>(dz + row * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+int check_segments(const ds_segments *s, int C, const char *who) {
+    DS_REQUIRE(s && s->nseg >= 1 && s->nseg <= 4, "%s: 1..4 segments required", who);
+    int covered = 0;
+    for (int i = 0; i < s->nseg; ++i) {
+        DS_REQUIRE(s->c_begin[i] % 4 == 0 && s->c_end[i] % 4 == 0 && s->ld[i] % 4 == 0 && s->ptr[i] &&
+                       (((uintptr_t)s->ptr[i]) & 15) == 0,
+                   "%s: segment %d not 4-channel / 16-byte aligned", who, i);
+        covered += s->c_end[i] - s->c_begin[i];
+    }
+    DS_REQUIRE(covered == C, "%s: segments cover %d of %d channels", who, covered, C);
+    return DS_OK;
+}
+
+}  // namespace
+
+extern "C" int ds_bn_finalize(const float *stats, int32_t P, int64_t count, int32_t C, const float *beta, float eps,
+                              float decay, float *mean, float *rstd, float *shift, float *moving_mean,
+                              float *moving_var, void *stream) {
+    DS_REQUIRE(stats && beta && mean && rstd && shift && P > 0 && count > 0 && C > 0, "ds_bn_finalize: bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, stats, P,
+                       1.0 / (double)count, C, beta, eps, decay, mean, rstd, shift, moving_mean, moving_var);
+    return ds::check_launch("ds_bn_finalize");
+}
+
+extern "C" int ds_bn_apply_relu(const float *z, int64_t M, int32_t C, const float *rstd, const float *shift,
+                                const ds_segments *dst, void *stream) {
+    DS_REQUIRE(z && rstd && shift && M > 0 && C > 0 && C % 4 == 0, "ds_bn_apply_relu: bad argument (C %% 4 != 0?)");
+    if (int e = check_segments(dst, C, "ds_bn_apply_relu")) return e;
+    hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(ds::stream_grid(M * (C / 4), 256 * 4)), dim3(256), 0,
+                       (hipStream_t)stream, z, M, C, rstd, shift, to_dev(dst));
+    return ds::check_launch("ds_bn_apply_relu");
+}
+
+extern "C" int ds_bn_bwd_partials(int64_t M, int32_t C) {
+    (void)C;
+    const int rpb = bwd_rows_per_block(M);
+    return (int)((M + rpb - 1) / rpb);
+}
+
+extern "C" int ds_bn_bwd_reduce(const float *z, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
+                                const float *rstd, const float *shift, float *partials, void *stream) {
+    DS_REQUIRE(z && mean && rstd && shift && partials && M > 0 && C > 0 && C % 4 == 0 && C <= 1024,
+               "ds_bn_bwd_reduce: bad argument (need C %% 4 == 0, C <= 1024)");
+    if (int e = check_segments(dy, C, "ds_bn_bwd_reduce")) return e;
+    const int C4 = C / 4;
+    const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
+    const size_t shmem = (size_t)RG * C4 * 8 * sizeof(float);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ds_bn_bwd_partials(M, C)), dim3(256), shmem, (hipStream_t)stream,
+                       z, to_dev(dy), M, C, mean, rstd, shift, partials, bwd_rows_per_block(M));
+    return ds::check_launch("ds_bn_bwd_reduce");
+}
+
+extern "C" int ds_bn_bwd_finalize(const float *partials, int32_t P, int64_t M, int32_t C, float *dbeta, float *coef,
+                                  void *stream) {
+    DS_REQUIRE(partials && dbeta && P > 0 && M > 0 && C > 0, "ds_bn_bwd_finalize: bad argument");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, P,
+                       1.0 / (double)M, C, dbeta, coef);
+    return ds::check_launch("ds_bn_bwd_finalize");
+}
+
+extern "C" int ds_bn_bwd_apply(const float *z, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
+                               const float *rstd, const float *shift, const float *coef, float *dz, void *stream) {
+    DS_REQUIRE(z && mean && rstd && shift && coef && dz && M > 0 && C > 0 && C % 4 == 0, "ds_bn_bwd_apply: bad argument");
+    if (int e = check_segments(dy, C, "ds_bn_bwd_apply")) return e;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ds::stream_grid(M * (C / 4), 256 * 4)), dim3(256), 0,
+                       (hipStream_t)stream, z, to_dev(dy), M, C, mean, rstd, shift, coef, dz);
+    return ds::check_launch("ds_bn_bwd_apply");
+}

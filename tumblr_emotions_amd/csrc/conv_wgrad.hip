@@ -1,0 +1,218 @@
+// Conv2DBackpropFilter / transposed MatMul (wgrad) on fp32 MFMA, split over the pixel dimension.
+//
+//   dw[tap, ci, co] = sum_m x[pixel(m) + tap, ci] * dz[m, co]
+//
+// Only the trainable scope needs it (image_model/inception_v1.py:229-250 Mixed_5c, :302-303
+// Logits, and the tf.get_variable matrices of im_text_rnn_model.py:89,98-104), i.e. ~4 % of the
+// backward FLOPs, so the kernel favours simplicity: both operands are staged pixel-major in LDS
+// exactly as they lie in HBM (NHWC rows), fragments are read with ds_read_b32 (32 consecutive
+// channels per half-wave: conflict-free), and the reduction over pixels is cut into `splits`
+// slabs that a second kernel sums in a fixed order (deterministic, no atomics).
+#include "ds_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int TI = 128;   // ci tile
+constexpr int TJ = 128;   // co tile
+constexpr int TP = 16;    // pixels per K-tile
+constexpr int LDT = TI + 4;
+
+struct WgradParams {
+    ds_conv_desc d;
+    const float *x;
+    const float *dz;
+    float *out;         // dw (splits==1) or workspace [splits][taps*Cin*Cout]
+    int lddz;
+    int M;
+    int ci_tiles;
+    int pix_per_split;  // multiple of TP
+    int x_vec, z_vec;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TP * LDT];
+    float *Xs = smem;                    // [2][TP][LDT]
+    float *Zs = smem + 2 * TP * LDT;     // [2][TP][LDT]
+    const ds_conv_desc &d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lk = lane >> 5;
+    const int tap = blockIdx.x / p.ci_tiles;
+    const int i0 = (blockIdx.x % p.ci_tiles) * TI;
+    const int j0 = blockIdx.y * TJ;
+    const int split = blockIdx.z;
+    const int dh = tap / d.KW, dw = tap % d.KW;
+    const int ohw = d.OH * d.OW;
+    const int m_begin = split * p.pix_per_split;
+    int m_end = m_begin + p.pix_per_split;
+    if (m_end > p.M) m_end = p.M;
+
+    int it_valid = (d.Cin - (i0 + wm * 64) + 31) / 32;
+    it_valid = it_valid < 0 ? 0 : (it_valid > 2 ? 2 : it_valid);
+    int jt_valid = (d.Cout - (j0 + wn * 64) + 31) / 32;
+    jt_valid = jt_valid < 0 ? 0 : (jt_valid > 2 ? 2 : jt_valid);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int lrow = tid >> 5;          // 0..7 (+8)
+    const int lc4 = (tid & 31) * 4;     // channel offset inside the 128-wide tile
+    float4 rx[2], rz[2];
+
+    auto load_tile = [&](int mt0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mt0 + lrow + 8 * i;
+            float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vz = vx;
+            if (m < m_end) {
+                const int n = m / ohw;
+                const int r = m - n * ohw;
+                const int oh = r / d.OW, ow = r - oh * d.OW;
+                const int ih = oh * d.stride - d.pad_t + dh, iw = ow * d.stride - d.pad_l + dw;
+                if ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W) {
+                    const int c = i0 + lc4;
+                    const float *ptr = p.x + (((int64_t)n * d.H + ih) * d.W + iw) * d.ldx + c;
+                    if (p.x_vec) {
+                        if (c < d.Cin) vx = *reinterpret_cast<const float4 *>(ptr);
+                    } else {
+                        if (c + 0 < d.Cin) vx.x = ptr[0];
+                        if (c + 1 < d.Cin) vx.y = ptr[1];
+                        if (c + 2 < d.Cin) vx.z = ptr[2];
+                        if (c + 3 < d.Cin) vx.w = ptr[3];
+                    }
+                }
+                const int c = j0 + lc4;
+                const float *ptr = p.dz + (int64_t)m * p.lddz + c;
+                if (p.z_vec) {
+                    if (c < d.Cout) vz = *reinterpret_cast<const float4 *>(ptr);
+                } else {
+                    if (c + 0 < d.Cout) vz.x = ptr[0];
+                    if (c + 1 < d.Cout) vz.y = ptr[1];
+                    if (c + 2 < d.Cout) vz.z = ptr[2];
+                    if (c + 3 < d.Cout) vz.w = ptr[3];
+                }
+            }
+            rx[i] = vx;
+            rz[i] = vz;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<float4 *>(Xs + (buf * TP + lrow + 8 * i) * LDT + lc4) = rx[i];
+            *reinterpret_cast<float4 *>(Zs + (buf * TP + lrow + 8 * i) * LDT + lc4) = rz[i];
+        }
+    };
+    auto compute = [&](int buf) {
+        const float *xs = Xs + buf * TP * LDT + wm * 64 + li;
+        const float *zs = Zs + buf * TP * LDT + wn * 64 + li;
+#pragma unroll
+        for (int s = 0; s < TP / 2; ++s) {
+            const int row = (2 * s + lk) * LDT;
+            float af[2], bf[2];
+            af[0] = xs[row];
+            af[1] = xs[row + 32];
+            bf[0] = zs[row];
+            bf[1] = zs[row + 32];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    if (a < it_valid && b < jt_valid)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    const int KT = (m_end - m_begin + TP - 1) / TP;
+    if (KT > 0) {
+        load_tile(m_begin);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) load_tile(m_begin + (kt + 1) * TP);
+            compute(cur);
+            if (kt + 1 < KT) store_tile(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    float *out = p.out + (int64_t)split * (d.KH * d.KW) * d.Cin * d.Cout + (int64_t)tap * d.Cin * d.Cout;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = j0 + wn * 64 + b * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < d.Cin && col < d.Cout) out[(int64_t)row * d.Cout + col] = acc[a][b][r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *ws, float *dw, int64_t n, int splits) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * n + i];
+        dw[i] = s;
+    }
+}
+
+int pick_splits(const ds_conv_desc *d, int64_t M) {
+    const int tiles = d->KH * d->KW * ((d->Cin + TI - 1) / TI) * ((d->Cout + TJ - 1) / TJ);
+    int splits = (2 * ds::kCUs + tiles - 1) / tiles;
+    const int max_splits = (int)((M + 255) / 256);    // keep >= 256 pixels per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
+}  // namespace
+
+extern "C" size_t ds_conv_wgrad_workspace(const ds_conv_desc *d) {
+    const int64_t M = (int64_t)d->N * d->OH * d->OW;
+    const int splits = pick_splits(d, M);
+    if (splits == 1) return 0;
+    return (size_t)splits * d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
+}
+
+extern "C" int ds_conv_wgrad(const ds_conv_desc *d, const float *x, const float *dz, int32_t lddz, float *dw,
+                             void *ws, size_t ws_bytes, void *stream) {
+    DS_REQUIRE(d && x && dz && dw, "ds_conv_wgrad: null argument");
+    const int64_t M = (int64_t)d->N * d->OH * d->OW;
+    DS_REQUIRE(M < (1ll << 31), "ds_conv_wgrad: M too large");
+    const int splits = pick_splits(d, M);
+    const size_t need = ds_conv_wgrad_workspace(d);
+    if (need > 0 && (ws == nullptr || ws_bytes < need)) {
+        ds::set_error("ds_conv_wgrad: workspace %zu bytes < required %zu", ws_bytes, need);
+        return DS_ERR_WORKSPACE;
+    }
+    WgradParams p;
+    p.d = *d;
+    p.x = x; p.dz = dz; p.lddz = lddz;
+    p.out = splits == 1 ? dw : (float *)ws;
+    p.M = (int)M;
+    p.ci_tiles = (d->Cin + TI - 1) / TI;
+    int pps = (int)((M + splits - 1) / splits);
+    p.pix_per_split = ((pps + TP - 1) / TP) * TP;
+    p.x_vec = (d->ldx % 4 == 0) && (d->Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    p.z_vec = (lddz % 4 == 0) && (d->Cout % 4 == 0) && (((uintptr_t)dz & 15) == 0);
+    dim3 grid(d->KH * d->KW * p.ci_tiles, (d->Cout + TJ - 1) / TJ, splits);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, s, p);
+    if (splits > 1) {
+        const int64_t n = (int64_t)d->KH * d->KW * d->Cin * d->Cout;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ds::stream_grid(n, 256)), dim3(256), 0, s,
+                           (const float *)ws, dw, n, splits);
+    }
+    return ds::check_launch("ds_conv_wgrad");
+}

@@ -1,0 +1,183 @@
+// Pooling kernels (HBM-bound, 16 B per lane, NHWC).
+//   max pool : slim.max_pool2d 3x3/2 SAME, 3x3/1 SAME, 2x2/2  image_model/inception_v1.py:67,79,94,118,208
+//              TF SAME geometry: pad_before = pad_total/2, padded cells never win (A1).
+//   MaxPoolGrad as a gather over the recorded arg-max (no atomics, deterministic).
+//   avg pool 7x7 VALID + dropout(keep 0.8)   image_model/inception_v1.py:299-301
+#include "ds_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float *x, float *y, uint8_t *am, int N, int H, int W,
+                                                          int C, int k, int stride, int pad_t, int pad_l, int OH,
+                                                          int OW) {
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)N * OH * OW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        int64_t p = i / C4;
+        const int ow = (int)(p % OW);
+        p /= OW;
+        const int oh = (int)(p % OH);
+        const int n = (int)(p / OH);
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int arg[4] = {0, 0, 0, 0};
+        bool any = false;
+        for (int kh = 0; kh < k; ++kh) {
+            const int ih = oh * stride - pad_t + kh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int kw = 0; kw < k; ++kw) {
+                const int iw = ow * stride - pad_l + kw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const float4 v = *reinterpret_cast<const float4 *>(x + (((int64_t)n * H + ih) * W + iw) * C + c);
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                const int t = kh * k + kw;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (!any || vv[j] > best[j]) {      // strict '>' keeps the first maximum (row-major)
+                        best[j] = vv[j];
+                        arg[j] = t;
+                    }
+                any = true;
+            }
+        }
+        const int64_t o = (((int64_t)n * OH + oh) * OW + ow) * C + c;
+        *reinterpret_cast<float4 *>(y + o) = make_float4(best[0], best[1], best[2], best[3]);
+        if (am) *reinterpret_cast<uchar4 *>(am + o) = make_uchar4(arg[0], arg[1], arg[2], arg[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *dy, const uint8_t *am, float *dx,
+                                                          int accumulate, int N, int H, int W, int C, int k,
+                                                          int stride, int pad_t, int pad_l, int OH, int OW) {
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)N * H * W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        int64_t p = i / C4;
+        const int iw = (int)(p % W);
+        p /= W;
+        const int ih = (int)(p % H);
+        const int n = (int)(p / H);
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        // windows (oh, ow) that contain (ih, iw): kh = ih + pad_t - oh*stride in [0, k)
+        for (int kh = 0; kh < k; ++kh) {
+            const int t_h = ih + pad_t - kh;
+            if (t_h < 0 || t_h % stride) continue;
+            const int oh = t_h / stride;
+            if (oh >= OH) continue;
+            for (int kw = 0; kw < k; ++kw) {
+                const int t_w = iw + pad_l - kw;
+                if (t_w < 0 || t_w % stride) continue;
+                const int ow = t_w / stride;
+                if (ow >= OW) continue;
+                const int64_t o = (((int64_t)n * OH + oh) * OW + ow) * C + c;
+                const uchar4 a = *reinterpret_cast<const uchar4 *>(am + o);
+                const float4 d = *reinterpret_cast<const float4 *>(dy + o);
+                const int t = kh * k + kw;
+                if (a.x == t) g[0] += d.x;
+                if (a.y == t) g[1] += d.y;
+                if (a.z == t) g[2] += d.z;
+                if (a.w == t) g[3] += d.w;
+            }
+        }
+        float4 *q = reinterpret_cast<float4 *>(dx + (((int64_t)n * H + ih) * W + iw) * C + c);
+        float4 out = make_float4(g[0], g[1], g[2], g[3]);
+        if (accumulate) {
+            const float4 e = *q;
+            out.x += e.x; out.y += e.y; out.z += e.z; out.w += e.w;
+        }
+        *q = out;
+    }
+}
+
+// counter-based uniform in [0,1): splitmix64 finaliser over (seed, element index)
+__device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(256) void avgpool_dropout_fwd_kernel(const float *x, int N, int HW, int C, float keep,
+                                                                  uint64_t seed, const float *mask_in,
+                                                                  float *mask_out, float *out) {
+    const int n = blockIdx.x;
+    const float inv = 1.f / (float)HW;
+    for (int c = threadIdx.x * 4; c < C; c += 256 * 4) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        const float *px = x + (int64_t)n * HW * C + c;
+        for (int p = 0; p < HW; ++p) {
+            const float4 v = *reinterpret_cast<const float4 *>(px + (int64_t)p * C);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        }
+        float m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t e = (int64_t)n * C + c + j;
+            if (keep >= 1.f) m[j] = 1.f;
+            else if (mask_in) m[j] = mask_in[e];
+            else m[j] = hash_uniform(seed, (uint64_t)e) < keep ? 1.f : 0.f;
+            s[j] = s[j] * inv * (keep >= 1.f ? 1.f : m[j] / keep);
+        }
+        *reinterpret_cast<float4 *>(out + (int64_t)n * C + c) = make_float4(s[0], s[1], s[2], s[3]);
+        if (mask_out) *reinterpret_cast<float4 *>(mask_out + (int64_t)n * C + c) = make_float4(m[0], m[1], m[2], m[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_dropout_bwd_kernel(const float *dout, const float *mask, int N, int HW,
+                                                                  int C, float scale, float *dx) {
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)N * HW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        const int n = (int)(i / ((int64_t)HW * C4));
+        float4 d = *reinterpret_cast<const float4 *>(dout + (int64_t)n * C + c);
+        if (mask) {
+            const float4 m = *reinterpret_cast<const float4 *>(mask + (int64_t)n * C + c);
+            d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w;
+        }
+        d.x *= scale; d.y *= scale; d.z *= scale; d.w *= scale;
+        *reinterpret_cast<float4 *>(dx + i * 4) = d;
+    }
+}
+
+}  // namespace
+
+extern "C" int ds_maxpool_fwd(const float *x, float *y, uint8_t *argmax, int32_t N, int32_t H, int32_t W, int32_t C,
+                              int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW,
+                              void *stream) {
+    DS_REQUIRE(x && y && C % 4 == 0 && k >= 1 && k <= 15 && stride >= 1, "ds_maxpool_fwd: bad argument (C %% 4?)");
+    const int64_t total = (int64_t)N * OH * OW * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ds::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       argmax, N, H, W, C, k, stride, pad_t, pad_l, OH, OW);
+    return ds::check_launch("ds_maxpool_fwd");
+}
+
+extern "C" int ds_maxpool_bwd(const float *dy, const uint8_t *argmax, float *dx, int32_t accumulate, int32_t N,
+                              int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
+                              int32_t OH, int32_t OW, void *stream) {
+    DS_REQUIRE(dy && argmax && dx && C % 4 == 0, "ds_maxpool_bwd: bad argument");
+    const int64_t total = (int64_t)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ds::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dy,
+                       argmax, dx, accumulate, N, H, W, C, k, stride, pad_t, pad_l, OH, OW);
+    return ds::check_launch("ds_maxpool_bwd");
+}
+
+extern "C" int ds_avgpool_dropout_fwd(const float *x, int32_t N, int32_t HW, int32_t C, float keep, uint64_t seed,
+                                      const float *mask_in, float *mask_out, float *out, void *stream) {
+    DS_REQUIRE(x && out && C % 4 == 0 && N > 0 && HW > 0 && keep > 0.f, "ds_avgpool_dropout_fwd: bad argument");
+    hipLaunchKernelGGL(avgpool_dropout_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, N, HW, C, keep, seed,
+                       mask_in, mask_out, out);
+    return ds::check_launch("ds_avgpool_dropout_fwd");
+}
+
+extern "C" int ds_avgpool_dropout_bwd(const float *dout, const float *mask, int32_t N, int32_t HW, int32_t C,
+                                      float keep, float *dx, void *stream) {
+    DS_REQUIRE(dout && dx && C % 4 == 0 && keep > 0.f, "ds_avgpool_dropout_bwd: bad argument");
+    const float scale = (keep >= 1.f ? 1.f : 1.f / keep) / (float)HW;
+    const int64_t total = (int64_t)N * HW * (C / 4);
+    hipLaunchKernelGGL(avgpool_dropout_bwd_kernel, dim3(ds::stream_grid(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, dout, keep >= 1.f ? nullptr : mask, N, HW, C, scale, dx);
+    return ds::check_launch("ds_avgpool_dropout_bwd");
+}

@@ -1,0 +1,314 @@
+// Text-tower, loss, optimiser and small plumbing kernels.  All HBM / latency bound.
+//   embedding gather  tf.nn.embedding_lookup            image_text_model/im_text_rnn_model.py:85
+//   LSTM cell         BasicLSTMCell + dynamic_rnn mask  im_text_rnn_model.py:89-90 (A7/A8)
+//   softmax CE        slim.losses.softmax_cross_entropy im_text_rnn_model.py:124-125 (A9)
+//   Adam              tf.train.AdamOptimizer            im_text_rnn_model.py:134-135 (A10)
+#include "ds_common.h"
+
+namespace {
+
+// ---- embedding gather: one float-vector per lane, rows written in the LSTM's time-major order ----
+template <int VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *table, const int64_t *ids, float *out, int B,
+                                                          int T, int D, int64_t rows, int time_major) {
+    const int DV = D / VEC;
+    const int64_t total = (int64_t)B * T * DV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int dv = (int)(i % DV);
+        const int64_t r = i / DV;            // r = b*T + t  (ids are batch-major)
+        const int b = (int)(r / T), t = (int)(r - (int64_t)b * T);
+        const int64_t id = ids[r];
+        const int64_t orow = time_major ? (int64_t)t * B + b : r;
+        const bool ok = id >= 0 && id < rows;
+        if (VEC == 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) v = *reinterpret_cast<const float4 *>(table + id * D + dv * 4);
+            *reinterpret_cast<float4 *>(out + orow * D + dv * 4) = v;
+        } else if (VEC == 2) {
+            float2 v = make_float2(0.f, 0.f);
+            if (ok) v = *reinterpret_cast<const float2 *>(table + id * D + dv * 2);
+            *reinterpret_cast<float2 *>(out + orow * D + dv * 2) = v;
+        } else {
+            out[orow * D + dv] = ok ? table[id * D + dv] : 0.f;
+        }
+    }
+}
+
+// ---- LSTM cell -----------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float *gates, const float *c_prev, const float *h_prev,
+                                                            const int64_t *seq_len, int t, int B, int H,
+                                                            float forget_bias, float *c_out, float *h_out) {
+    const int64_t total = (int64_t)B * H;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / H), h = (int)(i - (int64_t)b * H);
+        float *g = gates + (int64_t)b * 4 * H + h;
+        const float si = sigmoidf_(g[0]);
+        const float tj = tanhf(g[H]);
+        const float sf = sigmoidf_(g[2 * H] + forget_bias);
+        const float so = sigmoidf_(g[3 * H]);
+        const float cp = c_prev[i], hp = h_prev[i];
+        const float cn = cp * sf + si * tj;
+        const float hn = tanhf(cn) * so;
+        const bool live = (int64_t)t < seq_len[b];
+        g[0] = si;
+        g[H] = tj;
+        g[2 * H] = sf;
+        g[3 * H] = so;
+        c_out[i] = live ? cn : cp;      // dynamic_rnn copies the state through past seq_len
+        h_out[i] = live ? hn : hp;
+    }
+}
+
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float *acts, const float *c_t, const float *c_prev,
+                                                            const float *dh, const float *dc, const int64_t *seq_len,
+                                                            int t, int B, int H, float *dgates, float *dc_prev,
+                                                            float *dh_carry) {
+    const int64_t total = (int64_t)B * H;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / H), h = (int)(i - (int64_t)b * H);
+        const float *a = acts + (int64_t)b * 4 * H + h;
+        float *dg = dgates + (int64_t)b * 4 * H + h;
+        const bool live = (int64_t)t < seq_len[b];
+        const float dhv = dh[i], dcv = dc[i];
+        if (live) {
+            const float si = a[0], tj = a[H], sf = a[2 * H], so = a[3 * H];
+            const float tc = tanhf(c_t[i]);
+            const float dct = dcv + dhv * so * (1.f - tc * tc);
+            dg[0] = dct * tj * si * (1.f - si);
+            dg[H] = dct * si * (1.f - tj * tj);
+            dg[2 * H] = dct * c_prev[i] * sf * (1.f - sf);
+            dg[3 * H] = dhv * tc * so * (1.f - so);
+            dc_prev[i] = dct * sf;
+            dh_carry[i] = 0.f;
+        } else {
+            dg[0] = 0.f;
+            dg[H] = 0.f;
+            dg[2 * H] = 0.f;
+            dg[3 * H] = 0.f;
+            dc_prev[i] = dcv;
+            dh_carry[i] = dhv;
+        }
+    }
+}
+
+// ---- softmax cross entropy (+ gradient), one workgroup, fixed summation order -----------------------
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float *logits, const int64_t *labels, int B, int C,
+                                                         float grad_scale, const float *grad_scale_dev,
+                                                         float *loss, float *dlogits) {
+    __shared__ float red[256];
+    if (grad_scale_dev) grad_scale *= grad_scale_dev[0];   // upstream d(loss) handed over on device
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float *z = logits + (int64_t)b * C;
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, z[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(z[c] - m);
+        const int y = (int)labels[b];
+        acc += (m + logf(s)) - z[y];
+        if (dlogits) {
+            const float k = grad_scale / (float)B, inv = 1.f / s;
+            for (int c = 0; c < C; ++c)
+                dlogits[(int64_t)b * C + c] = (expf(z[c] - m) * inv - (c == y ? 1.f : 0.f)) * k;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss) loss[0] = red[0] / (float)B;
+}
+
+// ---- TF Adam over a flat buffer ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_tf_kernel(float *theta, const float *g, float *m, float *v, int64_t n,
+                                                      int64_t n_wd, float wd, float grad_scale, float lr_t, float b1,
+                                                      float b2, float eps) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float w = theta[i];
+        float gi = g[i] * grad_scale;
+        if (i < n_wd) gi += wd * w;                       // d/dw of wd * sum(w^2)/2
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        theta[i] = w - lr_t * mi / (sqrtf(vi) + eps);     // epsilon outside the bias correction (A10)
+    }
+}
+
+// ---- reductions / plumbing ---------------------------------------------------------------------------
+constexpr int kSumsqBlocks = 256;
+
+__global__ __launch_bounds__(256) void sumsq_stage1(const float *x, int64_t n, float *partials) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += x[i] * x[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void sum_stage2(const float *partials, int n, float *out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += (double)partials[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)red[0];
+}
+
+// column sums of x[M, C] (BiasAddGrad): grid (C/64, RS); thread = (column, one of 4 row lanes)
+__global__ __launch_bounds__(256) void colsum_stage1(const float *x, int64_t M, int C, int ld, int rows_per_split,
+                                                     float *partials) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
+    int64_t r1 = r0 + rows_per_split;
+    if (r1 > M) r1 = M;
+    float acc = 0.f;
+    if (c < C)
+        for (int64_t r = r0 + rl; r < r1; r += 4) acc += x[r * ld + c];
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) partials[(int64_t)blockIdx.y * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+
+__global__ __launch_bounds__(256) void colsum_stage2(const float *partials, int RS, int C, float *out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double acc = 0.0;
+    for (int s = 0; s < RS; ++s) acc += (double)partials[(int64_t)s * C + c];
+    out[c] = (float)acc;
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(const float *src, int lds, float *dst, int ldd, int64_t rows,
+                                                     int cols) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        dst[r * ldd + c] = src[r * lds + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void pad_channels_kernel(const float *src, int cs, float *dst, int cd,
+                                                           int64_t pixels) {
+    const int64_t total = pixels * cd;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i / cd;
+        const int c = (int)(i - p * cd);
+        dst[i] = c < cs ? src[p * cs + c] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float *dst, int64_t n, float value) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = value;
+}
+
+}  // namespace
+
+extern "C" int ds_gather_rows(const float *table, const int64_t *ids, float *out, int32_t B, int32_t T, int32_t D,
+                              int64_t table_rows, int32_t time_major, void *stream) {
+    DS_REQUIRE(table && ids && out && B > 0 && T > 0 && D > 0 && table_rows > 0, "ds_gather_rows: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const bool a16 = (((uintptr_t)table | (uintptr_t)out) & 15) == 0, a8 = (((uintptr_t)table | (uintptr_t)out) & 7) == 0;
+    if (D % 4 == 0 && a16) {
+        hipLaunchKernelGGL(gather_rows_kernel<4>, dim3(ds::stream_grid((int64_t)B * T * (D / 4), 256)), dim3(256), 0, s,
+                           table, ids, out, B, T, D, table_rows, time_major);
+    } else if (D % 2 == 0 && a8) {
+        hipLaunchKernelGGL(gather_rows_kernel<2>, dim3(ds::stream_grid((int64_t)B * T * (D / 2), 256)), dim3(256), 0, s,
+                           table, ids, out, B, T, D, table_rows, time_major);
+    } else {
+        hipLaunchKernelGGL(gather_rows_kernel<1>, dim3(ds::stream_grid((int64_t)B * T * D, 256)), dim3(256), 0, s, table,
+                           ids, out, B, T, D, table_rows, time_major);
+    }
+    return ds::check_launch("ds_gather_rows");
+}
+
+extern "C" int ds_lstm_cell_fwd(float *gates, const float *c_prev, const float *h_prev, const int64_t *seq_len,
+                                int32_t t, int32_t B, int32_t H, float forget_bias, float *c_out, float *h_out,
+                                void *stream) {
+    DS_REQUIRE(gates && c_prev && h_prev && seq_len && c_out && h_out && B > 0 && H > 0, "ds_lstm_cell_fwd: bad argument");
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ds::stream_grid((int64_t)B * H, 256)), dim3(256), 0,
+                       (hipStream_t)stream, gates, c_prev, h_prev, seq_len, t, B, H, forget_bias, c_out, h_out);
+    return ds::check_launch("ds_lstm_cell_fwd");
+}
+
+extern "C" int ds_lstm_cell_bwd(const float *acts, const float *c_t, const float *c_prev, const float *dh,
+                                const float *dc, const int64_t *seq_len, int32_t t, int32_t B, int32_t H,
+                                float *dgates, float *dc_prev, float *dh_carry, void *stream) {
+    DS_REQUIRE(acts && c_t && c_prev && dh && dc && seq_len && dgates && dc_prev && dh_carry,
+               "ds_lstm_cell_bwd: null argument");
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ds::stream_grid((int64_t)B * H, 256)), dim3(256), 0,
+                       (hipStream_t)stream, acts, c_t, c_prev, dh, dc, seq_len, t, B, H, dgates, dc_prev, dh_carry);
+    return ds::check_launch("ds_lstm_cell_bwd");
+}
+
+extern "C" int ds_softmax_ce(const float *logits, const int64_t *labels, int32_t B, int32_t C, float grad_scale,
+                             const float *grad_scale_dev, float *loss, float *dlogits, void *stream) {
+    DS_REQUIRE(logits && labels && B > 0 && C > 0, "ds_softmax_ce: bad argument");
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, B, C, grad_scale,
+                       grad_scale_dev, loss, dlogits);
+    return ds::check_launch("ds_softmax_ce");
+}
+
+extern "C" int ds_adam_tf(float *theta, const float *g, float *m, float *v, int64_t n, int64_t n_wd, float wd,
+                          float grad_scale, float lr_t, float beta1, float beta2, float eps, void *stream) {
+    DS_REQUIRE(theta && g && m && v && n > 0 && n_wd >= 0 && n_wd <= n, "ds_adam_tf: bad argument");
+    hipLaunchKernelGGL(adam_tf_kernel, dim3(ds::stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, theta, g, m, v,
+                       n, n_wd, wd, grad_scale, lr_t, beta1, beta2, eps);
+    return ds::check_launch("ds_adam_tf");
+}
+
+extern "C" int ds_sumsq(const float *x, int64_t n, float *scratch, float *out, void *stream) {
+    DS_REQUIRE(x && scratch && out && n > 0, "ds_sumsq: bad argument");
+    int blocks = ds::stream_grid(n, 256 * 8);
+    if (blocks > kSumsqBlocks) blocks = kSumsqBlocks;
+    hipLaunchKernelGGL(sumsq_stage1, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, scratch);
+    hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, blocks, out);
+    return ds::check_launch("ds_sumsq");
+}
+
+extern "C" int ds_colsum(const float *x, int64_t M, int32_t C, int32_t ld, float *scratch, float *out, void *stream) {
+    DS_REQUIRE(x && scratch && out && M > 0 && C > 0 && ld >= C, "ds_colsum: bad argument");
+    int RS = (int)((M + 63) / 64);
+    if (RS > 64) RS = 64;
+    const int rps = (int)((M + RS - 1) / RS);
+    hipLaunchKernelGGL(colsum_stage1, dim3((C + 63) / 64, RS), dim3(256), 0, (hipStream_t)stream, x, M, C, ld, rps,
+                       scratch);
+    hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, RS, C, out);
+    return ds::check_launch("ds_colsum");
+}
+
+extern "C" int ds_copy2d(const float *src, int32_t lds, float *dst, int32_t ldd, int64_t rows, int32_t cols,
+                         void *stream) {
+    DS_REQUIRE(src && dst && rows > 0 && cols > 0, "ds_copy2d: bad argument");
+    hipLaunchKernelGGL(copy2d_kernel, dim3(ds::stream_grid(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       lds, dst, ldd, rows, cols);
+    return ds::check_launch("ds_copy2d");
+}
+
+extern "C" int ds_pad_channels(const float *src, int32_t cs, float *dst, int32_t cd, int64_t pixels, void *stream) {
+    DS_REQUIRE(src && dst && cs > 0 && cd >= cs && pixels > 0, "ds_pad_channels: bad argument");
+    hipLaunchKernelGGL(pad_channels_kernel, dim3(ds::stream_grid(pixels * cd, 256)), dim3(256), 0, (hipStream_t)stream,
+                       src, cs, dst, cd, pixels);
+    return ds::check_launch("ds_pad_channels");
+}
+
+extern "C" int ds_fill(float *dst, int64_t n, float value, void *stream) {
+    DS_REQUIRE(dst && n > 0, "ds_fill: bad argument");
+    hipLaunchKernelGGL(fill_kernel, dim3(ds::stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, dst, n, value);
+    return ds::check_launch("ds_fill");
+}

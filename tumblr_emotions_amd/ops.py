@@ -1,0 +1,203 @@
+"""Thin, typed wrappers over the C ABI (include/ds_kernels.h) taking torch CUDA tensors.
+
+PyTorch is used for device memory and streams only; every FLOP on the path runs in
+libds_kernels.so.  All wrappers enqueue on the *current* torch stream (so they are captured by
+torch.cuda.graph) and never synchronise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, Segments, DS_EPI_ACCUM, DS_EPI_BIAS, DS_EPI_MASK, DS_EPI_RELU, DS_EPI_STATS  # noqa: F401
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    """Device pointer of a tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("tumblr_emotions_amd kernels need CUDA/HIP tensors; there is no CPU fallback")
+    return C.c_void_p(t.data_ptr())
+
+
+def same_pad(n, k, s):
+    """TF SAME geometry: out = ceil(n/s), extra padding goes bottom/right."""
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return out, total // 2
+
+
+def make_segments(entries):
+    """entries: list of (c_begin, c_end, tensor_view, ld) -> Segments struct."""
+    sg = Segments()
+    sg.nseg = len(entries)
+    for i, (c0, c1, ptr, ld) in enumerate(entries):
+        sg.c_begin[i], sg.c_end[i], sg.ld[i] = c0, c1, ld
+        sg.ptr[i] = ptr
+    return sg
+
+
+class ConvPlan:
+    """A ds_conv_desc plus its launch-derived constants, built once per layer."""
+
+    def __init__(self, N, H, W, Cin, ldx, KH, KW, stride, Cout, ldz, w_tap_stride, w_n_stride, w_k_stride,
+                 flip=0, fold_cin=0, flags=0, ldmask=0, pad_t=None, pad_l=None, OH=None, OW=None):
+        d = ConvDesc()
+        d.N, d.H, d.W, d.Cin, d.ldx = N, H, W, Cin, ldx
+        d.KH, d.KW, d.stride = KH, KW, stride
+        if OH is None:
+            OH, pt = same_pad(H, KH, stride)
+            OW, pl = same_pad(W, KW if not fold_cin else (Cin // fold_cin), stride)
+            pad_t = pt if pad_t is None else pad_t
+            pad_l = pl if pad_l is None else pad_l
+        d.pad_t, d.pad_l, d.OH, d.OW = pad_t, pad_l, OH, OW
+        d.Cout, d.ldz = Cout, ldz
+        d.w_tap_stride, d.w_n_stride, d.w_k_stride = w_tap_stride, w_n_stride, w_k_stride
+        d.flip, d.fold_cin, d.flags, d.ldmask = flip, fold_cin, flags, ldmask
+        self.d = d
+        self.M = N * OH * OW
+        self.partials = _lib.load().ds_conv_igemm_partials(C.byref(d)) if flags & DS_EPI_STATS else 0
+
+    def run(self, x, w, z, bias=None, mask=None, stats=None):
+        _lib.check(_lib.load().ds_conv_igemm(C.byref(self.d), x, w, z, bias, mask, stats, _stream()), "ds_conv_igemm")
+
+
+def gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=False, flags=0, ldmask=0):
+    """C[M,N] = A[M,K] * W (row-major W[K,N] with row stride w_ld), or * W^T when transposed_w
+    (then W is [N,K] row-major): both are read in place."""
+    if transposed_w:
+        return ConvPlan(M, 1, 1, K, lda, 1, 1, 1, N, ldc, 0, w_ld, 1, flags=flags, ldmask=ldmask,
+                        pad_t=0, pad_l=0, OH=1, OW=1)
+    return ConvPlan(M, 1, 1, K, lda, 1, 1, 1, N, ldc, 0, 1, w_ld, flags=flags, ldmask=ldmask,
+                    pad_t=0, pad_l=0, OH=1, OW=1)
+
+
+class WgradPlan:
+    """dw[tap, ci, co] = sum_m x[pixel(m)+tap, ci] * dz[m, co]; geometry given by a forward ConvPlan-like desc."""
+
+    def __init__(self, N, H, W, Cin, ldx, KH, KW, stride, Cout, lddz, pad_t=None, pad_l=None, OH=None, OW=None):
+        d = ConvDesc()
+        d.N, d.H, d.W, d.Cin, d.ldx = N, H, W, Cin, ldx
+        d.KH, d.KW, d.stride = KH, KW, stride
+        if OH is None:
+            OH, pad_t = same_pad(H, KH, stride)
+            OW, pad_l = same_pad(W, KW, stride)
+        d.pad_t, d.pad_l, d.OH, d.OW = pad_t, pad_l, OH, OW
+        d.Cout, d.ldz = Cout, Cout
+        self.d = d
+        self.lddz = lddz
+        self.ws_bytes = int(_lib.load().ds_conv_wgrad_workspace(C.byref(d)))
+
+    def run(self, x, dz, dw, ws, ws_bytes):
+        _lib.check(_lib.load().ds_conv_wgrad(C.byref(self.d), x, dz, self.lddz, dw, ws, ws_bytes, _stream()),
+                   "ds_conv_wgrad")
+
+
+def bn_finalize(stats, P, count, C_, beta, eps, decay, mean, rstd, shift, mm, mv):
+    _lib.check(_lib.load().ds_bn_finalize(_p(stats), P, count, C_, _p(beta), eps, decay, _p(mean), _p(rstd),
+                                          _p(shift), _p(mm), _p(mv), _stream()), "ds_bn_finalize")
+
+
+def bn_apply_relu(z, M, C_, rstd, shift, segs):
+    _lib.check(_lib.load().ds_bn_apply_relu(_p(z), M, C_, _p(rstd), _p(shift), C.byref(segs), _stream()),
+               "ds_bn_apply_relu")
+
+
+def bn_bwd_partials(M, C_):
+    return _lib.load().ds_bn_bwd_partials(M, C_)
+
+
+def bn_bwd_reduce(z, segs, M, C_, mean, rstd, shift, partials):
+    _lib.check(_lib.load().ds_bn_bwd_reduce(_p(z), C.byref(segs), M, C_, _p(mean), _p(rstd), _p(shift),
+                                            _p(partials), _stream()), "ds_bn_bwd_reduce")
+
+
+def bn_bwd_finalize(partials, P, M, C_, dbeta, coef):
+    _lib.check(_lib.load().ds_bn_bwd_finalize(_p(partials), P, M, C_, _p(dbeta), _p(coef), _stream()),
+               "ds_bn_bwd_finalize")
+
+
+def bn_bwd_apply(z, segs, M, C_, mean, rstd, shift, coef, dz):
+    _lib.check(_lib.load().ds_bn_bwd_apply(_p(z), C.byref(segs), M, C_, _p(mean), _p(rstd), _p(shift), _p(coef),
+                                           _p(dz), _stream()), "ds_bn_bwd_apply")
+
+
+def maxpool_fwd(x, y, argmax, N, H, W, C_, k, stride, mode="SAME"):
+    if mode == "SAME":
+        OH, pt = same_pad(H, k, stride)
+        OW, pl = same_pad(W, k, stride)
+    else:
+        OH, OW, pt, pl = (H - k) // stride + 1, (W - k) // stride + 1, 0, 0
+    _lib.check(_lib.load().ds_maxpool_fwd(_p(x), _p(y), _p(argmax), N, H, W, C_, k, stride, pt, pl, OH, OW,
+                                          _stream()), "ds_maxpool_fwd")
+    return OH, OW
+
+
+def maxpool_bwd(dy, argmax, dx, accumulate, N, H, W, C_, k, stride, mode="SAME"):
+    if mode == "SAME":
+        OH, pt = same_pad(H, k, stride)
+        OW, pl = same_pad(W, k, stride)
+    else:
+        OH, OW, pt, pl = (H - k) // stride + 1, (W - k) // stride + 1, 0, 0
+    _lib.check(_lib.load().ds_maxpool_bwd(_p(dy), _p(argmax), _p(dx), int(accumulate), N, H, W, C_, k, stride, pt,
+                                          pl, OH, OW, _stream()), "ds_maxpool_bwd")
+
+
+def avgpool_dropout_fwd(x, N, HW, C_, keep, seed, mask_in, mask_out, out):
+    _lib.check(_lib.load().ds_avgpool_dropout_fwd(_p(x), N, HW, C_, keep, seed, _p(mask_in), _p(mask_out), _p(out),
+                                                  _stream()), "ds_avgpool_dropout_fwd")
+
+
+def avgpool_dropout_bwd(dout, mask, N, HW, C_, keep, dx):
+    _lib.check(_lib.load().ds_avgpool_dropout_bwd(_p(dout), _p(mask), N, HW, C_, keep, _p(dx), _stream()),
+               "ds_avgpool_dropout_bwd")
+
+
+def gather_rows(table, ids, out, B, T, D, time_major=True):
+    _lib.check(_lib.load().ds_gather_rows(_p(table), _p(ids), _p(out), B, T, D, table.shape[0], int(time_major),
+                                          _stream()), "ds_gather_rows")
+
+
+def lstm_cell_fwd(gates, c_prev, h_prev, seq_len, t, B, H, forget_bias, c_out, h_out):
+    _lib.check(_lib.load().ds_lstm_cell_fwd(_p(gates), _p(c_prev), _p(h_prev), _p(seq_len), t, B, H, forget_bias,
+                                            _p(c_out), _p(h_out), _stream()), "ds_lstm_cell_fwd")
+
+
+def lstm_cell_bwd(acts, c_t, c_prev, dh, dc, seq_len, t, B, H, dgates, dc_prev, dh_carry):
+    _lib.check(_lib.load().ds_lstm_cell_bwd(_p(acts), _p(c_t), _p(c_prev), _p(dh), _p(dc), _p(seq_len), t, B, H,
+                                            _p(dgates), _p(dc_prev), _p(dh_carry), _stream()), "ds_lstm_cell_bwd")
+
+
+def softmax_ce(logits, labels, B, C_, grad_scale, grad_scale_dev, loss, dlogits):
+    _lib.check(_lib.load().ds_softmax_ce(_p(logits), _p(labels), B, C_, grad_scale, _p(grad_scale_dev), _p(loss),
+                                         _p(dlogits), _stream()), "ds_softmax_ce")
+
+
+def adam_tf(theta, g, m, v, n, n_wd, wd, grad_scale, lr_t, b1, b2, eps):
+    _lib.check(_lib.load().ds_adam_tf(_p(theta), _p(g), _p(m), _p(v), n, n_wd, wd, grad_scale, lr_t, b1, b2, eps,
+                                      _stream()), "ds_adam_tf")
+
+
+def sumsq(x, n, scratch, out):
+    _lib.check(_lib.load().ds_sumsq(_p(x), n, _p(scratch), _p(out), _stream()), "ds_sumsq")
+
+
+def colsum(x, M, C_, ld, scratch, out):
+    _lib.check(_lib.load().ds_colsum(_p(x), M, C_, ld, _p(scratch), _p(out), _stream()), "ds_colsum")
+
+
+def copy2d(src, lds, dst, ldd, rows, cols):
+    _lib.check(_lib.load().ds_copy2d(_p(src), lds, _p(dst), ldd, rows, cols, _stream()), "ds_copy2d")
+
+
+def pad_channels(src, cs, dst, cd, pixels):
+    _lib.check(_lib.load().ds_pad_channels(_p(src), cs, _p(dst), cd, pixels, _stream()), "ds_pad_channels")
+
+
+def fill(dst, n, value):
+    _lib.check(_lib.load().ds_fill(_p(dst), n, value, _stream()), "ds_fill")
