@@ -1,0 +1,150 @@
+#!/usr/bin/env python
+"""Headline benchmark: Deep Sentiment training samples/s (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = forward + backward + (RCCL gradient all-reduce) + TF-Adam of train_deep_sentiment on a
+synthetic batch resident in HBM: 224x224x3 images + 32-token posts, Inception-v1 + 300-d embedding +
+LSTM-512, batch 256 per GPU (BASELINE cfg3; weak scaling under data parallelism), fp32 arithmetic
+(the precision the 1e-3 parity gate is stated in), dropout and BatchNorm in train mode, reference
+freeze (conv weights below Mixed_5c frozen, every BatchNorm beta trainable).
+
+Prints ONE JSON line (rank 0) carrying `roofline` for the dominant kernel (the implicit-GEMM fp32
+MFMA conv/GEMM kernel, timed live with HIP events around every launch on its stream) and
+`cpu_baseline` (the PyTorch-CPU oracle timed on this box's host cores on a bounded sample; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_SAMPLE = 6.169          # fwd+bwd, reference-faithful freeze (BASELINE.md section 2 / SURVEY 8d)
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(batch, steps, post_size, vocab, dim, rnn):
+    """The oracle ("port" of the reference's TF-CPU step) on the host cores, bounded sample."""
+    import numpy as np
+    import torch
+    from oracle import tf_semantics as S
+    from oracle import torch_ref as R
+    rng = np.random.RandomState(1)
+    params = R.make_params("joint", rng, num_classes=15, im_features_size=256, embed_dim=dim, rnn_size=rnn, fc_size=512)
+    emb = S.synthetic_embedding(vocab, dim)
+    b = S.synthetic_batch(batch, post_size, vocab, seed=0)
+    ref = R.DeepSentimentRef(params, emb, "joint", torch.float32)
+    mask = (rng.uniform(size=(batch, 1024)) < 0.8).astype(np.float32)
+    ref.train_step(b, 1e-3, torch.tensor(mask))            # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        ref.train_step(b, 1e-3, torch.tensor(mask))
+    dt = time.time() - t0
+    return dict(value=round(batch * steps / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample="joint train step (fwd+bwd+Adam), batch %d, %d timed steps after 1 warm-up, fp32, "
+                       "PyTorch-CPU restatement of the TF1 step (TensorFlow 1.x not installable here); host has %d "
+                       "logical CPUs" % (batch, steps, os.cpu_count()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--mode", default="joint", choices=["joint", "image", "text"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-conv-timing", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tumblr_emotions_amd import ops
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    T, V, D, H = 32, 10000, 300, 512
+    net = SentimentNet(mode=args.mode, nb_emotions=15, im_features_size=256, rnn_size=H, fc_size=512, vocab_size=V,
+                       embedding_dim=D, post_size=T, dropout_keep_prob=0.8)
+    net.initialize(seed=1)
+    gb = args.batch * world
+    batch = to_device(synthetic_batch_numpy(gb, T, V, 15, seed=0, with_images=args.mode != "text"), "cuda", rank, world)
+    lr = 1e-3
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        net.train_step(batch, lr)
+    timer = None
+    if not args.no_conv_timing:
+        timer = ops.ConvTimer()
+        ops.CONV_TIMER = timer
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net.train_step(batch, lr)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.CONV_TIMER = None
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss = net.total_loss_value()
+
+    if rank == 0:
+        value = gb * args.steps / dt
+        flop_per_sample = {"joint": GFLOP_PER_SAMPLE, "image": 5.885, "text": 0.280}[args.mode]
+        roof = None
+        if timer is not None:
+            n, ms, flops = timer.summary()
+            ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            roof = dict(bound="mfma", kernel="conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32; conv fwd, dgrad, GEMMs)",
+                        achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        launches_per_step=n // max(args.steps, 1), avg_launch_us=round(1e3 * ms / max(n, 1), 2),
+                        kernel_time_share=round(ms * 1e-3 / dt, 3),
+                        whole_step_tflops=round(value * flop_per_sample / 1e3, 2),
+                        whole_step_frac=round(value * flop_per_sample / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4))
+        out = {
+            "metric": "training samples/sec (224x224 img + 32-tok text, batch 256)",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s train step (fwd+bwd+all-reduce+Adam): Inception-v1 224x224x3 + 300-d embedding + "
+                                   "LSTM-512, T=32, V=10000, 15 classes, batch %d per GPU, reference freeze "
+                                   "(<=Mixed_5b conv weights frozen, all BN betas trainable), dropout 0.8, BN train mode"
+                                   % (args.mode, args.batch),
+                       "global_batch": gb, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
+                       "gflop_per_sample": flop_per_sample, "final_loss": round(loss, 5)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline and args.mode == "joint":
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps, T, V, D, H)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

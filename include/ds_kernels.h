@@ -119,9 +119,11 @@ int ds_maxpool_bwd(const float *dy, const uint8_t *argmax, float *dx, int32_t ac
 
 /* slim.avg_pool2d 7x7 VALID + slim.dropout (inception_v1.py:299-301).  mask_in==NULL: draw
  * Bernoulli(keep) from a counter-based generator keyed by (seed, element); the mask used is
- * written to mask_out (needed by the backward).  keep>=1 disables dropout.                 */
+ * written to mask_out (needed by the backward).  keep>=1 disables dropout.  seed_dev (nullable)
+ * is a device counter added to `seed`, so a captured hipGraph draws a fresh mask per replay.  */
 int ds_avgpool_dropout_fwd(const float *x, int32_t N, int32_t HW, int32_t C, float keep, uint64_t seed,
-                           const float *mask_in, float *mask_out, float *out, void *stream);
+                           const uint64_t *seed_dev, const float *mask_in, float *mask_out, float *out,
+                           void *stream);
 int ds_avgpool_dropout_bwd(const float *dout, const float *mask, int32_t N, int32_t HW, int32_t C,
                            float keep, float *dx, void *stream);
 
@@ -153,9 +155,11 @@ int ds_softmax_ce(const float *logits, const int64_t *labels, int32_t B, int32_t
 /* tf.train.AdamOptimizer.apply_gradients over one flat parameter buffer
  * (im_text_rnn_model.py:134-135).  g_eff = g*grad_scale + (i < n_wd ? wd*theta : 0): the first
  * n_wd entries are the slim conv `weights` that carry the L2 regulariser
- * (slim/nets/inception_utils.py:63-64).  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the host. */
+ * (slim/nets/inception_utils.py:63-64).  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the host;
+ * lr_t_dev (nullable) overrides it from device memory (hipGraph replay). */
 int ds_adam_tf(float *theta, const float *g, float *m, float *v, int64_t n, int64_t n_wd, float wd,
-               float grad_scale, float lr_t, float beta1, float beta2, float eps, void *stream);
+               float grad_scale, float lr_t, const float *lr_t_dev, float beta1, float beta2, float eps,
+               void *stream);
 
 /* small helpers (deterministic two-stage reductions; scratch is caller-provided) */
 /* out[0] = sum x^2 (= 2*tf.nn.l2_loss); scratch >= 256 floats                                */

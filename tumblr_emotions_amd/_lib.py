@@ -48,13 +48,13 @@ SIGNATURES = {
     "ds_bn_bwd_apply": (C.c_int, [_P, _SG, _i64, _i32, _P, _P, _P, _P, _P, _P]),
     "ds_maxpool_fwd": (C.c_int, [_P, _P, _P] + [_i32] * 10 + [_P]),
     "ds_maxpool_bwd": (C.c_int, [_P, _P, _P] + [_i32] * 11 + [_P]),
-    "ds_avgpool_dropout_fwd": (C.c_int, [_P, _i32, _i32, _i32, _f32, _u64, _P, _P, _P, _P]),
+    "ds_avgpool_dropout_fwd": (C.c_int, [_P, _i32, _i32, _i32, _f32, _u64, _P, _P, _P, _P, _P]),
     "ds_avgpool_dropout_bwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _f32, _P, _P]),
     "ds_gather_rows": (C.c_int, [_P, _P, _P, _i32, _i32, _i32, _i64, _i32, _P]),
     "ds_lstm_cell_fwd": (C.c_int, [_P, _P, _P, _P, _i32, _i32, _i32, _f32, _P, _P, _P]),
     "ds_lstm_cell_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _P, _P, _P, _P]),
     "ds_softmax_ce": (C.c_int, [_P, _P, _i32, _i32, _f32, _P, _P, _P, _P]),
-    "ds_adam_tf": (C.c_int, [_P, _P, _P, _P, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _P]),
+    "ds_adam_tf": (C.c_int, [_P, _P, _P, _P, _i64, _i64, _f32, _f32, _f32, _P, _f32, _f32, _f32, _P]),
     "ds_sumsq": (C.c_int, [_P, _i64, _P, _P, _P]),
     "ds_colsum": (C.c_int, [_P, _i64, _i32, _i32, _P, _P, _P]),
     "ds_copy2d": (C.c_int, [_P, _i32, _P, _i32, _i64, _i32, _P]),

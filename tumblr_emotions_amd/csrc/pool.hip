@@ -100,9 +100,10 @@ __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
 }
 
 __global__ __launch_bounds__(256) void avgpool_dropout_fwd_kernel(const float *x, int N, int HW, int C, float keep,
-                                                                  uint64_t seed, const float *mask_in,
-                                                                  float *mask_out, float *out) {
+                                                                  uint64_t seed, const uint64_t *seed_dev,
+                                                                  const float *mask_in, float *mask_out, float *out) {
     const int n = blockIdx.x;
+    if (seed_dev) seed += seed_dev[0];        // per-step seed kept on device (hipGraph replay safe)
     const float inv = 1.f / (float)HW;
     for (int c = threadIdx.x * 4; c < C; c += 256 * 4) {
         float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -165,10 +166,11 @@ extern "C" int ds_maxpool_bwd(const float *dy, const uint8_t *argmax, float *dx,
 }
 
 extern "C" int ds_avgpool_dropout_fwd(const float *x, int32_t N, int32_t HW, int32_t C, float keep, uint64_t seed,
-                                      const float *mask_in, float *mask_out, float *out, void *stream) {
+                                      const uint64_t *seed_dev, const float *mask_in, float *mask_out, float *out,
+                                      void *stream) {
     DS_REQUIRE(x && out && C % 4 == 0 && N > 0 && HW > 0 && keep > 0.f, "ds_avgpool_dropout_fwd: bad argument");
     hipLaunchKernelGGL(avgpool_dropout_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, N, HW, C, keep, seed,
-                       mask_in, mask_out, out);
+                       seed_dev, mask_in, mask_out, out);
     return ds::check_launch("ds_avgpool_dropout_fwd");
 }
 

@@ -125,8 +125,9 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float *logits, co
 
 // ---- TF Adam over a flat buffer ------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_tf_kernel(float *theta, const float *g, float *m, float *v, int64_t n,
-                                                      int64_t n_wd, float wd, float grad_scale, float lr_t, float b1,
-                                                      float b2, float eps) {
+                                                      int64_t n_wd, float wd, float grad_scale, float lr_t,
+                                                      const float *lr_t_dev, float b1, float b2, float eps) {
+    if (lr_t_dev) lr_t = lr_t_dev[0];         // step size kept on device (hipGraph replay safe)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float w = theta[i];
         float gi = g[i] * grad_scale;
@@ -265,10 +266,11 @@ extern "C" int ds_softmax_ce(const float *logits, const int64_t *labels, int32_t
 }
 
 extern "C" int ds_adam_tf(float *theta, const float *g, float *m, float *v, int64_t n, int64_t n_wd, float wd,
-                          float grad_scale, float lr_t, float beta1, float beta2, float eps, void *stream) {
+                          float grad_scale, float lr_t, const float *lr_t_dev, float beta1, float beta2, float eps,
+                          void *stream) {
     DS_REQUIRE(theta && g && m && v && n > 0 && n_wd >= 0 && n_wd <= n, "ds_adam_tf: bad argument");
     hipLaunchKernelGGL(adam_tf_kernel, dim3(ds::stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, theta, g, m, v,
-                       n, n_wd, wd, grad_scale, lr_t, beta1, beta2, eps);
+                       n, n_wd, wd, grad_scale, lr_t, lr_t_dev, beta1, beta2, eps);
     return ds::check_launch("ds_adam_tf");
 }
 

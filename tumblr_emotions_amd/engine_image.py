@@ -1,0 +1,405 @@
+"""Inception-v1 image tower: forward + backward orchestration of the HIP kernels.
+
+What is computed is fixed by the reference (image_model/inception_v1.py:29-309 under
+slim/nets/inception_utils.py:32-71); how is MI355X-first:
+
+  * NHWC activations; every conv is one implicit-GEMM MFMA launch reading the TF HWIO weights in
+    place; the three 1x1 convs that read a block's input run as ONE GEMM (N = b0+b1a+b2a);
+  * BatchNorm statistics come out of the conv epilogue; normalise+ReLU writes the branch outputs
+    straight into channel slices of the block's concat buffer (tf.concat never materialises);
+  * backward: BN/ReLU backward overwrites the saved pre-activation z with dz in place; dgrad is the
+    same MFMA kernel with flipped taps over the untouched HWIO weights; wgrad only for the
+    trainable scope (Mixed_5c :229-250 and Logits :302-303); BatchNorm beta gradients for all 57
+    layers;
+  * all buffers are allocated once per batch size; nothing is allocated or synchronised per step.
+"""
+import ctypes as C
+
+import torch
+
+from . import ops
+from .ops import ConvPlan, WgradPlan, gemm_plan, make_segments, same_pad, DS_EPI_BIAS, DS_EPI_STATS
+
+BN_EPS = 0.001         # slim/nets/inception_utils.py:35
+BN_DECAY = 0.9997      # slim/nets/inception_utils.py:34
+WEIGHT_DECAY = 0.00004  # slim/nets/inception_utils.py:32
+
+# Topology of image_model/inception_v1.py (endpoint names and channel counts, :62-250)
+TOPOLOGY = [
+    ("conv", "Conv2d_1a_7x7", 7, 2, 64),
+    ("maxpool", "MaxPool_2a_3x3", 3, 2),
+    ("conv", "Conv2d_2b_1x1", 1, 1, 64),
+    ("conv", "Conv2d_2c_3x3", 3, 1, 192),
+    ("maxpool", "MaxPool_3a_3x3", 3, 2),
+    ("mixed", "Mixed_3b", 64, (96, 128), (16, 32), 32),
+    ("mixed", "Mixed_3c", 128, (128, 192), (32, 96), 64),
+    ("maxpool", "MaxPool_4a_3x3", 3, 2),
+    ("mixed", "Mixed_4b", 192, (96, 208), (16, 48), 64),
+    ("mixed", "Mixed_4c", 160, (112, 224), (24, 64), 64),
+    ("mixed", "Mixed_4d", 128, (128, 256), (24, 64), 64),
+    ("mixed", "Mixed_4e", 112, (144, 288), (32, 64), 64),
+    ("mixed", "Mixed_4f", 256, (160, 320), (32, 128), 128),
+    ("maxpool", "MaxPool_5a_2x2", 2, 2),
+    ("mixed", "Mixed_5b", 256, (160, 320), (32, 128), 128),
+    ("mixed", "Mixed_5c", 384, (192, 384), (48, 128), 128),
+]
+ENDPOINTS = [t[1] for t in TOPOLOGY]
+TRAINABLE_ENDPOINTS = ("Mixed_5c",)      # inception_v1.py:229-231; earlier scopes are trainable=False (:57-59)
+
+
+def _vp(addr):
+    return C.c_void_p(addr)
+
+
+class ConvBN:
+    """slim.conv2d under inception_arg_scope: conv (no bias) -> BatchNorm(train, beta only) -> ReLU.
+    `scopes` lists (tf_scope, c0, c1): more than one entry = horizontally fused 1x1 convs."""
+
+    def __init__(self, eng, scopes, k, stride, cin, cout, H, W, trainable, beta_bucket, fold=False):
+        self.eng, self.scopes, self.k, self.stride = eng, scopes, k, stride
+        self.cin, self.cout, self.H, self.W = cin, cout, H, W
+        self.trainable, self.fold = trainable, fold
+        self.OH, _ = same_pad(H, k, stride)
+        self.OW, _ = same_pad(W, k, stride)
+        st = eng.store
+        self.key = scopes[0][0] if len(scopes) == 1 else scopes[0][0].rsplit("/", 2)[0] + "/fused_1x1"
+        cin_store = 4 if fold else cin            # stem: Cin 3 zero-padded to 4 (one float4 per tap)
+        cols = lambda suffix: [(s + suffix, c0, c1) for (s, c0, c1) in scopes]
+        st.declare(self.key + "/weights", (k, k, cin_store, cout), trainable, l2=trainable, bucket=1,
+                   columns=cols("/weights"))
+        st.declare(self.key + "/BatchNorm/beta", (cout,), eng.trainable_bn_beta, bucket=beta_bucket,
+                   columns=cols("/BatchNorm/beta"))
+        st.declare(self.key + "/BatchNorm/moving_mean", (cout,), False, columns=cols("/BatchNorm/moving_mean"))
+        st.declare(self.key + "/BatchNorm/moving_variance", (cout,), False,
+                   columns=cols("/BatchNorm/moving_variance"))
+
+    def alloc(self, B):
+        eng, dev = self.eng, self.eng.device
+        k, cin, cout = self.k, self.cin, self.cout
+        self.B = B
+        self.M = B * self.OH * self.OW
+        self.z = torch.empty(self.M, cout, device=dev)
+        self.mean = torch.empty(cout, device=dev)
+        self.rstd = torch.empty(cout, device=dev)
+        self.shift = torch.empty(cout, device=dev)
+        self.coef = torch.empty(2, cout, device=dev)
+        if self.fold:
+            # Conv2d_1a_7x7: KW folded into the channel axis (28 contiguous floats per kernel row)
+            self.fwd = ConvPlan(B, self.H, self.W, 7 * 4, 4, 7, 1, self.stride, cout, cout, 28 * cout, 1, cout,
+                                fold_cin=4, flags=DS_EPI_STATS)
+        else:
+            self.fwd = ConvPlan(B, self.H, self.W, cin, 0, k, k, self.stride, cout, cout, cin * cout, 1, cout,
+                                flags=DS_EPI_STATS)
+        eng.need_stats(self.fwd.partials * 2 * cout)
+        self.bwd_P = ops.bn_bwd_partials(self.M, cout)
+        eng.need_bwd_partials(self.bwd_P * 2 * cout)
+        self.dgrad = None
+        self.wgrad = None
+        if self.trainable:
+            self.wgrad = WgradPlan(B, self.H, self.W, cin, 0, k, k, self.stride, cout, cout)
+            eng.need_ws(self.wgrad.ws_bytes)
+
+    def bind(self):
+        st = self.eng.store
+        self.w_ptr = _vp(st.ptr(self.key + "/weights"))
+        self.beta = st.view(self.key + "/BatchNorm/beta")
+        self.mm = st.view(self.key + "/BatchNorm/moving_mean")
+        self.mv = st.view(self.key + "/BatchNorm/moving_variance")
+        self.gw_ptr = _vp(st.grad_ptr(self.key + "/weights")) if self.trainable else None
+        self.gbeta = st.grad_view(self.key + "/BatchNorm/beta") if self.eng.trainable_bn_beta else None
+
+    def make_dgrad(self, lddx):
+        """Conv2DBackpropInput as a forward conv over dz with flipped taps (stride-1 SAME convs only)."""
+        assert self.stride == 1
+        k, cin, cout = self.k, self.cin, self.cout
+        self.dgrad = ConvPlan(self.B, self.H, self.W, cout, cout, k, k, 1, cin, lddx, cin * cout, cout, 1, flip=1)
+
+    # x_ptr: input activations [B,H,W,ldx]; segs: where relu(bn(conv)) is scattered
+    def forward(self, x_ptr, ldx, segs):
+        eng = self.eng
+        if not self.fold:
+            self.fwd.d.ldx = ldx
+        self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z), stats=ops._p(eng.stats))
+        ops.bn_finalize(eng.stats, self.fwd.partials, self.M, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
+                        self.rstd, self.shift, self.mm if eng.update_moving else None,
+                        self.mv if eng.update_moving else None)
+        ops.bn_apply_relu(self.z, self.M, self.cout, self.rstd, self.shift, segs)
+
+    def backward(self, dy_segs, x_ptr=None, ldx=0, dx_ptr=None, need_dx=True):
+        eng = self.eng
+        M, Cc = self.M, self.cout
+        if self.gbeta is None and not need_dx and not self.trainable:
+            return
+        ops.bn_bwd_reduce(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, eng.bwd_partials)
+        ops.bn_bwd_finalize(eng.bwd_partials, self.bwd_P, M, Cc, self.gbeta if self.gbeta is not None else eng.dummy,
+                            self.coef)
+        if not (need_dx or self.trainable):
+            return
+        ops.bn_bwd_apply(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.coef, self.z)   # dz over z
+        if self.trainable:
+            self.wgrad.d.ldx = ldx
+            self.wgrad.run(x_ptr, ops._p(self.z), self.gw_ptr, ops._p(eng.ws), eng.ws_bytes)
+        if need_dx:
+            self.dgrad.run(ops._p(self.z), self.w_ptr, dx_ptr)
+
+
+class Stage:
+    """A node of the tower whose output is a dense NHWC tensor `out` with gradient buffer `dout`."""
+    name = ""
+    out = None
+    dout = None
+
+
+class InputStage(Stage):
+    def __init__(self, eng, size):
+        self.eng, self.H, self.W, self.C = eng, size, size, 4
+        self.name = "input"
+
+    def alloc(self, B):
+        self.out = torch.zeros(B, self.H, self.W, 4, device=self.eng.device)
+
+
+class ConvStage(Stage):
+    def __init__(self, eng, name, prev, k, stride, cout, trainable, beta_bucket):
+        self.eng, self.name, self.prev = eng, name, prev
+        fold = isinstance(prev, InputStage)
+        cin = 3 if fold else prev.C
+        self.layer = ConvBN(eng, [("InceptionV1/" + name, 0, cout)], k, stride, cin, cout, prev.H, prev.W, trainable,
+                            beta_bucket, fold=fold)
+        self.H, self.W, self.C = self.layer.OH, self.layer.OW, cout
+        self.layers = [self.layer]
+
+    def alloc(self, B):
+        dev = self.eng.device
+        self.layer.alloc(B)
+        self.out = torch.empty(B, self.H, self.W, self.C, device=dev)
+        self.dout = torch.empty_like(self.out)
+        self.segs = make_segments([(0, self.C, self.out.data_ptr(), self.C)])
+        self.dsegs = make_segments([(0, self.C, self.dout.data_ptr(), self.C)])
+        if not self.layer.fold:
+            self.layer.make_dgrad(self.prev.C)
+
+    def forward(self):
+        self.layer.forward(ops._p(self.prev.out), self.prev.C, self.segs)
+
+    def backward(self, need_dx):
+        need_dx = need_dx and not self.layer.fold
+        self.layer.backward(self.dsegs, ops._p(self.prev.out), self.prev.C,
+                            ops._p(self.prev.dout) if need_dx else None, need_dx)
+
+
+class PoolStage(Stage):
+    def __init__(self, eng, name, prev, k, stride):
+        self.eng, self.name, self.prev, self.k, self.stride = eng, name, prev, k, stride
+        self.H, _ = same_pad(prev.H, k, stride)
+        self.W, _ = same_pad(prev.W, k, stride)
+        self.C = prev.C
+        self.layers = []
+
+    def alloc(self, B):
+        dev = self.eng.device
+        self.B = B
+        self.out = torch.empty(B, self.H, self.W, self.C, device=dev)
+        self.dout = torch.empty_like(self.out)
+        self.argmax = torch.empty(B, self.H, self.W, self.C, dtype=torch.uint8, device=dev)
+
+    def forward(self):
+        p = self.prev
+        ops.maxpool_fwd(p.out, self.out, self.argmax, self.B, p.H, p.W, p.C, self.k, self.stride, "SAME")
+
+    def backward(self, need_dx):
+        if need_dx:
+            p = self.prev
+            ops.maxpool_bwd(self.dout, self.argmax, p.dout, False, self.B, p.H, p.W, p.C, self.k, self.stride, "SAME")
+
+
+class MixedStage(Stage):
+    """One Inception block (e.g. inception_v1.py:83-96): four branches concatenated on channels."""
+
+    def __init__(self, eng, name, prev, b0, b1, b2, b3, trainable, beta_bucket):
+        self.eng, self.name, self.prev = eng, name, prev
+        (b1a, b1b), (b2a, b2b) = b1, b2
+        self.b = (b0, b1a, b1b, b2a, b2b, b3)
+        self.H, self.W, self.C = prev.H, prev.W, b0 + b1b + b2b + b3
+        cin = prev.C
+        pre = "InceptionV1/%s/" % name
+        b2b_scope = "Conv2d_0a_3x3" if name == "Mixed_5b" else "Conv2d_0b_3x3"   # reference quirk, :221
+        nf = b0 + b1a + b2a
+        self.fused = ConvBN(eng, [(pre + "Branch_0/Conv2d_0a_1x1", 0, b0),
+                                  (pre + "Branch_1/Conv2d_0a_1x1", b0, b0 + b1a),
+                                  (pre + "Branch_2/Conv2d_0a_1x1", b0 + b1a, nf)],
+                            1, 1, cin, nf, self.H, self.W, trainable, beta_bucket)
+        self.c1 = ConvBN(eng, [(pre + "Branch_1/Conv2d_0b_3x3", 0, b1b)], 3, 1, b1a, b1b, self.H, self.W, trainable,
+                         beta_bucket)
+        self.c2 = ConvBN(eng, [(pre + "Branch_2/" + b2b_scope, 0, b2b)], 3, 1, b2a, b2b, self.H, self.W, trainable,
+                         beta_bucket)
+        self.c3 = ConvBN(eng, [(pre + "Branch_3/Conv2d_0b_1x1", 0, b3)], 1, 1, cin, b3, self.H, self.W, trainable,
+                         beta_bucket)
+        self.layers = [self.fused, self.c1, self.c2, self.c3]
+
+    def alloc(self, B):
+        dev = self.eng.device
+        b0, b1a, b1b, b2a, b2b, b3 = self.b
+        cin, Ct = self.prev.C, self.C
+        self.B = B
+        M = B * self.H * self.W
+        for l in self.layers:
+            l.alloc(B)
+        self.out = torch.empty(B, self.H, self.W, Ct, device=dev)
+        self.dout = torch.empty_like(self.out)
+        self.r1 = torch.empty(M, b1a, device=dev)
+        self.r2 = torch.empty(M, b2a, device=dev)
+        self.dr1 = torch.empty_like(self.r1)
+        self.dr2 = torch.empty_like(self.r2)
+        self.pooled = torch.empty(M, cin, device=dev)
+        self.dpooled = torch.empty_like(self.pooled)
+        self.argmax = torch.empty(M, cin, dtype=torch.uint8, device=dev)
+        o, do = self.out.data_ptr(), self.dout.data_ptr()
+        off1, off2, off3 = b0, b0 + b1b, b0 + b1b + b2b
+        nf = b0 + b1a + b2a
+        self.seg_f = make_segments([(0, b0, o, Ct), (b0, b0 + b1a, self.r1.data_ptr(), b1a),
+                                    (b0 + b1a, nf, self.r2.data_ptr(), b2a)])
+        self.seg_1 = make_segments([(0, b1b, o + 4 * off1, Ct)])
+        self.seg_2 = make_segments([(0, b2b, o + 4 * off2, Ct)])
+        self.seg_3 = make_segments([(0, b3, o + 4 * off3, Ct)])
+        self.dseg_f = make_segments([(0, b0, do, Ct), (b0, b0 + b1a, self.dr1.data_ptr(), b1a),
+                                     (b0 + b1a, nf, self.dr2.data_ptr(), b2a)])
+        self.dseg_1 = make_segments([(0, b1b, do + 4 * off1, Ct)])
+        self.dseg_2 = make_segments([(0, b2b, do + 4 * off2, Ct)])
+        self.dseg_3 = make_segments([(0, b3, do + 4 * off3, Ct)])
+        self.fused.make_dgrad(cin)
+        self.c1.make_dgrad(b1a)
+        self.c2.make_dgrad(b2a)
+        self.c3.make_dgrad(cin)
+
+    def forward(self):
+        p = self.prev
+        b0, b1a, b1b, b2a, b2b, b3 = self.b
+        x = ops._p(p.out)
+        self.fused.forward(x, p.C, self.seg_f)
+        self.c1.forward(ops._p(self.r1), b1a, self.seg_1)
+        self.c2.forward(ops._p(self.r2), b2a, self.seg_2)
+        ops.maxpool_fwd(p.out, self.pooled, self.argmax, self.B, p.H, p.W, p.C, 3, 1, "SAME")
+        self.c3.forward(ops._p(self.pooled), p.C, self.seg_3)
+
+    def backward(self, need_dx):
+        p = self.prev
+        b0, b1a, b1b, b2a, b2b, b3 = self.b
+        x = ops._p(p.out)
+        self.c3.backward(self.dseg_3, ops._p(self.pooled), p.C, ops._p(self.dpooled), need_dx)
+        self.c1.backward(self.dseg_1, ops._p(self.r1), b1a, ops._p(self.dr1), True)
+        self.c2.backward(self.dseg_2, ops._p(self.r2), b2a, ops._p(self.dr2), True)
+        self.fused.backward(self.dseg_f, x, p.C, ops._p(p.dout) if need_dx else None, need_dx)
+        if need_dx:      # AddN of the two paths into the block input: fused dgrad wrote, the pool path adds
+            ops.maxpool_bwd(self.dpooled, self.argmax, p.dout, True, self.B, p.H, p.W, p.C, 3, 1, "SAME")
+
+
+class InceptionV1Engine:
+    """inception_v1(images, final_endpoint='Mixed_5c', num_classes, is_training=True, dropout_keep_prob)
+    (image_model/inception_v1.py:254-309) as explicit forward()/backward() over HIP kernels."""
+
+    def __init__(self, store, num_classes, image_size=224, dropout_keep_prob=0.8, trainable_bn_beta=True,
+                 device="cuda"):
+        self.store, self.num_classes, self.keep = store, num_classes, dropout_keep_prob
+        self.trainable_bn_beta = trainable_bn_beta
+        self.device = torch.device(device)
+        self.update_moving = True
+        self._stats_n = self._bwdp_n = self._ws_bytes = 0
+        self.B = None
+        self.input = InputStage(self, image_size)
+        self.stages = []
+        prev = self.input
+        for item in TOPOLOGY:
+            kind, name = item[0], item[1]
+            tr = name in TRAINABLE_ENDPOINTS
+            bucket = 1 if tr else 2
+            if kind == "conv":
+                st = ConvStage(self, name, prev, item[2], item[3], item[4], tr, bucket)
+            elif kind == "maxpool":
+                st = PoolStage(self, name, prev, item[2], item[3])
+            else:
+                st = MixedStage(self, name, prev, item[2], item[3], item[4], item[5], tr, bucket)
+            self.stages.append(st)
+            prev = st
+        self.last = prev
+        assert self.last.H == 7 and self.last.W == 7, "AvgPool_0a_7x7 + SpatialSqueeze need a 7x7 map (224x224 input)"
+        self.feat = self.last.C
+        lg = "InceptionV1/Logits/Conv2d_0c_1x1"
+        store.declare(lg + "/weights", (1, 1, self.feat, num_classes), True, l2=True, bucket=1)
+        store.declare(lg + "/biases", (num_classes,), True, bucket=1)
+        self.lg = lg
+        # first stage (from the top) below which nothing is trainable -> backward can stop there
+        self.layers = [l for s in self.stages for l in s.layers]
+
+    # scratch sizing (called by layers during alloc)
+    def need_stats(self, n):
+        self._stats_n = max(self._stats_n, n)
+
+    def need_bwd_partials(self, n):
+        self._bwdp_n = max(self._bwdp_n, n)
+
+    def need_ws(self, nbytes):
+        self._ws_bytes = max(self._ws_bytes, nbytes)
+
+    def alloc(self, B):
+        if self.B == B:
+            return
+        dev = self.device
+        self.B = B
+        self.input.alloc(B)
+        for s in self.stages:
+            s.alloc(B)
+        nc, F = self.num_classes, self.feat
+        self.pooled = torch.empty(B, F, device=dev)
+        self.dpooled = torch.empty(B, F, device=dev)
+        self.mask = torch.ones(B, F, device=dev)
+        self.logits = torch.empty(B, nc, device=dev)
+        self.fc = gemm_plan(B, F, nc, F, nc, nc, flags=DS_EPI_BIAS)
+        self.fc_dgrad = gemm_plan(B, nc, F, nc, F, nc, transposed_w=True)
+        self.fc_wgrad = WgradPlan(B, 1, 1, F, F, 1, 1, 1, nc, nc, pad_t=0, pad_l=0, OH=1, OW=1)
+        self.need_ws(self.fc_wgrad.ws_bytes)
+        self.colsum_scratch = torch.empty(64 * max(nc, 4), device=dev)
+        self.stats = torch.empty(max(self._stats_n, 4), device=dev)
+        self.bwd_partials = torch.empty(max(self._bwdp_n, 4), device=dev)
+        self.ws = torch.empty(max(self._ws_bytes // 4, 4), device=dev)
+        self.ws_bytes = self._ws_bytes
+        self.dummy = torch.empty(1024, device=dev)
+        for l in self.layers:
+            l.bind()
+        st = self.store
+        self.w_fc = _vp(st.ptr(self.lg + "/weights"))
+        self.b_fc = _vp(st.ptr(self.lg + "/biases"))
+        self.gw_fc = _vp(st.grad_ptr(self.lg + "/weights"))
+        self.gb_fc = st.grad_view(self.lg + "/biases")
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, images, dropout_mask=None, seed=0):
+        """images: [B,224,224,3] fp32 NHWC in [-1,1] (preprocess_for_eval range).  Returns the
+        internal logits buffer [B,num_classes]."""
+        B = images.shape[0]
+        self.alloc(B)
+        ops.pad_channels(images, 3, self.input.out, 4, B * self.input.H * self.input.W)
+        for s in self.stages:
+            s.forward()
+        last = self.last
+        ops.avgpool_dropout_fwd(last.out, B, last.H * last.W, self.feat, self.keep, seed, dropout_mask, self.mask,
+                                self.pooled)
+        self.fc.run(ops._p(self.pooled), self.w_fc, ops._p(self.logits), bias=self.b_fc)
+        return self.logits
+
+    def backward(self, dlogits):
+        """dlogits [B,num_classes] -> gradients of every trainable image-tower variable in store.grad."""
+        B, nc, F = self.B, self.num_classes, self.feat
+        last = self.last
+        dl = ops._p(dlogits)
+        self.fc_wgrad.run(ops._p(self.pooled), dl, self.gw_fc, ops._p(self.ws), self.ws_bytes)
+        ops.colsum(dlogits, B, nc, nc, self.colsum_scratch, self.gb_fc)
+        self.fc_dgrad.run(dl, self.w_fc, ops._p(self.dpooled))
+        ops.avgpool_dropout_bwd(self.dpooled, self.mask, B, last.H * last.W, F, self.keep, last.dout)
+        n = len(self.stages)
+        # below the last trainable stage only BatchNorm betas still need gradients
+        stop = 0
+        if not self.trainable_bn_beta:
+            stop = min(i for i, s in enumerate(self.stages) if any(l.trainable for l in s.layers))
+        for i in range(n - 1, stop - 1, -1):
+            self.stages[i].backward(need_dx=(i > stop))

@@ -1,0 +1,203 @@
+"""SentimentNet: parameters + engines + one training step, shared by the three reference-shaped
+front ends (image_model/im_model.py, text_model/text_embedding.py,
+image_text_model/im_text_rnn_model.py in this package).
+
+One step = what `slim.learning.train_step` runs for the reference's train_op
+(im_text_rnn_model.py:124-135,152): forward, total loss (CE + L2 of every conv `weights`),
+gradients of every trainable variable, BatchNorm moving-average updates, TF Adam.
+Data-parallel: gradients are summed over ranks with RCCL all-reduce on two contiguous
+buckets of the flat gradient buffer and scaled by 1/world inside the Adam kernel; the L2 term is
+applied once, locally, after the reduction (slim/deployment/model_deploy.py:221-223,301-302).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .engine_image import InceptionV1Engine, WEIGHT_DECAY
+from .engine_text import JointHeadEngine, TextHeadEngine, TextTowerEngine
+from .functions import (InceptionV1Function, JointHeadFunction, SoftmaxCrossEntropyFunction, TextHeadFunction,
+                        TextTowerFunction)
+from .params import ParamStore
+
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-8      # tf.train.AdamOptimizer defaults (:134)
+
+
+class SentimentNet:
+    def __init__(self, mode="joint", nb_emotions=15, im_features_size=256, rnn_size=512, fc_size=512,
+                 vocab_size=10000, embedding_dim=300, post_size=32, image_size=224, dropout_keep_prob=0.8,
+                 trainable_bn_beta=True, device="cuda", process_group=None, overlap_comm=True):
+        assert mode in ("joint", "image", "text")
+        if not torch.cuda.is_available():
+            raise RuntimeError("tumblr_emotions_amd needs an MI355X (HIP) device: the training path has no CPU fallback")
+        self.mode, self.nb_emotions, self.device = mode, nb_emotions, torch.device(device)
+        self.store = ParamStore(device)
+        self.image = self.text = self.head = None
+        if mode in ("joint", "image"):
+            nc = im_features_size if mode == "joint" else nb_emotions
+            self.image = InceptionV1Engine(self.store, nc, image_size, dropout_keep_prob, trainable_bn_beta, device)
+        if mode in ("joint", "text"):
+            self.text = TextTowerEngine(self.store, vocab_size + 1, embedding_dim, rnn_size, post_size, device)
+        if mode == "joint":
+            self.head = JointHeadEngine(self.store, im_features_size, rnn_size, fc_size, nb_emotions, device)
+        elif mode == "text":
+            self.head = TextHeadEngine(self.store, rnn_size, nb_emotions, device)
+        self.store.finalize()
+        st = self.store
+        self.leaves = {e.name: st.view(e.name).detach().requires_grad_() for e in st.entries.values() if e.trainable}
+        if self.image is not None:
+            self.image_param_names = [n for n in self.leaves if n.startswith("InceptionV1/")]
+            self.image.param_grads = [st.grad_view(n) for n in self.image_param_names]
+            self.image_params = [self.leaves[n] for n in self.image_param_names]
+        self.step = 0
+        self.frozen_l2_sumsq = 0.0
+        self.loss_buf = torch.zeros(1, device=self.device)
+        self.l2_buf = torch.zeros(1, device=self.device)
+        self.l2_scratch = torch.zeros(256, device=self.device)
+        self.lr_t_dev = torch.zeros(1, device=self.device)
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.dlogits = None
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.overlap_comm = overlap_comm and self.world > 1
+        self.comm_stream = torch.cuda.Stream() if self.world > 1 else None
+        self.logits = None
+
+    # ---- variables --------------------------------------------------------------------------------
+    def initialize(self, seed=1):
+        """Reference initialisers: conv trunc-normal(0.01) (inception_v1.py:26,59), Logits
+        variance-scaling (inception_utils.py:67), tf.get_variable default glorot-uniform for LSTM kernel,
+        W_fc, b_fc, W_softmax, b_softmax (im_text_rnn_model.py:89,98-104), zeros for beta / LSTM bias,
+        moving mean 0 / variance 1; embedding N(0, 0.4) with a zero <ukn> row (:75)."""
+        rng = np.random.RandomState(seed)
+        sd = {}
+
+        def trunc(shape, std):
+            a = rng.standard_normal(size=shape)
+            bad = np.abs(a) > 2
+            while bad.any():
+                a[bad] = rng.standard_normal(size=int(bad.sum()))
+                bad = np.abs(a) > 2
+            return (a * std).astype(np.float32)
+
+        def glorot(shape):
+            fi, fo = (shape[0], shape[0]) if len(shape) == 1 else (int(np.prod(shape[:-1])), shape[-1])
+            lim = math.sqrt(6.0 / (fi + fo))
+            return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+        for e in self.store.entries.values():
+            n, shp = e.name, e.shape
+            if n.endswith("/weights") and "/Logits/" in n:
+                v = trunc(shp, math.sqrt(1.3 * 2.0 / (shp[0] * shp[1] * shp[2])))
+            elif n.endswith("/weights"):
+                v = trunc(shp, 0.01)
+                if shp[2] == 4 and shp[0] == 7:
+                    v[:, :, 3, :] = 0                      # stem: the zero-padded 4th input channel
+            elif n.endswith("moving_variance"):
+                v = np.ones(shp, np.float32)
+            elif n.endswith("beta") or n.endswith("moving_mean") or n.endswith("/biases") or n.endswith("cell/bias"):
+                v = np.zeros(shp, np.float32)
+            elif n == "Text/W_embedding":
+                v = rng.normal(0, 0.4, size=shp).astype(np.float32)
+                v[-1] = 0
+            else:
+                v = glorot(shp)
+            self.store.view(n).copy_(torch.from_numpy(v))
+        self.after_load()
+
+    def load_state_dict(self, sd, strict=True):
+        """sd uses the reference's TF variable names; the stem's [7,7,3,64] weights are zero-padded to 4 inputs."""
+        sd = dict(sd)
+        k = "InceptionV1/Conv2d_1a_7x7/weights"
+        if k in sd and np.asarray(sd[k]).shape[2] == 3:
+            w = np.zeros((7, 7, 4, 64), np.float32)
+            w[:, :, :3, :] = np.asarray(sd[k])
+            sd[k] = w
+        seen = self.store.load_state_dict(sd, strict)
+        self.after_load()
+        return seen
+
+    def state_dict(self):
+        sd = self.store.state_dict()
+        k = "InceptionV1/Conv2d_1a_7x7/weights"
+        if k in sd:
+            sd[k] = sd[k][:, :, :3, :].copy()
+        return sd
+
+    def grads_state_dict(self):
+        torch.cuda.synchronize()
+        return self.store.state_dict(grads=True)
+
+    def after_load(self):
+        """L2 of the frozen conv weights is a constant of the run: sum it once."""
+        tot = 0.0
+        for e in self.store.entries.values():
+            if (not e.trainable) and e.name.endswith("/weights"):
+                ops.sumsq(self.store.view(e.name), e.numel, self.l2_scratch, self.l2_buf)
+                tot += float(self.l2_buf.item())
+        self.frozen_l2_sumsq = tot
+
+    # ---- forward / loss ---------------------------------------------------------------------------
+    def forward(self, batch, dropout_mask=None, seed=0):
+        """batch: dict with device tensors images [B,224,224,3] f32, texts [B,T] i64, seq_lens [B] i64."""
+        L = self.leaves
+        tx = im = None
+        if self.text is not None:
+            tx = TextTowerFunction.apply(self.text, batch["texts"], batch["seq_lens"], L[self.text.KERNEL],
+                                         L[self.text.BIAS])
+        if self.image is not None:
+            im = InceptionV1Function.apply(self.image, batch["images"], dropout_mask, seed, *self.image_params)
+        if self.mode == "image":
+            self.logits = im
+        elif self.mode == "text":
+            self.logits = TextHeadFunction.apply(self.head, tx, L["W_softmax"], L["b_softmax"])
+        else:
+            self.logits = JointHeadFunction.apply(self.head, im, tx, L["W_fc"], L["b_fc"], L["W_softmax"],
+                                                  L["b_softmax"])
+        return self.logits
+
+    def cross_entropy(self, logits, labels):
+        if self.dlogits is None or self.dlogits.shape != logits.shape:
+            self.dlogits = torch.empty(logits.shape, device=self.device)
+        return SoftmaxCrossEntropyFunction.apply(logits, labels, self.loss_buf, self.dlogits)
+
+    def total_loss_value(self):
+        """Host value of slim.losses.get_total_loss(): CE + sum_conv wd*||W||^2/2 (syncs)."""
+        reg = 0.0
+        if self.store.n_l2 > 0 or self.frozen_l2_sumsq:
+            reg = 0.5 * WEIGHT_DECAY * (self.frozen_l2_sumsq + float(self.l2_buf.item()))
+        return float(self.loss_buf.item()) + reg
+
+    # ---- one training step -----------------------------------------------------------------------
+    def train_step(self, batch, lr, dropout_mask=None, seed=None):
+        st = self.store
+        for p in self.leaves.values():
+            p.grad = None
+        self.step += 1
+        seed = self.step if seed is None else seed
+        logits = self.forward(batch, dropout_mask, seed)
+        ce = self.cross_entropy(logits, batch["labels"])
+        if st.n_l2 > 0:      # trainable part of the L2 loss, on the pre-update weights
+            ops.sumsq(st.theta, st.n_l2, self.l2_scratch, self.l2_buf)
+        ce.backward()
+        grad_scale = 1.0
+        if self.world > 1:
+            self._allreduce_grads()
+            grad_scale = 1.0 / self.world
+        t = self.step
+        lr_t = lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
+        ops.adam_tf(st.theta, st.grad, st.m, st.v, st.n_trainable_padded, st.n_l2, WEIGHT_DECAY, grad_scale, lr_t,
+                    ADAM_B1, ADAM_B2, ADAM_EPS)
+        return ce
+
+    def _allreduce_grads(self):
+        """Sum-all-reduce of the flat gradient (RCCL over xGMI).  Bucket 1 = [0, n_bucket1): everything
+        complete once Mixed_5c's backward is done; bucket 2 = upstream BatchNorm betas."""
+        import torch.distributed as dist
+        g, n1 = self.store.grad, self.store.n_bucket1
+        dist.all_reduce(g[:n1], op=dist.ReduceOp.SUM, group=self.pg)
+        if g.numel() > n1:
+            dist.all_reduce(g[n1:], op=dist.ReduceOp.SUM, group=self.pg)

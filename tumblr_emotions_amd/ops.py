@@ -62,9 +62,43 @@ class ConvPlan:
         self.d = d
         self.M = N * OH * OW
         self.partials = _lib.load().ds_conv_igemm_partials(C.byref(d)) if flags & DS_EPI_STATS else 0
+        # algorithmic FLOPs of one launch (2*M*N*K over the real, unpadded reduction; the folded
+        # stem carries a zero 4th input channel that is not counted)
+        k_alg = KH * KW * Cin if not fold_cin else KH * (Cin // fold_cin) * 3
+        self.alg_flops = 2.0 * self.M * Cout * k_alg
 
     def run(self, x, w, z, bias=None, mask=None, stats=None):
+        t = CONV_TIMER
+        if t is not None:
+            t.begin()
         _lib.check(_lib.load().ds_conv_igemm(C.byref(self.d), x, w, z, bias, mask, stats, _stream()), "ds_conv_igemm")
+        if t is not None:
+            t.end(self)
+
+
+class ConvTimer:
+    """HIP-event timing of every ds_conv_igemm launch on the stream it is launched on (bench.py)."""
+
+    def __init__(self):
+        self.records = []      # (start_event, end_event, alg_flops)
+        self._start = None
+
+    def begin(self):
+        self._start = torch.cuda.Event(enable_timing=True)
+        self._start.record(torch.cuda.current_stream())
+
+    def end(self, plan):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        self.records.append((self._start, e, plan.alg_flops))
+
+    def summary(self):
+        """(launches, total_ms, total_flops) -- call after a device synchronise."""
+        ms = sum(s.elapsed_time(e) for (s, e, _) in self.records)
+        return len(self.records), ms, sum(f for (_, _, f) in self.records)
+
+
+CONV_TIMER = None      # set to a ConvTimer to time the dominant kernel
 
 
 def gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=False, flags=0, ldmask=0):
@@ -148,9 +182,9 @@ def maxpool_bwd(dy, argmax, dx, accumulate, N, H, W, C_, k, stride, mode="SAME")
                                           pl, OH, OW, _stream()), "ds_maxpool_bwd")
 
 
-def avgpool_dropout_fwd(x, N, HW, C_, keep, seed, mask_in, mask_out, out):
-    _lib.check(_lib.load().ds_avgpool_dropout_fwd(_p(x), N, HW, C_, keep, seed, _p(mask_in), _p(mask_out), _p(out),
-                                                  _stream()), "ds_avgpool_dropout_fwd")
+def avgpool_dropout_fwd(x, N, HW, C_, keep, seed, mask_in, mask_out, out, seed_dev=None):
+    _lib.check(_lib.load().ds_avgpool_dropout_fwd(_p(x), N, HW, C_, keep, seed, _p(seed_dev), _p(mask_in),
+                                                  _p(mask_out), _p(out), _stream()), "ds_avgpool_dropout_fwd")
 
 
 def avgpool_dropout_bwd(dout, mask, N, HW, C_, keep, dx):
@@ -178,9 +212,9 @@ def softmax_ce(logits, labels, B, C_, grad_scale, grad_scale_dev, loss, dlogits)
                                          _p(dlogits), _stream()), "ds_softmax_ce")
 
 
-def adam_tf(theta, g, m, v, n, n_wd, wd, grad_scale, lr_t, b1, b2, eps):
-    _lib.check(_lib.load().ds_adam_tf(_p(theta), _p(g), _p(m), _p(v), n, n_wd, wd, grad_scale, lr_t, b1, b2, eps,
-                                      _stream()), "ds_adam_tf")
+def adam_tf(theta, g, m, v, n, n_wd, wd, grad_scale, lr_t, b1, b2, eps, lr_t_dev=None):
+    _lib.check(_lib.load().ds_adam_tf(_p(theta), _p(g), _p(m), _p(v), n, n_wd, wd, grad_scale, lr_t, _p(lr_t_dev),
+                                      b1, b2, eps, _stream()), "ds_adam_tf")
 
 
 def sumsq(x, n, scratch, out):
