@@ -102,11 +102,20 @@ class ParamStore:
                 out.append(e.name)
         return out
 
-    def load_state_dict(self, sd, strict=True):
-        """sd: {tf_name: array-like}.  Fused tensors are assembled from their column ranges."""
+    def slot_view(self, name, which):
+        """View of an Adam slot ('m' / 'v') of a trainable variable."""
+        e = self.entries[name]
+        assert e.trainable
+        return getattr(self, which)[e.offset:e.offset + e.numel].view(e.shape)
+
+    def load_state_dict(self, sd, strict=True, which="value"):
+        """sd: {tf_name: array-like}.  Fused tensors are assembled from their column ranges.
+        which='value' loads variables; 'm' / 'v' load the Adam slots of the trainable ones."""
         seen = set()
         for e in self.entries.values():
-            dst = self.view(e.name)
+            if which != "value" and not e.trainable:
+                continue
+            dst = self.view(e.name) if which == "value" else self.slot_view(e.name, which)
             if e.columns:
                 for (n, c0, c1) in e.columns:
                     if n in sd:
