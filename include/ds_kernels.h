@@ -67,9 +67,11 @@ typedef struct ds_conv_desc {
     int32_t ldmask;           /* row stride of the DS_EPI_MASK source                               */
 } ds_conv_desc;
 
+/* Tuning aid: pin the workgroup tile to (128*mt) x (32*nt) rows x columns; 0,0 = automatic.  */
+int ds_conv_set_tile(int mt, int nt);
 /* Number of row-tile blocks (P) the launch for `d` will use = number of stats partials.   */
 int ds_conv_igemm_partials(const ds_conv_desc *d);
-/* stats (DS_EPI_STATS): float[P][2][Cout] partial column sums / sums of squares.          */
+/* stats (DS_EPI_STATS): float[2][Cout][P] partial column sums / sums of squares.          */
 int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float *w, float *z, const float *bias,
                   const float *mask, float *stats, void *stream);
 

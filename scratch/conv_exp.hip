@@ -230,10 +230,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         __syncthreads();
         for (int kt = 0; kt < KT; ++kt) {
             const int cur = kt & 1;
+#if DS_EXP == 1      /* no global loads after the first tile */
+            compute(cur);
+            if (kt + 1 < KT) store_tile(cur ^ 1);
+            __syncthreads();
+#elif DS_EXP == 2    /* loads but no LDS stores */
+            if (kt + 1 < KT) load_tile();
+            compute(cur);
+            asm volatile("" :: "v"(ra[0]), "v"(rb[0]));
+            __syncthreads();
+#elif DS_EXP == 3    /* no loads, no stores: compute + barrier */
+            compute(cur);
+            __syncthreads();
+#else
             if (kt + 1 < KT) load_tile();
             compute(cur);
             if (kt + 1 < KT) store_tile(cur ^ 1);
             __syncthreads();
+#endif
         }
 
         // ---- epilogue: bias / accumulate / mask / relu, store, BatchNorm column statistics -------
@@ -287,9 +301,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 s += red[(w * BN + tid) * 2 + 0];
                 q += red[(w * BN + tid) * 2 + 1];
             }
-            // partials laid out [2][Cout][P] (P = gridDim.x) so ds_bn_finalize reads them contiguously
-            p.stats[(int64_t)(n0 + tid) * gridDim.x + blockIdx.x] = s;
-            p.stats[((int64_t)d.Cout + n0 + tid) * gridDim.x + blockIdx.x] = q;
+            float *o = p.stats + (int64_t)blockIdx.x * 2 * d.Cout;
+            o[n0 + tid] = s;
+            o[d.Cout + n0 + tid] = q;
         }
     }
 }
@@ -299,126 +313,82 @@ struct TileCfg {
     int mt, nt;
 };
 
-typedef void (*KernelFn)(const ConvParams);
-
 int64_t conv_M(const ds_conv_desc *d) { return (int64_t)d->N * d->OH * d->OW; }
 
-struct Variant {
-    bool bnmajor, fold, vec;
-};
-
-Variant variant_of(const ds_conv_desc *d, const float *x, const float *w) {
-    Variant v;
-    v.bnmajor = d->w_n_stride == 1 && d->w_k_stride != 1;
-    v.fold = d->fold_cin > 0;
-    const bool a_vec = (d->ldx % 4 == 0) && (d->Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
-    bool b_vec;
-    if (v.bnmajor)
-        b_vec = (d->Cout % 4 == 0) && (d->w_k_stride % 4 == 0) && (d->w_tap_stride % 4 == 0) && (((uintptr_t)w & 15) == 0);
-    else
-        b_vec = (d->Cin % 4 == 0) && (d->w_n_stride % 4 == 0) && (d->w_tap_stride % 4 == 0) && (((uintptr_t)w & 15) == 0);
-    v.vec = a_vec && b_vec;
-    return v;
-}
-
-template <int MT, int NT>
-KernelFn kernel_mn(Variant v) {
-    if (v.bnmajor) {
-        if (v.fold) return conv_igemm_kernel<MT, NT, true, true, true>;
-        return v.vec ? conv_igemm_kernel<MT, NT, true, false, true> : conv_igemm_kernel<MT, NT, true, false, false>;
-    }
-    return v.vec ? conv_igemm_kernel<MT, NT, false, false, true> : conv_igemm_kernel<MT, NT, false, false, false>;
-}
-
-template <int MT>
-KernelFn kernel_m(int nt, Variant v) {
-    switch (nt) {
-        case 1: return kernel_mn<MT, 1>(v);
-        case 2: return kernel_mn<MT, 2>(v);
-        case 3: return kernel_mn<MT, 3>(v);
-        case 4: return kernel_mn<MT, 4>(v);
-        case 5: return kernel_mn<MT, 5>(v);
-        default: return kernel_mn<MT, 6>(v);
-    }
-}
-
-KernelFn kernel_for(TileCfg c, Variant v) { return c.mt == 2 ? kernel_m<2>(c.nt, v) : kernel_m<1>(c.nt, v); }
-
-// Resident workgroups per CU of one instantiation (register/LDS limited), queried once and cached.
-// The persistent grid is sized to exactly one resident wave of workgroups so no CU idles while a
-// partial second wave runs; correctness never depends on it (no inter-workgroup communication).
-int resident_per_cu(TileCfg c, Variant v) {
-    static int cache[2][6][2][2][2];
-    int &slot = cache[c.mt - 1][c.nt - 1][v.bnmajor][v.fold][v.vec];
-    if (slot == 0) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kernel_for(c, v), 256, 0) != hipSuccess || n < 1)
-            n = 1;
-        slot = n > 6 ? 6 : n;
-    }
-    return slot;
-}
-
-// Tile = (128*mt) x (32*nt).  nt: least column padding (+ a charge per column tile, each of which
-// re-reads the A rows); mt = 2 unless the problem is too small to give every CU a workgroup.
-int force_mt = -1, force_nt = -1;     // tuning aid: ds_conv_set_tile() / DS_CONV_CFG="mt,nt" pin the tile
-
+// Tile = (128*mt) x (32*nt).  nt: least column padding, ties -> wider tile (fewer re-reads of A);
+// mt = 2 unless the problem is too small to give every CU a workgroup.
 TileCfg pick_cfg(const ds_conv_desc *d) {
-    if (force_mt < 0) {
+    static int force_mt = -1, force_nt = -1;
+    if (force_mt < 0) {      // DS_CONV_CFG="mt,nt" pins the tile (tuning aid)
         force_mt = force_nt = 0;
         if (const char *e = getenv("DS_CONV_CFG")) sscanf(e, "%d,%d", &force_mt, &force_nt);
     }
-    // Measured on MI355X over every conv/GEMM shape of the joint step (profiles/r01_tile_sweep.txt):
-    // the kernel is latency-bound per wave, so small tiles at 3-5 resident workgroups per CU beat wide
-    // ones (which drop to 1-2 per CU) almost everywhere.  128x64 when 64-wide tiles pad Cout by
-    // <= 12 % and the grid still fills the chip three times over, else 128x32.
     const int64_t M = conv_M(d);
     const int N = d->Cout;
-    const int pad32 = (N + 31) / 32 * 32, pad64 = (N + 63) / 64 * 64;
-    const int64_t row_tiles = (M + 127) / 128;
-    TileCfg c = {1, 1};
-    if (pad64 * 100 <= pad32 * 112 && row_tiles * (pad64 / 64) >= 3 * ds::kCUs) c.nt = 2;
+    // cost in "columns": padded width + 8 per column tile (each extra tile re-reads the A rows)
+    auto padw = [&](int nt) { return ((N + 32 * nt - 1) / (32 * nt)) * 32 * nt; };
+    auto cost = [&](int nt) { return padw(nt) + 8 * ((N + 32 * nt - 1) / (32 * nt)); };
+    int best_nt = 1;
+    for (int nt = 2; nt <= 6; ++nt)
+        if (cost(nt) <= cost(best_nt)) best_nt = nt;
+    TileCfg c = {2, best_nt};
+    auto blocks = [&](int mt, int nt) { return ((M + 128 * mt - 1) / (128 * mt)) * ((N + 32 * nt - 1) / (32 * nt)); };
+    if (blocks(c.mt, c.nt) < 2 * ds::kCUs) c.mt = 1;
+    if (blocks(c.mt, c.nt) < ds::kCUs) {
+        // small GEMMs (LSTM steps, heads): narrower tiles -> more workgroups, without much more padding
+        for (int nt = c.nt - 1; nt >= 1; --nt) {
+            if (padw(nt) * 100 > padw(best_nt) * 115) continue;
+            c.nt = nt;
+            if (blocks(c.mt, nt) >= ds::kCUs) break;
+        }
+    }
     if (force_mt > 0) c.mt = force_mt;
     if (force_nt > 0) c.nt = force_nt;
     return c;
 }
 
-void grid_for(const ds_conv_desc *d, TileCfg c, Variant v, int *gx, int *gy, int *row_tiles) {
+void grid_for(const ds_conv_desc *d, TileCfg c, int *gx, int *gy, int *row_tiles) {
     const int64_t M = conv_M(d);
     const int bm = 128 * c.mt, bn = 32 * c.nt;
     *row_tiles = (int)((M + bm - 1) / bm);
     *gy = (d->Cout + bn - 1) / bn;
-    int target = (resident_per_cu(c, v) * ds::kCUs) / *gy;     // one resident wave of workgroups
+    int target = (3 * ds::kCUs) / *gy;       // ~3 resident workgroups per CU in total
     if (target < 8) target = 8;
     int x = *row_tiles < target ? *row_tiles : target;
     if (x >= 8) x &= ~7;                      // multiple of 8: column tiles of a row tile share an XCD
     *gx = x;
 }
 
-}  // namespace
-
-extern "C" int ds_conv_set_tile(int mt, int nt) {
-    DS_REQUIRE((mt == 0 && nt == 0) || ((mt == 1 || mt == 2) && nt >= 1 && nt <= 6), "ds_conv_set_tile: mt in {1,2}, nt in 1..6, or 0,0 = automatic");
-    force_mt = mt;
-    force_nt = nt;
-    return DS_OK;
+template <int MT, int NT>
+void launch_mn(const ConvParams &p, dim3 grid, hipStream_t s, bool bnmajor, bool fold, bool vec) {
+    if (bnmajor) {
+        if (fold) hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, true, true, true>), grid, dim3(256), 0, s, p);
+        else if (vec) hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, true, false, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, true, false, false>), grid, dim3(256), 0, s, p);
+    } else {
+        if (vec) hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, false, false, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, false, false, false>), grid, dim3(256), 0, s, p);
+    }
 }
 
-extern "C" int ds_conv_igemm_partials(const ds_conv_desc *d) {
-    // the variant only matters through its occupancy; alignment-dependent variants of one tile have
-    // the same residency class in practice, but to be exact callers get the worst case (max) here
-    int best = 0;
-    const TileCfg c = pick_cfg(d);
-    for (int vec = 0; vec < 2; ++vec) {
-        Variant v;
-        v.bnmajor = d->w_n_stride == 1 && d->w_k_stride != 1;
-        v.fold = d->fold_cin > 0;
-        v.vec = vec || v.fold;
-        int gx, gy, rt;
-        grid_for(d, c, v, &gx, &gy, &rt);
-        if (gx > best) best = gx;
+template <int MT>
+void launch_m(const ConvParams &p, int nt, dim3 grid, hipStream_t s, bool bnmajor, bool fold, bool vec) {
+    switch (nt) {
+        case 1: launch_mn<MT, 1>(p, grid, s, bnmajor, fold, vec); break;
+        case 2: launch_mn<MT, 2>(p, grid, s, bnmajor, fold, vec); break;
+        case 3: launch_mn<MT, 3>(p, grid, s, bnmajor, fold, vec); break;
+        case 4: launch_mn<MT, 4>(p, grid, s, bnmajor, fold, vec); break;
+        case 5: launch_mn<MT, 5>(p, grid, s, bnmajor, fold, vec); break;
+        default: launch_mn<MT, 6>(p, grid, s, bnmajor, fold, vec); break;
     }
-    return best;
+}
+
+}  // namespace
+
+extern "C" int ds_conv_igemm_partials(const ds_conv_desc *d) {
+    int gx, gy, rt;
+    grid_for(d, pick_cfg(d), &gx, &gy, &rt);
+    return gx;
 }
 
 extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float *w, float *z, const float *bias,
@@ -430,7 +400,8 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     DS_REQUIRE(!(d->flags & DS_EPI_MASK) || mask, "ds_conv_igemm: DS_EPI_MASK without mask");
     DS_REQUIRE(!(d->flags & DS_EPI_STATS) || stats, "ds_conv_igemm: DS_EPI_STATS without stats buffer");
     DS_REQUIRE(conv_M(d) < (1ll << 31), "ds_conv_igemm: M too large");
-    const Variant v = variant_of(d, x, w);
+    const bool bnmajor = d->w_n_stride == 1 && d->w_k_stride != 1;
+    const bool fold = d->fold_cin > 0;
 
     ConvParams p;
     p.d = *d;
@@ -438,20 +409,30 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     p.M = (int)conv_M(d);
     p.taps = d->KH * d->KW;
     // extents of the two buffer descriptors (bytes from the operand pointer to the last float read)
-    const int64_t x_elems = ((int64_t)d->N * d->H * d->W - 1) * d->ldx + (v.fold ? d->fold_cin : d->Cin);
+    const int64_t x_elems = ((int64_t)d->N * d->H * d->W - 1) * d->ldx + (fold ? d->fold_cin : d->Cin);
     const int64_t w_elems = (int64_t)(p.taps - 1) * d->w_tap_stride + (int64_t)(d->Cout - 1) * d->w_n_stride +
                             (int64_t)(d->Cin - 1) * d->w_k_stride + 1;
     DS_REQUIRE(x_elems * 4 < (1ll << 31) && w_elems * 4 < (1ll << 31),
                "ds_conv_igemm: operand larger than 2 GiB (split the batch)");
     p.x_bytes = (unsigned)(x_elems * 4);
     p.w_bytes = (unsigned)(w_elems * 4);
-    DS_REQUIRE(!v.fold || (v.bnmajor && v.vec && d->KW == 1 && d->fold_cin % 4 == 0 && d->ldx == d->fold_cin),
+    const bool a_vec = (d->ldx % 4 == 0) && (d->Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    bool b_vec;
+    if (bnmajor)
+        b_vec = (d->Cout % 4 == 0) && (d->w_k_stride % 4 == 0) && (d->w_tap_stride % 4 == 0) && (((uintptr_t)w & 15) == 0);
+    else
+        b_vec = (d->Cin % 4 == 0) && (d->w_n_stride % 4 == 0) && (d->w_tap_stride % 4 == 0) && (((uintptr_t)w & 15) == 0);
+    const bool vec = a_vec && b_vec;
+    DS_REQUIRE(!fold || (bnmajor && vec && d->KW == 1 && d->fold_cin % 4 == 0 && d->ldx == d->fold_cin),
                "ds_conv_igemm: fold_cin needs KW=1, n-contiguous 16-byte-aligned weights, ldx==fold_cin");
 
     const TileCfg c = pick_cfg(d);
     int gx, gy, rt;
-    grid_for(d, c, v, &gx, &gy, &rt);
+    grid_for(d, c, &gx, &gy, &rt);
     p.row_tiles = rt;
-    hipLaunchKernelGGL(kernel_for(c, v), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, p);
+    dim3 grid(gx, gy);
+    hipStream_t s = (hipStream_t)stream;
+    if (c.mt == 2) launch_m<2>(p, c.nt, grid, s, bnmajor, fold, vec);
+    else launch_m<1>(p, c.nt, grid, s, bnmajor, fold, vec);
     return ds::check_launch("ds_conv_igemm");
 }

@@ -54,12 +54,12 @@ def test_conv_forward_with_stats(case):
     plan = ops.ConvPlan(N, H, W, Ci, Ci, k, k, s, Co, Co, Ci * Co, 1, Co, flags=ops.DS_EPI_STATS)
     M = plan.M
     z = torch.empty(M, Co, device="cuda")
-    stats = torch.zeros(plan.partials, 2, Co, device="cuda")
+    stats = torch.zeros(2, Co, plan.partials, device="cuda")
     plan.run(ops._p(xd), ops._p(wd), ops._p(z), stats=ops._p(stats))
     torch.cuda.synchronize()
     close(z, ref.reshape(M, Co))
-    close(stats[:, 0, :].sum(0), ref.reshape(M, Co).sum(0), 1e-3)
-    close(stats[:, 1, :].sum(0), (ref.reshape(M, Co) ** 2).sum(0), 1e-3)
+    close(stats[0].sum(1), ref.reshape(M, Co).sum(0), 1e-3)
+    close(stats[1].sum(1), (ref.reshape(M, Co) ** 2).sum(0), 1e-3)
 
 
 def test_conv_stem_7x7_stride2_folded():
@@ -174,7 +174,7 @@ def test_batch_norm_forward_backward_with_segments():
     y_ref = S.relu(y_ref)
     zd, bd = dev(z), dev(beta)
     # forward statistics through the conv epilogue path is covered elsewhere; here feed exact partials
-    stats = torch.stack([zd.sum(0), (zd * zd).sum(0)]).reshape(1, 2, Cc).contiguous()
+    stats = torch.stack([zd.sum(0), (zd * zd).sum(0)]).reshape(2, Cc, 1).contiguous()
     mean_d, rstd_d, shift_d = (torch.empty(Cc, device="cuda") for _ in range(3))
     mm, mv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
     ops.bn_finalize(stats, 1, M, Cc, bd, S.BN_EPS, S.BN_DECAY, mean_d, rstd_d, shift_d, mm, mv)
@@ -200,7 +200,7 @@ def test_batch_norm_forward_backward_with_segments():
     dsegs = ops.make_segments([(0, 64, dyc.data_ptr(), 256), (64, 160, dr1.data_ptr(), 96),
                                (160, 176, dr2.data_ptr(), 16)])
     P = ops.bn_bwd_partials(M, Cc)
-    part = torch.empty(P, 2, Cc, device="cuda")
+    part = torch.empty(2, Cc, P, device="cuda")
     dbeta, coef = torch.empty(Cc, device="cuda"), torch.empty(2, Cc, device="cuda")
     ops.bn_bwd_reduce(zd, dsegs, M, Cc, mean_d, rstd_d, shift_d, part)
     ops.bn_bwd_finalize(part, P, M, Cc, dbeta, coef)

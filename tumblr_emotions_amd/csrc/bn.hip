@@ -38,29 +38,29 @@ __device__ __forceinline__ float *seg_addr(const SegDev &sg, int64_t row, int c)
     return nullptr;
 }
 
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
 // ---- forward ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *stats, int P, double inv_count, int C,
                                                           const float *beta, float eps, float decay, float *mean,
                                                           float *rstd, float *shift, float *mm, float *mv) {
-    // 16 channels x 16 partial-lanes per workgroup; partials are combined in double
-    __shared__ double sh[2][16][16];
-    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    // one wave per channel; partials are laid out [2][C][P] so the 64 lanes read contiguous floats;
+    // combined in double with a fixed butterfly order (deterministic)
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
     double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int p = pl; p < P; p += 16) {
-            s += (double)stats[(int64_t)p * 2 * C + c];
-            q += (double)stats[(int64_t)p * 2 * C + C + c];
-        }
-    sh[0][pl][cl] = s;
-    sh[1][pl][cl] = q;
-    __syncthreads();
-    if (pl == 0 && c < C) {
-        s = q = 0.0;
-        for (int k = 0; k < 16; ++k) {
-            s += sh[0][k][cl];
-            q += sh[1][k][cl];
-        }
+    for (int p = lane; p < P; p += 64) {
+        s += (double)stats[(int64_t)c * P + p];
+        q += (double)stats[((int64_t)C + c) * P + p];
+    }
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    if (lane == 0) {
         const double mu = s * inv_count;
         double var = q * inv_count - mu * mu;          // biased variance (A3)
         if (var < 0.0) var = 0.0;
@@ -150,35 +150,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *z, SegD
         for (int g = 0; g < RG; ++g)
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] += sh[((int64_t)g * C4 + tid) * 8 + j];
-        float *o = partials + (int64_t)blockIdx.x * 2 * C;
+        const int P = gridDim.x;                       // partials laid out [2][C][P]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            o[tid * 4 + j] = a[j];
-            o[C + tid * 4 + j] = a[4 + j];
+            partials[(int64_t)(tid * 4 + j) * P + blockIdx.x] = a[j];
+            partials[((int64_t)C + tid * 4 + j) * P + blockIdx.x] = a[4 + j];
         }
     }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *partials, int P, double inv_count, int C,
                                                               float *dbeta, float *coef) {
-    __shared__ double sh[2][16][16];
-    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
     double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int p = pl; p < P; p += 16) {
-            s += (double)partials[(int64_t)p * 2 * C + c];
-            q += (double)partials[(int64_t)p * 2 * C + C + c];
-        }
-    sh[0][pl][cl] = s;
-    sh[1][pl][cl] = q;
-    __syncthreads();
-    if (pl == 0 && c < C) {
-        s = q = 0.0;
-        for (int k = 0; k < 16; ++k) {
-            s += sh[0][k][cl];
-            q += sh[1][k][cl];
-        }
+    for (int p = lane; p < P; p += 64) {
+        s += (double)partials[(int64_t)c * P + p];
+        q += (double)partials[((int64_t)C + c) * P + p];
+    }
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    if (lane == 0) {
         dbeta[c] = (float)s;
         if (coef) {
             coef[c] = (float)(s * inv_count);          // mean(g)
@@ -235,7 +228,7 @@ extern "C" int ds_bn_finalize(const float *stats, int32_t P, int64_t count, int3
                               float decay, float *mean, float *rstd, float *shift, float *moving_mean,
                               float *moving_var, void *stream) {
     DS_REQUIRE(stats && beta && mean && rstd && shift && P > 0 && count > 0 && C > 0, "ds_bn_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, stats, P,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats, P,
                        1.0 / (double)count, C, beta, eps, decay, mean, rstd, shift, moving_mean, moving_var);
     return ds::check_launch("ds_bn_finalize");
 }
@@ -271,7 +264,7 @@ extern "C" int ds_bn_bwd_reduce(const float *z, const ds_segments *dy, int64_t M
 extern "C" int ds_bn_bwd_finalize(const float *partials, int32_t P, int64_t M, int32_t C, float *dbeta, float *coef,
                                   void *stream) {
     DS_REQUIRE(partials && dbeta && P > 0 && M > 0 && C > 0, "ds_bn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, P,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, P,
                        1.0 / (double)M, C, dbeta, coef);
     return ds::check_launch("ds_bn_bwd_finalize");
 }
