@@ -65,6 +65,10 @@ typedef struct ds_conv_desc {
     int32_t fold_cin;         /* >0: KW is folded into Cin (stem conv): real channels per pixel     */
     int32_t flags;            /* DS_EPI_*                                                           */
     int32_t ldmask;           /* row stride of the DS_EPI_MASK source                               */
+    int32_t splits;           /* 0/1: none.  >1: split-K for small-M GEMMs (LSTM steps): split s     */
+                              /* writes its partial sum to z + s*z_split_stride; the consumer adds    */
+                              /* the slabs (flags must be 0)                                          */
+    int64_t z_split_stride;   /* floats between output slabs                                          */
 } ds_conv_desc;
 
 /* Tuning aid: pin the workgroup tile to (128*mt) x (32*nt) rows x columns; 0,0 = automatic.  */
@@ -135,17 +139,20 @@ int ds_gather_rows(const float *table, const int64_t *ids, float *out, int32_t B
                    int64_t table_rows, int32_t time_major, void *stream);
 
 /* BasicLSTMCell gate math + dynamic_rnn length masking (im_text_rnn_model.py:89-90).
- * gates [B,4H] holds the pre-activations (i,j,f,o) on entry and the activations
- * (sigmoid i, tanh j, sigmoid(f+forget_bias), sigmoid o) on exit.                          */
-int ds_lstm_cell_fwd(float *gates, const float *c_prev, const float *h_prev, const int64_t *seq_len,
-                     int32_t t, int32_t B, int32_t H, float forget_bias, float *c_out, float *h_out,
-                     void *stream);
-/* one BPTT step: consumes dh (grad wrt h_t), dc (grad wrt c_t); writes dgates [B,4H],
- * dc_prev, and dh_carry (= dh for rows with t >= seq_len, else 0; the recurrent dgrad GEMM
- * then accumulates dgates*Wh^T onto it).                                                   */
+ * gates [B,4H] holds x_t*Wx+bias (i,j,f,o) on entry -- the recurrent term h_{t-1}*Wh is added
+ * from `nslabs` split-K slabs rec_slabs[s*slab_stride + ...] (nslabs may be 0 when the GEMM
+ * accumulated in place) -- and the activations (sigmoid i, tanh j, sigmoid(f+forget_bias),
+ * sigmoid o) on exit.                                                                        */
+int ds_lstm_cell_fwd(float *gates, const float *rec_slabs, int32_t nslabs, int64_t slab_stride,
+                     const float *c_prev, const float *h_prev, const int64_t *seq_len, int32_t t, int32_t B,
+                     int32_t H, float forget_bias, float *c_out, float *h_out, void *stream);
+/* one BPTT step: d(loss)/d(h_t) = dh + sum of `nslabs` split-K slabs of dgates_{t+1}*Wh^T;
+ * dc = grad wrt c_t; writes dgates [B,4H], dc_prev, and dh_carry (= the h-gradient for rows with
+ * t >= seq_len, which dynamic_rnn copies through, else 0).                                   */
 int ds_lstm_cell_bwd(const float *acts, const float *c_t, const float *c_prev, const float *dh,
-                     const float *dc, const int64_t *seq_len, int32_t t, int32_t B, int32_t H,
-                     float *dgates, float *dc_prev, float *dh_carry, void *stream);
+                     const float *dh_slabs, int32_t nslabs, int64_t slab_stride, const float *dc,
+                     const int64_t *seq_len, int32_t t, int32_t B, int32_t H, float *dgates, float *dc_prev,
+                     float *dh_carry, void *stream);
 
 /* slim.losses.softmax_cross_entropy + its gradient (im_text_rnn_model.py:124-125):
  * loss[0] = mean_b(logsumexp(z_b) - z_b[y_b]); dlogits = (softmax - onehot) * grad_scale / B;

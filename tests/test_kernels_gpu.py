@@ -343,3 +343,35 @@ def test_softmax_ce_and_adam_and_reductions():
     ops.sumsq(dev(x), x.size, scratch, ss)
     torch.cuda.synchronize()
     close(ss, np.array([(x ** 2).sum()]), 1e-5)
+
+
+def test_split_k_gemm_slabs_feed_lstm_cell():
+    """LSTM step as the engine runs it: split-K recurrent GEMM -> slabs -> cell kernel adds them."""
+    ops = _ops()
+    rng = np.random.RandomState(13)
+    B, H, S = 40, 96, 3
+    h0, c0 = rng.normal(size=(B, H)), rng.normal(size=(B, H))
+    wh = rng.normal(size=(H, 4 * H)) * 0.2
+    xw = rng.normal(size=(B, 4 * H))
+    seq = rng.randint(1, 6, size=B)
+    t = 2
+    slabs = torch.full((S, B, 4 * H), 7.0, device="cuda")
+    hd, whd = dev(h0), dev(wh)
+    ops.gemm_plan(B, H, 4 * H, H, 4 * H, 4 * H, splits=S, z_split_stride=B * 4 * H).run(
+        ops._p(hd), ops._p(whd), ops._p(slabs))
+    torch.cuda.synchronize()
+    close(slabs.sum(0), h0 @ wh, 1e-5)
+    g = dev(xw)
+    cd, hn = torch.empty(B, H, device="cuda"), torch.empty(B, H, device="cuda")
+    ops.lstm_cell_fwd(g, dev(c0), hd, dev(seq, torch.int64), t, B, H, 1.0, cd, hn, slabs, S, B * 4 * H)
+    pre = xw + h0 @ wh
+    i, j, f, o = np.split(pre, 4, axis=1)
+    cn = c0 * S_sigmoid(f + 1.0) + S_sigmoid(i) * np.tanh(j)
+    live = (t < seq)[:, None]
+    torch.cuda.synchronize()
+    close(cd, np.where(live, cn, c0), 1e-5)
+    close(hn, np.where(live, np.tanh(cn) * S_sigmoid(o), h0), 1e-5)
+
+
+def S_sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))

@@ -19,6 +19,7 @@ class ConvDesc(C.Structure):
         ("OH", C.c_int32), ("OW", C.c_int32), ("Cout", C.c_int32), ("ldz", C.c_int32),
         ("w_tap_stride", C.c_int64), ("w_n_stride", C.c_int32), ("w_k_stride", C.c_int32),
         ("flip", C.c_int32), ("fold_cin", C.c_int32), ("flags", C.c_int32), ("ldmask", C.c_int32),
+        ("splits", C.c_int32), ("z_split_stride", C.c_int64),
     ]
 
 
@@ -52,8 +53,8 @@ SIGNATURES = {
     "ds_avgpool_dropout_fwd": (C.c_int, [_P, _i32, _i32, _i32, _f32, _u64, _P, _P, _P, _P, _P]),
     "ds_avgpool_dropout_bwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _f32, _P, _P]),
     "ds_gather_rows": (C.c_int, [_P, _P, _P, _i32, _i32, _i32, _i64, _i32, _P]),
-    "ds_lstm_cell_fwd": (C.c_int, [_P, _P, _P, _P, _i32, _i32, _i32, _f32, _P, _P, _P]),
-    "ds_lstm_cell_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _P, _P, _P, _P]),
+    "ds_lstm_cell_fwd": (C.c_int, [_P, _P, _i32, _i64, _P, _P, _P, _i32, _i32, _i32, _f32, _P, _P, _P]),
+    "ds_lstm_cell_bwd": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i64, _P, _P, _i32, _i32, _i32, _P, _P, _P, _P]),
     "ds_softmax_ce": (C.c_int, [_P, _P, _i32, _i32, _f32, _P, _P, _P, _P]),
     "ds_adam_tf": (C.c_int, [_P, _P, _P, _P, _i64, _i64, _f32, _f32, _f32, _P, _f32, _f32, _f32, _P]),
     "ds_sumsq": (C.c_int, [_P, _i64, _P, _P, _P]),

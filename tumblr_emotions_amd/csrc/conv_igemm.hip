@@ -83,7 +83,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int n0 = blockIdx.y * BN;
     const int ohw = d.OH * d.OW;
     const int chunks = (d.Cin + BK - 1) / BK;
-    const int KT = p.taps * chunks;
+    // split-K (small-M GEMMs): blockIdx.z owns K-tiles [kt0, kt1) and writes its own output slab
+    const int KT_all = p.taps * chunks;
+    const int kts = (KT_all + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int kt0 = (int)blockIdx.z * kts;
+    const int KT = (kt0 + kts < KT_all ? kt0 + kts : KT_all) - kt0;     // K-tiles of this split (may be <= 0)
+    float *const zout = p.z + (int64_t)blockIdx.z * p.d.z_split_stride;
     const int flags = d.flags;
     const __amdgpu_buffer_rsrc_t srd_x = make_srd(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t srd_w = make_srd(p.w, p.w_bytes);
@@ -140,7 +145,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
         f32x4 ra[AR], rb[BR];
-        int tap = 0, c0 = 0, dh = 0, dw = 0;   // K-tile that the next load_tile() fetches
+        // K-tile that the next load_tile() fetches (starts at this split's first tile)
+        int tap = kt0 / chunks, c0 = (kt0 - tap * chunks) * BK;
+        int dh = tap / d.KW, dw = tap - dh * d.KW;
 
         auto load_tile = [&]() {
             // ---- A: activations ----------------------------------------------------------------
@@ -251,10 +258,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     if (row < p.M && colok) {
                         float v = acc[a][b][r] + bv;
                         const int64_t off = (int64_t)row * d.ldz + col;
-                        if (flags & DS_EPI_ACCUM) v += p.z[off];
+                        if (flags & DS_EPI_ACCUM) v += zout[off];
                         if (flags & DS_EPI_MASK) v = p.mask[(int64_t)row * d.ldmask + col] > 0.f ? v : 0.f;
                         if (flags & DS_EPI_RELU) v = fmaxf(v, 0.f);
-                        p.z[off] = v;
+                        zout[off] = v;
                         s += v;
                         q += v * v;
                     }
@@ -448,10 +455,14 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     DS_REQUIRE(!v.fold || (v.bnmajor && v.vec && d->KW == 1 && d->fold_cin % 4 == 0 && d->ldx == d->fold_cin),
                "ds_conv_igemm: fold_cin needs KW=1, n-contiguous 16-byte-aligned weights, ldx==fold_cin");
 
+    const int splits = d->splits > 1 ? d->splits : 1;
+    DS_REQUIRE(splits == 1 || (d->flags == 0 && d->z_split_stride >= (int64_t)(conv_M(d) - 1) * d->ldz + d->Cout),
+               "ds_conv_igemm: split-K needs flags == 0 and non-overlapping output slabs");
+    if (splits == 1) p.d.z_split_stride = 0;
     const TileCfg c = pick_cfg(d);
     int gx, gy, rt;
     grid_for(d, c, v, &gx, &gy, &rt);
     p.row_tiles = rt;
-    hipLaunchKernelGGL(kernel_for(c, v), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kernel_for(c, v), dim3(gx, gy, splits), dim3(256), 0, (hipStream_t)stream, p);
     return ds::check_launch("ds_conv_igemm");
 }

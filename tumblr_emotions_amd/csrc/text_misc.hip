@@ -37,17 +37,23 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *table, co
 // ---- LSTM cell -----------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
-__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float *gates, const float *c_prev, const float *h_prev,
-                                                            const int64_t *seq_len, int t, int B, int H,
-                                                            float forget_bias, float *c_out, float *h_out) {
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float *gates, const float *rec, int nslabs,
+                                                            int64_t slab_stride, const float *c_prev,
+                                                            const float *h_prev, const int64_t *seq_len, int t, int B,
+                                                            int H, float forget_bias, float *c_out, float *h_out) {
     const int64_t total = (int64_t)B * H;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int b = (int)(i / H), h = (int)(i - (int64_t)b * H);
         float *g = gates + (int64_t)b * 4 * H + h;
-        const float si = sigmoidf_(g[0]);
-        const float tj = tanhf(g[H]);
-        const float sf = sigmoidf_(g[2 * H] + forget_bias);
-        const float so = sigmoidf_(g[3 * H]);
+        float pi = g[0], pj = g[H], pf = g[2 * H], po = g[3 * H];     // x_t*Wx + bias (hoisted GEMM)
+        for (int s = 0; s < nslabs; ++s) {                             // + h_{t-1}*Wh, split-K slabs
+            const float *r = rec + s * slab_stride + (int64_t)b * 4 * H + h;
+            pi += r[0]; pj += r[H]; pf += r[2 * H]; po += r[3 * H];
+        }
+        const float si = sigmoidf_(pi);
+        const float tj = tanhf(pj);
+        const float sf = sigmoidf_(pf + forget_bias);
+        const float so = sigmoidf_(po);
         const float cp = c_prev[i], hp = h_prev[i];
         const float cn = cp * sf + si * tj;
         const float hn = tanhf(cn) * so;
@@ -62,16 +68,19 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float *gates, const 
 }
 
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float *acts, const float *c_t, const float *c_prev,
-                                                            const float *dh, const float *dc, const int64_t *seq_len,
-                                                            int t, int B, int H, float *dgates, float *dc_prev,
-                                                            float *dh_carry) {
+                                                            const float *dh, const float *dh_slabs, int nslabs,
+                                                            int64_t slab_stride, const float *dc,
+                                                            const int64_t *seq_len, int t, int B, int H,
+                                                            float *dgates, float *dc_prev, float *dh_carry) {
     const int64_t total = (int64_t)B * H;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int b = (int)(i / H), h = (int)(i - (int64_t)b * H);
         const float *a = acts + (int64_t)b * 4 * H + h;
         float *dg = dgates + (int64_t)b * 4 * H + h;
         const bool live = (int64_t)t < seq_len[b];
-        const float dhv = dh[i], dcv = dc[i];
+        float dhv = dh[i];                                     // carried / injected part of d(loss)/d(h_t)
+        for (int s = 0; s < nslabs; ++s) dhv += dh_slabs[s * slab_stride + i];   // + dgates_{t+1}*Wh^T (split-K slabs)
+        const float dcv = dc[i];
         if (live) {
             const float si = a[0], tj = a[H], sf = a[2 * H], so = a[3 * H];
             const float tc = tanhf(c_t[i]);
@@ -238,22 +247,28 @@ extern "C" int ds_gather_rows(const float *table, const int64_t *ids, float *out
     return ds::check_launch("ds_gather_rows");
 }
 
-extern "C" int ds_lstm_cell_fwd(float *gates, const float *c_prev, const float *h_prev, const int64_t *seq_len,
-                                int32_t t, int32_t B, int32_t H, float forget_bias, float *c_out, float *h_out,
-                                void *stream) {
-    DS_REQUIRE(gates && c_prev && h_prev && seq_len && c_out && h_out && B > 0 && H > 0, "ds_lstm_cell_fwd: bad argument");
+extern "C" int ds_lstm_cell_fwd(float *gates, const float *rec_slabs, int32_t nslabs, int64_t slab_stride,
+                                const float *c_prev, const float *h_prev, const int64_t *seq_len, int32_t t, int32_t B,
+                                int32_t H, float forget_bias, float *c_out, float *h_out, void *stream) {
+    DS_REQUIRE(gates && c_prev && h_prev && seq_len && c_out && h_out && B > 0 && H > 0 && nslabs >= 0 &&
+                   (nslabs == 0 || rec_slabs),
+               "ds_lstm_cell_fwd: bad argument");
     hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ds::stream_grid((int64_t)B * H, 256)), dim3(256), 0,
-                       (hipStream_t)stream, gates, c_prev, h_prev, seq_len, t, B, H, forget_bias, c_out, h_out);
+                       (hipStream_t)stream, gates, rec_slabs, nslabs, slab_stride, c_prev, h_prev, seq_len, t, B, H,
+                       forget_bias, c_out, h_out);
     return ds::check_launch("ds_lstm_cell_fwd");
 }
 
 extern "C" int ds_lstm_cell_bwd(const float *acts, const float *c_t, const float *c_prev, const float *dh,
-                                const float *dc, const int64_t *seq_len, int32_t t, int32_t B, int32_t H,
-                                float *dgates, float *dc_prev, float *dh_carry, void *stream) {
-    DS_REQUIRE(acts && c_t && c_prev && dh && dc && seq_len && dgates && dc_prev && dh_carry,
-               "ds_lstm_cell_bwd: null argument");
+                                const float *dh_slabs, int32_t nslabs, int64_t slab_stride, const float *dc,
+                                const int64_t *seq_len, int32_t t, int32_t B, int32_t H, float *dgates,
+                                float *dc_prev, float *dh_carry, void *stream) {
+    DS_REQUIRE(acts && c_t && c_prev && dh && dc && seq_len && dgates && dc_prev && dh_carry && nslabs >= 0 &&
+                   (nslabs == 0 || dh_slabs),
+               "ds_lstm_cell_bwd: bad argument");
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ds::stream_grid((int64_t)B * H, 256)), dim3(256), 0,
-                       (hipStream_t)stream, acts, c_t, c_prev, dh, dc, seq_len, t, B, H, dgates, dc_prev, dh_carry);
+                       (hipStream_t)stream, acts, c_t, c_prev, dh, dh_slabs, nslabs, slab_stride, dc, seq_len, t, B,
+                       H, dgates, dc_prev, dh_carry);
     return ds::check_launch("ds_lstm_cell_bwd");
 }
 

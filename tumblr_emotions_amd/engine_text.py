@@ -66,8 +66,17 @@ class TextTowerEngine:
         self.gwx, self.gwh = _vp(gk), _vp(gk + 4 * D * 4 * H)
         self.gbias = st.grad_view(self.BIAS)
         self.xproj = gemm_plan(T * B, D, 4 * H, D, 4 * H, 4 * H, flags=DS_EPI_BIAS)
-        self.rec = gemm_plan(B, H, 4 * H, H, 4 * H, 4 * H, flags=DS_EPI_ACCUM)
-        self.rec_dgrad = gemm_plan(B, 4 * H, H, 4 * H, H, 4 * H, transposed_w=True, flags=DS_EPI_ACCUM)
+        # The per-step GEMMs have M = B rows only: split K so that ~2 workgroups per CU exist, each
+        # split writing its own slab; the cell kernels add the slabs (deterministic, no atomics).
+        def nsplit(m, n, k):
+            blocks = -(-m // 128) * -(-n // 32)
+            return int(max(1, min(512 // max(blocks, 1), (k // 16) // 4)))
+        self.sf, self.sb = nsplit(B, 4 * H, H), nsplit(B, H, 4 * H)
+        self.rec_slabs = torch.empty(self.sf, B, 4 * H, device=dev)
+        self.dh_slabs = torch.empty(self.sb, B, H, device=dev)
+        self.rec = gemm_plan(B, H, 4 * H, H, 4 * H, 4 * H, splits=self.sf, z_split_stride=B * 4 * H)
+        self.rec_dgrad = gemm_plan(B, 4 * H, H, 4 * H, H, 4 * H, transposed_w=True, splits=self.sb,
+                                   z_split_stride=B * H)
         self.wgrad_x = _gemm_wgrad(T * B, D, 4 * H, D, 4 * H)
         self.wgrad_h = _gemm_wgrad(T * B, H, 4 * H, H, 4 * H)
         self.ws_bytes = max(self.wgrad_x.ws_bytes, self.wgrad_h.ws_bytes)
@@ -83,10 +92,14 @@ class TextTowerEngine:
         self.seq_lens = seq_lens
         ops.gather_rows(self.table, texts, self.x, B, T, self.D, time_major=True)
         self.xproj.run(ops._p(self.x), self.wx, ops._p(self.gates), bias=self.bias)
+        slab = B * 4 * H
         for t in range(T):
-            g = self.gates[t]
-            self.rec.run(ops._p(self.h[t]), self.wh, ops._p(g))
-            ops.lstm_cell_fwd(g, self.c[t], self.h[t], seq_lens, t, B, H, FORGET_BIAS, self.c[t + 1], self.h[t + 1])
+            ns = 0
+            if t > 0:           # h_0 = 0: the first step has no recurrent term
+                self.rec.run(ops._p(self.h[t]), self.wh, ops._p(self.rec_slabs))
+                ns = self.sf
+            ops.lstm_cell_fwd(self.gates[t], self.c[t], self.h[t], seq_lens, t, B, H, FORGET_BIAS, self.c[t + 1],
+                              self.h[t + 1], self.rec_slabs, ns, slab)
         return self.h[T]
 
     def backward(self, dh_last):
@@ -94,11 +107,14 @@ class TextTowerEngine:
         dh, dh2 = self.dh
         ops.copy2d(dh_last, dh_last.stride(0), dh, H, B, H)
         ops.fill(self.dc, B * H, 0.0)
+        ns = 0                  # d(h_{T-1}) is just the injected gradient
         for t in range(T - 1, -1, -1):
+            # d(h_t) = carried part (dh) + dgates_{t+1} * Wh^T (split-K slabs from the previous iteration)
             ops.lstm_cell_bwd(self.gates[t], self.c[t + 1], self.c[t], dh, self.dc, self.seq_lens, t, B, H,
-                              self.dgates[t], self.dc, dh2)
+                              self.dgates[t], self.dc, dh2, self.dh_slabs, ns, B * H)
             if t > 0:
-                self.rec_dgrad.run(ops._p(self.dgates[t]), self.wh, ops._p(dh2))
+                self.rec_dgrad.run(ops._p(self.dgates[t]), self.wh, ops._p(self.dh_slabs))
+                ns = self.sb
             dh, dh2 = dh2, dh
         dg = ops._p(self.dgates)
         self.wgrad_x.run(ops._p(self.x), dg, self.gwx, ops._p(self.ws), self.ws_bytes)

@@ -46,7 +46,8 @@ class ConvPlan:
     """A ds_conv_desc plus its launch-derived constants, built once per layer."""
 
     def __init__(self, N, H, W, Cin, ldx, KH, KW, stride, Cout, ldz, w_tap_stride, w_n_stride, w_k_stride,
-                 flip=0, fold_cin=0, flags=0, ldmask=0, pad_t=None, pad_l=None, OH=None, OW=None):
+                 flip=0, fold_cin=0, flags=0, ldmask=0, pad_t=None, pad_l=None, OH=None, OW=None,
+                 splits=1, z_split_stride=0):
         d = ConvDesc()
         d.N, d.H, d.W, d.Cin, d.ldx = N, H, W, Cin, ldx
         d.KH, d.KW, d.stride = KH, KW, stride
@@ -59,6 +60,7 @@ class ConvPlan:
         d.Cout, d.ldz = Cout, ldz
         d.w_tap_stride, d.w_n_stride, d.w_k_stride = w_tap_stride, w_n_stride, w_k_stride
         d.flip, d.fold_cin, d.flags, d.ldmask = flip, fold_cin, flags, ldmask
+        d.splits, d.z_split_stride = splits, z_split_stride
         self.d = d
         self.M = N * OH * OW
         self.partials = _lib.load().ds_conv_igemm_partials(C.byref(d)) if flags & DS_EPI_STATS else 0
@@ -101,14 +103,15 @@ class ConvTimer:
 CONV_TIMER = None      # set to a ConvTimer to time the dominant kernel
 
 
-def gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=False, flags=0, ldmask=0):
+def gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=False, flags=0, ldmask=0, splits=1, z_split_stride=0):
     """C[M,N] = A[M,K] * W (row-major W[K,N] with row stride w_ld), or * W^T when transposed_w
-    (then W is [N,K] row-major): both are read in place."""
+    (then W is [N,K] row-major): both are read in place.  splits>1: split-K, slab s of partial
+    sums at C + s*z_split_stride (the consumer adds the slabs)."""
     if transposed_w:
         return ConvPlan(M, 1, 1, K, lda, 1, 1, 1, N, ldc, 0, w_ld, 1, flags=flags, ldmask=ldmask,
-                        pad_t=0, pad_l=0, OH=1, OW=1)
+                        pad_t=0, pad_l=0, OH=1, OW=1, splits=splits, z_split_stride=z_split_stride)
     return ConvPlan(M, 1, 1, K, lda, 1, 1, 1, N, ldc, 0, 1, w_ld, flags=flags, ldmask=ldmask,
-                    pad_t=0, pad_l=0, OH=1, OW=1)
+                    pad_t=0, pad_l=0, OH=1, OW=1, splits=splits, z_split_stride=z_split_stride)
 
 
 class WgradPlan:
@@ -197,14 +200,18 @@ def gather_rows(table, ids, out, B, T, D, time_major=True):
                                           _stream()), "ds_gather_rows")
 
 
-def lstm_cell_fwd(gates, c_prev, h_prev, seq_len, t, B, H, forget_bias, c_out, h_out):
-    _lib.check(_lib.load().ds_lstm_cell_fwd(_p(gates), _p(c_prev), _p(h_prev), _p(seq_len), t, B, H, forget_bias,
-                                            _p(c_out), _p(h_out), _stream()), "ds_lstm_cell_fwd")
+def lstm_cell_fwd(gates, c_prev, h_prev, seq_len, t, B, H, forget_bias, c_out, h_out, rec_slabs=None, nslabs=0,
+                  slab_stride=0):
+    _lib.check(_lib.load().ds_lstm_cell_fwd(_p(gates), _p(rec_slabs), nslabs, slab_stride, _p(c_prev), _p(h_prev),
+                                            _p(seq_len), t, B, H, forget_bias, _p(c_out), _p(h_out), _stream()),
+               "ds_lstm_cell_fwd")
 
 
-def lstm_cell_bwd(acts, c_t, c_prev, dh, dc, seq_len, t, B, H, dgates, dc_prev, dh_carry):
-    _lib.check(_lib.load().ds_lstm_cell_bwd(_p(acts), _p(c_t), _p(c_prev), _p(dh), _p(dc), _p(seq_len), t, B, H,
-                                            _p(dgates), _p(dc_prev), _p(dh_carry), _stream()), "ds_lstm_cell_bwd")
+def lstm_cell_bwd(acts, c_t, c_prev, dh, dc, seq_len, t, B, H, dgates, dc_prev, dh_carry, dh_slabs=None, nslabs=0,
+                  slab_stride=0):
+    _lib.check(_lib.load().ds_lstm_cell_bwd(_p(acts), _p(c_t), _p(c_prev), _p(dh), _p(dh_slabs), nslabs, slab_stride,
+                                            _p(dc), _p(seq_len), t, B, H, _p(dgates), _p(dc_prev), _p(dh_carry),
+                                            _stream()), "ds_lstm_cell_bwd")
 
 
 def softmax_ce(logits, labels, B, C_, grad_scale, grad_scale_dev, loss, dlogits):
