@@ -64,8 +64,11 @@ __device__ __forceinline__ f32x4 load4(__amdgpu_buffer_rsrc_t r, unsigned off, b
     }
 }
 
+// second launch-bound = waves per SIMD the register allocator must leave room for: the small tiles
+// are the workhorses and measured fastest at 3-4 resident workgroups per CU
 template <int MT, int NT, bool BNMAJOR, bool FOLD, bool VEC>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2) ? 3 : 1) void conv_igemm_kernel(
+    const ConvParams p) {
     constexpr int WM = 4;
     constexpr int BM = WM * MT * 32, BN = NT * 32;
     constexpr int AR = BM / 64;                       // float4 A loads per thread per K-tile
@@ -118,10 +121,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         b_ok[i] = idx < BN * 4 && b_n[i] < d.Cout;
     }
 
-    for (int tile = blockIdx.x; tile < p.row_tiles; tile += gridDim.x) {
+    // ---- loader state: the row tile and K-tile that the next load_tile() fetches ------------------
+    int ih0[AR], iw0[AR];
+    unsigned xb[AR];         // element offset of the image that row i belongs to
+    int tap, c0, dh, dw;
+    f32x4 ra[AR], rb[BR];
+    f32x16 acc[MT][NT];
+
+    auto setup_tile = [&](int tile) {      // point the loader at the first K-tile of row tile `tile`
         const int m0 = tile * BM;
-        int ih0[AR], iw0[AR];
-        unsigned xb[AR];     // element offset of the image that row i belongs to
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int m = m0 + arow + 64 * i;
@@ -135,19 +143,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             iw0[i] = ow * d.stride - d.pad_l;
             xb[i] = (unsigned)n * (unsigned)(d.H * d.W) * (unsigned)d.ldx;
         }
+        tap = kt0 / chunks;
+        c0 = (kt0 - tap * chunks) * BK;
+        dh = tap / d.KW;
+        dw = tap - dh * d.KW;
+    };
 
-        f32x16 acc[MT][NT];
-#pragma unroll
-        for (int a = 0; a < MT; ++a)
-#pragma unroll
-            for (int b = 0; b < NT; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-        f32x4 ra[AR], rb[BR];
-        // K-tile that the next load_tile() fetches (starts at this split's first tile)
-        int tap = kt0 / chunks, c0 = (kt0 - tap * chunks) * BK;
-        int dh = tap / d.KW, dw = tap - dh * d.KW;
+    {
 
         auto load_tile = [&]() {
             // ---- A: activations ----------------------------------------------------------------
@@ -232,15 +234,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][s], bf[b][s], acc[a][b], 0, 0, 0);
         };
 
+    // One continuous software pipeline over (row tile, K-tile): while the MFMAs of K-tile kt run, the
+    // loads of kt+1 are in flight; on the LAST K-tile of a row tile the loads already belong to the
+    // first K-tile of the NEXT row tile, so the pipeline never drains between tiles and the epilogue
+    // of tile t starts with tile t+1's operands already staged in LDS.
+    int par = 0;                                   // LDS buffer holding the K-tile about to be computed
+    if (blockIdx.x < p.row_tiles) {
+        setup_tile(blockIdx.x);
         load_tile();
         store_tile(0);
-        __syncthreads();
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < p.row_tiles; tile += gridDim.x) {
+        const int m0 = tile * BM;
+        const bool has_next = tile + (int)gridDim.x < p.row_tiles;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
         for (int kt = 0; kt < KT; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < KT) load_tile();
-            compute(cur);
-            if (kt + 1 < KT) store_tile(cur ^ 1);
+            const bool last = kt + 1 == KT;
+            if (last && has_next) setup_tile(tile + gridDim.x);
+            const bool fetch = !last || has_next;
+            if (fetch) load_tile();
+            compute(par);
+            if (fetch) store_tile(par ^ 1);
             __syncthreads();
+            par ^= 1;
         }
 
         // ---- epilogue: bias / accumulate / mask / relu, store, BatchNorm column statistics -------
@@ -270,6 +292,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             csum[b] += s;
             csq[b] += q;
         }
+    }
     }
 
     if (flags & DS_EPI_STATS) {

@@ -90,6 +90,153 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *dy, const
     }
 }
 
+// ---- 3x3 pools with a rolling window -----------------------------------------------------------
+// A thread owns one (image, output column, 4-channel group) and walks down the rows keeping the
+// per-row maxima of the last rows in registers: 3*stride neighbour loads per output instead of 9
+// (the 3x3/1 pools of the nine Inception blocks read every input 9x otherwise).  The arg-max is
+// separable too: first maximum inside a row (kw), then first row holding the maximum (kh), which
+// is the row-major first maximum the reference semantics ask for.
+struct RowMax {
+    float v[4];
+    int k[4];
+};
+
+__device__ __forceinline__ RowMax row_max3(const float *x, int64_t row_base, int iw0, int W, int C, int c, bool row_ok) {
+    RowMax r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r.v[j] = -INFINITY;
+        r.k[j] = 0;
+    }
+    if (!row_ok) return r;
+    bool any = false;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int iw = iw0 + kw;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const float4 v = *reinterpret_cast<const float4 *>(x + (row_base + iw) * C + c);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (!any || vv[j] > r.v[j]) {
+                r.v[j] = vv[j];
+                r.k[j] = kw;
+            }
+        any = true;
+    }
+    return r;
+}
+
+template <int STRIDE>
+__global__ __launch_bounds__(256) void maxpool3_fwd_rolling(const float *x, float *y, uint8_t *am, int N, int H, int W,
+                                                            int C, int pad_t, int pad_l, int OH, int OW) {
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)N * OW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        const int ow = (int)((i / C4) % OW);
+        const int n = (int)(i / ((int64_t)C4 * OW));
+        const int iw0 = ow * STRIDE - pad_l;
+        const int64_t img = (int64_t)n * H;
+        RowMax r0, r1, r2;      // input rows ih0, ih0+1, ih0+2 of the current output row
+        int ih0 = -pad_t;
+        r0 = row_max3(x, (img + ih0) * W, iw0, W, C, c, (unsigned)ih0 < (unsigned)H);
+        r1 = row_max3(x, (img + ih0 + 1) * W, iw0, W, C, c, (unsigned)(ih0 + 1) < (unsigned)H);
+        for (int oh = 0; oh < OH; ++oh) {
+            r2 = row_max3(x, (img + ih0 + 2) * W, iw0, W, C, c, (unsigned)(ih0 + 2) < (unsigned)H);
+            float best[4];
+            int arg[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {      // strict '>' keeps the first (lowest kh) maximum
+                best[j] = r0.v[j];
+                arg[j] = r0.k[j];
+                if (r1.v[j] > best[j]) { best[j] = r1.v[j]; arg[j] = 3 + r1.k[j]; }
+                if (r2.v[j] > best[j]) { best[j] = r2.v[j]; arg[j] = 6 + r2.k[j]; }
+            }
+            const int64_t o = (((int64_t)n * OH + oh) * OW + ow) * C + c;
+            *reinterpret_cast<float4 *>(y + o) = make_float4(best[0], best[1], best[2], best[3]);
+            if (am) *reinterpret_cast<uchar4 *>(am + o) = make_uchar4(arg[0], arg[1], arg[2], arg[3]);
+            if (STRIDE == 1) {
+                r0 = r1;
+                r1 = r2;
+            } else {
+                r0 = r2;
+                r1 = row_max3(x, (img + ih0 + 3) * W, iw0, W, C, c, (unsigned)(ih0 + 3) < (unsigned)H);
+            }
+            ih0 += STRIDE;
+        }
+    }
+}
+
+// MaxPoolGrad of the 3x3 stride-1 SAME pool: input pixel (ih, iw) lies in the windows (oh, ow) with
+// oh in [ih-1, ih+1], ow in [iw-1, iw+1]; window (oh, ow) names it iff argmax == (ih-oh+1)*3 + (iw-ow+1).
+struct WinRow {
+    float d[3][4];
+    unsigned a[3];      // packed uchar4 arg-max of the three windows of one output row
+};
+
+__device__ __forceinline__ WinRow load_win_row(const float *dy, const uint8_t *am, int64_t row_base, int iw, int W, int C,
+                                               int c, bool row_ok) {
+    WinRow r;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int ow = iw - 1 + q;
+        const bool ok = row_ok && (unsigned)ow < (unsigned)W;
+        r.a[q] = 0xFFFFFFFFu;      // never matches a window index
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.d[q][j] = 0.f;
+        if (ok) {
+            const int64_t o = (row_base + ow) * C + c;
+            r.a[q] = *reinterpret_cast<const unsigned *>(am + o);
+            const float4 v = *reinterpret_cast<const float4 *>(dy + o);
+            r.d[q][0] = v.x; r.d[q][1] = v.y; r.d[q][2] = v.z; r.d[q][3] = v.w;
+        }
+    }
+    return r;
+}
+
+__device__ __forceinline__ void win_row_grad(const WinRow &w, int p, float g[4]) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {      // output col ow = iw-1+q  -> kw = 2-q
+        const unsigned t = (unsigned)((2 - p) * 3 + (2 - q));
+        const unsigned a = w.a[q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (((a >> (8 * j)) & 0xFFu) == t) g[j] += w.d[q][j];
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool3s1_bwd_rolling(const float *dy, const uint8_t *am, float *dx,
+                                                              int accumulate, int N, int H, int W, int C) {
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)N * W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        const int iw = (int)((i / C4) % W);
+        const int n = (int)(i / ((int64_t)C4 * W));
+        const int64_t img = (int64_t)n * H;
+        WinRow w0, w1, w2;      // output rows ih-1, ih, ih+1
+        w0 = load_win_row(dy, am, (img - 1) * W, iw, W, C, c, false);
+        w1 = load_win_row(dy, am, img * W, iw, W, C, c, true);
+        for (int ih = 0; ih < H; ++ih) {
+            w2 = load_win_row(dy, am, (img + ih + 1) * W, iw, W, C, c, ih + 1 < H);
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+            win_row_grad(w0, 0, g);                // output row oh = ih-1+p  -> kh = 2-p
+            win_row_grad(w1, 1, g);
+            win_row_grad(w2, 2, g);
+            float4 *dst = reinterpret_cast<float4 *>(dx + ((img + ih) * W + iw) * C + c);
+            float4 out = make_float4(g[0], g[1], g[2], g[3]);
+            if (accumulate) {
+                const float4 e = *dst;
+                out.x += e.x; out.y += e.y; out.z += e.z; out.w += e.w;
+            }
+            *dst = out;
+            w0 = w1;
+            w1 = w2;
+        }
+    }
+}
+
 // counter-based uniform in [0,1): splitmix64 finaliser over (seed, element index)
 __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
     uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
@@ -149,6 +296,16 @@ extern "C" int ds_maxpool_fwd(const float *x, float *y, uint8_t *argmax, int32_t
                               int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW,
                               void *stream) {
     DS_REQUIRE(x && y && C % 4 == 0 && k >= 1 && k <= 15 && stride >= 1, "ds_maxpool_fwd: bad argument (C %% 4?)");
+    if (k == 3 && (stride == 1 || stride == 2)) {      // every 3x3 pool of Inception-v1: rolling window
+        const int64_t cols = (int64_t)N * OW * (C / 4);
+        if (stride == 1)
+            hipLaunchKernelGGL(maxpool3_fwd_rolling<1>, dim3(ds::stream_grid(cols, 256)), dim3(256), 0,
+                               (hipStream_t)stream, x, y, argmax, N, H, W, C, pad_t, pad_l, OH, OW);
+        else
+            hipLaunchKernelGGL(maxpool3_fwd_rolling<2>, dim3(ds::stream_grid(cols, 256)), dim3(256), 0,
+                               (hipStream_t)stream, x, y, argmax, N, H, W, C, pad_t, pad_l, OH, OW);
+        return ds::check_launch("ds_maxpool_fwd");
+    }
     const int64_t total = (int64_t)N * OH * OW * (C / 4);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ds::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
                        argmax, N, H, W, C, k, stride, pad_t, pad_l, OH, OW);
@@ -159,6 +316,11 @@ extern "C" int ds_maxpool_bwd(const float *dy, const uint8_t *argmax, float *dx,
                               int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
                               int32_t OH, int32_t OW, void *stream) {
     DS_REQUIRE(dy && argmax && dx && C % 4 == 0, "ds_maxpool_bwd: bad argument");
+    if (k == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && OH == H && OW == W) {
+        hipLaunchKernelGGL(maxpool3s1_bwd_rolling, dim3(ds::stream_grid((int64_t)N * W * (C / 4), 256)), dim3(256), 0,
+                           (hipStream_t)stream, dy, argmax, dx, accumulate, N, H, W, C);
+        return ds::check_launch("ds_maxpool_bwd");
+    }
     const int64_t total = (int64_t)N * H * W * (C / 4);
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ds::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dy,
                        argmax, dx, accumulate, N, H, W, C, k, stride, pad_t, pad_l, OH, OW);
