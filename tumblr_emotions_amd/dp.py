@@ -1,0 +1,84 @@
+"""Data parallelism for the Deep Sentiment step: one process per GPU, RCCL over xGMI.
+
+The reference has no distributed code of its own; the only data-parallel semantics in the tree are
+slim's in-graph clones (slim/deployment/model_deploy.py): per-clone loss divided by num_clones
+(:221-223), clone gradients summed (:414-444), the regularisation term counted once (:301-302),
+BatchNorm statistics and moving averages per clone (:353-355).  Here that becomes:
+
+  * rank r trains on the r-th contiguous slice of the same seeded global batch;
+  * gradients of all trainable variables lie in ONE flat fp32 buffer (params.ParamStore), laid out
+    [ bucket 1: L2-regularised conv weights | Logits bias, LSTM, heads, Mixed_5c betas ][ bucket 2:
+    BatchNorm betas below Mixed_5c ];
+  * bucket 1 (~14.7 MB at the BASELINE dims) is complete as soon as Mixed_5c's backward is done, so
+    its sum-all-reduce is launched right there on a side stream and overlaps the remaining ~90 % of
+    the Inception backward (dgrad through 5b ... 2b); bucket 2 (~25 KB) is reduced at the end;
+  * the 1/world scale and the L2 gradient are applied inside the fused Adam kernel, after the
+    reduction (L2 counted once, like slim);
+  * BatchNorm uses per-rank batch statistics (slim keeps them per clone).
+
+Nothing here needs a GPU: the same functions run under gloo on CPU tensors (tests/test_dp_cpu.py).
+"""
+import torch
+import torch.distributed as dist
+
+
+def world_info(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous slice [lo, hi) of a global batch of n samples owned by `rank`."""
+    return rank * n // world, (rank + 1) * n // world
+
+
+class GradientReducer:
+    """Sum-all-reduce of the flat gradient in two buckets, the first one optionally launched early on
+    a side stream (overlap with the rest of the backward pass)."""
+
+    def __init__(self, flat_grad, n_bucket1, group=None, overlap=True):
+        self.g, self.n1, self.group = flat_grad, int(n_bucket1), group
+        self.rank, self.world = world_info(group)
+        self.overlap = overlap and self.world > 1 and flat_grad.is_cuda
+        self.stream = torch.cuda.Stream() if self.overlap else None
+        self._pending = None
+        self._ready = set()
+        self._needed = set()
+
+    # -- early launch of bucket 1 ----------------------------------------------------------------
+    def expect(self, *names):
+        """Names of the backward stages that must have finished before bucket 1 is complete."""
+        self._needed = set(names)
+
+    def begin_step(self):
+        self._ready.clear()
+        self._pending = None
+
+    def stage_done(self, name):
+        """Called by the engines from inside backward(); launches bucket 1 when the last stage reports."""
+        if self.world == 1:
+            return
+        self._ready.add(name)
+        if self.overlap and self._pending is None and self._needed and self._needed <= self._ready:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self._pending = dist.all_reduce(self.g[:self.n1], op=dist.ReduceOp.SUM, group=self.group,
+                                                async_op=True)
+
+    # -- end of backward -------------------------------------------------------------------------
+    def finish(self):
+        """Reduce whatever has not been reduced yet and make the current stream wait for all of it.
+        Returns the scale (1/world) the optimiser must apply to the summed gradient."""
+        if self.world == 1:
+            return 1.0
+        if self._pending is not None:
+            self._pending.wait()
+            if self.stream is not None:
+                torch.cuda.current_stream().wait_stream(self.stream)
+        else:
+            dist.all_reduce(self.g[:self.n1], op=dist.ReduceOp.SUM, group=self.group)
+        if self.g.numel() > self.n1:
+            dist.all_reduce(self.g[self.n1:], op=dist.ReduceOp.SUM, group=self.group)
+        self._pending = None
+        return 1.0 / self.world

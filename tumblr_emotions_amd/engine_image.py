@@ -304,6 +304,7 @@ class InceptionV1Engine:
         self.trainable_bn_beta = trainable_bn_beta
         self.device = torch.device(device)
         self.update_moving = True
+        self.reducer = None          # dp.GradientReducer, set by SentimentNet
         self._stats_n = self._bwdp_n = self._ws_bytes = 0
         self.B = None
         self.input = InputStage(self, image_size)
@@ -403,3 +404,7 @@ class InceptionV1Engine:
             stop = min(i for i, s in enumerate(self.stages) if any(l.trainable for l in s.layers))
         for i in range(n - 1, stop - 1, -1):
             self.stages[i].backward(need_dx=(i > stop))
+            if self.reducer is not None and self.stages[i].name in TRAINABLE_ENDPOINTS:
+                # every conv-weight gradient and the Logits gradients now sit in bucket 1 of the flat
+                # gradient: its all-reduce can start while dgrad continues through the frozen blocks
+                self.reducer.stage_done(self.stages[i].name)

@@ -44,6 +44,7 @@ class TextTowerEngine:
         store.declare(self.KERNEL, (embed_dim + rnn_size, 4 * rnn_size), True, bucket=1)
         store.declare(self.BIAS, (4 * rnn_size,), True, bucket=1)
         self.B = None
+        self.reducer = None          # dp.GradientReducer, set by SentimentNet
 
     def alloc(self, B):
         if self.B == B:
@@ -120,6 +121,8 @@ class TextTowerEngine:
         self.wgrad_x.run(ops._p(self.x), dg, self.gwx, ops._p(self.ws), self.ws_bytes)
         self.wgrad_h.run(ops._p(self.h), dg, self.gwh, ops._p(self.ws), self.ws_bytes)
         ops.colsum(self.dgates, T * B, 4 * H, 4 * H, self.colsum_scratch, self.gbias)
+        if self.reducer is not None:
+            self.reducer.stage_done("text")
 
 
 class JointHeadEngine:
@@ -133,6 +136,7 @@ class JointHeadEngine:
         store.declare("W_softmax", (fc_size, nb_emotions), True, bucket=1)
         store.declare("b_softmax", (nb_emotions,), True, bucket=1)
         self.B = None
+        self.reducer = None          # dp.GradientReducer, set by SentimentNet
 
     def alloc(self, B):
         if self.B == B:
@@ -195,6 +199,8 @@ class JointHeadEngine:
         ops.colsum(self.ddense, B, fc, fc, self.colsum_scratch, self.gb_fc)
         self.im_dgrad.run(dd, self.w_im, ops._p(self.d_im))
         self.tx_dgrad.run(dd, self.w_tx, ops._p(self.d_tx))
+        if self.reducer is not None:
+            self.reducer.stage_done("head")
         return self.d_im, self.d_tx
 
 
@@ -207,6 +213,7 @@ class TextHeadEngine:
         store.declare("W_softmax", (rnn_size, nb_emotions), True, bucket=1)
         store.declare("b_softmax", (nb_emotions,), True, bucket=1)
         self.B = None
+        self.reducer = None          # dp.GradientReducer, set by SentimentNet
 
     def alloc(self, B):
         if self.B == B:
@@ -237,4 +244,6 @@ class TextHeadEngine:
         self.sm_wgrad.run(ops._p(self.tx_feat), dl, self.gw_sm, ops._p(self.ws), self.ws_bytes)
         ops.colsum(dlogits, self.B, self.nc, self.nc, self.colsum_scratch, self.gb_sm)
         self.sm_dgrad.run(dl, self.w_sm, ops._p(self.d_tx))
+        if self.reducer is not None:
+            self.reducer.stage_done("head")
         return self.d_tx

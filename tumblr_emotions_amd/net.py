@@ -19,6 +19,7 @@ from .engine_image import InceptionV1Engine, WEIGHT_DECAY
 from .engine_text import JointHeadEngine, TextHeadEngine, TextTowerEngine
 from .functions import (InceptionV1Function, JointHeadFunction, SoftmaxCrossEntropyFunction, TextHeadFunction,
                         TextTowerFunction)
+from .dp import GradientReducer
 from .params import ParamStore
 
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-8      # tf.train.AdamOptimizer defaults (:134)
@@ -59,11 +60,14 @@ class SentimentNet:
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.dlogits = None
         self.pg = process_group
-        self.world = 1
-        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            self.world = torch.distributed.get_world_size(process_group)
-        self.overlap_comm = overlap_comm and self.world > 1
-        self.comm_stream = torch.cuda.Stream() if self.world > 1 else None
+        self.reducer = GradientReducer(st.grad, st.n_bucket1, process_group, overlap_comm)
+        self.world = self.reducer.world
+        # bucket 1 of the flat gradient is complete once these backward stages have run
+        self.reducer.expect(*[n for n, e in (("Mixed_5c", self.image), ("text", self.text), ("head", self.head))
+                              if e is not None])
+        for e in (self.image, self.text, self.head):
+            if e is not None:
+                e.reducer = self.reducer
         self.logits = None
 
     # ---- variables --------------------------------------------------------------------------------
@@ -145,11 +149,13 @@ class SentimentNet:
         """batch: dict with device tensors images [B,224,224,3] f32, texts [B,T] i64, seq_lens [B] i64."""
         L = self.leaves
         tx = im = None
+        # image tower first: autograd runs later-created nodes first, so the (short) text backward runs
+        # before the Inception backward and bucket 1 of the gradient is complete right after Mixed_5c
+        if self.image is not None:
+            im = InceptionV1Function.apply(self.image, batch["images"], dropout_mask, seed, *self.image_params)
         if self.text is not None:
             tx = TextTowerFunction.apply(self.text, batch["texts"], batch["seq_lens"], L[self.text.KERNEL],
                                          L[self.text.BIAS])
-        if self.image is not None:
-            im = InceptionV1Function.apply(self.image, batch["images"], dropout_mask, seed, *self.image_params)
         if self.mode == "image":
             self.logits = im
         elif self.mode == "text":
@@ -182,22 +188,11 @@ class SentimentNet:
         ce = self.cross_entropy(logits, batch["labels"])
         if st.n_l2 > 0:      # trainable part of the L2 loss, on the pre-update weights
             ops.sumsq(st.theta, st.n_l2, self.l2_scratch, self.l2_buf)
-        ce.backward()
-        grad_scale = 1.0
-        if self.world > 1:
-            self._allreduce_grads()
-            grad_scale = 1.0 / self.world
+        self.reducer.begin_step()
+        ce.backward()          # engines call reducer.stage_done(...): bucket 1 is all-reduced under the backward
+        grad_scale = self.reducer.finish()
         t = self.step
         lr_t = lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
         ops.adam_tf(st.theta, st.grad, st.m, st.v, st.n_trainable_padded, st.n_l2, WEIGHT_DECAY, grad_scale, lr_t,
                     ADAM_B1, ADAM_B2, ADAM_EPS)
         return ce
-
-    def _allreduce_grads(self):
-        """Sum-all-reduce of the flat gradient (RCCL over xGMI).  Bucket 1 = [0, n_bucket1): everything
-        complete once Mixed_5c's backward is done; bucket 2 = upstream BatchNorm betas."""
-        import torch.distributed as dist
-        g, n1 = self.store.grad, self.store.n_bucket1
-        dist.all_reduce(g[:n1], op=dist.ReduceOp.SUM, group=self.pg)
-        if g.numel() > n1:
-            dist.all_reduce(g[n1:], op=dist.ReduceOp.SUM, group=self.pg)
