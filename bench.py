@@ -50,6 +50,22 @@ def cpu_baseline(batch, steps, post_size, vocab, dim, rnn):
                        "logical CPUs" % (batch, steps, os.cpu_count()))
 
 
+def pmc_traffic(args):
+    """HBM bytes per conv_igemm launch from the committed rocprofv3 PMC passes of THIS workload
+    (profiles/rNN_pmc.json, made by scripts/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs,
+    FETCH doubled as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the timed
+    process, so the figure is null unless a profile of the default workload is present."""
+    import glob
+    if args.batch != 256 or args.mode != "joint" or args.gpus != 1:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return round(d["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,9 +133,11 @@ def main():
         if timer is not None:
             n, ms, flops = timer.summary()
             ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            traffic, traffic_src = pmc_traffic(args)
             roof = dict(bound="mfma", kernel="conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32; conv fwd, dgrad, GEMMs)",
                         achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_unit="HBM bytes per launch",
+                        traffic_source=traffic_src, alg_flops_per_launch=round(flops / max(n, 1)),
                         launches_per_step=n // max(args.steps, 1), avg_launch_us=round(1e3 * ms / max(n, 1), 2),
                         kernel_time_share=round(ms * 1e-3 / dt, 3),
                         whole_step_tflops=round(value * flop_per_sample / 1e3, 2),

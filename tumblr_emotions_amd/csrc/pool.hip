@@ -46,9 +46,12 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float *x, float 
     }
 }
 
+// KK/SS > 0 fix the window / stride at compile time (the divisions below become shifts)
+template <int KK, int SS>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *dy, const uint8_t *am, float *dx,
-                                                          int accumulate, int N, int H, int W, int C, int k,
-                                                          int stride, int pad_t, int pad_l, int OH, int OW) {
+                                                          int accumulate, int N, int H, int W, int C, int k_rt,
+                                                          int stride_rt, int pad_t, int pad_l, int OH, int OW) {
+    const int k = KK > 0 ? KK : k_rt, stride = SS > 0 ? SS : stride_rt;
     const int C4 = C >> 2;
     const int64_t total = (int64_t)N * H * W * C4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -322,8 +325,16 @@ extern "C" int ds_maxpool_bwd(const float *dy, const uint8_t *argmax, float *dx,
         return ds::check_launch("ds_maxpool_bwd");
     }
     const int64_t total = (int64_t)N * H * W * (C / 4);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ds::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dy,
-                       argmax, dx, accumulate, N, H, W, C, k, stride, pad_t, pad_l, OH, OW);
+    const dim3 grid(ds::stream_grid(total, 256));
+    if (k == 3 && stride == 2)
+        hipLaunchKernelGGL((maxpool_bwd_kernel<3, 2>), grid, dim3(256), 0, (hipStream_t)stream, dy, argmax, dx,
+                           accumulate, N, H, W, C, k, stride, pad_t, pad_l, OH, OW);
+    else if (k == 2 && stride == 2)
+        hipLaunchKernelGGL((maxpool_bwd_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, dy, argmax, dx,
+                           accumulate, N, H, W, C, k, stride, pad_t, pad_l, OH, OW);
+    else
+        hipLaunchKernelGGL((maxpool_bwd_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, dy, argmax, dx,
+                           accumulate, N, H, W, C, k, stride, pad_t, pad_l, OH, OW);
     return ds::check_launch("ds_maxpool_bwd");
 }
 
