@@ -104,6 +104,10 @@ typedef struct ds_segments {
 } ds_segments;
 int ds_bn_apply_relu(const float *z, int64_t M, int32_t C, const float *rstd, const float *shift,
                      const ds_segments *dst, void *stream);
+/* slim.batch_norm with is_training=False (evaluate_*, mode != 'train': im_text_rnn_model.py:65,171-207):
+ * rstd = rsqrt(moving_variance + eps), shift = beta - moving_mean*rstd, then ds_bn_apply_relu.  */
+int ds_bn_infer_prepare(const float *beta, const float *moving_mean, const float *moving_var, float eps,
+                        int32_t C, float *rstd, float *shift, void *stream);
 
 /* BatchNorm(train)+ReLU backward: g = dy*(y>0); dbeta = sum g; dz = rstd*(g - mean(g) - xhat*mean(g*xhat)).
  * dy is gathered from the same segments the forward scattered to.                          */

@@ -233,6 +233,24 @@ extern "C" int ds_bn_finalize(const float *stats, int32_t P, int64_t count, int3
     return ds::check_launch("ds_bn_finalize");
 }
 
+__global__ __launch_bounds__(256) void bn_infer_prepare_kernel(const float *beta, const float *mm, const float *mv,
+                                                               float eps, int C, float *rstd, float *shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) {
+        const float r = 1.0f / sqrtf(mv[c] + eps);
+        rstd[c] = r;
+        shift[c] = beta[c] - mm[c] * r;
+    }
+}
+
+extern "C" int ds_bn_infer_prepare(const float *beta, const float *moving_mean, const float *moving_var, float eps,
+                                   int32_t C, float *rstd, float *shift, void *stream) {
+    DS_REQUIRE(beta && moving_mean && moving_var && rstd && shift && C > 0, "ds_bn_infer_prepare: bad argument");
+    hipLaunchKernelGGL(bn_infer_prepare_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, beta,
+                       moving_mean, moving_var, eps, C, rstd, shift);
+    return ds::check_launch("ds_bn_infer_prepare");
+}
+
 extern "C" int ds_bn_apply_relu(const float *z, int64_t M, int32_t C, const float *rstd, const float *shift,
                                 const ds_segments *dst, void *stream) {
     DS_REQUIRE(z && rstd && shift && M > 0 && C > 0 && C % 4 == 0, "ds_bn_apply_relu: bad argument (C %% 4 != 0?)");

@@ -119,10 +119,16 @@ class ConvBN:
         eng = self.eng
         if not self.fold:
             self.fwd.d.ldx = ldx
-        self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z), stats=ops._p(eng.stats))
-        ops.bn_finalize(eng.stats, self.fwd.partials, self.M, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
-                        self.rstd, self.shift, self.mm if eng.update_moving else None,
-                        self.mv if eng.update_moving else None)
+        if eng.training:       # batch statistics (slim.batch_norm is_training=True)
+            self.fwd.d.flags = DS_EPI_STATS
+            self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z), stats=ops._p(eng.stats))
+            ops.bn_finalize(eng.stats, self.fwd.partials, self.M, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
+                            self.rstd, self.shift, self.mm if eng.update_moving else None,
+                            self.mv if eng.update_moving else None)
+        else:                  # moving statistics (is_training=False: evaluate_* on the validation split)
+            self.fwd.d.flags = 0
+            self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z))
+            ops.bn_infer_prepare(self.beta, self.mm, self.mv, BN_EPS, self.cout, self.rstd, self.shift)
         ops.bn_apply_relu(self.z, self.M, self.cout, self.rstd, self.shift, segs)
 
     def backward(self, dy_segs, x_ptr=None, ldx=0, dx_ptr=None, need_dx=True):
@@ -304,6 +310,7 @@ class InceptionV1Engine:
         self.trainable_bn_beta = trainable_bn_beta
         self.device = torch.device(device)
         self.update_moving = True
+        self.training = True         # False: BatchNorm uses moving statistics, dropout is the identity
         self.reducer = None          # dp.GradientReducer, set by SentimentNet
         self._stats_n = self._bwdp_n = self._ws_bytes = 0
         self.B = None
@@ -383,8 +390,8 @@ class InceptionV1Engine:
         for s in self.stages:
             s.forward()
         last = self.last
-        ops.avgpool_dropout_fwd(last.out, B, last.H * last.W, self.feat, self.keep, seed, dropout_mask, self.mask,
-                                self.pooled)
+        ops.avgpool_dropout_fwd(last.out, B, last.H * last.W, self.feat, self.keep if self.training else 1.0, seed,
+                                dropout_mask, self.mask, self.pooled)
         self.fc.run(ops._p(self.pooled), self.w_fc, ops._p(self.logits), bias=self.b_fc)
         return self.logits
 

@@ -56,3 +56,11 @@ def train_image_model(checkpoints_dir, train_dir, num_steps, *, config=None, qui
     if init_fn is not None:
         init_fn(model.net)
     return run_training(model, train_dir, num_steps, quiet=quiet)
+
+
+def evaluate_image_model(checkpoint_dir, log_dir, mode, num_evals, *, config=None, quiet=False):
+    """Accuracy of the newest checkpoint on `mode` ('train' | 'validation') over num_evals batches
+    (im_model.py:227-262)."""
+    from ..training import run_evaluation
+    model = ImageModel(dict(_CONFIG, mode=mode, **(config or {})))
+    return run_evaluation(model, checkpoint_dir, log_dir, mode, num_evals, quiet=quiet)

@@ -66,3 +66,10 @@ def train_deep_sentiment(checkpoints_dir, train_dir, num_steps, *, config=None, 
     if init_fn is not None:
         init_fn(model.net)
     return run_training(model, train_dir, num_steps, quiet=quiet)
+
+
+def evaluate_deep_sentiment(checkpoint_dir, log_dir, mode, num_evals, *, config=None, quiet=False):
+    """Accuracy of the newest checkpoint (im_text_rnn_model.py:171-207)."""
+    from ..training import run_evaluation
+    model = DeepSentiment(dict(_CONFIG, mode=mode, **(config or {})))
+    return run_evaluation(model, checkpoint_dir, log_dir, mode, num_evals, quiet=quiet)

@@ -165,6 +165,19 @@ class SentimentNet:
                                                   L["b_softmax"])
         return self.logits
 
+    def predict(self, batch, is_training=False):
+        """Forward only (evaluate_*): is_training=False -> BatchNorm moving statistics, no dropout;
+        is_training=True reproduces the reference's evaluation on mode='train' (batch statistics and
+        dropout stay on, im_text_rnn_model.py:65) but never touches the moving averages."""
+        if self.image is not None:
+            self.image.training, self.image.update_moving = is_training, False
+        try:
+            with torch.no_grad():
+                return self.forward(batch, None, seed=0)
+        finally:
+            if self.image is not None:
+                self.image.training, self.image.update_moving = True, True
+
     def cross_entropy(self, logits, labels):
         if self.dlogits is None or self.dlogits.shape != logits.shape:
             self.dlogits = torch.empty(logits.shape, device=self.device)

@@ -145,6 +145,11 @@ def bn_apply_relu(z, M, C_, rstd, shift, segs):
                "ds_bn_apply_relu")
 
 
+def bn_infer_prepare(beta, mm, mv, eps, C_, rstd, shift):
+    _lib.check(_lib.load().ds_bn_infer_prepare(_p(beta), _p(mm), _p(mv), eps, C_, _p(rstd), _p(shift), _stream()),
+               "ds_bn_infer_prepare")
+
+
 def bn_bwd_partials(M, C_):
     return _lib.load().ds_bn_bwd_partials(M, C_)
 

@@ -44,3 +44,10 @@ def train_text_model(train_dir, num_steps, *, config=None, quiet=False):
     """Train rnn text model (text_embedding.py:89-150)."""
     model = TextModel(dict(_CONFIG, **(config or {})))
     return run_training(model, train_dir, num_steps, quiet=quiet)
+
+
+def evaluate_text_model(checkpoint_dir, log_dir, mode, num_evals, *, config=None, quiet=False):
+    """Accuracy of the newest checkpoint (text_embedding.py:152-187)."""
+    from ..training import run_evaluation
+    model = TextModel(dict(_CONFIG, mode=mode, **(config or {})))
+    return run_evaluation(model, checkpoint_dir, log_dir, mode, num_evals, quiet=quiet)

@@ -88,6 +88,44 @@ def run_training(model, train_dir, num_steps, batch_fn=None, log_every=10, save_
     return loss_val
 
 
+def load_checkpoint(model, path):
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    model.net.load_state_dict(ck["variables"])
+    model.net.store.m.copy_(ck["adam_m"])
+    model.net.store.v.copy_(ck["adam_v"])
+    model.net.step = int(ck["global_step"])
+    return ck["global_step"]
+
+
+def run_evaluation(model, checkpoint_dir, log_dir, mode, num_evals, batch_fn=None, quiet=False):
+    """What evaluate_* do with slim.evaluation.evaluation_loop + streaming_accuracy
+    (im_text_rnn_model.py:171-207): restore the newest checkpoint of `checkpoint_dir`, run `num_evals`
+    batches, accumulate accuracy = mean(argmax(logits) == labels).  The reference's loop then waits for
+    the next checkpoint forever and writes TensorBoard summaries; here one pass is made, the result is
+    returned, printed and appended to <log_dir>/<mode>/accuracy.jsonl.
+    As in the reference the graph is built with is_training = (mode == 'train') (:65)."""
+    path = latest_checkpoint(checkpoint_dir)
+    if path is None:
+        raise FileNotFoundError("no checkpoint in %s" % checkpoint_dir)
+    step = load_checkpoint(model, path)
+    is_training = mode == "train"
+    correct = total = 0
+    for i in range(num_evals):
+        batch = batch_fn(i) if batch_fn is not None else model.next_batch(10 ** 6 + i)
+        logits = model.net.predict(batch, is_training=is_training)
+        model.logits, model.labels = logits, batch["labels"]
+        correct += int((logits.argmax(dim=1) == batch["labels"]).sum().item())     # streaming_accuracy
+        total += int(batch["labels"].shape[0])
+    acc = correct / max(total, 1)
+    out_dir = os.path.join(log_dir, mode)
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "accuracy.jsonl"), "a") as f:
+        f.write(json.dumps({"global_step": step, "accuracy": acc, "num_evals": num_evals, "mode": mode}) + "\n")
+    if not quiet:
+        print("global step %d: accuracy = %.4f (%d samples, mode %s)" % (step, acc, total, mode))
+    return acc
+
+
 class SyntheticInput:
     """Mixin: the input side of the reference's model constructors on synthetic data."""
 
