@@ -73,6 +73,8 @@ typedef struct ds_conv_desc {
 
 /* Tuning aid: pin the workgroup tile to (128*mt) x (32*nt) rows x columns; 0,0 = automatic.  */
 int ds_conv_set_tile(int mt, int nt);
+/* Tuning aid: 0 = automatic, 1 = LDS-staged kernel, 2 = register-direct (LDS-free) kernel.     */
+int ds_conv_set_path(int path);
 /* Number of row-tile blocks (P) the launch for `d` will use = number of stats partials.   */
 int ds_conv_igemm_partials(const ds_conv_desc *d);
 /* stats (DS_EPI_STATS): float[2][Cout][P] partial column sums / sums of squares.          */

@@ -24,7 +24,7 @@ lib = _lib.load()
 big = torch.empty(900_000_000, device='cuda')   # generic operand storage
 w = torch.randn(4_000_000, device='cuda') * 0.05
 bias = torch.zeros(4096, device='cuda')
-CFGS = [(1,1),(1,2),(1,3),(1,4),(2,1),(2,2),(2,3),(2,4)]
+CFGS = [(p,mt,nt) for p in (1,2) for (mt,nt) in ((1,1),(1,2),(2,1),(2,2),(1,3))]
 rows = []
 for key, (plan, count) in plans.items():
     M, N, K, taps, kc, flags, fold = key
@@ -35,8 +35,8 @@ for key, (plan, count) in plans.items():
     z_off = ((x_need + 1023)//1024)*1024
     stats = big[z_off + M*d.ldz + 4096:]
     res = {}
-    for cfg in [(0,0)] + CFGS:
-        lib.ds_conv_set_tile(*cfg)
+    for cfg in [(0,0,0)] + CFGS:
+        lib.ds_conv_set_path(cfg[0]); lib.ds_conv_set_tile(cfg[1], cfg[2])
         def run(): plan.run(C.c_void_p(big.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(big.data_ptr()+4*z_off), bias=C.c_void_p(bias.data_ptr()), stats=C.c_void_p(stats.data_ptr()))
         run(); torch.cuda.synchronize()
         reps = 5 if plan.alg_flops > 1e10 else 20
@@ -47,13 +47,13 @@ for key, (plan, count) in plans.items():
         res[cfg] = e0.elapsed_time(e1)/reps
     d.flags = saved
     best = min(CFGS, key=lambda c: res[c])
-    rows.append((res[(0,0)]*count, key, count, res, best))
-lib.ds_conv_set_tile(0,0)
+    rows.append((res[(0,0,0)]*count, key, count, res, best))
+lib.ds_conv_set_tile(0,0); lib.ds_conv_set_path(0)
 rows.sort(key=lambda r: -r[0])
 tot_auto = sum(r[0] for r in rows); tot_best = sum(r[3][r[4]]*r[2] for r in rows)
-print("%9s %5s %5s %4s %2s %3s | %8s | %s | best" % ("M","N","K","taps","kc","cnt","auto_us", " ".join("%d,%d" % c for c in CFGS)))
+print("%9s %5s %5s %4s %2s %3s | %8s | %s | best" % ("M","N","K","taps","kc","cnt","auto_us", " ".join("%s%d,%d" % ("LD"[c[0]-1], c[1], c[2]) for c in CFGS)))
 for t, key, count, res, best in rows:
-    print("%9d %5d %5d %4d %2d %3d | %8.1f | %s | %d,%d %.1f" % (key[0], key[1], key[2], key[3], key[4], count, res[(0,0)]*1e3,
-          " ".join("%6.0f" % (res[c]*1e3) for c in CFGS), best[0], best[1], res[best]*1e3))
+    print("%9d %5d %5d %4d %2d %3d | %8.1f | %s | %s%d,%d %.1f" % (key[0], key[1], key[2], key[3], key[4], count, res[(0,0,0)]*1e3,
+          " ".join("%6.0f" % (res[c]*1e3) for c in CFGS), "LD"[best[0]-1], best[1], best[2], res[best]*1e3))
 print("total auto %.3f ms/step   total best-per-shape %.3f ms/step" % (tot_auto, tot_best))
-for c in CFGS: print("all %d,%d: %.3f" % (c[0], c[1], sum(r[3][c]*r[2] for r in rows)))
+for c in CFGS: print("all %s%d,%d: %.3f" % ("LD"[c[0]-1], c[1], c[2], sum(r[3][c]*r[2] for r in rows)))

@@ -45,6 +45,7 @@ class GradientReducer:
         self._pending = None
         self._ready = set()
         self._needed = set()
+        self._events = []
 
     # -- early launch of bucket 1 ----------------------------------------------------------------
     def expect(self, *names):
@@ -53,6 +54,7 @@ class GradientReducer:
 
     def begin_step(self):
         self._ready.clear()
+        self._events = []
         self._pending = None
 
     def stage_done(self, name):
@@ -60,8 +62,13 @@ class GradientReducer:
         if self.world == 1:
             return
         self._ready.add(name)
+        if self.overlap:       # stages may run on different streams (text tower): remember where each finished
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._events.append(ev)
         if self.overlap and self._pending is None and self._needed and self._needed <= self._ready:
-            self.stream.wait_stream(torch.cuda.current_stream())
+            for ev in self._events:
+                self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
                 self._pending = dist.all_reduce(self.g[:self.n1], op=dist.ReduceOp.SUM, group=self.group,
                                                 async_op=True)

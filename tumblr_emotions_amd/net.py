@@ -28,7 +28,8 @@ ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-8      # tf.train.AdamOptimizer defa
 class SentimentNet:
     def __init__(self, mode="joint", nb_emotions=15, im_features_size=256, rnn_size=512, fc_size=512,
                  vocab_size=10000, embedding_dim=300, post_size=32, image_size=224, dropout_keep_prob=0.8,
-                 trainable_bn_beta=True, device="cuda", process_group=None, overlap_comm=True):
+                 trainable_bn_beta=True, device="cuda", process_group=None, overlap_comm=True,
+                 concurrent_towers=True):
         assert mode in ("joint", "image", "text")
         if not torch.cuda.is_available():
             raise RuntimeError("tumblr_emotions_amd needs an MI355X (HIP) device: the training path has no CPU fallback")
@@ -60,6 +61,7 @@ class SentimentNet:
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.dlogits = None
         self.pg = process_group
+        self.text_stream = torch.cuda.Stream() if (mode == "joint" and concurrent_towers) else None
         self.reducer = GradientReducer(st.grad, st.n_bucket1, process_group, overlap_comm)
         self.world = self.reducer.world
         # bucket 1 of the flat gradient is complete once these backward stages have run
@@ -151,11 +153,27 @@ class SentimentNet:
         tx = im = None
         # image tower first: autograd runs later-created nodes first, so the (short) text backward runs
         # before the Inception backward and bucket 1 of the gradient is complete right after Mixed_5c
+        inputs_ready = None
+        if self.image is not None and self.text is not None and self.text_stream is not None:
+            inputs_ready = torch.cuda.Event()
+            inputs_ready.record(torch.cuda.current_stream())
         if self.image is not None:
             im = InceptionV1Function.apply(self.image, batch["images"], dropout_mask, seed, *self.image_params)
         if self.text is not None:
-            tx = TextTowerFunction.apply(self.text, batch["texts"], batch["seq_lens"], L[self.text.KERNEL],
-                                         L[self.text.BIAS])
+            # The text tower is ~130 launch-latency-bound kernels (LSTM steps): in the joint model it runs
+            # on its own HIP stream, concurrently with the Inception tower; autograd replays the backward
+            # of each node on its forward stream, so the BPTT overlaps the Inception backward too.
+            side = self.text_stream if inputs_ready is not None else None
+            if side is not None:
+                main = torch.cuda.current_stream()
+                side.wait_event(inputs_ready)          # NOT wait_stream: the image tower is already enqueued on main
+                with torch.cuda.stream(side):
+                    tx = TextTowerFunction.apply(self.text, batch["texts"], batch["seq_lens"], L[self.text.KERNEL],
+                                                 L[self.text.BIAS])
+                main.wait_stream(side)
+            else:
+                tx = TextTowerFunction.apply(self.text, batch["texts"], batch["seq_lens"], L[self.text.KERNEL],
+                                             L[self.text.BIAS])
         if self.mode == "image":
             self.logits = im
         elif self.mode == "text":
