@@ -126,6 +126,22 @@ def main():
         dt = float(tmax.item())
     loss = net.total_loss_value()
 
+    # In the timed region the text tower's kernels run concurrently with the Inception kernels on a
+    # second stream, so a conv launch's event-timed duration there includes the time it shared the CUs.
+    # For reference also time the same launches with the towers serialised (3 untimed-for-throughput steps).
+    isolated = None
+    if timer is not None and getattr(net, "text_stream", None) is not None and world == 1:
+        side, net.text_stream = net.text_stream, None
+        t2 = ops.ConvTimer()
+        ops.CONV_TIMER = t2
+        for _ in range(3):
+            net.train_step(batch, lr)
+        torch.cuda.synchronize()
+        ops.CONV_TIMER = None
+        net.text_stream = side
+        n2, ms2, fl2 = t2.summary()
+        isolated = round(fl2 / (ms2 * 1e-3) / 1e12, 2)
+
     if rank == 0:
         value = gb * args.steps / dt
         flop_per_sample = {"joint": GFLOP_PER_SAMPLE, "image": 5.885, "text": 0.280}[args.mode]
@@ -138,6 +154,7 @@ def main():
                         achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_unit="HBM bytes per launch",
                         traffic_source=traffic_src, alg_flops_per_launch=round(flops / max(n, 1)),
+                        achieved_towers_serialised=isolated,
                         launches_per_step=n // max(args.steps, 1), avg_launch_us=round(1e3 * ms / max(n, 1), 2),
                         kernel_time_share=round(ms * 1e-3 / dt, 3),
                         whole_step_tflops=round(value * flop_per_sample / 1e3, 2),

@@ -240,6 +240,71 @@ __global__ __launch_bounds__(256) void maxpool3s1_bwd_rolling(const float *dy, c
     }
 }
 
+// MaxPoolGrad of the 3x3 stride-2 pools: a thread owns the 2x2 input patch
+//   rows {2p-pt+1, 2p-pt+2} x cols {2q-pl+1, 2q-pl+2},   p in [-1, OH-1], q in [-1, OW-1]
+// which only the four windows (p..p+1, q..q+1) can name: one (arg-max, dy) load per input pixel instead of
+// four.  Row 2p-pt+1 is the middle row (kh=1) of window p only; row 2p-pt+2 is kh=2 of window p and kh=0
+// of window p+1; same for columns.
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_patch(const float *dy, const uint8_t *am, float *dx,
+                                                            int accumulate, int N, int H, int W, int C, int pad_t,
+                                                            int pad_l, int OH, int OW) {
+    const int C4 = C >> 2;
+    const int PH = OH + 1, PW = OW + 1;
+    const int64_t total = (int64_t)N * PH * PW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        int64_t r = i / C4;
+        const int q = (int)(r % PW) - 1;
+        r /= PW;
+        const int p = (int)(r % PH) - 1;
+        const int n = (int)(r / PH);
+        float d[2][2][4];
+        unsigned a[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int oh = p + u, ow = q + v;
+                a[u][v] = 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[u][v][j] = 0.f;
+                if ((unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW) {
+                    const int64_t o = (((int64_t)n * OH + oh) * OW + ow) * C + c;
+                    a[u][v] = *reinterpret_cast<const unsigned *>(am + o);
+                    const float4 t = *reinterpret_cast<const float4 *>(dy + o);
+                    d[u][v][0] = t.x; d[u][v][1] = t.y; d[u][v][2] = t.z; d[u][v][3] = t.w;
+                }
+            }
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int ih = 2 * p - pad_t + 1 + y;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int iw = 2 * q - pad_l + 1 + x;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u <= y; ++u)          // window row p+u sees this input row as kh = (y+1) - 2u
+#pragma unroll
+                    for (int v = 0; v <= x; ++v) {    // window col q+v sees this input col as kw = (x+1) - 2v
+                        const unsigned t = (unsigned)(((y + 1) - 2 * u) * 3 + ((x + 1) - 2 * v));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (((a[u][v] >> (8 * j)) & 0xFFu) == t) g[j] += d[u][v][j];
+                    }
+                float4 *dst = reinterpret_cast<float4 *>(dx + (((int64_t)n * H + ih) * W + iw) * C + c);
+                float4 out = make_float4(g[0], g[1], g[2], g[3]);
+                if (accumulate) {
+                    const float4 e = *dst;
+                    out.x += e.x; out.y += e.y; out.z += e.z; out.w += e.w;
+                }
+                *dst = out;
+            }
+        }
+    }
+}
+
 // counter-based uniform in [0,1): splitmix64 finaliser over (seed, element index)
 __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
     uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
@@ -326,7 +391,11 @@ extern "C" int ds_maxpool_bwd(const float *dy, const uint8_t *argmax, float *dx,
     }
     const int64_t total = (int64_t)N * H * W * (C / 4);
     const dim3 grid(ds::stream_grid(total, 256));
-    if (k == 3 && stride == 2)
+    if (k == 3 && stride == 2 && H <= 2 * OH && W <= 2 * OW)
+        hipLaunchKernelGGL(maxpool3s2_bwd_patch, dim3(ds::stream_grid((int64_t)N * (OH + 1) * (OW + 1) * (C / 4), 256)),
+                           dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, accumulate, N, H, W, C, pad_t, pad_l, OH,
+                           OW);
+    else if (k == 3 && stride == 2)
         hipLaunchKernelGGL((maxpool_bwd_kernel<3, 2>), grid, dim3(256), 0, (hipStream_t)stream, dy, argmax, dx,
                            accumulate, N, H, W, C, k, stride, pad_t, pad_l, OH, OW);
     else if (k == 2 && stride == 2)

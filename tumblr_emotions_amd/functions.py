@@ -24,7 +24,10 @@ class InceptionV1Function(torch.autograd.Function):
     def backward(ctx, dlogits):
         eng = ctx.engine
         eng.backward(dlogits if dlogits.is_contiguous() else dlogits.contiguous())
-        return (None, None, None, None) + tuple(eng.param_grads)
+        # fresh views of the flat gradient buffer: autograd's AccumulateGrad can then adopt them as
+        # `.grad` without a copy (a view object that is also referenced elsewhere would be cloned)
+        g = eng.store.grad_view
+        return (None, None, None, None) + tuple(g(n) for n in eng.param_names)
 
 
 class TextTowerFunction(torch.autograd.Function):

@@ -50,7 +50,7 @@ class SentimentNet:
         self.leaves = {e.name: st.view(e.name).detach().requires_grad_() for e in st.entries.values() if e.trainable}
         if self.image is not None:
             self.image_param_names = [n for n in self.leaves if n.startswith("InceptionV1/")]
-            self.image.param_grads = [st.grad_view(n) for n in self.image_param_names]
+            self.image.param_names = self.image_param_names
             self.image_params = [self.leaves[n] for n in self.image_param_names]
         self.step = 0
         self.frozen_l2_sumsq = 0.0
