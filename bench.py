@@ -89,10 +89,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local_rank)
+    # DS_BENCH_ONE_DEVICE=1 (self-test on a 1-GPU box): every rank uses cuda:0 and gloo carries the
+    # all-reduce, because RCCL refuses two ranks on one device.  Never set for a real measurement.
+    one_device = os.environ.get("DS_BENCH_ONE_DEVICE") == "1"
+    torch.cuda.set_device(0 if one_device else local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     T, V, D, H = 32, 10000, 300, 512
     net = SentimentNet(mode=args.mode, nb_emotions=15, im_features_size=256, rnn_size=H, fc_size=512, vocab_size=V,

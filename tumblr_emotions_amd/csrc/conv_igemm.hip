@@ -143,8 +143,12 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
             iw0[i] = ow * d.stride - d.pad_l;
             xb[i] = (unsigned)n * (unsigned)(d.H * d.W) * (unsigned)d.ldx;
         }
-        tap = kt0 / chunks;
-        c0 = (kt0 - tap * chunks) * BK;
+        // K-tile order: channel chunk OUTER, tap INNER -- the KH*KW taps of one 16-channel chunk touch the
+        // same (tile + halo) pixels' 64-byte segments, ~15 KB per workgroup, which stays in the XCD's L2
+        // (tap-outer order streamed 9 x the whole tile through L2: measured 8x over-fetch on the 3x3 layers)
+        const int chunk = kt0 / p.taps;
+        tap = kt0 - chunk * p.taps;
+        c0 = chunk * BK;
         dh = tap / d.KW;
         dw = tap - dh * d.KW;
     };
@@ -172,12 +176,11 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
                 const bool ok = b_ok[i] && c0 + b_k[i] < d.Cin;
                 rb[i] = load4<VEC>(srd_w, (wt + b_off[i]) * 4u, ok, BNMAJOR ? d.Cout - b_n[i] : d.Cin - c0 - b_k[i]);
             }
-            // ---- advance to the next K-tile ----------------------------------------------------
-            c0 += BK;
-            if (c0 >= d.Cin) {
-                c0 = 0;
-                ++tap;
-                if (++dw == d.KW) { dw = 0; ++dh; }
+            // ---- advance to the next K-tile: next tap of the same channel chunk, then the next chunk ----
+            ++tap;
+            if (++dw == d.KW) {
+                dw = 0;
+                if (++dh == d.KH) { dh = 0; tap = 0; c0 += BK; }
             }
         };
 
@@ -392,8 +395,12 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
             iw0[a] = ow * d.stride - d.pad_l;
             xb[a] = (unsigned)n * (unsigned)(d.H * d.W) * (unsigned)d.ldx;
         }
-        tap = kt0 / chunks;
-        c0 = (kt0 - tap * chunks) * BK;
+        // K-tile order: channel chunk OUTER, tap INNER -- the KH*KW taps of one 16-channel chunk touch the
+        // same (tile + halo) pixels' 64-byte segments, ~15 KB per workgroup, which stays in the XCD's L2
+        // (tap-outer order streamed 9 x the whole tile through L2: measured 8x over-fetch on the 3x3 layers)
+        const int chunk = kt0 / p.taps;
+        tap = kt0 - chunk * p.taps;
+        c0 = chunk * BK;
         dh = tap / d.KW;
         dw = tap - dh * d.KW;
     };
@@ -430,11 +437,10 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
                 f.bhi[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_w, (b_ok[b] && k + 4 < d.Cin) ? off + 16u : kOOB, 0, 0));
             }
         }
-        c0 += BK;
-        if (c0 >= d.Cin) {
-            c0 = 0;
-            ++tap;
-            if (++dw == d.KW) { dw = 0; ++dh; }
+        ++tap;
+        if (++dw == d.KW) {
+            dw = 0;
+            if (++dh == d.KH) { dh = 0; tap = 0; c0 += BK; }
         }
     };
 
