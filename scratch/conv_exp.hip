@@ -44,6 +44,7 @@ struct ConvParams {
     int taps;       // KH*KW
     int row_tiles;  // ceil(M/BM)
     unsigned x_bytes, w_bytes;   // extents covered by the two buffer descriptors
+    int prio_mode;               // 1: staggered static wave priorities (see kernel)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *p, unsigned bytes) {
@@ -64,8 +65,11 @@ __device__ __forceinline__ f32x4 load4(__amdgpu_buffer_rsrc_t r, unsigned off, b
     }
 }
 
+// second launch-bound = waves per SIMD the register allocator must leave room for: the small tiles
+// are the workhorses and measured fastest at 3-4 resident workgroups per CU
 template <int MT, int NT, bool BNMAJOR, bool FOLD, bool VEC>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2) ? 3 : 1) void conv_igemm_kernel(
+    const ConvParams p) {
     constexpr int WM = 4;
     constexpr int BM = WM * MT * 32, BN = NT * 32;
     constexpr int AR = BM / 64;                       // float4 A loads per thread per K-tile
@@ -83,10 +87,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int n0 = blockIdx.y * BN;
     const int ohw = d.OH * d.OW;
     const int chunks = (d.Cin + BK - 1) / BK;
-    const int KT = p.taps * chunks;
+    // split-K (small-M GEMMs): blockIdx.z owns K-tiles [kt0, kt1) and writes its own output slab
+    const int KT_all = p.taps * chunks;
+    const int kts = (KT_all + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int kt0 = (int)blockIdx.z * kts;
+    const int KT = (kt0 + kts < KT_all ? kt0 + kts : KT_all) - kt0;     // K-tiles of this split (may be <= 0)
+    float *const zout = p.z + (int64_t)blockIdx.z * p.d.z_split_stride;
     const int flags = d.flags;
     const __amdgpu_buffer_rsrc_t srd_x = make_srd(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t srd_w = make_srd(p.w, p.w_bytes);
+
+    // De-convoy the waves that share a SIMD.  With equal priority the matrix pipe is arbitrated fairly
+    // among the 3-4 resident waves (one per co-resident workgroup), so they all finish their MFMA burst
+    // together, all do their address/LDS/barrier phase together, and the pipe idles for that whole phase
+    // (PMC: MFMA busy 72 %, idle share = non-MFMA phase / K-step).  Distinct static priorities make the
+    // arbitration unfair: the phases stagger and one wave's non-MFMA work hides under another's MFMAs.
+    // Co-resident workgroups are ~256 apart in dispatch order (id % 8 -> XCD, (id / 8) % 32 -> CU); a
+    // different placement only costs speed.  s_setprio is scalar: the switch is wave-uniform.
+    switch (p.prio_mode ? ((blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y) >> 8) & 3 : 0) {
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+    }
 
     float csum[NT], csq[NT];
 #pragma unroll
@@ -113,10 +136,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         b_ok[i] = idx < BN * 4 && b_n[i] < d.Cout;
     }
 
-    for (int tile = blockIdx.x; tile < p.row_tiles; tile += gridDim.x) {
+    // ---- loader state: the row tile and K-tile that the next load_tile() fetches ------------------
+    int ih0[AR], iw0[AR];
+    unsigned xb[AR];         // element offset of the image that row i belongs to
+    int tap, c0, dh, dw;
+    f32x4 ra[AR], rb[BR];
+    f32x16 acc[MT][NT];
+
+    auto setup_tile = [&](int tile) {      // point the loader at the first K-tile of row tile `tile`
         const int m0 = tile * BM;
-        int ih0[AR], iw0[AR];
-        unsigned xb[AR];     // element offset of the image that row i belongs to
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int m = m0 + arow + 64 * i;
@@ -130,17 +158,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             iw0[i] = ow * d.stride - d.pad_l;
             xb[i] = (unsigned)n * (unsigned)(d.H * d.W) * (unsigned)d.ldx;
         }
+        // K-tile order: channel chunk OUTER, tap INNER -- the KH*KW taps of one 16-channel chunk touch the
+        // same (tile + halo) pixels' 64-byte segments, ~15 KB per workgroup, which stays in the XCD's L2
+        // (tap-outer order streamed 9 x the whole tile through L2: measured 8x over-fetch on the 3x3 layers)
+        const int chunk = kt0 / p.taps;
+        tap = kt0 - chunk * p.taps;
+        c0 = chunk * BK;
+        dh = tap / d.KW;
+        dw = tap - dh * d.KW;
+    };
 
-        f32x16 acc[MT][NT];
-#pragma unroll
-        for (int a = 0; a < MT; ++a)
-#pragma unroll
-            for (int b = 0; b < NT; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-        f32x4 ra[AR], rb[BR];
-        int tap = 0, c0 = 0, dh = 0, dw = 0;   // K-tile that the next load_tile() fetches
+    {
 
         auto load_tile = [&]() {
             // ---- A: activations ----------------------------------------------------------------
@@ -163,12 +191,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 const bool ok = b_ok[i] && c0 + b_k[i] < d.Cin;
                 rb[i] = load4<VEC>(srd_w, (wt + b_off[i]) * 4u, ok, BNMAJOR ? d.Cout - b_n[i] : d.Cin - c0 - b_k[i]);
             }
-            // ---- advance to the next K-tile ----------------------------------------------------
-            c0 += BK;
-            if (c0 >= d.Cin) {
-                c0 = 0;
-                ++tap;
-                if (++dw == d.KW) { dw = 0; ++dh; }
+            // ---- advance to the next K-tile: next tap of the same channel chunk, then the next chunk ----
+            ++tap;
+            if (++dw == d.KW) {
+                dw = 0;
+                if (++dh == d.KH) { dh = 0; tap = 0; c0 += BK; }
             }
         };
 
@@ -225,28 +252,56 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][s], bf[b][s], acc[a][b], 0, 0, 0);
         };
 
+    // One continuous software pipeline over (row tile, K-tile): while the MFMAs of K-tile kt run, the
+    // loads of kt+1 are in flight; on the LAST K-tile of a row tile the loads already belong to the
+    // first K-tile of the NEXT row tile, so the pipeline never drains between tiles and the epilogue
+    // of tile t starts with tile t+1's operands already staged in LDS.
+    int par = 0;                                   // LDS buffer holding the K-tile about to be computed
+    if (blockIdx.x < p.row_tiles) {
+        setup_tile(blockIdx.x);
         load_tile();
         store_tile(0);
-        __syncthreads();
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < p.row_tiles; tile += gridDim.x) {
+        const int m0 = tile * BM;
+        const bool has_next = tile + (int)gridDim.x < p.row_tiles;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
         for (int kt = 0; kt < KT; ++kt) {
-            const int cur = kt & 1;
-#if DS_EXP == 1      /* no global loads after the first tile */
-            compute(cur);
-            if (kt + 1 < KT) store_tile(cur ^ 1);
+            const bool last = kt + 1 == KT;
+            if (last && has_next) setup_tile(tile + gridDim.x);
+            const bool fetch = !last || has_next;
+#if DS_EXP == 1      /* no global loads in the loop (stores of stale registers kept) */
+            compute(par);
+            if (fetch) store_tile(par ^ 1);
             __syncthreads();
+            par ^= 1;
 #elif DS_EXP == 2    /* loads but no LDS stores */
-            if (kt + 1 < KT) load_tile();
-            compute(cur);
+            if (fetch) load_tile();
+            compute(par);
             asm volatile("" :: "v"(ra[0]), "v"(rb[0]));
             __syncthreads();
-#elif DS_EXP == 3    /* no loads, no stores: compute + barrier */
-            compute(cur);
+            par ^= 1;
+#elif DS_EXP == 3    /* compute + barrier only */
+            compute(par);
             __syncthreads();
+            par ^= 1;
+#elif DS_EXP == 4    /* everything but no barrier (racy, timing only) */
+            if (fetch) load_tile();
+            compute(par);
+            if (fetch) store_tile(par ^ 1);
+            par ^= 1;
 #else
-            if (kt + 1 < KT) load_tile();
-            compute(cur);
-            if (kt + 1 < KT) store_tile(cur ^ 1);
+            if (fetch) load_tile();
+            compute(par);
+            if (fetch) store_tile(par ^ 1);
             __syncthreads();
+            par ^= 1;
 #endif
         }
 
@@ -265,10 +320,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     if (row < p.M && colok) {
                         float v = acc[a][b][r] + bv;
                         const int64_t off = (int64_t)row * d.ldz + col;
-                        if (flags & DS_EPI_ACCUM) v += p.z[off];
+                        if (flags & DS_EPI_ACCUM) v += zout[off];
                         if (flags & DS_EPI_MASK) v = p.mask[(int64_t)row * d.ldmask + col] > 0.f ? v : 0.f;
                         if (flags & DS_EPI_RELU) v = fmaxf(v, 0.f);
-                        p.z[off] = v;
+                        zout[off] = v;
                         s += v;
                         q += v * v;
                     }
@@ -277,6 +332,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             csum[b] += s;
             csq[b] += q;
         }
+    }
     }
 
     if (flags & DS_EPI_STATS) {
@@ -301,9 +357,217 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 s += red[(w * BN + tid) * 2 + 0];
                 q += red[(w * BN + tid) * 2 + 1];
             }
-            float *o = p.stats + (int64_t)blockIdx.x * 2 * d.Cout;
-            o[n0 + tid] = s;
-            o[d.Cout + n0 + tid] = q;
+            // partials laid out [2][Cout][P] (P = gridDim.x) so ds_bn_finalize reads them contiguously
+            p.stats[(int64_t)(n0 + tid) * gridDim.x + blockIdx.x] = s;
+            p.stats[((int64_t)d.Cout + n0 + tid) * gridDim.x + blockIdx.x] = q;
+        }
+    }
+}
+
+// ================================================================================================
+// Register-direct variant: no LDS, no barriers.
+//
+// In the kernel above a wave only ever reads ITS OWN 32*MT rows of the A tile back from LDS, and the
+// fp32 MFMA fragment layout (lane (i, kh) holds A[i][kh*8 .. kh*8+7]) is exactly two 16-byte loads of
+// a row's K-chunk -- so each wave can fetch its A fragments straight from global memory into the
+// registers the MFMA reads, and do the same for the weight fragments (two float4 per row when the
+// weights are k-contiguous, eight coalesced dwords when they are n-contiguous; co-resident waves hit
+// the same weight lines in L1/L2).  That removes every ds_read/ds_write and, more importantly, every
+// workgroup barrier: the four waves of a workgroup become independent pipelines (load K-tile t+1 ->
+// MFMAs of K-tile t), so a wave delayed by matrix-pipe contention on its SIMD no longer stalls its
+// three block-mates on the other SIMDs.  Registers double-buffer one K-tile; the loop is unrolled by
+// two so both buffers are statically indexed.
+// ================================================================================================
+template <int MT, int NT, bool BNMAJOR>
+struct Frag {
+    f32x4 alo[MT], ahi[MT];                  // A[row][kh*8 + 0..3], [.. + 4..7]
+    f32x4 blo[BNMAJOR ? 1 : NT], bhi[BNMAJOR ? 1 : NT];
+    float bs[BNMAJOR ? NT : 1][8];           // n-contiguous weights: B[kh*8 + s][col]
+};
+
+template <int MT, int NT, bool BNMAJOR, bool FOLD>
+__global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
+    const ds_conv_desc &d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    const int n0 = blockIdx.y * BN;
+    const int ohw = d.OH * d.OW;
+    const int chunks = (d.Cin + BK - 1) / BK;
+    const int KT_all = p.taps * chunks;
+    const int kts = (KT_all + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int kt0 = (int)blockIdx.z * kts;
+    const int KT = (kt0 + kts < KT_all ? kt0 + kts : KT_all) - kt0;
+    float *const zout = p.z + (int64_t)blockIdx.z * p.d.z_split_stride;
+    const int flags = d.flags;
+    const __amdgpu_buffer_rsrc_t srd_x = make_srd(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t srd_w = make_srd(p.w, p.w_bytes);
+    const int wave_id = blockIdx.x * 4 + wave, waves = gridDim.x * 4;
+
+    unsigned b_off[NT];
+    bool b_ok[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int n = n0 + b * 32 + li;
+        b_ok[b] = n < d.Cout;
+        b_off[b] = BNMAJOR ? (unsigned)n + (unsigned)(lk * 8) * (unsigned)d.w_k_stride
+                           : (unsigned)n * (unsigned)d.w_n_stride + (unsigned)(lk * 8);
+    }
+
+    int ih0[MT], iw0[MT];
+    unsigned xb[MT];
+    int tap, c0, dh, dw;
+    auto setup_tile = [&](int tile) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int m = tile * BM + a * 32 + li;
+            const bool rv = m < p.M;
+            const int mm = rv ? m : 0;
+            const int n = mm / ohw;
+            const int r = mm - n * ohw;
+            const int oh = r / d.OW;
+            const int ow = r - oh * d.OW;
+            ih0[a] = rv ? oh * d.stride - d.pad_t : -(1 << 20);
+            iw0[a] = ow * d.stride - d.pad_l;
+            xb[a] = (unsigned)n * (unsigned)(d.H * d.W) * (unsigned)d.ldx;
+        }
+        // K-tile order: channel chunk OUTER, tap INNER -- the KH*KW taps of one 16-channel chunk touch the
+        // same (tile + halo) pixels' 64-byte segments, ~15 KB per workgroup, which stays in the XCD's L2
+        // (tap-outer order streamed 9 x the whole tile through L2: measured 8x over-fetch on the 3x3 layers)
+        const int chunk = kt0 / p.taps;
+        tap = kt0 - chunk * p.taps;
+        c0 = chunk * BK;
+        dh = tap / d.KW;
+        dw = tap - dh * d.KW;
+    };
+
+    typedef Frag<MT, NT, BNMAJOR> F;
+    auto load = [&](F &f) {
+        const int k = c0 + lk * 8;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int ih = ih0[a] + dh, iw = iw0[a] + dw;
+            const bool pix = (unsigned)ih < (unsigned)d.H;
+            const bool ok0 = pix && (unsigned)(FOLD ? iw + k / d.fold_cin : iw) < (unsigned)d.W && k < d.Cin;
+            const bool ok1 = pix && (unsigned)(FOLD ? iw + (k + 4) / d.fold_cin : iw) < (unsigned)d.W && k + 4 < d.Cin;
+            const unsigned off = (xb[a] + (unsigned)(ih * d.W + iw) * (unsigned)d.ldx + (unsigned)k) * 4u;
+            f.alo[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, ok0 ? off : kOOB, 0, 0));
+            f.ahi[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, ok1 ? off + 16u : kOOB, 0, 0));
+        }
+        const int tap_eff = d.flip ? p.taps - 1 - tap : tap;
+        const unsigned wt = (unsigned)tap_eff * (unsigned)d.w_tap_stride + (unsigned)c0 * (BNMAJOR ? (unsigned)d.w_k_stride : 1u);
+        if (BNMAJOR) {
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const bool ok = b_ok[b] && k + s < d.Cin;
+                    const unsigned off = (wt + b_off[b] + (unsigned)s * (unsigned)d.w_k_stride) * 4u;
+                    f.bs[b][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_w, ok ? off : kOOB, 0, 0));
+                }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const unsigned off = (wt + b_off[b]) * 4u;
+                f.blo[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_w, (b_ok[b] && k < d.Cin) ? off : kOOB, 0, 0));
+                f.bhi[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_w, (b_ok[b] && k + 4 < d.Cin) ? off + 16u : kOOB, 0, 0));
+            }
+        }
+        ++tap;
+        if (++dw == d.KW) {
+            dw = 0;
+            if (++dh == d.KH) { dh = 0; tap = 0; c0 += BK; }
+        }
+    };
+
+    f32x16 acc[MT][NT];
+    auto mma = [&](const F &f) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const float av = s < 4 ? f.alo[a][s & 3] : f.ahi[a][s & 3];
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const float bv = BNMAJOR ? f.bs[b][s] : (s < 4 ? f.blo[b][s & 3] : f.bhi[b][s & 3]);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
+                }
+            }
+    };
+
+    float csum[NT], csq[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) csum[j] = csq[j] = 0.f;
+
+    F f0, f1;
+    if (wave_id < p.row_tiles) {
+        setup_tile(wave_id);
+        load(f0);
+    }
+    for (int tile = wave_id; tile < p.row_tiles; tile += waves) {
+        const int m0 = tile * BM;
+        const bool has_next = tile + waves < p.row_tiles;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        int kt = 0;
+        for (; kt + 2 <= KT; kt += 2) {
+            load(f1);                                   // K-tile kt+1 (always inside this row tile)
+            mma(f0);
+            if (kt + 2 < KT) load(f0);                  // K-tile kt+2 ...
+            else if (has_next) { setup_tile(tile + waves); load(f0); }   // ... or the next row tile's first
+            mma(f1);
+        }
+        const bool odd = kt < KT;
+        if (odd) {                                      // odd K-tile count: one more step out of f0
+            if (has_next) { setup_tile(tile + waves); load(f1); }
+            mma(f0);
+        }
+
+        // ---- epilogue (same contract as the LDS kernel) -----------------------------------------------
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int col = n0 + b * 32 + li;
+            const bool colok = col < d.Cout;
+            const float bv = ((flags & DS_EPI_BIAS) && colok) ? p.bias[col] : 0.f;
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (row < p.M && colok) {
+                        float v = acc[a][b][r] + bv;
+                        const int64_t off = (int64_t)row * d.ldz + col;
+                        if (flags & DS_EPI_ACCUM) v += zout[off];
+                        if (flags & DS_EPI_MASK) v = p.mask[(int64_t)row * d.ldmask + col] > 0.f ? v : 0.f;
+                        if (flags & DS_EPI_RELU) v = fmaxf(v, 0.f);
+                        zout[off] = v;
+                        s += v;
+                        q += v * v;
+                    }
+                }
+            }
+            csum[b] += s;
+            csq[b] += q;
+        }
+        if (odd) f0 = f1;      // the next row tile's first K-tile was fetched into f1: move it (after the epilogue, so the loads had time to land)
+    }
+
+    if (flags & DS_EPI_STATS) {      // one partial per wave: [2][Cout][P], P = 4 * gridDim.x
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const float s = csum[b] + __shfl_xor(csum[b], 32);
+            const float q = csq[b] + __shfl_xor(csq[b], 32);
+            const int col = n0 + b * 32 + li;
+            if (lk == 0 && col < d.Cout) {
+                p.stats[(int64_t)col * waves + wave_id] = s;
+                p.stats[((int64_t)d.Cout + col) * waves + wave_id] = q;
+            }
         }
     }
 }
@@ -311,84 +575,168 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // ---- host-side dispatch -----------------------------------------------------------------------
 struct TileCfg {
     int mt, nt;
+    bool direct;     // register-direct kernel (tile = per-WAVE 32*mt x 32*nt) instead of the LDS kernel
 };
+
+typedef void (*KernelFn)(const ConvParams);
 
 int64_t conv_M(const ds_conv_desc *d) { return (int64_t)d->N * d->OH * d->OW; }
 
-// Tile = (128*mt) x (32*nt).  nt: least column padding, ties -> wider tile (fewer re-reads of A);
-// mt = 2 unless the problem is too small to give every CU a workgroup.
-TileCfg pick_cfg(const ds_conv_desc *d) {
-    static int force_mt = -1, force_nt = -1;
-    if (force_mt < 0) {      // DS_CONV_CFG="mt,nt" pins the tile (tuning aid)
+struct Variant {
+    bool bnmajor, fold, vec;
+};
+
+// vector (16-byte) loads are legal when every stride is a multiple of 4 floats; pointer alignment is
+// checked separately at launch
+bool dims_vec(const ds_conv_desc *d) {
+    const bool bnmajor = d->w_n_stride == 1 && d->w_k_stride != 1;
+    const bool a_vec = (d->ldx % 4 == 0) && (d->Cin % 4 == 0);
+    const bool b_vec = bnmajor ? (d->Cout % 4 == 0) && (d->w_k_stride % 4 == 0) && (d->w_tap_stride % 4 == 0)
+                               : (d->Cin % 4 == 0) && (d->w_n_stride % 4 == 0) && (d->w_tap_stride % 4 == 0);
+    return a_vec && b_vec;
+}
+
+Variant variant_of(const ds_conv_desc *d, const float *x, const float *w) {
+    Variant v;
+    v.bnmajor = d->w_n_stride == 1 && d->w_k_stride != 1;
+    v.fold = d->fold_cin > 0;
+    v.vec = dims_vec(d) && ((((uintptr_t)x | (uintptr_t)w) & 15) == 0);
+    return v;
+}
+
+template <int MT, int NT>
+KernelFn lds_kernel_mn(Variant v) {
+    if (v.bnmajor) {
+        if (v.fold) return conv_igemm_kernel<MT, NT, true, true, true>;
+        return v.vec ? conv_igemm_kernel<MT, NT, true, false, true> : conv_igemm_kernel<MT, NT, true, false, false>;
+    }
+    return v.vec ? conv_igemm_kernel<MT, NT, false, false, true> : conv_igemm_kernel<MT, NT, false, false, false>;
+}
+
+template <int MT>
+KernelFn lds_kernel_m(int nt, Variant v) {
+    switch (nt) {
+        case 1: return lds_kernel_mn<MT, 1>(v);
+        case 2: return lds_kernel_mn<MT, 2>(v);
+        case 3: return lds_kernel_mn<MT, 3>(v);
+        case 4: return lds_kernel_mn<MT, 4>(v);
+        case 5: return lds_kernel_mn<MT, 5>(v);
+        default: return lds_kernel_mn<MT, 6>(v);
+    }
+}
+
+template <int MT, int NT>
+KernelFn direct_kernel_mn(Variant v) {
+    if (v.bnmajor) return v.fold ? conv_direct_kernel<MT, NT, true, true> : conv_direct_kernel<MT, NT, true, false>;
+    return conv_direct_kernel<MT, NT, false, false>;
+}
+
+template <int MT>
+KernelFn direct_kernel_m(int nt, Variant v) {
+    switch (nt) {
+        case 1: return direct_kernel_mn<MT, 1>(v);
+        case 2: return direct_kernel_mn<MT, 2>(v);
+        case 3: return direct_kernel_mn<MT, 3>(v);
+        default: return direct_kernel_mn<MT, 4>(v);
+    }
+}
+
+KernelFn kernel_for(TileCfg c, Variant v) {
+    if (c.direct) return c.mt == 2 ? direct_kernel_m<2>(c.nt, v) : direct_kernel_m<1>(c.nt, v);
+    return c.mt == 2 ? lds_kernel_m<2>(c.nt, v) : lds_kernel_m<1>(c.nt, v);
+}
+
+// Resident workgroups per CU of one instantiation (register/LDS limited), queried once and cached.
+// The persistent grid is sized to exactly one resident wave of workgroups so no CU idles while a
+// partial second wave runs; correctness never depends on it (no inter-workgroup communication).
+int resident_per_cu(TileCfg c, Variant v) {
+    static int cache[2][2][6][2][2][2];
+    int &slot = cache[c.direct][c.mt - 1][c.nt - 1][v.bnmajor][v.fold][v.vec];
+    if (slot == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kernel_for(c, v), 256, 0) != hipSuccess || n < 1)
+            n = 1;
+        slot = n > 8 ? 8 : n;
+    }
+    return slot;
+}
+
+// tuning aids: ds_conv_set_tile() / DS_CONV_CFG="mt,nt" pin the tile; ds_conv_set_path() /
+// DS_CONV_PATH=lds|direct pins the kernel family
+int force_mt = -1, force_nt = -1, force_path = -1;
+
+TileCfg pick_cfg(const ds_conv_desc *d, bool vec) {
+    if (force_mt < 0) {
         force_mt = force_nt = 0;
         if (const char *e = getenv("DS_CONV_CFG")) sscanf(e, "%d,%d", &force_mt, &force_nt);
     }
+    if (force_path < 0) {
+        force_path = 0;
+        if (const char *e = getenv("DS_CONV_PATH")) force_path = e[0] == 'l' ? 1 : (e[0] == 'd' ? 2 : 0);
+    }
     const int64_t M = conv_M(d);
     const int N = d->Cout;
-    // cost in "columns": padded width + 8 per column tile (each extra tile re-reads the A rows)
-    auto padw = [&](int nt) { return ((N + 32 * nt - 1) / (32 * nt)) * 32 * nt; };
-    auto cost = [&](int nt) { return padw(nt) + 8 * ((N + 32 * nt - 1) / (32 * nt)); };
-    int best_nt = 1;
-    for (int nt = 2; nt <= 6; ++nt)
-        if (cost(nt) <= cost(best_nt)) best_nt = nt;
-    TileCfg c = {2, best_nt};
-    auto blocks = [&](int mt, int nt) { return ((M + 128 * mt - 1) / (128 * mt)) * ((N + 32 * nt - 1) / (32 * nt)); };
-    if (blocks(c.mt, c.nt) < 2 * ds::kCUs) c.mt = 1;
-    if (blocks(c.mt, c.nt) < ds::kCUs) {
-        // small GEMMs (LSTM steps, heads): narrower tiles -> more workgroups, without much more padding
-        for (int nt = c.nt - 1; nt >= 1; --nt) {
-            if (padw(nt) * 100 > padw(best_nt) * 115) continue;
-            c.nt = nt;
-            if (blocks(c.mt, nt) >= ds::kCUs) break;
-        }
+    const int pad32 = (N + 31) / 32 * 32, pad64 = (N + 63) / 64 * 64;
+    TileCfg c = {1, 1, false};
+    // Measured (profiles/r01_lds_vs_direct_sweep.txt): the LDS-staged kernel wins on every shape of this
+    // model -- fragment-shaped global loads touch 32 cache lines per wave instruction and are TA-bound --
+    // so the register-direct family is opt-in only.
+    c.direct = vec && force_path == 2;
+    if (c.direct) {
+        // per-WAVE tile 32*mt x 32*nt
+        const int64_t row_tiles = (M + 31) / 32;
+        if (pad64 * 100 <= pad32 * 112 && row_tiles * (pad64 / 64) >= 12 * ds::kCUs) c.nt = 2;
+    } else {
+        // Measured on MI355X over every conv/GEMM shape of the joint step (profiles/r01_tile_sweep.txt):
+        // latency-bound per wave, so small tiles at 3-5 resident workgroups per CU beat wide ones.
+        const int64_t row_tiles = (M + 127) / 128;
+        if (pad64 * 100 <= pad32 * 112 && row_tiles * (pad64 / 64) >= 3 * ds::kCUs) c.nt = 2;
     }
     if (force_mt > 0) c.mt = force_mt;
     if (force_nt > 0) c.nt = force_nt;
+    if (c.direct && c.nt > 4) c.nt = 4;
     return c;
 }
 
-void grid_for(const ds_conv_desc *d, TileCfg c, int *gx, int *gy, int *row_tiles) {
+void grid_for(const ds_conv_desc *d, TileCfg c, Variant v, int *gx, int *gy, int *row_tiles) {
     const int64_t M = conv_M(d);
-    const int bm = 128 * c.mt, bn = 32 * c.nt;
+    const int bm = (c.direct ? 32 : 128) * c.mt, bn = 32 * c.nt;
     *row_tiles = (int)((M + bm - 1) / bm);
     *gy = (d->Cout + bn - 1) / bn;
-    int target = (3 * ds::kCUs) / *gy;       // ~3 resident workgroups per CU in total
+    const int wg_tiles = c.direct ? (*row_tiles + 3) / 4 : *row_tiles;     // row tiles in units of workgroups
+    int target = (resident_per_cu(c, v) * ds::kCUs) / *gy;                 // one resident wave of workgroups
     if (target < 8) target = 8;
-    int x = *row_tiles < target ? *row_tiles : target;
+    int x = wg_tiles < target ? wg_tiles : target;
     if (x >= 8) x &= ~7;                      // multiple of 8: column tiles of a row tile share an XCD
     *gx = x;
 }
 
-template <int MT, int NT>
-void launch_mn(const ConvParams &p, dim3 grid, hipStream_t s, bool bnmajor, bool fold, bool vec) {
-    if (bnmajor) {
-        if (fold) hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, true, true, true>), grid, dim3(256), 0, s, p);
-        else if (vec) hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, true, false, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, true, false, false>), grid, dim3(256), 0, s, p);
-    } else {
-        if (vec) hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, false, false, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, false, false, false>), grid, dim3(256), 0, s, p);
-    }
-}
-
-template <int MT>
-void launch_m(const ConvParams &p, int nt, dim3 grid, hipStream_t s, bool bnmajor, bool fold, bool vec) {
-    switch (nt) {
-        case 1: launch_mn<MT, 1>(p, grid, s, bnmajor, fold, vec); break;
-        case 2: launch_mn<MT, 2>(p, grid, s, bnmajor, fold, vec); break;
-        case 3: launch_mn<MT, 3>(p, grid, s, bnmajor, fold, vec); break;
-        case 4: launch_mn<MT, 4>(p, grid, s, bnmajor, fold, vec); break;
-        case 5: launch_mn<MT, 5>(p, grid, s, bnmajor, fold, vec); break;
-        default: launch_mn<MT, 6>(p, grid, s, bnmajor, fold, vec); break;
-    }
-}
-
 }  // namespace
 
+extern "C" int ds_conv_set_tile(int mt, int nt) {
+    DS_REQUIRE((mt == 0 && nt == 0) || ((mt == 1 || mt == 2) && nt >= 1 && nt <= 6), "ds_conv_set_tile: mt in {1,2}, nt in 1..6, or 0,0 = automatic");
+    force_mt = mt;
+    force_nt = nt;
+    return DS_OK;
+}
+
+extern "C" int ds_conv_set_path(int path) {
+    DS_REQUIRE(path >= 0 && path <= 2, "ds_conv_set_path: 0 = automatic, 1 = LDS-staged kernel, 2 = register-direct kernel");
+    force_path = path;
+    return DS_OK;
+}
+
 extern "C" int ds_conv_igemm_partials(const ds_conv_desc *d) {
+    // BatchNorm convs are always 16-byte aligned in this model; ds_conv_igemm refuses DS_EPI_STATS
+    // when the operands turn out not to be, so the count returned here is the one the launch uses.
+    Variant v;
+    v.bnmajor = d->w_n_stride == 1 && d->w_k_stride != 1;
+    v.fold = d->fold_cin > 0;
+    v.vec = dims_vec(d);
+    const TileCfg c = pick_cfg(d, v.vec);
     int gx, gy, rt;
-    grid_for(d, pick_cfg(d), &gx, &gy, &rt);
-    return gx;
+    grid_for(d, c, v, &gx, &gy, &rt);
+    return c.direct ? gx * 4 : gx;
 }
 
 extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float *w, float *z, const float *bias,
@@ -400,39 +748,40 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     DS_REQUIRE(!(d->flags & DS_EPI_MASK) || mask, "ds_conv_igemm: DS_EPI_MASK without mask");
     DS_REQUIRE(!(d->flags & DS_EPI_STATS) || stats, "ds_conv_igemm: DS_EPI_STATS without stats buffer");
     DS_REQUIRE(conv_M(d) < (1ll << 31), "ds_conv_igemm: M too large");
-    const bool bnmajor = d->w_n_stride == 1 && d->w_k_stride != 1;
-    const bool fold = d->fold_cin > 0;
+    const Variant v = variant_of(d, x, w);
+    DS_REQUIRE(!(d->flags & DS_EPI_STATS) || v.vec == dims_vec(d),
+               "ds_conv_igemm: DS_EPI_STATS needs 16-byte aligned operand pointers");
 
     ConvParams p;
     p.d = *d;
     p.x = x; p.w = w; p.z = z; p.bias = bias; p.mask = mask; p.stats = stats;
     p.M = (int)conv_M(d);
     p.taps = d->KH * d->KW;
+    static int prio_mode = -1;
+    if (prio_mode < 0) {
+        const char *e = getenv("DS_CONV_PRIO");
+        prio_mode = e ? atoi(e) : 0;   // opt-in: measured neutral-to-negative (profiles/r01_notes.md)
+    }
+    p.prio_mode = prio_mode;
     // extents of the two buffer descriptors (bytes from the operand pointer to the last float read)
-    const int64_t x_elems = ((int64_t)d->N * d->H * d->W - 1) * d->ldx + (fold ? d->fold_cin : d->Cin);
+    const int64_t x_elems = ((int64_t)d->N * d->H * d->W - 1) * d->ldx + (v.fold ? d->fold_cin : d->Cin);
     const int64_t w_elems = (int64_t)(p.taps - 1) * d->w_tap_stride + (int64_t)(d->Cout - 1) * d->w_n_stride +
                             (int64_t)(d->Cin - 1) * d->w_k_stride + 1;
     DS_REQUIRE(x_elems * 4 < (1ll << 31) && w_elems * 4 < (1ll << 31),
                "ds_conv_igemm: operand larger than 2 GiB (split the batch)");
     p.x_bytes = (unsigned)(x_elems * 4);
     p.w_bytes = (unsigned)(w_elems * 4);
-    const bool a_vec = (d->ldx % 4 == 0) && (d->Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
-    bool b_vec;
-    if (bnmajor)
-        b_vec = (d->Cout % 4 == 0) && (d->w_k_stride % 4 == 0) && (d->w_tap_stride % 4 == 0) && (((uintptr_t)w & 15) == 0);
-    else
-        b_vec = (d->Cin % 4 == 0) && (d->w_n_stride % 4 == 0) && (d->w_tap_stride % 4 == 0) && (((uintptr_t)w & 15) == 0);
-    const bool vec = a_vec && b_vec;
-    DS_REQUIRE(!fold || (bnmajor && vec && d->KW == 1 && d->fold_cin % 4 == 0 && d->ldx == d->fold_cin),
+    DS_REQUIRE(!v.fold || (v.bnmajor && v.vec && d->KW == 1 && d->fold_cin % 4 == 0 && d->ldx == d->fold_cin),
                "ds_conv_igemm: fold_cin needs KW=1, n-contiguous 16-byte-aligned weights, ldx==fold_cin");
 
-    const TileCfg c = pick_cfg(d);
+    const int splits = d->splits > 1 ? d->splits : 1;
+    DS_REQUIRE(splits == 1 || (d->flags == 0 && d->z_split_stride >= (int64_t)(conv_M(d) - 1) * d->ldz + d->Cout),
+               "ds_conv_igemm: split-K needs flags == 0 and non-overlapping output slabs");
+    if (splits == 1) p.d.z_split_stride = 0;
+    const TileCfg c = pick_cfg(d, v.vec);
     int gx, gy, rt;
-    grid_for(d, c, &gx, &gy, &rt);
+    grid_for(d, c, v, &gx, &gy, &rt);
     p.row_tiles = rt;
-    dim3 grid(gx, gy);
-    hipStream_t s = (hipStream_t)stream;
-    if (c.mt == 2) launch_m<2>(p, c.nt, grid, s, bnmajor, fold, vec);
-    else launch_m<1>(p, c.nt, grid, s, bnmajor, fold, vec);
+    hipLaunchKernelGGL(kernel_for(c, v), dim3(gx, gy, splits), dim3(256), 0, (hipStream_t)stream, p);
     return ds::check_launch("ds_conv_igemm");
 }

@@ -1,5 +1,2 @@
 export PYTHONPATH=$GRAFT_REPO_ROOT
-for i in 1 2; do
-python scratch/conv_bench.py scratch/libcur.so 0,0 2>&1 | grep cfg
-python scratch/conv_bench.py scratch/libnew.so 0,0 2>&1 | grep cfg
-done
+for e in 0 1 2 3 4; do python scratch/conv_bench.py scratch/libexp$e.so 0,0 2>&1 | grep cfg; done

@@ -44,6 +44,7 @@ struct ConvParams {
     int taps;       // KH*KW
     int row_tiles;  // ceil(M/BM)
     unsigned x_bytes, w_bytes;   // extents covered by the two buffer descriptors
+    int prio_mode;               // 1: staggered static wave priorities (see kernel)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *p, unsigned bytes) {
@@ -95,6 +96,20 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
     const int flags = d.flags;
     const __amdgpu_buffer_rsrc_t srd_x = make_srd(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t srd_w = make_srd(p.w, p.w_bytes);
+
+    // De-convoy the waves that share a SIMD.  With equal priority the matrix pipe is arbitrated fairly
+    // among the 3-4 resident waves (one per co-resident workgroup), so they all finish their MFMA burst
+    // together, all do their address/LDS/barrier phase together, and the pipe idles for that whole phase
+    // (PMC: MFMA busy 72 %, idle share = non-MFMA phase / K-step).  Distinct static priorities make the
+    // arbitration unfair: the phases stagger and one wave's non-MFMA work hides under another's MFMAs.
+    // Co-resident workgroups are ~256 apart in dispatch order (id % 8 -> XCD, (id / 8) % 32 -> CU); a
+    // different placement only costs speed.  s_setprio is scalar: the switch is wave-uniform.
+    switch (p.prio_mode ? ((blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y) >> 8) & 3 : 0) {
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+    }
 
     float csum[NT], csq[NT];
 #pragma unroll
@@ -720,6 +735,12 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     p.x = x; p.w = w; p.z = z; p.bias = bias; p.mask = mask; p.stats = stats;
     p.M = (int)conv_M(d);
     p.taps = d->KH * d->KW;
+    static int prio_mode = -1;
+    if (prio_mode < 0) {
+        const char *e = getenv("DS_CONV_PRIO");
+        prio_mode = e ? atoi(e) : 0;   // opt-in: measured neutral-to-negative (profiles/r01_notes.md)
+    }
+    p.prio_mode = prio_mode;
     // extents of the two buffer descriptors (bytes from the operand pointer to the last float read)
     const int64_t x_elems = ((int64_t)d->N * d->H * d->W - 1) * d->ldx + (v.fold ? d->fold_cin : d->Cin);
     const int64_t w_elems = (int64_t)(p.taps - 1) * d->w_tap_stride + (int64_t)(d->Cout - 1) * d->w_n_stride +
