@@ -1,0 +1,105 @@
+"""TFRecord / tf.Example codec, dataset side files and the eval preprocessing (row 8f-2), CPU only.
+Pinned: CRC-32C check value; bilinear resize against scipy/torch on the align_corners=False legacy
+grid; everything else by round trips (no TensorFlow-written artefact exists in the reference tree)."""
+import io
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from tumblr_emotions_amd.datasets import convert_to_dataset as cd
+from tumblr_emotions_amd.datasets import dataset_utils as du
+from tumblr_emotions_amd.datasets import tfrecord as T
+from tumblr_emotions_amd.preprocessing import inception_preprocessing as ip
+
+
+def test_crc32c_check_value_and_mask():
+    assert T.crc32c(b"123456789") == 0xE3069283          # CRC-32C (Castagnoli) standard check value
+    assert T.crc32c(b"") == 0
+    assert T.masked_crc(b"") == 0xA282EAD8               # mask of crc 0
+
+
+def test_example_codec_round_trip_and_negative_int64():
+    feats = {'image/encoded': b'\xff\xd8abc', 'image/format': b'jpg', 'image/class/label': 7,
+             'text': list(range(45)) + [400000] * 5, 'seq_len': 45, 'post_id': -3, 'day': 6, 'f': [0.25, -1.5]}
+    got = T.decode_example(T.encode_example(feats))
+    assert got['image/encoded'] == [b'\xff\xd8abc'] and got['text'] == feats['text']
+    assert got['post_id'] == [-3] and got['f'] == [0.25, -1.5] and got['image/class/label'] == [7]
+
+
+def _make_dataset(root, n_train=7, n_valid=3):
+    from PIL import Image
+    os.makedirs(os.path.join(root, "photos"))
+    os.makedirs(os.path.join(root, "tfrecords"))
+    du.write_label_file({0: "happy", 1: "sad", 2: "angry"}, root, "photos")
+    with open(os.path.join(root, "photos", cd._TRAIN_VALID_FILENAME), "w") as f:
+        f.write("train:%d\nvalidation:%d\n" % (n_train, n_valid))
+    rng = np.random.RandomState(0)
+    truth = {}
+    for split, n in (("train", n_train), ("validation", n_valid)):
+        recs = [[], []]
+        for i in range(n):
+            img = rng.randint(0, 256, size=(40 + i, 52, 3)).astype(np.uint8)
+            b = io.BytesIO()
+            Image.fromarray(img).save(b, format="PNG")        # lossless, so pixels can be compared exactly
+            text = rng.randint(0, 100, size=50).tolist()
+            recs[i % 2].append(du.image_to_tfexample_with_text(b.getvalue(), b'png', img.shape[0], img.shape[1], text,
+                                                               10 + i, i % 3, 1000 + i, i % 7))
+            truth[(split, 1000 + i)] = (img, text, 10 + i, i % 3, i % 7)
+        for shard in range(2):
+            T.write_records(cd.dataset_filename(root, "tfrecords", split, shard, 2), recs[shard])
+    return truth
+
+
+def test_dataset_write_read_round_trip(tmp_path):
+    truth = _make_dataset(str(tmp_path))
+    ds = cd.get_split_with_text("train", str(tmp_path))
+    assert ds.num_samples == 7 and ds.num_classes == 3 and ds.labels_to_names[1] == "sad"
+    assert [os.path.basename(p) for p in ds.data_sources] == ["tumblr_train_00000-of-00002.tfrecord",
+                                                              "tumblr_train_00001-of-00002.tfrecord"]
+    seen = 0
+    for ex in ds.examples(verify_crc=True):
+        img, text, seq_len, label, day = truth[("train", ex["post_id"])]
+        assert np.array_equal(ex["image"], img) and ex["text"].tolist() == text
+        assert (ex["seq_len"], ex["label"], ex["day"]) == (seq_len, label, day)
+        seen += 1
+    assert seen == 7
+    assert cd.get_split_with_text("validation", str(tmp_path)).num_samples == 3
+
+
+def test_corrupt_record_is_detected(tmp_path):
+    p = str(tmp_path / "x.tfrecord")
+    T.write_records(p, [b"hello world"])
+    raw = bytearray(open(p, "rb").read())
+    raw[14] ^= 1
+    open(p, "wb").write(bytes(raw))
+    try:
+        list(T.read_records(p, verify=True))
+        assert False, "corruption not detected"
+    except IOError:
+        pass
+
+
+def test_preprocess_for_eval_geometry_and_range():
+    rng = np.random.RandomState(1)
+    img = rng.randint(0, 256, size=(300, 200, 3)).astype(np.uint8)
+    out = ip.preprocess_for_eval(img, 224, 224)
+    assert out.shape == (224, 224, 3) and out.dtype == np.float32
+    assert out.min() >= -1.0 and out.max() <= 1.0
+    crop = ip.central_crop(img, 0.875)
+    assert crop.shape == (300 - 2 * 18, 200 - 2 * 12, 3)          # start = int((300-262.5)/2) = 18, int(12.5) = 12
+    # identity resize and a pure 2x down-sample pick source pixels exactly (src = dst * in/out)
+    x = rng.uniform(size=(8, 6, 2)).astype(np.float32)
+    np.testing.assert_array_equal(ip.resize_bilinear(x, 8, 6), x)
+    np.testing.assert_allclose(ip.resize_bilinear(x, 4, 3), x[::2, ::2], rtol=0, atol=0)
+    # up-sampling agrees with an independent implementation of the same legacy grid
+    up = ip.resize_bilinear(x, 16, 9)
+    ys = np.arange(16) * (8 / 16)
+    xs = np.arange(9) * (6 / 9)
+    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    y1, x1 = np.minimum(y0 + 1, 7), np.minimum(x0 + 1, 5)
+    fy, fx = (ys - y0)[:, None, None], (xs - x0)[None, :, None]
+    ref = (x[y0][:, x0] * (1 - fy) * (1 - fx) + x[y0][:, x1] * (1 - fy) * fx + x[y1][:, x0] * fy * (1 - fx)
+           + x[y1][:, x1] * fy * fx)
+    np.testing.assert_allclose(up, ref, atol=1e-6)

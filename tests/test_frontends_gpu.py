@@ -86,6 +86,27 @@ def test_train_deep_sentiment_and_image_model_entry_points(tmp_path):
     assert torch.equal(cf[:, 256:], m.net.text.h[m.net.text.T])
 
 
+def test_train_from_tfrecords(tmp_path):
+    """Real-data input path (row 8f-2): sharded TFRecords of (png, token ids) written with this build's
+    writer, read back through get_split_with_text + load_batch_with_text + preprocess_for_eval."""
+    from test_datasets_cpu import _make_dataset
+    from tumblr_emotions_amd.image_text_model.im_text_rnn_model import DeepSentiment, train_deep_sentiment
+    root = str(tmp_path / "data")
+    os.makedirs(root)
+    _make_dataset(root, n_train=9, n_valid=4)
+    cfg = dict(dataset_dir=root, batch_size=4, rnn_size=32, vocab_size=100, embedding_dim=20, post_size=50)
+    m = DeepSentiment(dict(mode="train", initial_lr=1e-3, decay_factor=0.3, im_features_size=256, fc_size=512,
+                           final_endpoint="Mixed_5c", **cfg))
+    assert m.dataset.num_samples == 9 and m.nb_emotions == 3
+    b = m.next_batch(0)
+    assert b["images"].shape == (4, 224, 224, 3) and b["images"].dtype == torch.float32
+    assert float(b["images"].min()) >= -1.0 and float(b["images"].max()) <= 1.0
+    assert b["texts"].shape == (4, 50) and b["texts"].dtype == torch.int64
+    assert set(b["post_ids"].tolist()) <= set(range(1000, 1009))
+    loss = train_deep_sentiment(None, str(tmp_path / "train"), 3, config=cfg, quiet=True)
+    assert np.isfinite(loss)
+
+
 def test_loss_decreases_over_a_short_joint_run():
     """Learning signal end to end: 30 Adam steps on one fixed batch drive the loss down."""
     from tumblr_emotions_amd.net import SentimentNet

@@ -64,3 +64,41 @@ def evaluate_image_model(checkpoint_dir, log_dir, mode, num_evals, *, config=Non
     from ..training import run_evaluation
     model = ImageModel(dict(_CONFIG, mode=mode, **(config or {})))
     return run_evaluation(model, checkpoint_dir, log_dir, mode, num_evals, quiet=quiet)
+
+
+def load_batch_with_text(dataset, batch_size=32, shuffle=True, height=299, width=299, is_training=False,
+                         device="cuda", rank=0, world=1, seed=0, loop=True):
+    """Generator of training batches from a `datasets.convert_to_dataset.Dataset` -- the role of
+    load_batch_with_text + tf.train.batch in the reference (im_model.py:78-116): decode the JPEG, apply the
+    EVAL preprocessing (is_training=False is what every reference call site uses, :78,102), batch.
+    Yields dicts of device tensors: images [B,height,width,3] f32 in [-1,1], texts [B,50] i64, seq_lens,
+    labels, post_ids, days.  Under data parallelism every rank reads the same stream and keeps examples
+    rank, rank+world, ... (disjoint shards of one global order)."""
+    import torch
+    from ..preprocessing.inception_preprocessing import preprocess_image
+    rng = np.random.RandomState(seed)
+    buf = {k: [] for k in ("images", "texts", "seq_lens", "labels", "post_ids", "days")}
+    while True:
+        sources = list(dataset.data_sources)
+        if shuffle:
+            rng.shuffle(sources)
+        view = type(dataset)(sources, dataset.num_samples, dataset.num_classes, dataset.labels_to_names)
+        n = 0
+        for i, ex in enumerate(view.examples()):
+            if i % world != rank:
+                continue
+            n += 1
+            buf["images"].append(preprocess_image(ex["image"], height, width, is_training=is_training))
+            buf["texts"].append(ex["text"])
+            for k, s in (("seq_lens", "seq_len"), ("labels", "label"), ("post_ids", "post_id"), ("days", "day")):
+                buf[k].append(ex[s])
+            if len(buf["labels"]) == batch_size:
+                order = rng.permutation(batch_size) if shuffle else np.arange(batch_size)
+                out = {"images": torch.from_numpy(np.stack(buf["images"])[order]).to(device),
+                       "texts": torch.from_numpy(np.stack(buf["texts"])[order]).to(device)}
+                for k in ("seq_lens", "labels", "post_ids", "days"):
+                    out[k] = torch.from_numpy(np.asarray(buf[k], np.int64)[order]).to(device)
+                buf = {k: [] for k in buf}
+                yield out
+        if not loop or n == 0:
+            return

@@ -127,19 +127,37 @@ def run_evaluation(model, checkpoint_dir, log_dir, mode, num_evals, batch_fn=Non
 
 
 class SyntheticInput:
-    """Mixin: the input side of the reference's model constructors on synthetic data."""
+    """Mixin: the input side of the reference's model constructors.  If `config['dataset_dir']` holds a
+    converted dataset (photos/train_valid_split.txt + tfrecords/tumblr_<mode>_*.tfrecord, the layout of
+    datasets/convert_to_dataset.py:117-198) batches are read from it; otherwise they are synthetic."""
 
     def _init_input(self, config, post_size, vocab_size, nb_emotions, with_images, device):
         from .synthetic import SyntheticDataset
-        self.dataset = SyntheticDataset(config.get("num_samples", 50000), nb_emotions)
         self._in = (post_size, vocab_size, nb_emotions, with_images, device)
         self.post_ids = self.days = self.labels = None
+        self._records = None
+        ddir = config.get("dataset_dir")
+        split = os.path.join(ddir or "", "photos", "train_valid_split.txt")
+        if ddir and os.path.exists(split) and not config.get("synthetic", False):
+            from .datasets.convert_to_dataset import get_split_with_text
+            self.dataset = get_split_with_text(config.get("mode", "train"), ddir)
+        else:
+            self.dataset = SyntheticDataset(config.get("num_samples", 50000), nb_emotions)
 
     def next_batch(self, step):
         post_size, vocab, nb, with_images, device = self._in
         rank, world = _rank_world()
-        gb = self.config["batch_size"] * world
-        b = synthetic_batch_numpy(gb, post_size, vocab, nb, seed=step, with_images=with_images)
-        b = to_device(b, device, rank, world)
+        if hasattr(self.dataset, "data_sources"):            # real TFRecords
+            if self._records is None:
+                from .image_model.im_model import load_batch_with_text
+                self._records = load_batch_with_text(self.dataset, self.config["batch_size"], height=224, width=224,
+                                                     device=device, rank=rank, world=world)
+            b = next(self._records)
+            if not with_images:
+                b.pop("images")
+        else:
+            gb = self.config["batch_size"] * world
+            b = synthetic_batch_numpy(gb, post_size, vocab, nb, seed=step, with_images=with_images)
+            b = to_device(b, device, rank, world)
         self.post_ids, self.days = b["post_ids"], b["days"]
         return b
