@@ -345,6 +345,43 @@ def test_softmax_ce_and_adam_and_reductions():
     close(ss, np.array([(x ** 2).sum()]), 1e-5)
 
 
+def test_every_conv_instantiation_matches_the_oracle():
+    """All tile shapes of both kernel families (LDS-staged: mt 1-2 x nt 1-6; register-direct: mt 1-2 x
+    nt 1-4), forward (n-contiguous weights, BN statistics) and dgrad (k-contiguous, flipped taps), on a
+    shape with ragged M, a K tail and a partial last column tile -- reached through the tuning knobs."""
+    ops = _ops()
+    from tumblr_emotions_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(14)
+    N, H, W, Ci, Co, k = 3, 13, 11, 40, 200, 3
+    x = rng.normal(size=(N, H, W, Ci))
+    w = rng.normal(size=(k, k, Ci, Co)) * 0.1
+    dy = rng.normal(size=(N, H, W, Co))
+    fwd_ref = S.conv2d_same(x, w, 1).reshape(-1, Co)
+    dgr_ref = S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1).reshape(-1, Ci)
+    xd, wd, dyd = dev(x), dev(w), dev(dy)
+    try:
+        for path, nts in ((1, range(1, 7)), (2, range(1, 5))):
+            for mt in (1, 2):
+                for nt in nts:
+                    assert lib.ds_conv_set_path(path) == 0 and lib.ds_conv_set_tile(mt, nt) == 0
+                    plan = ops.ConvPlan(N, H, W, Ci, Ci, k, k, 1, Co, Co, Ci * Co, 1, Co, flags=ops.DS_EPI_STATS)
+                    z = torch.empty(plan.M, Co, device="cuda")
+                    stats = torch.zeros(2, Co, plan.partials, device="cuda")
+                    plan.run(ops._p(xd), ops._p(wd), ops._p(z), stats=ops._p(stats))
+                    g = ops.ConvPlan(N, H, W, Co, Co, k, k, 1, Ci, Ci, Ci * Co, Co, 1, flip=1)
+                    dx = torch.empty(g.M, Ci, device="cuda")
+                    g.run(ops._p(dyd), ops._p(wd), ops._p(dx))
+                    torch.cuda.synchronize()
+                    tag = "path %d tile %d,%d" % (path, mt, nt)
+                    assert np.abs(z.cpu().numpy() - fwd_ref).max() <= 2e-4 * np.abs(fwd_ref).max(), tag
+                    assert np.abs(stats[0].sum(1).cpu().numpy() - fwd_ref.sum(0)).max() <= 1e-3 * np.abs(fwd_ref.sum(0)).max() + 1e-3, tag
+                    assert np.abs(dx.cpu().numpy() - dgr_ref).max() <= 2e-4 * np.abs(dgr_ref).max(), tag
+    finally:
+        lib.ds_conv_set_path(0)
+        lib.ds_conv_set_tile(0, 0)
+
+
 def test_split_k_gemm_slabs_feed_lstm_cell():
     """LSTM step as the engine runs it: split-K recurrent GEMM -> slabs -> cell kernel adds them."""
     ops = _ops()
