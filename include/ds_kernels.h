@@ -69,6 +69,9 @@ typedef struct ds_conv_desc {
                               /* writes its partial sum to z + s*z_split_stride; the consumer adds    */
                               /* the slabs (flags must be 0)                                          */
     int64_t z_split_stride;   /* floats between output slabs                                          */
+    int32_t tile_nt;          /* 0: automatic.  1..6: workgroup tile is 128 rows x 32*tile_nt columns  */
+    int32_t grid_x;           /* 0: automatic.  >0: persistent workgroups per column tile (each walks  */
+                              /* row tiles blockIdx.x, +grid_x, ...); also the stats partial count P   */
 } ds_conv_desc;
 
 /* Tuning aid: pin the workgroup tile to (128*mt) x (32*nt) rows x columns; 0,0 = automatic.  */

@@ -20,6 +20,7 @@ class ConvDesc(C.Structure):
         ("w_tap_stride", C.c_int64), ("w_n_stride", C.c_int32), ("w_k_stride", C.c_int32),
         ("flip", C.c_int32), ("fold_cin", C.c_int32), ("flags", C.c_int32), ("ldmask", C.c_int32),
         ("splits", C.c_int32), ("z_split_stride", C.c_int64),
+        ("tile_nt", C.c_int32), ("grid_x", C.c_int32),
     ]
 
 

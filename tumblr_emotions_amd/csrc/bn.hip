@@ -48,19 +48,27 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *stats, int P, double inv_count, int C,
                                                           const float *beta, float eps, float decay, float *mean,
                                                           float *rstd, float *shift, float *mm, float *mv) {
-    // one wave per channel; partials are laid out [2][C][P] so the 64 lanes read contiguous floats;
-    // combined in double with a fixed butterfly order (deterministic)
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    // one workgroup per channel; partials are laid out [2][C][P] so the threads read contiguous floats
+    // (P is a few hundred for the persistent conv launches, one per row tile -- up to 2048 -- otherwise);
+    // combined in double in a fixed order: strided per thread, butterfly per wave, waves 0..3 (deterministic)
+    __shared__ double red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int p = lane; p < P; p += 64) {
+    for (int p = threadIdx.x; p < P; p += 256) {
         s += (double)stats[(int64_t)c * P + p];
         q += (double)stats[((int64_t)C + c) * P + p];
     }
     s = wave_sum_f64(s);
     q = wave_sum_f64(q);
     if (lane == 0) {
+        red[0][wave] = s;
+        red[1][wave] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        q = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
         const double mu = s * inv_count;
         double var = q * inv_count - mu * mu;          // biased variance (A3)
         if (var < 0.0) var = 0.0;
@@ -228,7 +236,7 @@ extern "C" int ds_bn_finalize(const float *stats, int32_t P, int64_t count, int3
                               float decay, float *mean, float *rstd, float *shift, float *moving_mean,
                               float *moving_var, void *stream) {
     DS_REQUIRE(stats && beta && mean && rstd && shift && P > 0 && count > 0 && C > 0, "ds_bn_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats, P,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, P,
                        1.0 / (double)count, C, beta, eps, decay, mean, rstd, shift, moving_mean, moving_var);
     return ds::check_launch("ds_bn_finalize");
 }

@@ -668,13 +668,24 @@ TileCfg pick_cfg(const ds_conv_desc *d, bool vec) {
         // Measured on MI355X over every conv/GEMM shape of the joint step (profiles/r01_tile_sweep.txt):
         // latency-bound per wave, so small tiles at 3-5 resident workgroups per CU beat wide ones.
         const int64_t row_tiles = (M + 127) / 128;
-        if (pad64 * 100 <= pad32 * 112 && row_tiles * (pad64 / 64) >= 3 * ds::kCUs) c.nt = 2;
+        if (pad64 * 100 <= pad32 * 112 && row_tiles * (pad64 / 64) >= 5 * ds::kCUs / 2) c.nt = 2;
     }
+    if (d->tile_nt > 0 && !c.direct) c.nt = d->tile_nt > 6 ? 6 : d->tile_nt;     // per-layer choice (tuning table)
     if (force_mt > 0) c.mt = force_mt;
     if (force_nt > 0) c.nt = force_nt;
     if (c.direct && c.nt > 4) c.nt = 4;
     return c;
 }
+
+// Launch geometry (measured over every shape of the joint step, profiles/r01_grid_search.txt):
+//   * up to kOneTilePerWg row tiles: one workgroup per tile, handed out by the hardware dispatcher as
+//     slots free up.  A static stride over few tiles per workgroup quantises badly (98 row tiles on
+//     96 workgroups = two rounds; 392 tiles on 256 = half the chip doing double work) and cost
+//     20-45 % on the 14x14 and 7x7 maps.
+//   * larger maps (conv2b/2c, stem: 6272 / 25088 row tiles): persistent workgroups, one resident wave,
+//     striding over row tiles -- same speed within 2 %, and the BatchNorm statistics stay at a few
+//     hundred partials per channel instead of one per row tile.
+constexpr int kOneTilePerWg = 2048;
 
 void grid_for(const ds_conv_desc *d, TileCfg c, Variant v, int *gx, int *gy, int *row_tiles) {
     const int64_t M = conv_M(d);
@@ -682,10 +693,16 @@ void grid_for(const ds_conv_desc *d, TileCfg c, Variant v, int *gx, int *gy, int
     *row_tiles = (int)((M + bm - 1) / bm);
     *gy = (d->Cout + bn - 1) / bn;
     const int wg_tiles = c.direct ? (*row_tiles + 3) / 4 : *row_tiles;     // row tiles in units of workgroups
-    int target = (resident_per_cu(c, v) * ds::kCUs) / *gy;                 // one resident wave of workgroups
-    if (target < 8) target = 8;
-    int x = wg_tiles < target ? wg_tiles : target;
-    if (x >= 8) x &= ~7;                      // multiple of 8: column tiles of a row tile share an XCD
+    int x;
+    if (wg_tiles <= kOneTilePerWg && !c.direct) {
+        x = wg_tiles;
+    } else {
+        int target = (resident_per_cu(c, v) * ds::kCUs) / *gy;             // one resident wave of workgroups
+        if (target < 8) target = 8;
+        x = wg_tiles < target ? wg_tiles : target;
+        if (x >= 8) x &= ~7;                  // multiple of 8: column tiles of a row tile share an XCD
+    }
+    if (d->grid_x > 0 && !c.direct) x = d->grid_x < wg_tiles ? d->grid_x : wg_tiles;   // per-layer override
     *gx = x;
 }
 
