@@ -21,6 +21,9 @@
 //     match a scalar fp32 reference to rounding.
 #include <stdlib.h>
 #include "ds_common.h"
+#ifndef DS_EXP
+#define DS_EXP 0
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector (HIP's float4 is a struct)
@@ -141,6 +144,7 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
     unsigned xb[AR];         // element offset of the image that row i belongs to
     int tap, c0, dh, dw;
     f32x4 ra[AR], rb[BR];
+    bool a_loaded = true;
     f32x16 acc[MT][NT];
 
     auto setup_tile = [&](int tile) {      // point the loader at the first K-tile of row tile `tile`
@@ -173,6 +177,8 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
         auto load_tile = [&]() {
             // ---- A: activations ----------------------------------------------------------------
             const int k = c0 + ak4;
+            a_loaded = !(DS_EXP == 6) || (dh == 0 && dw == 0);
+            if (a_loaded)
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 const int ih = ih0[i] + dh;
@@ -202,6 +208,7 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
         auto store_tile = [&](int buf) {
             float *a_s = As + buf * BM * LDK;
             float *b_s = Bs + buf * BSZ;
+            if (a_loaded)
 #pragma unroll
             for (int i = 0; i < AR; ++i)
                 *reinterpret_cast<f32x4 *>(a_s + (arow + 64 * i) * LDK + ak4) = ra[i];
@@ -295,11 +302,7 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * MT * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-#if DS_EXP == 5
-                    if (row < p.M && colok && acc[a][b][r] == 123.456f) {   /* epilogue work elided (timing only) */
-#else
                     if (row < p.M && colok) {
-#endif
                         float v = acc[a][b][r] + bv;
                         const int64_t off = (int64_t)row * d.ldz + col;
                         if (flags & DS_EPI_ACCUM) v += zout[off];
@@ -672,13 +675,24 @@ TileCfg pick_cfg(const ds_conv_desc *d, bool vec) {
         // Measured on MI355X over every conv/GEMM shape of the joint step (profiles/r01_tile_sweep.txt):
         // latency-bound per wave, so small tiles at 3-5 resident workgroups per CU beat wide ones.
         const int64_t row_tiles = (M + 127) / 128;
-        if (pad64 * 100 <= pad32 * 112 && row_tiles * (pad64 / 64) >= 3 * ds::kCUs) c.nt = 2;
+        if (pad64 * 100 <= pad32 * 112 && row_tiles * (pad64 / 64) >= 5 * ds::kCUs / 2) c.nt = 2;
     }
+    if (d->tile_nt > 0 && !c.direct) c.nt = d->tile_nt > 6 ? 6 : d->tile_nt;     // per-layer choice (tuning table)
     if (force_mt > 0) c.mt = force_mt;
     if (force_nt > 0) c.nt = force_nt;
     if (c.direct && c.nt > 4) c.nt = 4;
     return c;
 }
+
+// Launch geometry (measured over every shape of the joint step, profiles/r01_grid_search.txt):
+//   * up to kOneTilePerWg row tiles: one workgroup per tile, handed out by the hardware dispatcher as
+//     slots free up.  A static stride over few tiles per workgroup quantises badly (98 row tiles on
+//     96 workgroups = two rounds; 392 tiles on 256 = half the chip doing double work) and cost
+//     20-45 % on the 14x14 and 7x7 maps.
+//   * larger maps (conv2b/2c, stem: 6272 / 25088 row tiles): persistent workgroups, one resident wave,
+//     striding over row tiles -- same speed within 2 %, and the BatchNorm statistics stay at a few
+//     hundred partials per channel instead of one per row tile.
+constexpr int kOneTilePerWg = 2048;
 
 void grid_for(const ds_conv_desc *d, TileCfg c, Variant v, int *gx, int *gy, int *row_tiles) {
     const int64_t M = conv_M(d);
@@ -686,10 +700,16 @@ void grid_for(const ds_conv_desc *d, TileCfg c, Variant v, int *gx, int *gy, int
     *row_tiles = (int)((M + bm - 1) / bm);
     *gy = (d->Cout + bn - 1) / bn;
     const int wg_tiles = c.direct ? (*row_tiles + 3) / 4 : *row_tiles;     // row tiles in units of workgroups
-    int target = (resident_per_cu(c, v) * ds::kCUs) / *gy;                 // one resident wave of workgroups
-    if (target < 8) target = 8;
-    int x = wg_tiles < target ? wg_tiles : target;
-    if (x >= 8) x &= ~7;                      // multiple of 8: column tiles of a row tile share an XCD
+    int x;
+    if (wg_tiles <= kOneTilePerWg && !c.direct) {
+        x = wg_tiles;
+    } else {
+        int target = (resident_per_cu(c, v) * ds::kCUs) / *gy;             // one resident wave of workgroups
+        if (target < 8) target = 8;
+        x = wg_tiles < target ? wg_tiles : target;
+        if (x >= 8) x &= ~7;                  // multiple of 8: column tiles of a row tile share an XCD
+    }
+    if (d->grid_x > 0 && !c.direct) x = d->grid_x < wg_tiles ? d->grid_x : wg_tiles;   // per-layer override
     *gx = x;
 }
 

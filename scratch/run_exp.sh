@@ -1,2 +1,2 @@
 export PYTHONPATH=$GRAFT_REPO_ROOT
-for e in 0 5 0 5; do python scratch/conv_bench.py scratch/libexp$e.so 0,0 2>&1 | grep cfg; done
+for e in 0 6 0 6; do python scratch/conv_bench.py scratch/libexp$e.so 0,0 2>&1 | grep cfg; done

@@ -169,17 +169,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *z, SegD
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *partials, int P, double inv_count, int C,
                                                               float *dbeta, float *coef) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    // one workgroup per channel, same fixed combination order as bn_finalize_kernel
+    __shared__ double red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int p = lane; p < P; p += 64) {
+    for (int p = threadIdx.x; p < P; p += 256) {
         s += (double)partials[(int64_t)c * P + p];
         q += (double)partials[((int64_t)C + c) * P + p];
     }
     s = wave_sum_f64(s);
     q = wave_sum_f64(q);
     if (lane == 0) {
+        red[0][wave] = s;
+        red[1][wave] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        q = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
         dbeta[c] = (float)s;
         if (coef) {
             coef[c] = (float)(s * inv_count);          // mean(g)
@@ -290,7 +298,7 @@ extern "C" int ds_bn_bwd_reduce(const float *z, const ds_segments *dy, int64_t M
 extern "C" int ds_bn_bwd_finalize(const float *partials, int32_t P, int64_t M, int32_t C, float *dbeta, float *coef,
                                   void *stream) {
     DS_REQUIRE(partials && dbeta && P > 0 && M > 0 && C > 0, "ds_bn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, P,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, P,
                        1.0 / (double)M, C, dbeta, coef);
     return ds::check_launch("ds_bn_bwd_finalize");
 }
