@@ -8,9 +8,12 @@
 // exactly as they lie in HBM (NHWC rows), fragments are read with ds_read_b32 (32 consecutive
 // channels per half-wave: conflict-free), and the reduction over pixels is cut into `splits`
 // slabs that a second kernel sums in a fixed order (deterministic, no atomics).
+#include <stdlib.h>
 #include "ds_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -29,7 +32,36 @@ struct WgradParams {
     int ci_tiles;
     int pix_per_split;  // multiple of TP
     int x_vec, z_vec;
+    unsigned x_bytes, z_bytes;   // extents covered by the two buffer descriptors
+    float inv_ohw, inv_ow;
 };
+
+constexpr unsigned kOOB = 0x80000000u;   // byte offset beyond any descriptor: the load returns 0
+
+// SRD buffer loads as in conv_igemm.hip: rows past the split, padding pixels and channels past the
+// tensor get an out-of-range offset and come back as zeros, so the loader has no branches and the
+// loads of a K-tile stay in flight under the MFMAs of the previous one.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ f32x4 load4(__amdgpu_buffer_rsrc_t r, unsigned off, bool ok, bool vec, int valid) {
+    if (vec) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, ok ? off : kOOB, 0, 0));
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (ok && j < valid) ? off + 4 * j : kOOB, 0, 0));
+    return v;
+}
+
+// floor(a / b) for 0 <= a < 2^24 with inv = 1.0f / b (one correction step each way)
+__device__ __forceinline__ int fdiv(int a, int b, float inv) {
+    int q = (int)((float)a * inv);
+    int r = a - q * b;
+    if (r < 0) --q;
+    if (r >= b) ++q;
+    return q;
+}
 
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TP * LDT];
@@ -65,50 +97,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 
     const int lrow = tid >> 5;          // 0..7 (+8)
     const int lc4 = (tid & 31) * 4;     // channel offset inside the 128-wide tile
-    float4 rx[2], rz[2];
+    f32x4 rx[2], rz[2];
+    const __amdgpu_buffer_rsrc_t srd_x = make_srd(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t srd_z = make_srd(p.dz, p.z_bytes);
+    const int cx = i0 + lc4, cz = j0 + lc4;
+    const bool small = p.M < (1 << 24);
 
     auto load_tile = [&](int mt0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = mt0 + lrow + 8 * i;
-            float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vz = vx;
-            if (m < m_end) {
-                const int n = m / ohw;
-                const int r = m - n * ohw;
-                const int oh = r / d.OW, ow = r - oh * d.OW;
-                const int ih = oh * d.stride - d.pad_t + dh, iw = ow * d.stride - d.pad_l + dw;
-                if ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W) {
-                    const int c = i0 + lc4;
-                    const float *ptr = p.x + (((int64_t)n * d.H + ih) * d.W + iw) * d.ldx + c;
-                    if (p.x_vec) {
-                        if (c < d.Cin) vx = *reinterpret_cast<const float4 *>(ptr);
-                    } else {
-                        if (c + 0 < d.Cin) vx.x = ptr[0];
-                        if (c + 1 < d.Cin) vx.y = ptr[1];
-                        if (c + 2 < d.Cin) vx.z = ptr[2];
-                        if (c + 3 < d.Cin) vx.w = ptr[3];
-                    }
-                }
-                const int c = j0 + lc4;
-                const float *ptr = p.dz + (int64_t)m * p.lddz + c;
-                if (p.z_vec) {
-                    if (c < d.Cout) vz = *reinterpret_cast<const float4 *>(ptr);
-                } else {
-                    if (c + 0 < d.Cout) vz.x = ptr[0];
-                    if (c + 1 < d.Cout) vz.y = ptr[1];
-                    if (c + 2 < d.Cout) vz.z = ptr[2];
-                    if (c + 3 < d.Cout) vz.w = ptr[3];
-                }
-            }
-            rx[i] = vx;
-            rz[i] = vz;
+            const bool rv = m < m_end;
+            const int mm = rv ? m : 0;
+            const int n = small ? fdiv(mm, ohw, p.inv_ohw) : mm / ohw;
+            const int r = mm - n * ohw;
+            const int oh = small ? fdiv(r, d.OW, p.inv_ow) : r / d.OW;
+            const int ow = r - oh * d.OW;
+            const int ih = oh * d.stride - d.pad_t + dh, iw = ow * d.stride - d.pad_l + dw;
+            const bool okx = rv && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W && cx < d.Cin;
+            const unsigned offx = ((unsigned)(n * d.H + ih) * (unsigned)d.W + (unsigned)iw) * (unsigned)d.ldx + (unsigned)cx;
+            rx[i] = load4(srd_x, offx * 4u, okx, p.x_vec, d.Cin - cx);
+            const bool okz = rv && cz < d.Cout;
+            const unsigned offz = (unsigned)mm * (unsigned)p.lddz + (unsigned)cz;
+            rz[i] = load4(srd_z, offz * 4u, okz, p.z_vec, d.Cout - cz);
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<float4 *>(Xs + (buf * TP + lrow + 8 * i) * LDT + lc4) = rx[i];
-            *reinterpret_cast<float4 *>(Zs + (buf * TP + lrow + 8 * i) * LDT + lc4) = rz[i];
+            *reinterpret_cast<f32x4 *>(Xs + (buf * TP + lrow + 8 * i) * LDT + lc4) = rx[i];
+            *reinterpret_cast<f32x4 *>(Zs + (buf * TP + lrow + 8 * i) * LDT + lc4) = rz[i];
         }
     };
     auto compute = [&](int buf) {
@@ -169,8 +187,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *ws, flo
 
 int pick_splits(const ds_conv_desc *d, int64_t M) {
     const int tiles = d->KH * d->KW * ((d->Cin + TI - 1) / TI) * ((d->Cout + TJ - 1) / TJ);
-    int splits = (2 * ds::kCUs + tiles - 1) / tiles;
-    const int max_splits = (int)((M + 255) / 256);    // keep >= 256 pixels per split
+    static int occ = 0, minpix = 0;
+    if (!occ) {
+        const char *e = getenv("DS_WGRAD_OCC");
+        occ = e ? atoi(e) : 3;          // measured best of 2/3/4/6 workgroups per CU (MI355X, joint step)
+        e = getenv("DS_WGRAD_MINPIX");
+        minpix = e ? atoi(e) : 64;
+    }
+    int splits = (occ * ds::kCUs + tiles - 1) / tiles;
+    const int max_splits = (int)((M + minpix - 1) / minpix);    // keep >= minpix pixels per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     return splits;
@@ -206,6 +231,13 @@ extern "C" int ds_conv_wgrad(const ds_conv_desc *d, const float *x, const float 
     p.pix_per_split = ((pps + TP - 1) / TP) * TP;
     p.x_vec = (d->ldx % 4 == 0) && (d->Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
     p.z_vec = (lddz % 4 == 0) && (d->Cout % 4 == 0) && (((uintptr_t)dz & 15) == 0);
+    const int64_t x_elems = ((int64_t)d->N * d->H * d->W - 1) * d->ldx + d->Cin;
+    const int64_t z_elems = (M - 1) * lddz + d->Cout;
+    DS_REQUIRE(x_elems * 4 < (1ll << 31) && z_elems * 4 < (1ll << 31), "ds_conv_wgrad: operand larger than 2 GiB (split the batch)");
+    p.x_bytes = (unsigned)(x_elems * 4);
+    p.z_bytes = (unsigned)(z_elems * 4);
+    p.inv_ohw = 1.0f / (float)(d->OH * d->OW);
+    p.inv_ow = 1.0f / (float)d->OW;
     dim3 grid(d->KH * d->KW * p.ci_tiles, (d->Cout + TJ - 1) / TJ, splits);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, s, p);
