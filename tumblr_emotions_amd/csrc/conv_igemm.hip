@@ -14,9 +14,11 @@
 //     stay in flight under the MFMAs of the current tile and are waited for only at the LDS store.
 //   * 4 waves per workgroup stacked along M; each wave owns (MT*32) rows x all BN = NT*32 columns,
 //     so the tile width is chosen per layer from NT = 1..6 to fit Cout with little padding.
-//   * workgroups are persistent over row tiles (grid.x is a multiple of 8 so that all column
-//     tiles of a row tile, which share the A rows, land on the same XCD/L2), which also lets the
-//     BatchNorm column statistics be accumulated in registers and emitted once per workgroup.
+//   * launch geometry (grid_for): one workgroup per row tile up to 2048 row tiles; above that the
+//     workgroups are persistent over row tiles (grid.x a multiple of 8 so that all column tiles of
+//     a row tile, which share the A rows, land on the same XCD/L2) with the K-loop pipeline running
+//     across tiles.  BatchNorm column statistics are accumulated in registers and emitted once per
+//     workgroup either way.
 //   * fp32 MFMA is an exact k-ordered fmaf chain (cdna_hip_programming.md section 3), so results
 //     match a scalar fp32 reference to rounding.
 #include <stdlib.h>
