@@ -121,6 +121,36 @@ def test_loss_decreases_over_a_short_joint_run():
     assert losses[-1] < 0.5 * losses[0], losses
 
 
+def test_image_only_baseline_config1_batch_128():
+    """BASELINE.json configs[1]: image-only Inception-v1, 15 classes, batch 128.  No oracle at this size:
+    the step is bit-reproducible, finite, moves every trainable tensor, leaves every frozen conv weight
+    untouched, and the first logits equal those of the same weights at batch 8 on the shared samples when
+    BatchNorm runs in inference mode (batch-size independence of the forward kernels and launch geometry)."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    B = 128
+    batch = to_device(synthetic_batch_numpy(B, 8, 10, seed=3))
+    thetas = []
+    for _ in range(2):
+        net = SentimentNet(mode="image", nb_emotions=15)
+        net.initialize(seed=2)
+        before = net.state_dict()
+        net.train_step(batch, 1e-3, seed=11)
+        torch.cuda.synchronize()
+        thetas.append(net.store.theta.clone())
+    assert torch.equal(thetas[0], thetas[1]) and torch.isfinite(thetas[0]).all()
+    after = net.state_dict()
+    moved = [k for k in before if not np.array_equal(before[k], after[k])]
+    frozen_w = [k for k in before if k.endswith("/weights") and "Mixed_5c" not in k and "Logits" not in k]
+    assert frozen_w and not set(frozen_w) & set(moved)
+    assert any("Mixed_5c" in k and k.endswith("/weights") for k in moved)
+    assert "InceptionV1/Conv2d_1a_7x7/BatchNorm/beta" in moved          # every BN beta is trainable
+    full = net.predict(batch, is_training=False)
+    small = {k: v[:8].contiguous() for k, v in batch.items()}
+    part = net.predict(small, is_training=False)
+    assert torch.allclose(full[:8], part, rtol=0, atol=1e-4 * max(1.0, float(full.abs().max())))
+
+
 def test_full_size_properties_batch_256():
     """BASELINE cfg3 dims (B=256): properties that need no oracle at this size.
     After BatchNorm(train) every channel of the normalised pre-activation has mean 0 / variance

@@ -131,6 +131,25 @@ def test_text_only_reference_default_dims_unaligned_embedding():
     _check_step(net, ref, batch, 1e-3)
 
 
+def test_text_only_baseline_config0_full_size():
+    """BASELINE.json configs[0] at its real size: 10k-vocab, 32-token posts, 300-d embedding, LSTM-512,
+    15 classes, batch 64 -- the whole step (logits, loss, every gradient, one TF-Adam update) against the
+    fp64 oracle; two consecutive steps."""
+    from tumblr_emotions_amd.net import SentimentNet
+    rng = np.random.RandomState(31)
+    V, D, H, T, B = 10000, 300, 512, 32, 64
+    params = R.make_params("text", rng, num_classes=15, embed_dim=D, rnn_size=H, dtype=np.float64)
+    emb = S.synthetic_embedding(V, D).astype(np.float64)
+    batch = S.synthetic_batch(B, T, V, seed=6, with_images=False)
+    ref = R.DeepSentimentRef(params, emb, "text", torch.float64)
+    net = SentimentNet(mode="text", nb_emotions=15, rnn_size=H, vocab_size=V, embedding_dim=D, post_size=T)
+    net.load_state_dict(dict(params, **{"Text/W_embedding": emb}))
+    for i in range(2):
+        if i:
+            _sync_from_oracle(net, ref, emb)
+        _check_step(net, ref, batch, 1e-3, first=(i == 0))
+
+
 def test_image_only_step_matches_oracle():
     """train_image_model: Inception-v1 with num_classes = nb_emotions, dropout mask injected."""
     from tumblr_emotions_amd.net import SentimentNet
