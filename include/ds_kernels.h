@@ -76,7 +76,8 @@ typedef struct ds_conv_desc {
 
 /* Tuning aid: pin the workgroup tile to (128*mt) x (32*nt) rows x columns; 0,0 = automatic.  */
 int ds_conv_set_tile(int mt, int nt);
-/* Tuning aid: 0 = automatic, 1 = LDS-staged kernel, 2 = register-direct (LDS-free) kernel.     */
+/* Tuning aid: 0 = automatic, 1 = register-staged LDS kernel (K-tile 16), 2 = register-direct (LDS-free)
+ * kernel, 3 = LDS-DMA kernel (buffer_load ... lds, K-tile 32; falls back to 1 where it does not apply). */
 int ds_conv_set_path(int path);
 /* Number of row-tile blocks (P) the launch for `d` will use = number of stats partials.   */
 int ds_conv_igemm_partials(const ds_conv_desc *d);

@@ -346,8 +346,8 @@ def test_softmax_ce_and_adam_and_reductions():
 
 
 def test_every_conv_instantiation_matches_the_oracle():
-    """All tile shapes of both kernel families (LDS-staged: mt 1-2 x nt 1-6; register-direct: mt 1-2 x
-    nt 1-4), forward (n-contiguous weights, BN statistics) and dgrad (k-contiguous, flipped taps), on a
+    """All tile shapes of the three kernel families (register-staged LDS: mt 1-2 x nt 1-6; register-direct:
+    mt 1-2 x nt 1-4; LDS-DMA with the 32-deep K-tile: nt 1-3), forward (n-contiguous weights, BN statistics) and dgrad (k-contiguous, flipped taps), on a
     shape with ragged M, a K tail and a partial last column tile -- reached through the tuning knobs."""
     ops = _ops()
     from tumblr_emotions_amd import _lib
@@ -361,7 +361,7 @@ def test_every_conv_instantiation_matches_the_oracle():
     dgr_ref = S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1).reshape(-1, Ci)
     xd, wd, dyd = dev(x), dev(w), dev(dy)
     try:
-        for path, nts in ((1, range(1, 7)), (2, range(1, 5))):
+        for path, nts in ((1, range(1, 7)), (2, range(1, 5)), (3, range(1, 4))):
             for mt in (1, 2):
                 for nt in nts:
                     assert lib.ds_conv_set_path(path) == 0 and lib.ds_conv_set_tile(mt, nt) == 0
