@@ -48,7 +48,44 @@ def cpu_baseline(batch, steps, post_size, vocab, dim, rnn):
     return dict(value=round(batch * steps / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind="port",
                 sample="joint train step (fwd+bwd+Adam), batch %d, %d timed steps after 1 warm-up, fp32, "
                        "PyTorch-CPU restatement of the TF1 step (TensorFlow 1.x not installable here); host has %d "
-                       "logical CPUs" % (batch, steps, os.cpu_count()))
+                       "logical CPUs (%s)" % (batch, steps, os.cpu_count(), cpu_model()))
+
+
+def gather_bandwidth():
+    """north_star: HBM GB/s on the embedding gather.  The step's own gather moves 19.7 MB (too small to show
+    bandwidth), so it is timed at B*T = 2^20 tokens: D = 300 fp32 rows out of the 10 001-row table
+    (12 MB, cache resident) written time-major = 1.26 GB of stores + 8 MB of ids per launch."""
+    import torch
+    from tumblr_emotions_amd import ops
+    V, D, B, T = 10000, 300, 8192, 128
+    table = torch.randn(V + 1, D, device="cuda")
+    ids = torch.randint(0, V + 1, (B, T), device="cuda", dtype=torch.int64)
+    out = torch.empty(T * B, D, device="cuda")
+    for _ in range(3):
+        ops.gather_rows(table, ids, out, B, T, D)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.gather_rows(table, ids, out, B, T, D)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    alg = B * T * (2 * D * 4 + 8)                       # read row + write row + id, SURVEY 8d
+    return dict(kernel="gather_rows_kernel", tokens=B * T, alg_bytes=alg, us=round(us, 1),
+                achieved_GBps=round(alg / us / 1e3, 1), peak_GBps=8000, frac=round(alg / us / 1e3 / 8000, 4),
+                note="algorithmic bytes count the row read although the 12 MB table is L2/MALL resident; "
+                     "HBM sees the 1.26 GB of row writes")
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def pmc_traffic(args):
@@ -70,9 +107,11 @@ def pmc_traffic(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: fixed global batch split over the ranks (BASELINE cfg4: 256 over 8 GPUs)")
     ap.add_argument("--mode", default="joint", choices=["joint", "image", "text"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
@@ -105,6 +144,10 @@ def main():
     net = SentimentNet(mode=args.mode, nb_emotions=15, im_features_size=256, rnn_size=H, fc_size=512, vocab_size=V,
                        embedding_dim=D, post_size=T, dropout_keep_prob=0.8)
     net.initialize(seed=1)
+    strong = args.global_batch > 0
+    if strong:
+        assert args.global_batch % world == 0, "--global-batch must divide by the number of ranks"
+        args.batch = args.global_batch // world
     gb = args.batch * world
     batch = to_device(synthetic_batch_numpy(gb, T, V, 15, seed=0, with_images=args.mode != "text"), "cuda", rank, world)
     lr = 1e-3
@@ -183,7 +226,7 @@ def main():
             "metric": "training samples/sec (224x224 img + 32-tok text, batch 256)",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "sec_per_step": round(dt / args.steps, 5), "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s train step (fwd+bwd+all-reduce+Adam): Inception-v1 224x224x3 + 300-d embedding + "
                                    "LSTM-512, T=32, V=10000, 15 classes, batch %d per GPU, reference freeze "
                                    "(<=Mixed_5b conv weights frozen, all BN betas trainable), dropout 0.8, BN train mode"
@@ -191,6 +234,7 @@ def main():
                        "global_batch": gb, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
                        "gflop_per_sample": flop_per_sample, "final_loss": round(loss, 5)},
             "roofline": roof,
+            "gather": gather_bandwidth() if args.mode != "image" else None,
         }
         if world == 1 and not args.no_cpu_baseline and args.mode == "joint":
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps, T, V, D, H)
