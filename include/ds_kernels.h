@@ -148,6 +148,13 @@ int ds_avgpool_dropout_bwd(const float *dout, const float *mask, int32_t N, int3
 int ds_gather_rows(const float *table, const int64_t *ids, float *out, int32_t B, int32_t T, int32_t D,
                    int64_t table_rows, int32_t time_major, void *stream);
 
+/* Gradient of tf.nn.embedding_lookup w.r.t. the table (a dense [table_rows, D] result of what TF returns as
+ * IndexedSlices): dtable[v] = sum_{(b,t): ids[b,t]==v} dx[row(b,t)], rows summed in ascending b*T+t order
+ * (deterministic).  The reference's table is trainable=False (im_text_rnn_model.py:82), so this only backs
+ * the optional fine-tuning switch.  D <= 512.                                                        */
+int ds_embedding_grad(const float *dx, const int64_t *ids, float *dtable, int32_t B, int32_t T, int32_t D,
+                      int64_t table_rows, int32_t time_major, void *stream);
+
 /* BasicLSTMCell gate math + dynamic_rnn length masking (im_text_rnn_model.py:89-90).
  * gates [B,4H] holds x_t*Wx+bias (i,j,f,o) on entry -- the recurrent term h_{t-1}*Wh is added
  * from `nslabs` split-K slabs rec_slabs[s*slab_stride + ...] (nslabs may be 0 when the GEMM

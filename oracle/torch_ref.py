@@ -53,7 +53,11 @@ class DeepSentimentRef:
     ImageModel (im_model.py:139-164), TextModel (text_embedding.py:37-86)."""
 
     def __init__(self, params, embedding=None, mode="joint", dtype=torch.float32,
-                 trainable_bn_beta=True, is_training=True):
+                 trainable_bn_beta=True, is_training=True, train_all=False, trainable_embedding=False):
+        """train_all / trainable_embedding are NOT reference behaviour (the reference freezes everything
+        below Mixed_5c, inception_v1.py:57-59, and the embedding, im_text_rnn_model.py:82): they restate
+        what plain TF autodiff would give if those `trainable=False` flags were dropped (SURVEY row 8f-4,
+        full-tower fine-tuning), for the build's optional switch of the same name."""
         self.mode = mode
         self.dtype = dtype
         self.is_training = is_training
@@ -61,9 +65,14 @@ class DeepSentimentRef:
         self.embedding = None if embedding is None else torch.tensor(np.asarray(embedding), dtype=dtype)
         self.trainable = []
         for name in self.p:
-            if self._is_trainable(name, trainable_bn_beta):
+            if self._is_trainable(name, trainable_bn_beta) or (
+                    train_all and name.startswith("InceptionV1/") and name.endswith("/weights")):
                 self.p[name].requires_grad_(True)
                 self.trainable.append(name)
+        if trainable_embedding and self.embedding is not None:
+            self.embedding.requires_grad_(True)
+            self.p["Text/W_embedding"] = self.embedding
+            self.trainable.append("Text/W_embedding")
         self.adam_m = {n: torch.zeros_like(self.p[n]) for n in self.trainable}
         self.adam_v = {n: torch.zeros_like(self.p[n]) for n in self.trainable}
         self.step = 0

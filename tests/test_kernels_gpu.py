@@ -278,6 +278,33 @@ def test_gather_rows_is_bit_exact(D):
     assert np.array_equal(out2.cpu().numpy(), table[ids])
 
 
+@pytest.mark.parametrize("D,B,T,V", [(300, 6, 9, 40), (50, 5, 70, 30), (7, 3, 5, 200), (512, 2, 3, 4)])
+def test_embedding_grad_scatter_add(D, B, T, V):
+    """dtable[v] = sum of the dx rows whose id is v (np.add.at), collisions, unused rows (zeros), the pad row,
+    both row orders, and bit-reproducibility (fixed summation order, no atomics)."""
+    ops = _ops()
+    rng = np.random.RandomState(15)
+    ids = rng.randint(0, V + 1, size=(B, T)).astype(np.int64)
+    ids[0, :3] = 1                                                  # guaranteed collisions
+    dx = rng.normal(size=(B, T, D)).astype(np.float32)
+    want = np.zeros((V + 1, D), np.float64)
+    np.add.at(want, ids.reshape(-1), dx.reshape(-1, D).astype(np.float64))
+    idd = dev(ids, torch.int64)
+    got_tm = torch.full((V + 1, D), 7.0, device="cuda")
+    dx_tm = dev(np.ascontiguousarray(dx.transpose(1, 0, 2)))        # time-major rows t*B+b
+    ops.embedding_grad(dx_tm, idd, got_tm, B, T, D, True)
+    got_bm = torch.full((V + 1, D), 7.0, device="cuda")
+    dx_bm = dev(dx)
+    ops.embedding_grad(dx_bm, idd, got_bm, B, T, D, False)
+    again = torch.empty(V + 1, D, device="cuda")
+    ops.embedding_grad(dx_tm, idd, again, B, T, D, True)
+    torch.cuda.synchronize()
+    close(got_tm, want, 1e-5)
+    assert torch.equal(got_tm, got_bm) and torch.equal(got_tm, again)
+    unused = np.setdiff1d(np.arange(V + 1), ids.reshape(-1))
+    assert unused.size == 0 or float(got_tm[torch.as_tensor(unused, device="cuda")].abs().max()) == 0.0
+
+
 def test_lstm_cell_forward_backward():
     ops = _ops()
     rng = np.random.RandomState(11)

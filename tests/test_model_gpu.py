@@ -150,6 +150,51 @@ def test_text_only_baseline_config0_full_size():
         _check_step(net, ref, batch, 1e-3, first=(i == 0))
 
 
+def test_full_fine_tuning_image_step_matches_oracle():
+    """train_all=True: every one of the 57 conv weight tensors is trainable -- wgrad for the
+    7x7/2 stem, the horizontally fused 1x1s, every 3x3 -- with L2 on all of them, against the oracle with the
+    same switch (plain autodiff of the reference graph without its trainable=False flags)."""
+    from tumblr_emotions_amd.net import SentimentNet
+    rng = np.random.RandomState(33)
+    B = 3
+    params = R.make_params("image", rng, num_classes=15, dtype=np.float64)
+    for k in params:
+        if k.endswith("beta"):
+            params[k] = rng.normal(0, 0.1, size=params[k].shape)
+    batch = S.synthetic_batch(B, 8, 10, seed=9)
+    mask = (rng.uniform(size=(B, 1024)) < 0.8).astype(np.float64)
+    ref = R.DeepSentimentRef(params, None, "image", torch.float64, train_all=True)
+    ref32 = R.DeepSentimentRef(params, None, "image", torch.float32, train_all=True)
+    net = SentimentNet(mode="image", nb_emotions=15, train_all=True)
+    net.load_state_dict(params)
+    assert net.frozen_l2_sumsq == 0.0
+    out = _check_step(net, ref, batch, 1e-3, mask, ref32=ref32)
+    conv_w = [n for n in out["grads"] if n.endswith("/weights")]
+    assert len(conv_w) == 58 and "InceptionV1/Conv2d_1a_7x7/weights" in conv_w          # 57 convs + Logits
+
+
+def test_trainable_embedding_text_step_matches_oracle():
+    """trainable_embedding=True: dX = dgates * Wx^T and the deterministic scatter-add into the table gradient
+    (rows hit several times, rows never hit, the pad row), then TF-Adam on the table."""
+    from tumblr_emotions_amd.net import SentimentNet
+    rng = np.random.RandomState(34)
+    V, D, H, T, B = 50, 20, 16, 11, 9
+    params = R.make_params("text", rng, num_classes=15, embed_dim=D, rnn_size=H, dtype=np.float64)
+    emb = S.synthetic_embedding(V, D).astype(np.float64)
+    batch = S.synthetic_batch(B, T, V, seed=12, with_images=False)
+    ref = R.DeepSentimentRef(params, emb, "text", torch.float64, trainable_embedding=True)
+    net = SentimentNet(mode="text", nb_emotions=15, rnn_size=H, vocab_size=V, embedding_dim=D, post_size=T,
+                       trainable_embedding=True)
+    net.load_state_dict(dict(params, **{"Text/W_embedding": emb}))
+    for i in range(2):
+        if i:
+            _sync_from_oracle(net, ref)
+        out = _check_step(net, ref, batch, 1e-3, first=(i == 0))
+    g = out["grads"]["Text/W_embedding"].numpy()
+    used = np.unique(batch["texts"])
+    assert np.abs(g[used]).max() > 0 and np.abs(np.delete(g, used, axis=0)).max() == 0
+
+
 def test_image_only_step_matches_oracle():
     """train_image_model: Inception-v1 with num_classes = nb_emotions, dropout mask injected."""
     from tumblr_emotions_amd.net import SentimentNet

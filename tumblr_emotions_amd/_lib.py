@@ -56,6 +56,7 @@ SIGNATURES = {
     "ds_avgpool_dropout_fwd": (C.c_int, [_P, _i32, _i32, _i32, _f32, _u64, _P, _P, _P, _P, _P]),
     "ds_avgpool_dropout_bwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _f32, _P, _P]),
     "ds_gather_rows": (C.c_int, [_P, _P, _P, _i32, _i32, _i32, _i64, _i32, _P]),
+    "ds_embedding_grad": (C.c_int, [_P, _P, _P, _i32, _i32, _i32, _i64, _i32, _P]),
     "ds_lstm_cell_fwd": (C.c_int, [_P, _P, _i32, _i64, _P, _P, _P, _i32, _i32, _i32, _f32, _P, _P, _P]),
     "ds_lstm_cell_bwd": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i64, _P, _P, _i32, _i32, _i32, _P, _P, _P, _P]),
     "ds_softmax_ce": (C.c_int, [_P, _P, _i32, _i32, _f32, _P, _P, _P, _P]),

@@ -34,6 +34,47 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *table, co
     }
 }
 
+// ---- embedding gradient: deterministic wavefront-reduced scatter-add ------------------------------
+// dtable[v, :] = sum over the positions p = b*T + t with ids[p] == v of dx[row(p), :], one wave per
+// vocabulary row.  The wave sweeps the id list 64 positions at a time, ballots the matches and adds the
+// matching rows in ascending position order -- no atomics, no sort, bit-reproducible -- with lane l owning
+// columns l, l+64, ... of the row.  Rows nobody referenced come out as zeros (the whole table is written).
+// Not reachable from the reference graph (its embedding is trainable=False, im_text_rnn_model.py:82); it
+// backs the optional full fine-tuning switch.
+template <int NQ>
+__global__ __launch_bounds__(256) void embedding_grad_kernel(const float *dx, const int64_t *ids, float *dtable, int B,
+                                                             int T, int D, int64_t rows, int time_major) {
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= rows) return;
+    float acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
+    const int BT = B * T;
+    for (int base = 0; base < BT; base += 64) {
+        const int pos = base + lane;
+        const int64_t id = pos < BT ? ids[pos] : -1;
+        unsigned long long mask = __ballot(id == v);
+        while (mask) {
+            const int j = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int p = base + j;
+            const int b = p / T, t = p - b * T;
+            const float *src = dx + (time_major ? (int64_t)t * B + b : (int64_t)p) * D;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c = lane + 64 * q;
+                if (c < D) acc[q] += src[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = lane + 64 * q;
+        if (c < D) dtable[v * D + c] = acc[q];
+    }
+}
+
 // ---- LSTM cell -----------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
@@ -245,6 +286,19 @@ extern "C" int ds_gather_rows(const float *table, const int64_t *ids, float *out
                            ids, out, B, T, D, table_rows, time_major);
     }
     return ds::check_launch("ds_gather_rows");
+}
+
+extern "C" int ds_embedding_grad(const float *dx, const int64_t *ids, float *dtable, int32_t B, int32_t T, int32_t D,
+                                 int64_t table_rows, int32_t time_major, void *stream) {
+    DS_REQUIRE(dx && ids && dtable && B > 0 && T > 0 && D > 0 && D <= 512 && table_rows > 0,
+               "ds_embedding_grad: bad argument (D <= 512)");
+    const dim3 grid((unsigned)((table_rows + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (D <= 64) hipLaunchKernelGGL(embedding_grad_kernel<1>, grid, block, 0, s, dx, ids, dtable, B, T, D, table_rows, time_major);
+    else if (D <= 128) hipLaunchKernelGGL(embedding_grad_kernel<2>, grid, block, 0, s, dx, ids, dtable, B, T, D, table_rows, time_major);
+    else if (D <= 320) hipLaunchKernelGGL(embedding_grad_kernel<5>, grid, block, 0, s, dx, ids, dtable, B, T, D, table_rows, time_major);
+    else hipLaunchKernelGGL(embedding_grad_kernel<8>, grid, block, 0, s, dx, ids, dtable, B, T, D, table_rows, time_major);
+    return ds::check_launch("ds_embedding_grad");
 }
 
 extern "C" int ds_lstm_cell_fwd(float *gates, const float *rec_slabs, int32_t nslabs, int64_t slab_stride,

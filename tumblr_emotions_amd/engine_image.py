@@ -96,7 +96,7 @@ class ConvBN:
         self.dgrad = None
         self.wgrad = None
         if self.trainable:
-            self.wgrad = WgradPlan(B, self.H, self.W, cin, 0, k, k, self.stride, cout, cout)
+            self.wgrad = WgradPlan(B, self.H, self.W, 4 if self.fold else cin, 0, k, k, self.stride, cout, cout)
             eng.need_ws(self.wgrad.ws_bytes)
 
     def bind(self):
@@ -305,9 +305,13 @@ class InceptionV1Engine:
     (image_model/inception_v1.py:254-309) as explicit forward()/backward() over HIP kernels."""
 
     def __init__(self, store, num_classes, image_size=224, dropout_keep_prob=0.8, trainable_bn_beta=True,
-                 device="cuda"):
+                 device="cuda", train_all=False):
         self.store, self.num_classes, self.keep = store, num_classes, dropout_keep_prob
         self.trainable_bn_beta = trainable_bn_beta
+        # train_all: full-tower fine-tuning (SURVEY row 8f-4) -- every conv weight trainable, i.e. the
+        # reference graph with the `trainable=False` of inception_v1.py:57-59 dropped; wgrad then runs for
+        # all 57 convs (the stem through its zero-padded 4-channel input) and every variable sits in bucket 1
+        self.train_all = train_all
         self.device = torch.device(device)
         self.update_moving = True
         self.training = True         # False: BatchNorm uses moving statistics, dropout is the identity
@@ -319,7 +323,7 @@ class InceptionV1Engine:
         prev = self.input
         for item in TOPOLOGY:
             kind, name = item[0], item[1]
-            tr = name in TRAINABLE_ENDPOINTS
+            tr = train_all or name in TRAINABLE_ENDPOINTS
             bucket = 1 if tr else 2
             if kind == "conv":
                 st = ConvStage(self, name, prev, item[2], item[3], item[4], tr, bucket)
@@ -411,7 +415,9 @@ class InceptionV1Engine:
             stop = min(i for i, s in enumerate(self.stages) if any(l.trainable for l in s.layers))
         for i in range(n - 1, stop - 1, -1):
             self.stages[i].backward(need_dx=(i > stop))
-            if self.reducer is not None and self.stages[i].name in TRAINABLE_ENDPOINTS:
+            if self.reducer is not None and not self.train_all and self.stages[i].name in TRAINABLE_ENDPOINTS:
                 # every conv-weight gradient and the Logits gradients now sit in bucket 1 of the flat
                 # gradient: its all-reduce can start while dgrad continues through the frozen blocks
                 self.reducer.stage_done(self.stages[i].name)
+        if self.reducer is not None and self.train_all:
+            self.reducer.stage_done(TRAINABLE_ENDPOINTS[0])      # whole tower trainable: bucket 1 closes with the stem

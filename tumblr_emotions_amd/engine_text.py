@@ -37,10 +37,13 @@ class TextTowerEngine:
     BIAS = "Text/rnn/basic_lstm_cell/bias"
     EMB = "Text/W_embedding"
 
-    def __init__(self, store, vocab_rows, embed_dim, rnn_size, post_size, device="cuda"):
+    def __init__(self, store, vocab_rows, embed_dim, rnn_size, post_size, device="cuda", trainable_embedding=False):
         self.store, self.V, self.D, self.H, self.T = store, vocab_rows, embed_dim, rnn_size, post_size
         self.device = torch.device(device)
-        store.declare(self.EMB, (vocab_rows, embed_dim), False)                      # trainable=False, :82
+        # reference: trainable=False (:82).  trainable_embedding=True is the optional fine-tuning switch
+        # (SURVEY row 8f-4): dX = dgates * Wx^T, then a deterministic scatter-add into the table gradient.
+        self.trainable_embedding = trainable_embedding
+        store.declare(self.EMB, (vocab_rows, embed_dim), trainable_embedding, bucket=1)
         store.declare(self.KERNEL, (embed_dim + rnn_size, 4 * rnn_size), True, bucket=1)
         store.declare(self.BIAS, (4 * rnn_size,), True, bucket=1)
         self.B = None
@@ -83,6 +86,10 @@ class TextTowerEngine:
         self.ws_bytes = max(self.wgrad_x.ws_bytes, self.wgrad_h.ws_bytes)
         self.ws = torch.empty(max(self.ws_bytes // 4, 4), device=dev)
         self.colsum_scratch = torch.empty(64 * 4 * H, device=dev)
+        if self.trainable_embedding:
+            self.dx = torch.empty(T * B, D, device=dev)
+            self.x_dgrad = gemm_plan(T * B, 4 * H, D, 4 * H, D, 4 * H, transposed_w=True)
+            self.gtable = st.grad_view(self.EMB)
 
     def forward(self, texts, seq_lens):
         """texts int64 [B,T] (pad id = vocab size), seq_lens int64 [B] (>= 1).  Returns h_last [B,H]
@@ -90,7 +97,7 @@ class TextTowerEngine:
         B, T, H = texts.shape[0], self.T, self.H
         assert texts.shape[1] == T and texts.dtype == torch.int64 and seq_lens.dtype == torch.int64
         self.alloc(B)
-        self.seq_lens = seq_lens
+        self.seq_lens, self.texts = seq_lens, texts
         ops.gather_rows(self.table, texts, self.x, B, T, self.D, time_major=True)
         self.xproj.run(ops._p(self.x), self.wx, ops._p(self.gates), bias=self.bias)
         slab = B * 4 * H
@@ -121,6 +128,9 @@ class TextTowerEngine:
         self.wgrad_x.run(ops._p(self.x), dg, self.gwx, ops._p(self.ws), self.ws_bytes)
         self.wgrad_h.run(ops._p(self.h), dg, self.gwh, ops._p(self.ws), self.ws_bytes)
         ops.colsum(self.dgates, T * B, 4 * H, 4 * H, self.colsum_scratch, self.gbias)
+        if self.trainable_embedding:
+            self.x_dgrad.run(dg, self.wx, ops._p(self.dx))
+            ops.embedding_grad(self.dx, self.texts, self.gtable, B, T, self.D, time_major=True)
         if self.reducer is not None:
             self.reducer.stage_done("text")
 

@@ -29,7 +29,7 @@ class SentimentNet:
     def __init__(self, mode="joint", nb_emotions=15, im_features_size=256, rnn_size=512, fc_size=512,
                  vocab_size=10000, embedding_dim=300, post_size=32, image_size=224, dropout_keep_prob=0.8,
                  trainable_bn_beta=True, device="cuda", process_group=None, overlap_comm=True,
-                 concurrent_towers=True):
+                 concurrent_towers=True, train_all=False, trainable_embedding=False):
         assert mode in ("joint", "image", "text")
         if not torch.cuda.is_available():
             raise RuntimeError("tumblr_emotions_amd needs an MI355X (HIP) device: the training path has no CPU fallback")
@@ -38,9 +38,11 @@ class SentimentNet:
         self.image = self.text = self.head = None
         if mode in ("joint", "image"):
             nc = im_features_size if mode == "joint" else nb_emotions
-            self.image = InceptionV1Engine(self.store, nc, image_size, dropout_keep_prob, trainable_bn_beta, device)
+            self.image = InceptionV1Engine(self.store, nc, image_size, dropout_keep_prob, trainable_bn_beta, device,
+                                           train_all=train_all)
         if mode in ("joint", "text"):
-            self.text = TextTowerEngine(self.store, vocab_size + 1, embedding_dim, rnn_size, post_size, device)
+            self.text = TextTowerEngine(self.store, vocab_size + 1, embedding_dim, rnn_size, post_size, device,
+                                        trainable_embedding=trainable_embedding)
         if mode == "joint":
             self.head = JointHeadEngine(self.store, im_features_size, rnn_size, fc_size, nb_emotions, device)
         elif mode == "text":
@@ -135,7 +137,11 @@ class SentimentNet:
 
     def grads_state_dict(self):
         torch.cuda.synchronize()
-        return self.store.state_dict(grads=True)
+        sd = self.store.state_dict(grads=True)
+        k = "InceptionV1/Conv2d_1a_7x7/weights"
+        if k in sd:                      # train_all: drop the zero-padded 4th input channel of the stem
+            sd[k] = sd[k][:, :, :3, :].copy()
+        return sd
 
     def after_load(self):
         """L2 of the frozen conv weights is a constant of the run: sum it once."""

@@ -205,6 +205,11 @@ def gather_rows(table, ids, out, B, T, D, time_major=True):
                                           _stream()), "ds_gather_rows")
 
 
+def embedding_grad(dx, ids, dtable, B, T, D, time_major=True):
+    _lib.check(_lib.load().ds_embedding_grad(_p(dx), _p(ids), _p(dtable), B, T, D, dtable.shape[0], int(time_major),
+                                             _stream()), "ds_embedding_grad")
+
+
 def lstm_cell_fwd(gates, c_prev, h_prev, seq_len, t, B, H, forget_bias, c_out, h_out, rec_slabs=None, nslabs=0,
                   slab_stride=0):
     _lib.check(_lib.load().ds_lstm_cell_fwd(_p(gates), _p(rec_slabs), nslabs, slab_stride, _p(c_prev), _p(h_prev),
