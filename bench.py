@@ -94,7 +94,7 @@ def pmc_traffic(args):
     FETCH doubled as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the timed
     process, so the figure is null unless a profile of the default workload is present."""
     import glob
-    if args.batch != 256 or args.mode != "joint" or args.gpus != 1:
+    if args.batch != 256 or args.mode != "joint" or args.gpus != 1 or args.train_all:
         return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: fixed global batch split over the ranks (BASELINE cfg4: 256 over 8 GPUs)")
     ap.add_argument("--mode", default="joint", choices=["joint", "image", "text"])
+    ap.add_argument("--train-all", action="store_true",
+                    help="optional full fine-tuning (not the BASELINE workload): every conv weight and the "
+                         "embedding trainable; 9.032 GFLOP/sample joint (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -142,7 +145,8 @@ def main():
 
     T, V, D, H = 32, 10000, 300, 512
     net = SentimentNet(mode=args.mode, nb_emotions=15, im_features_size=256, rnn_size=H, fc_size=512, vocab_size=V,
-                       embedding_dim=D, post_size=T, dropout_keep_prob=0.8)
+                       embedding_dim=D, post_size=T, dropout_keep_prob=0.8, train_all=args.train_all,
+                       trainable_embedding=args.train_all)
     net.initialize(seed=1)
     strong = args.global_batch > 0
     if strong:
@@ -206,6 +210,8 @@ def main():
     if rank == 0:
         value = gb * args.steps / dt
         flop_per_sample = {"joint": GFLOP_PER_SAMPLE, "image": 5.885, "text": 0.280}[args.mode]
+        if args.train_all:            # whole tower unfrozen; the embedding's dX GEMM adds 0.039
+            flop_per_sample = {"joint": 9.032 + 0.039, "image": 8.748, "text": 0.280 + 0.039}[args.mode]
         roof = None
         if timer is not None:
             n, ms, flops = timer.summary()
@@ -228,15 +234,17 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "sec_per_step": round(dt / args.steps, 5), "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s train step (fwd+bwd+all-reduce+Adam): Inception-v1 224x224x3 + 300-d embedding + "
-                                   "LSTM-512, T=32, V=10000, 15 classes, batch %d per GPU, reference freeze "
-                                   "(<=Mixed_5b conv weights frozen, all BN betas trainable), dropout 0.8, BN train mode"
-                                   % (args.mode, args.batch),
+                                   "LSTM-512, T=32, V=10000, 15 classes, batch %d per GPU, %s, dropout 0.8, BN train mode"
+                                   % (args.mode, args.batch,
+                                      "FULL FINE-TUNING (every conv weight and the embedding trainable: NOT the "
+                                      "BASELINE workload)" if args.train_all else
+                                      "reference freeze (<=Mixed_5b conv weights frozen, all BN betas trainable)"),
                        "global_batch": gb, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
                        "gflop_per_sample": flop_per_sample, "final_loss": round(loss, 5)},
             "roofline": roof,
             "gather": gather_bandwidth() if args.mode != "image" else None,
         }
-        if world == 1 and not args.no_cpu_baseline and args.mode == "joint":
+        if world == 1 and not args.no_cpu_baseline and args.mode == "joint" and not args.train_all:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps, T, V, D, H)
         else:
             out["cpu_baseline"] = None

@@ -4,7 +4,7 @@ import torch
 from tumblr_emotions_amd import ops
 from tumblr_emotions_amd.net import SentimentNet
 from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
-net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=512, vocab_size=10000, embedding_dim=300, post_size=32, concurrent_towers=False)
+net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=512, vocab_size=10000, embedding_dim=300, post_size=32, concurrent_towers=False, train_all=True, trainable_embedding=True)
 net.initialize(seed=1)
 batch = to_device(synthetic_batch_numpy(256, 32, 10000, 15, seed=0))
 for _ in range(2): net.train_step(batch, 1e-3)

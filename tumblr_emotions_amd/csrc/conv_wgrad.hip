@@ -114,8 +114,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             const int oh = small ? fdiv(r, d.OW, p.inv_ow) : r / d.OW;
             const int ow = r - oh * d.OW;
             const int ih = oh * d.stride - d.pad_t + dh, iw = ow * d.stride - d.pad_l + dw;
-            const bool okx = rv && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W && cx < d.Cin;
-            const unsigned offx = ((unsigned)(n * d.H + ih) * (unsigned)d.W + (unsigned)iw) * (unsigned)d.ldx + (unsigned)cx;
+            // fold_cin > 0 (stem): KW is folded into the channel axis, channel cx lives in pixel iw + cx/fold_cin
+            const int iwc = d.fold_cin > 0 ? iw + cx / d.fold_cin : iw;
+            const bool okx = rv && (unsigned)ih < (unsigned)d.H && (unsigned)iwc < (unsigned)d.W && cx < d.Cin;
+            const unsigned offx = (unsigned)(((n * d.H + ih) * d.W + iw) * d.ldx + cx);
             rx[i] = load4(srd_x, offx * 4u, okx, p.x_vec, d.Cin - cx);
             const bool okz = rv && cz < d.Cout;
             const unsigned offz = (unsigned)mm * (unsigned)p.lddz + (unsigned)cz;
@@ -215,6 +217,8 @@ extern "C" int ds_conv_wgrad(const ds_conv_desc *d, const float *x, const float 
     DS_REQUIRE(d && x && dz && dw, "ds_conv_wgrad: null argument");
     const int64_t M = (int64_t)d->N * d->OH * d->OW;
     DS_REQUIRE(M < (1ll << 31), "ds_conv_wgrad: M too large");
+    DS_REQUIRE(d->fold_cin == 0 || (d->KW == 1 && d->ldx == d->fold_cin && d->fold_cin % 4 == 0 && d->Cin % d->fold_cin == 0),
+               "ds_conv_wgrad: fold_cin needs KW=1, ldx==fold_cin, fold_cin %% 4 == 0");
     const int splits = pick_splits(d, M);
     const size_t need = ds_conv_wgrad_workspace(d);
     if (need > 0 && (ws == nullptr || ws_bytes < need)) {

@@ -96,7 +96,10 @@ class ConvBN:
         self.dgrad = None
         self.wgrad = None
         if self.trainable:
-            self.wgrad = WgradPlan(B, self.H, self.W, 4 if self.fold else cin, 0, k, k, self.stride, cout, cout)
+            if self.fold:      # stem (train_all only): KW folded into the channel axis like the forward conv
+                self.wgrad = WgradPlan(B, self.H, self.W, 7 * 4, 4, 7, 1, self.stride, cout, cout, fold_cin=4)
+            else:
+                self.wgrad = WgradPlan(B, self.H, self.W, cin, 0, k, k, self.stride, cout, cout)
             eng.need_ws(self.wgrad.ws_bytes)
 
     def bind(self):

@@ -44,6 +44,9 @@ class ImageModel(SyntheticInput):
         self.learning_rate = config['initial_lr']
         self._init_input(config, config.get('post_size', 50), config.get('vocab_size', 400000), nb_emotions, True, device)
         self.nb_emotions = self.dataset.num_classes
+        for key in ("train_all", "trainable_embedding"):      # optional fine-tuning switches (not in the reference _CONFIG)
+            if key in config:
+                net_kw.setdefault(key, bool(config[key]))
         self.net = SentimentNet(mode="image", nb_emotions=self.nb_emotions, device=device, **net_kw)
         self.net.initialize(seed=config.get('seed', 1))
         self.logits = None

@@ -38,6 +38,9 @@ class DeepSentiment(SyntheticInput):
             vocab, dim = embedding.shape[0] - 1, embedding.shape[1]
         self._init_input(config, post, vocab, nb_emotions, True, device)
         self.nb_emotions = self.dataset.num_classes
+        for key in ("train_all", "trainable_embedding"):      # optional fine-tuning switches (not in the reference _CONFIG)
+            if key in config:
+                net_kw.setdefault(key, bool(config[key]))
         self.net = SentimentNet(mode="joint", nb_emotions=self.nb_emotions,
                                 im_features_size=config['im_features_size'], rnn_size=config['rnn_size'],
                                 fc_size=config['fc_size'], vocab_size=vocab, embedding_dim=dim, post_size=post,

@@ -117,13 +117,15 @@ def gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=False, flags=0, ldmask=0, sp
 class WgradPlan:
     """dw[tap, ci, co] = sum_m x[pixel(m)+tap, ci] * dz[m, co]; geometry given by a forward ConvPlan-like desc."""
 
-    def __init__(self, N, H, W, Cin, ldx, KH, KW, stride, Cout, lddz, pad_t=None, pad_l=None, OH=None, OW=None):
+    def __init__(self, N, H, W, Cin, ldx, KH, KW, stride, Cout, lddz, pad_t=None, pad_l=None, OH=None, OW=None,
+                 fold_cin=0):
         d = ConvDesc()
+        d.fold_cin = fold_cin
         d.N, d.H, d.W, d.Cin, d.ldx = N, H, W, Cin, ldx
         d.KH, d.KW, d.stride = KH, KW, stride
         if OH is None:
             OH, pad_t = same_pad(H, KH, stride)
-            OW, pad_l = same_pad(W, KW, stride)
+            OW, pad_l = same_pad(W, KW if not fold_cin else Cin // fold_cin, stride)
         d.pad_t, d.pad_l, d.OH, d.OW = pad_t, pad_l, OH, OW
         d.Cout, d.ldz = Cout, Cout
         self.d = d

@@ -31,6 +31,9 @@ class TextModel(SyntheticInput):
             vocab, dim = embedding.shape[0] - 1, embedding.shape[1]
         self._init_input(config, post, vocab, nb_emotions, False, device)
         self.nb_emotions = self.dataset.num_classes
+        for key in ("train_all", "trainable_embedding"):      # optional fine-tuning switches (not in the reference _CONFIG)
+            if key in config:
+                net_kw.setdefault(key, bool(config[key]))
         self.net = SentimentNet(mode="text", nb_emotions=self.nb_emotions, rnn_size=config['rnn_size'],
                                 vocab_size=vocab, embedding_dim=dim, post_size=post, device=device, **net_kw)
         self.net.initialize(seed=config.get('seed', 1))
