@@ -86,6 +86,43 @@ def test_train_deep_sentiment_and_image_model_entry_points(tmp_path):
     assert torch.equal(cf[:, 256:], m.net.text.h[m.net.text.T])
 
 
+def test_analysis_functions_row_8f3(tmp_path):
+    """correlation_matrix / day_of_week_trend / outliers_detection / word_most_relevant on a freshly trained
+    checkpoint: output files and shapes of the reference (:342-575), and the numbers re-derived from the
+    model's own forward passes."""
+    from tumblr_emotions_amd.image_text_model import im_text_rnn_model as M
+    cfg = dict(SMALL_TEXT, batch_size=4, num_samples=12)
+    ckpt, out = str(tmp_path / "joint"), str(tmp_path / "data")
+    M.train_deep_sentiment(None, ckpt, 2, config=cfg, quiet=True)
+    logits, labels = M.correlation_matrix(3, ckpt, config=cfg, out_dir=out)
+    assert logits.shape == (12, 15) and labels.shape == (12,)
+    assert np.array_equal(np.load(os.path.join(out, "posts_logits.npy")), logits)
+    wl, wlab, days, ids = M.day_of_week_trend(ckpt, config=cfg, out_dir=out)
+    assert wl.shape == (12, 15) and wlab.shape == days.shape == ids.shape == (12,)
+    np.testing.assert_array_equal(wl, logits)            # same validation stream, same weights, deterministic
+    assert set(np.unique(days)) <= set(range(7))
+    for f in ("posts_logits_week", "posts_labels_week", "posts_days_week", "posts_ids_week"):
+        assert os.path.exists(os.path.join(out, f + ".npy"))
+    norms, pids, mlog = M.outliers_detection(ckpt, config=cfg, out_dir=out)
+    assert norms.shape == (4,) and pids.shape == (4,) and mlog.shape == (4, 15)
+    # re-derive: features of the three validation batches, per-slot maximum distance to the mean of batch means
+    model = M._restored_validation_model(ckpt, cfg)
+    feats, lg, pid = [], [], []
+    for l, _, _, p, f in M._forward_batches(model, 3, want_features=True):
+        feats.append(f), lg.append(l), pid.append(p)
+    mean = np.mean([f.mean(0) for f in feats], axis=0)
+    dist = np.stack([np.linalg.norm(f - mean, axis=1) for f in feats])          # [batch, slot]
+    np.testing.assert_allclose(norms, dist.max(0), rtol=1e-5)
+    arg = dist.argmax(0)
+    np.testing.assert_array_equal(pids, np.stack(pid)[arg, np.arange(4)])
+    np.testing.assert_allclose(mlog, np.stack(lg)[arg, np.arange(4)], rtol=1e-6)
+    # single-word posts next to a zero image: 120 words -> 2 batches of 50, the ragged tail is dropped
+    scores, vocab, w2i = M.word_most_relevant(np.arange(120) % 60, 15, ckpt, config=cfg, out_dir=out)
+    assert scores.shape == (100, 15) and w2i['<ukn>'] == len(vocab)
+    np.testing.assert_allclose(scores[0], scores[60], rtol=0, atol=0)            # same word -> same score
+    assert np.load(os.path.join(out, "top_words_scores.npy")).shape == (100, 15)
+
+
 def test_train_from_tfrecords(tmp_path):
     """Real-data input path (row 8f-2): sharded TFRecords of (png, token ids) written with this build's
     writer, read back through get_split_with_text + load_batch_with_text + preprocess_for_eval."""
