@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-conv-timing", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the embedding-gather bandwidth measurement")
     args = ap.parse_args()
 
     import torch
@@ -217,7 +218,7 @@ def main():
             n, ms, flops = timer.summary()
             ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic, traffic_src = pmc_traffic(args)
-            roof = dict(bound="mfma", kernel="conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32; conv fwd, dgrad, GEMMs)",
+            roof = dict(bound="mfma", kernel="conv_igemm_kernel + conv_glds_kernel (ds_conv_igemm: fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; conv fwd, dgrad, GEMMs)",
                         achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_unit="HBM bytes per launch",
                         traffic_source=traffic_src, alg_flops_per_launch=round(flops / max(n, 1)),
@@ -242,7 +243,7 @@ def main():
                        "global_batch": gb, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
                        "gflop_per_sample": flop_per_sample, "final_loss": round(loss, 5)},
             "roofline": roof,
-            "gather": gather_bandwidth() if args.mode != "image" else None,
+            "gather": gather_bandwidth() if (args.mode != "image" and not args.no_gather) else None,
         }
         if world == 1 and not args.no_cpu_baseline and args.mode == "joint" and not args.train_all:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps, T, V, D, H)
