@@ -21,17 +21,24 @@ def download_pretrained_model(url, checkpoint_dir):
     raise RuntimeError("no network: cannot download %s into %s" % (url, checkpoint_dir))
 
 
-def get_init_fn(checkpoints_dir, model_name='inception_v1.npz'):
+def get_init_fn(checkpoints_dir, model_name=None):
     """Warm start (im_model.py:118-137): restore every slim model variable except those under
-    InceptionV1/Logits / InceptionV1/AuxLogits.  The checkpoint is a .npz of TF-named arrays (a
-    reader for TF's own checkpoint format is out of scope).  Returns fn(net) or None."""
-    path = os.path.join(checkpoints_dir or "", model_name)
-    if not checkpoints_dir or not os.path.exists(path):
-        return None
+    InceptionV1/Logits / InceptionV1/AuxLogits.  Looks for `inception_v1.ckpt` (TensorFlow's V1 checkpoint,
+    read by checkpoint_tf.read_tf_v1_checkpoint without TensorFlow) and then for `inception_v1.npz` (a dump
+    of TF-named arrays) in `checkpoints_dir`.  Returns fn(net) or None when neither exists."""
     exclusions = ("InceptionV1/Logits", "InceptionV1/AuxLogits")
+    candidates = [model_name] if model_name else ["inception_v1.ckpt", "inception_v1.npz"]
+    path = next((os.path.join(checkpoints_dir, n) for n in candidates
+                 if checkpoints_dir and os.path.exists(os.path.join(checkpoints_dir, n))), None)
+    if path is None:
+        return None
 
     def init_fn(net):
-        sd = {k: v for k, v in np.load(path).items() if not k.startswith(exclusions)}
+        if path.endswith(".npz"):
+            sd = {k: v for k, v in np.load(path).items() if not k.startswith(exclusions)}
+        else:
+            from ..checkpoint_tf import read_tf_v1_checkpoint
+            sd = read_tf_v1_checkpoint(path, names=lambda n: n.startswith("InceptionV1/") and not n.startswith(exclusions))
         net.load_state_dict(sd, strict=False)
     return init_fn
 
