@@ -14,9 +14,11 @@
 //     stay in flight under the MFMAs of the current tile and are waited for only at the LDS store.
 //   * 4 waves per workgroup stacked along M; each wave owns (MT*32) rows x all BN = NT*32 columns,
 //     so the tile width is chosen per layer from NT = 1..6 to fit Cout with little padding.
-//   * workgroups are persistent over row tiles (grid.x is a multiple of 8 so that all column
-//     tiles of a row tile, which share the A rows, land on the same XCD/L2), which also lets the
-//     BatchNorm column statistics be accumulated in registers and emitted once per workgroup.
+//   * launch geometry (grid_for): one workgroup per row tile up to 2048 row tiles; above that the
+//     workgroups are persistent over row tiles (grid.x a multiple of 8 so that all column tiles of
+//     a row tile, which share the A rows, land on the same XCD/L2) with the K-loop pipeline running
+//     across tiles.  BatchNorm column statistics are accumulated in registers and emitted once per
+//     workgroup either way.
 //   * fp32 MFMA is an exact k-ordered fmaf chain (cdna_hip_programming.md section 3), so results
 //     match a scalar fp32 reference to rounding.
 #include <stdlib.h>
@@ -117,6 +119,10 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
     float csum[NT], csq[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) csum[j] = csq[j] = 0.f;
+#if DS_EXP == 8
+    float tph[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const long long tk0 = __builtin_amdgcn_s_memtime();
+#endif
 
     const int arow = tid >> 2, ak4 = (tid & 3) * 4;
 
@@ -144,7 +150,6 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
     unsigned xb[AR];         // element offset of the image that row i belongs to
     int tap, c0, dh, dw;
     f32x4 ra[AR], rb[BR];
-    bool a_loaded = true;
     f32x16 acc[MT][NT];
 
     auto setup_tile = [&](int tile) {      // point the loader at the first K-tile of row tile `tile`
@@ -177,8 +182,6 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
         auto load_tile = [&]() {
             // ---- A: activations ----------------------------------------------------------------
             const int k = c0 + ak4;
-            a_loaded = !(DS_EXP == 6) || (dh == 0 && dw == 0);
-            if (a_loaded)
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 const int ih = ih0[i] + dh;
@@ -186,7 +189,11 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
                 const int iwc = FOLD ? iw + k / d.fold_cin : iw;
                 const bool ok = (unsigned)ih < (unsigned)d.H && (unsigned)iwc < (unsigned)d.W && k < d.Cin;
                 const unsigned off = xb[i] + (unsigned)(ih * d.W + iw) * (unsigned)d.ldx + (unsigned)k;
+#if DS_EXP == 9
+                ra[i] = load4<VEC>(srd_x, (off * 4u) & 0x3FF0u, ok, d.Cin - k);      /* every load hits a 16 KB window: L1-resident */
+#else
                 ra[i] = load4<VEC>(srd_x, off * 4u, ok, d.Cin - k);
+#endif
             }
             // ---- B: weights, read in place from the HWIO tensor --------------------------------
             const int tap_eff = d.flip ? p.taps - 1 - tap : tap;
@@ -195,7 +202,11 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
 #pragma unroll
             for (int i = 0; i < BR; ++i) {
                 const bool ok = b_ok[i] && c0 + b_k[i] < d.Cin;
+#if DS_EXP == 9
+                rb[i] = load4<VEC>(srd_w, ((wt + b_off[i]) * 4u) & 0x3FF0u, ok, BNMAJOR ? d.Cout - b_n[i] : d.Cin - c0 - b_k[i]);
+#else
                 rb[i] = load4<VEC>(srd_w, (wt + b_off[i]) * 4u, ok, BNMAJOR ? d.Cout - b_n[i] : d.Cin - c0 - b_k[i]);
+#endif
             }
             // ---- advance to the next K-tile: next tap of the same channel chunk, then the next chunk ----
             ++tap;
@@ -208,7 +219,6 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
         auto store_tile = [&](int buf) {
             float *a_s = As + buf * BM * LDK;
             float *b_s = Bs + buf * BSZ;
-            if (a_loaded)
 #pragma unroll
             for (int i = 0; i < AR; ++i)
                 *reinterpret_cast<f32x4 *>(a_s + (arow + 64 * i) * LDK + ak4) = ra[i];
@@ -281,12 +291,32 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
         for (int kt = 0; kt < KT; ++kt) {
             const bool last = kt + 1 == KT;
+#if DS_EXP == 8
+            const long long t0 = __builtin_amdgcn_s_memtime();
+#endif
             if (last && has_next) setup_tile(tile + gridDim.x);
             const bool fetch = !last || has_next;
             if (fetch) load_tile();
+#if DS_EXP == 8
+            __builtin_amdgcn_sched_barrier(0);
+            const long long t1 = __builtin_amdgcn_s_memtime();      // loads issued
+#endif
             compute(par);
+#if DS_EXP == 8
+            __builtin_amdgcn_sched_barrier(0);
+            const long long t2 = __builtin_amdgcn_s_memtime();      // fragments read, MFMAs issued
+#endif
             if (fetch) store_tile(par ^ 1);
+#if DS_EXP == 8
+            __builtin_amdgcn_sched_barrier(0);
+            const long long t3 = __builtin_amdgcn_s_memtime();      // vmcnt wait + ds_writes issued
+#endif
             __syncthreads();
+#if DS_EXP == 8
+            const long long t4 = __builtin_amdgcn_s_memtime();      // barrier passed
+            tph[0] += (float)(t1 - t0); tph[1] += (float)(t2 - t1); tph[2] += (float)(t3 - t2); tph[3] += (float)(t4 - t3);
+            tph[4] += 1.f;
+#endif
             par ^= 1;
         }
 
@@ -320,6 +350,13 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
     }
     }
 
+#if DS_EXP == 8
+    if (p.stats && (tid & 63) == 0) {        // per wave: 4 phase sums, K-steps, total kernel cycles
+        float *o = p.stats + ((int64_t)(blockIdx.x + blockIdx.y * gridDim.x) * 4 + (tid >> 6)) * 8;
+        o[0] = tph[0]; o[1] = tph[1]; o[2] = tph[2]; o[3] = tph[3]; o[4] = tph[4];
+        o[5] = (float)(__builtin_amdgcn_s_memtime() - tk0);
+    }
+#endif
     if (flags & DS_EPI_STATS) {
         // rows of a column live in lanes l and l^32, and in the 4 waves stacked along M
         float *red = smem;   // [WM][BN][2]; safe: every wave passed the last K-loop barrier
@@ -557,10 +594,273 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
     }
 }
 
+// ================================================================================================
+// LDS-DMA variant (gfx950): K-tile 32, operands go global -> LDS with buffer_load_dwordx4 ... lds.
+//
+// Same implicit GEMM, same epilogue, different staging.  The loop above moves every operand through
+// VGPRs (buffer_load -> s_waitcnt -> ds_write_b128): 12 staging registers per thread, three 13-cycle
+// LDS stores per K-tile and a vmcnt(0) in the middle of every K-step.  Here each lane's 16 bytes land
+// directly in LDS (a wave-instruction fills 1 KiB at M0 + lane*16; out-of-range lanes write zeros --
+// probed in scratch/glds/glds_test.hip), so there are no staging registers and no LDS stores, and the
+// freed registers pay for a 32-deep K-tile: half as many barriers and fragment-read restarts per MFMA.
+// Rows are 128 bytes and unpadded (the DMA destination is lane-linear), so the bank-conflict-free layout
+// is an XOR swizzle applied on the SOURCE side: LDS slot (row, pc) holds the row's logical 16-byte chunk
+// pc ^ ((row >> 1) & 7), and fragment reads apply the same involution (cdna_hip_programming.md rule 21).
+// With ds_read_b128's lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} the eight rows of equal parity
+// in a group map to eight different chunk columns: conflict-free.
+// Per K-step: read all fragments of the current tile, issue the DMAs of the next tile, run the MFMAs,
+// __syncthreads() (hipcc puts the vmcnt(0) for the DMAs there).
+// ================================================================================================
+constexpr int GK = 32;            // K-tile (floats)
+constexpr int GCH = GK / 4;       // 16-byte chunks per row
+
+template <int NT, bool BNMAJOR>
+__global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? 3 : 2)) void conv_glds_kernel(const ConvParams p) {
+    constexpr int BM = 128, BN = NT * 32;
+    constexpr int ASZ = BM * GK, BSZ = BN * GK;       // floats per buffer
+    constexpr int AJ = BM * GCH / 256;                // A DMA instructions per thread per K-tile (4)
+    constexpr int BJ = BN * GCH / 256;                // B DMA instructions per thread per K-tile (NT)
+    __shared__ __attribute__((aligned(128))) float smem[2 * ASZ + 2 * BSZ];
+    float *As = smem;
+    float *Bs = smem + 2 * ASZ;
+
+    const ds_conv_desc &d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const int ohw = d.OH * d.OW;
+    const int chunks = (d.Cin + GK - 1) / GK;
+    const int KT_all = p.taps * chunks;
+    const int kts = (KT_all + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int kt0 = (int)blockIdx.z * kts;
+    const int KT = (kt0 + kts < KT_all ? kt0 + kts : KT_all) - kt0;
+    float *const zout = p.z + (int64_t)blockIdx.z * p.d.z_split_stride;
+    const int flags = d.flags;
+    const __amdgpu_buffer_rsrc_t srd_x = make_srd(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t srd_w = make_srd(p.w, p.w_bytes);
+
+    float csum[NT], csq[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) csum[j] = csq[j] = 0.f;
+
+    // ---- DMA slot of this thread: slot = j*256 + tid -> (row j*32 + tid/8, physical chunk tid%8) ------
+    const int srow = tid >> 3;                                   // + 32*j
+    const int slc4 = ((tid & 7) ^ ((tid >> 4) & 7)) * 4;         // logical k offset of the chunk it fetches
+    // B, k-contiguous weights: same slot shape, rows are output channels
+    // B, n-contiguous weights: tile is [k][n], slot -> (k = slot / (BN/4), n4 = slot % (BN/4)), no swizzle
+    int b_row[BJ], b_col[BJ];
+    bool b_ok[BJ];
+#pragma unroll
+    for (int i = 0; i < BJ; ++i) {
+        const int slot = i * 256 + tid;
+        if (BNMAJOR) {
+            b_row[i] = slot / (BN / 4);                          // k inside the tile
+            b_col[i] = n0 + (slot % (BN / 4)) * 4;               // first of 4 output channels
+            b_ok[i] = b_col[i] < d.Cout;
+        } else {
+            b_row[i] = n0 + i * 32 + srow;                       // output channel
+            b_col[i] = slc4;                                     // k inside the tile
+            b_ok[i] = b_row[i] < d.Cout;
+        }
+    }
+
+    int ih0[AJ], iw0[AJ];
+    unsigned xb[AJ];
+    int tap, c0, dh, dw;
+    f32x16 acc[NT];
+
+    auto setup_tile = [&](int tile) {
+        const int m0 = tile * BM;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int m = m0 + j * 32 + srow;
+            const bool rv = m < p.M;
+            const int mm = rv ? m : 0;
+            const int n = mm / ohw;
+            const int r = mm - n * ohw;
+            const int oh = r / d.OW;
+            const int ow = r - oh * d.OW;
+            ih0[j] = rv ? oh * d.stride - d.pad_t : -(1 << 20);
+            iw0[j] = ow * d.stride - d.pad_l;
+            xb[j] = (unsigned)n * (unsigned)(d.H * d.W) * (unsigned)d.ldx;
+        }
+        const int chunk = kt0 / p.taps;                          // channel chunk outer, tap inner
+        tap = kt0 - chunk * p.taps;
+        c0 = chunk * GK;
+        dh = tap / d.KW;
+        dw = tap - dh * d.KW;
+    };
+
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+
+    auto issue_tile = [&](int buf) {       // DMA the K-tile the loader points at into buffer `buf`, then advance
+        float *a_s = As + buf * ASZ + wm * 256;                  // this wave's 1 KiB window of pass j = 0
+        const int ka = c0 + slc4;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int ih = ih0[j] + dh;
+            const int iw = iw0[j] + dw;
+            const bool ok = (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W && ka < d.Cin;
+            const unsigned off = xb[j] + (unsigned)(ih * d.W + iw) * (unsigned)d.ldx + (unsigned)ka;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_x, (lds_ptr)(a_s + j * 1024), 16, ok ? off * 4u : kOOB, 0, 0, 0);
+        }
+        const int tap_eff = d.flip ? p.taps - 1 - tap : tap;
+        const unsigned wt = (unsigned)tap_eff * (unsigned)d.w_tap_stride;
+        float *b_s = Bs + buf * BSZ + wm * 256;
+#pragma unroll
+        for (int i = 0; i < BJ; ++i) {
+            bool ok;
+            unsigned off;
+            if (BNMAJOR) {
+                const int k = c0 + b_row[i];
+                ok = b_ok[i] && k < d.Cin;
+                off = wt + (unsigned)k * (unsigned)d.w_k_stride + (unsigned)b_col[i];
+            } else {
+                const int k = c0 + b_col[i];
+                ok = b_ok[i] && k < d.Cin;
+                off = wt + (unsigned)b_row[i] * (unsigned)d.w_n_stride + (unsigned)k;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr)(b_s + i * 1024), 16, ok ? off * 4u : kOOB, 0, 0, 0);
+        }
+        ++tap;
+        if (++dw == d.KW) {
+            dw = 0;
+            if (++dh == d.KH) { dh = 0; tap = 0; c0 += GK; }
+        }
+    };
+
+    // fragment addresses: lane (li, lk) owns k = lk*16 .. lk*16+15 of its row = logical chunks lk*4 .. lk*4+3
+    const int arow = wm * 32 + li;
+    const int asw = (arow >> 1) & 7;
+    int a_off[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a_off[c] = arow * GK + (((lk * 4 + c) ^ asw) * 4);
+    int b_offk[NT][4];
+    if (!BNMAJOR) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int brow = b * 32 + li;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b_offk[b][c] = brow * GK + (((lk * 4 + c) ^ ((brow >> 1) & 7)) * 4);
+        }
+    }
+
+    float af[16], bf[NT][16];
+    auto read_frags = [&](int buf) {
+        const float *a_s = As + buf * ASZ;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(a_s + a_off[c]);
+            af[4 * c + 0] = v.x; af[4 * c + 1] = v.y; af[4 * c + 2] = v.z; af[4 * c + 3] = v.w;
+        }
+        const float *b_s = Bs + buf * BSZ;
+        if (BNMAJOR) {
+            const float *bp = b_s + (lk * 16) * BN + li;
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) bf[b][s] = bp[s * BN + b * 32];
+        } else {
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(b_s + b_offk[b][c]);
+                    bf[b][4 * c + 0] = v.x; bf[b][4 * c + 1] = v.y; bf[b][4 * c + 2] = v.z; bf[b][4 * c + 3] = v.w;
+                }
+        }
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[b][s], acc[b], 0, 0, 0);
+    };
+
+    int par = 0;
+    if (blockIdx.x < p.row_tiles) {
+        setup_tile(blockIdx.x);
+        issue_tile(0);
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < p.row_tiles; tile += gridDim.x) {
+        const int m0 = tile * BM;
+        const bool has_next = tile + (int)gridDim.x < p.row_tiles;
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        for (int kt = 0; kt < KT; ++kt) {
+            const bool last = kt + 1 == KT;
+            read_frags(par);
+            if (last && has_next) setup_tile(tile + gridDim.x);
+            if (!last || has_next) issue_tile(par ^ 1);
+            __builtin_amdgcn_sched_barrier(0);     // DMAs are issued before the MFMAs ...
+            mfmas();
+            __builtin_amdgcn_sched_barrier(0);     // ... and the MFMAs stay above the barrier's vmcnt(0)
+            __syncthreads();
+            par ^= 1;
+        }
+
+        // ---- epilogue: bias / accumulate / mask / relu, store, BatchNorm column statistics -------
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int col = n0 + b * 32 + li;
+            const bool colok = col < d.Cout;
+            const float bv = ((flags & DS_EPI_BIAS) && colok) ? p.bias[col] : 0.f;
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < p.M && colok) {
+                    float v = acc[b][r] + bv;
+                    const int64_t off = (int64_t)row * d.ldz + col;
+                    if (flags & DS_EPI_ACCUM) v += zout[off];
+                    if (flags & DS_EPI_MASK) v = p.mask[(int64_t)row * d.ldmask + col] > 0.f ? v : 0.f;
+                    if (flags & DS_EPI_RELU) v = fmaxf(v, 0.f);
+                    zout[off] = v;
+                    s += v;
+                    q += v * v;
+                }
+            }
+            csum[b] += s;
+            csq[b] += q;
+        }
+    }
+
+    if (flags & DS_EPI_STATS) {
+        float *red = smem;   // [4][BN][2]; safe: every wave passed the last K-loop barrier and no DMA is in flight
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const float s = csum[b] + __shfl_xor(csum[b], 32);
+            const float q = csq[b] + __shfl_xor(csq[b], 32);
+            if (lk == 0) {
+                const int c = b * 32 + li;
+                red[(wm * BN + c) * 2 + 0] = s;
+                red[(wm * BN + c) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < d.Cout) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                s += red[(w * BN + tid) * 2 + 0];
+                q += red[(w * BN + tid) * 2 + 1];
+            }
+            p.stats[(int64_t)(n0 + tid) * gridDim.x + blockIdx.x] = s;
+            p.stats[((int64_t)d.Cout + n0 + tid) * gridDim.x + blockIdx.x] = q;
+        }
+    }
+}
+
 // ---- host-side dispatch -----------------------------------------------------------------------
 struct TileCfg {
     int mt, nt;
     bool direct;     // register-direct kernel (tile = per-WAVE 32*mt x 32*nt) instead of the LDS kernel
+    bool glds;       // LDS-DMA kernel, K-tile 32 (128 x 32*nt tile)
 };
 
 typedef void (*KernelFn)(const ConvParams);
@@ -626,7 +926,16 @@ KernelFn direct_kernel_m(int nt, Variant v) {
     }
 }
 
+KernelFn glds_kernel(int nt, Variant v) {
+    switch (nt) {
+        case 1: return v.bnmajor ? conv_glds_kernel<1, true> : conv_glds_kernel<1, false>;
+        case 2: return v.bnmajor ? conv_glds_kernel<2, true> : conv_glds_kernel<2, false>;
+        default: return v.bnmajor ? conv_glds_kernel<3, true> : conv_glds_kernel<3, false>;
+    }
+}
+
 KernelFn kernel_for(TileCfg c, Variant v) {
+    if (c.glds) return glds_kernel(c.nt, v);
     if (c.direct) return c.mt == 2 ? direct_kernel_m<2>(c.nt, v) : direct_kernel_m<1>(c.nt, v);
     return c.mt == 2 ? lds_kernel_m<2>(c.nt, v) : lds_kernel_m<1>(c.nt, v);
 }
@@ -635,8 +944,8 @@ KernelFn kernel_for(TileCfg c, Variant v) {
 // The persistent grid is sized to exactly one resident wave of workgroups so no CU idles while a
 // partial second wave runs; correctness never depends on it (no inter-workgroup communication).
 int resident_per_cu(TileCfg c, Variant v) {
-    static int cache[2][2][6][2][2][2];
-    int &slot = cache[c.direct][c.mt - 1][c.nt - 1][v.bnmajor][v.fold][v.vec];
+    static int cache[3][2][6][2][2][2];
+    int &slot = cache[c.glds ? 2 : (int)c.direct][c.mt - 1][c.nt - 1][v.bnmajor][v.fold][v.vec];
     if (slot == 0) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kernel_for(c, v), 256, 0) != hipSuccess || n < 1)
@@ -657,12 +966,12 @@ TileCfg pick_cfg(const ds_conv_desc *d, bool vec) {
     }
     if (force_path < 0) {
         force_path = 0;
-        if (const char *e = getenv("DS_CONV_PATH")) force_path = e[0] == 'l' ? 1 : (e[0] == 'd' ? 2 : 0);
+        if (const char *e = getenv("DS_CONV_PATH")) force_path = e[0] == 'l' ? 1 : (e[0] == 'd' ? 2 : (e[0] == 'g' ? 3 : 0));
     }
     const int64_t M = conv_M(d);
     const int N = d->Cout;
     const int pad32 = (N + 31) / 32 * 32, pad64 = (N + 63) / 64 * 64;
-    TileCfg c = {1, 1, false};
+    TileCfg c = {1, 1, false, false};
     // Measured (profiles/r01_lds_vs_direct_sweep.txt): the LDS-staged kernel wins on every shape of this
     // model -- fragment-shaped global loads touch 32 cache lines per wave instruction and are TA-bound --
     // so the register-direct family is opt-in only.
@@ -681,6 +990,18 @@ TileCfg pick_cfg(const ds_conv_desc *d, bool vec) {
     if (force_mt > 0) c.mt = force_mt;
     if (force_nt > 0) c.nt = force_nt;
     if (c.direct && c.nt > 4) c.nt = 4;
+    // LDS-DMA kernel (K-tile 32): needs 16-byte aligned operands and no folded stem.  Automatic for the
+    // multi-tap convs whose reduction the 32-deep K-tile pads by no more than ~12 % over the 16-deep one:
+    // measured 3-10 % faster there (long K loops), 5-10 % slower on the 1x1 layers whose 9-26 K-tiles
+    // leave the prologue/epilogue exposed (profiles/r01_glds_sweep.txt).
+    if (!c.direct && vec && d->fold_cin == 0 && force_path != 1) {
+        const int k16 = (d->Cin + 15) / 16 * 16, k32 = (d->Cin + 31) / 32 * 32;
+        if (force_path == 3 || (d->KH * d->KW >= 4 && k32 * 100 <= k16 * 112)) {
+            c.glds = true;
+            c.mt = 1;
+            if (c.nt > 3) c.nt = 3;
+        }
+    }
     return c;
 }
 
@@ -696,7 +1017,7 @@ constexpr int kOneTilePerWg = 2048;
 
 void grid_for(const ds_conv_desc *d, TileCfg c, Variant v, int *gx, int *gy, int *row_tiles) {
     const int64_t M = conv_M(d);
-    const int bm = (c.direct ? 32 : 128) * c.mt, bn = 32 * c.nt;
+    const int bm = (c.direct ? 32 : 128) * (c.glds ? 1 : c.mt), bn = 32 * c.nt;
     *row_tiles = (int)((M + bm - 1) / bm);
     *gy = (d->Cout + bn - 1) / bn;
     const int wg_tiles = c.direct ? (*row_tiles + 3) / 4 : *row_tiles;     // row tiles in units of workgroups
@@ -723,7 +1044,7 @@ extern "C" int ds_conv_set_tile(int mt, int nt) {
 }
 
 extern "C" int ds_conv_set_path(int path) {
-    DS_REQUIRE(path >= 0 && path <= 2, "ds_conv_set_path: 0 = automatic, 1 = LDS-staged kernel, 2 = register-direct kernel");
+    DS_REQUIRE(path >= 0 && path <= 3, "ds_conv_set_path: 0 = automatic, 1 = register-staged LDS kernel, 2 = register-direct kernel, 3 = LDS-DMA kernel");
     force_path = path;
     return DS_OK;
 }
