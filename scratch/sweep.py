@@ -51,9 +51,9 @@ for key, (plan, count) in plans.items():
 lib.ds_conv_set_tile(0,0); lib.ds_conv_set_path(0)
 rows.sort(key=lambda r: -r[0])
 tot_auto = sum(r[0] for r in rows); tot_best = sum(r[3][r[4]]*r[2] for r in rows)
-print("%9s %5s %5s %4s %2s %3s | %8s | %s | best" % ("M","N","K","taps","kc","cnt","auto_us", " ".join("%s%d,%d" % ("ALDGP"[c[0]], c[1], c[2]) for c in CFGS)))
+print("%9s %5s %5s %4s %2s %3s | %8s | %s | best" % ("M","N","K","taps","kc","cnt","auto_us", " ".join("%s%d,%d" % ("ALDGW"[c[0]], c[1], c[2]) for c in CFGS)))
 for t, key, count, res, best in rows:
     print("%9d %5d %5d %4d %2d %3d | %8.1f | %s | %s%d,%d %.1f" % (key[0], key[1], key[2], key[3], key[4], count, res[(0,0,0)]*1e3,
-          " ".join("%6.0f" % (res[c]*1e3) for c in CFGS), "ALDGP"[best[0]], best[1], best[2], res[best]*1e3))
+          " ".join("%6.0f" % (res[c]*1e3) for c in CFGS), "ALDGW"[best[0]], best[1], best[2], res[best]*1e3))
 print("total auto %.3f ms/step   total best-per-shape %.3f ms/step" % (tot_auto, tot_best))
-for c in CFGS: print("all %s%d,%d: %.3f" % ("ALDGP"[c[0]], c[1], c[2], sum(r[3][c]*r[2] for r in rows)))
+for c in CFGS: print("all %s%d,%d: %.3f" % ("ALDGW"[c[0]], c[1], c[2], sum(r[3][c]*r[2] for r in rows)))
