@@ -12,7 +12,14 @@ from . import _lib
 from ._lib import ConvDesc, Segments, DS_EPI_ACCUM, DS_EPI_BIAS, DS_EPI_MASK, DS_EPI_RELU, DS_EPI_STATS  # noqa: F401
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream.  The raw-stream query is ~10x cheaper than building a
+    torch.cuda.Stream object, which matters at ~900 launches per step."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
