@@ -17,10 +17,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int TI = 128;   // ci tile
 constexpr int TJ = 128;   // co tile
 constexpr int TP = 16;    // pixels per K-tile
-constexpr int LDT = TI + 4;
 
 struct WgradParams {
     ds_conv_desc d;
@@ -63,17 +61,28 @@ __device__ __forceinline__ int fdiv(int a, int b, float inv) {
     return q;
 }
 
+// TIT = ci tile: 128 (4 waves as 2x2, 64x64 each) or 64 (4 waves side by side, 64x32 each) for layers whose Cin
+// a 128-wide tile would pad by a quarter or more (Cin <= 64, 144, 160, 192 ...: every conv below Mixed_5c under
+// train_all, Branch_2 of Mixed_5c in the reference freeze).
+template <int TIT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TP * LDT];
-    float *Xs = smem;                    // [2][TP][LDT]
-    float *Zs = smem + 2 * TP * LDT;     // [2][TP][LDT]
+    constexpr int LDX = TIT + 4, LDZ = TJ + 4;
+    constexpr int WNW = TIT == 128 ? 2 : 4;              // waves along co
+    constexpr int CW = TJ / WNW;                          // co columns per wave: 64 or 32
+    constexpr int BS = CW / 32;                           // 32-wide co sub-tiles per wave
+    constexpr int XQ = TIT / 4;                           // float4 per X row
+    constexpr int XROWS = 256 / XQ;                       // X rows fetched per pass: 8 or 16
+    constexpr int XP = TP / XROWS;                        // X passes per K-tile: 2 or 1
+    __shared__ __attribute__((aligned(16))) float smem[2 * TP * LDX + 2 * TP * LDZ];
+    float *Xs = smem;                    // [2][TP][LDX]
+    float *Zs = smem + 2 * TP * LDX;     // [2][TP][LDZ]
     const ds_conv_desc &d = p.d;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = TIT == 128 ? wave >> 1 : 0, wn = TIT == 128 ? wave & 1 : wave;
     const int li = lane & 31, lk = lane >> 5;
     const int tap = blockIdx.x / p.ci_tiles;
-    const int i0 = (blockIdx.x % p.ci_tiles) * TI;
+    const int i0 = (blockIdx.x % p.ci_tiles) * TIT;
     const int j0 = blockIdx.y * TJ;
     const int split = blockIdx.z;
     const int dh = tap / d.KW, dw = tap % d.KW;
@@ -84,29 +93,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 
     int it_valid = (d.Cin - (i0 + wm * 64) + 31) / 32;
     it_valid = it_valid < 0 ? 0 : (it_valid > 2 ? 2 : it_valid);
-    int jt_valid = (d.Cout - (j0 + wn * 64) + 31) / 32;
-    jt_valid = jt_valid < 0 ? 0 : (jt_valid > 2 ? 2 : jt_valid);
+    int jt_valid = (d.Cout - (j0 + wn * CW) + 31) / 32;
+    jt_valid = jt_valid < 0 ? 0 : (jt_valid > BS ? BS : jt_valid);
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][BS];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < BS; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int lrow = tid >> 5;          // 0..7 (+8)
-    const int lc4 = (tid & 31) * 4;     // channel offset inside the 128-wide tile
-    f32x4 rx[2], rz[2];
+    const int xrow = tid / XQ, xc4 = (tid % XQ) * 4;     // this thread's float4 of the X tile
+    const int zrow = tid >> 5, zc4 = (tid & 31) * 4;     // ... and of the dz tile (two passes of 8 rows)
+    f32x4 rx[XP], rz[2];
     const __amdgpu_buffer_rsrc_t srd_x = make_srd(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t srd_z = make_srd(p.dz, p.z_bytes);
-    const int cx = i0 + lc4, cz = j0 + lc4;
+    const int cx = i0 + xc4, cz = j0 + zc4;
     const bool small = p.M < (1 << 24);
 
     auto load_tile = [&](int mt0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = mt0 + lrow + 8 * i;
+        for (int i = 0; i < XP; ++i) {
+            const int m = mt0 + xrow + XROWS * i;
             const bool rv = m < m_end;
             const int mm = rv ? m : 0;
             const int n = small ? fdiv(mm, ohw, p.inv_ohw) : mm / ohw;
@@ -119,33 +128,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             const bool okx = rv && (unsigned)ih < (unsigned)d.H && (unsigned)iwc < (unsigned)d.W && cx < d.Cin;
             const unsigned offx = (unsigned)(((n * d.H + ih) * d.W + iw) * d.ldx + cx);
             rx[i] = load4(srd_x, offx * 4u, okx, p.x_vec, d.Cin - cx);
-            const bool okz = rv && cz < d.Cout;
-            const unsigned offz = (unsigned)mm * (unsigned)p.lddz + (unsigned)cz;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mt0 + zrow + 8 * i;
+            const bool okz = m < m_end && cz < d.Cout;
+            const unsigned offz = (unsigned)(m < m_end ? m : 0) * (unsigned)p.lddz + (unsigned)cz;
             rz[i] = load4(srd_z, offz * 4u, okz, p.z_vec, d.Cout - cz);
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<f32x4 *>(Xs + (buf * TP + lrow + 8 * i) * LDT + lc4) = rx[i];
-            *reinterpret_cast<f32x4 *>(Zs + (buf * TP + lrow + 8 * i) * LDT + lc4) = rz[i];
-        }
+        for (int i = 0; i < XP; ++i)
+            *reinterpret_cast<f32x4 *>(Xs + (buf * TP + xrow + XROWS * i) * LDX + xc4) = rx[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<f32x4 *>(Zs + (buf * TP + zrow + 8 * i) * LDZ + zc4) = rz[i];
     };
     auto compute = [&](int buf) {
-        const float *xs = Xs + buf * TP * LDT + wm * 64 + li;
-        const float *zs = Zs + buf * TP * LDT + wn * 64 + li;
+        const float *xs = Xs + buf * TP * LDX + wm * 64 + li;
+        const float *zs = Zs + buf * TP * LDZ + wn * CW + li;
 #pragma unroll
         for (int s = 0; s < TP / 2; ++s) {
-            const int row = (2 * s + lk) * LDT;
-            float af[2], bf[2];
-            af[0] = xs[row];
-            af[1] = xs[row + 32];
-            bf[0] = zs[row];
-            bf[1] = zs[row + 32];
+            const int row = 2 * s + lk;
+            float af[2], bf[BS];
+            af[0] = xs[row * LDX];
+            af[1] = xs[row * LDX + 32];
+#pragma unroll
+            for (int b = 0; b < BS; ++b) bf[b] = zs[row * LDZ + 32 * b];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < BS; ++b)
                     if (a < it_valid && b < jt_valid)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
@@ -169,8 +183,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = j0 + wn * 64 + b * 32 + li;
+        for (int b = 0; b < BS; ++b) {
+            const int col = j0 + wn * CW + b * 32 + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -187,8 +201,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *ws, flo
     }
 }
 
+// 64-wide ci tiles when they cut the padded reduction width by a fifth or more
+int pick_ti(const ds_conv_desc *d) {
+    const int p128 = (d->Cin + 127) / 128 * 128, p64 = (d->Cin + 63) / 64 * 64;
+    return (p128 - p64) * 5 >= p128 ? 64 : 128;
+}
+
 int pick_splits(const ds_conv_desc *d, int64_t M) {
-    const int tiles = d->KH * d->KW * ((d->Cin + TI - 1) / TI) * ((d->Cout + TJ - 1) / TJ);
+    const int ti = pick_ti(d);
+    const int tiles = d->KH * d->KW * ((d->Cin + ti - 1) / ti) * ((d->Cout + TJ - 1) / TJ);
     static int occ = 0, minpix = 0;
     if (!occ) {
         const char *e = getenv("DS_WGRAD_OCC");
@@ -230,7 +251,8 @@ extern "C" int ds_conv_wgrad(const ds_conv_desc *d, const float *x, const float 
     p.x = x; p.dz = dz; p.lddz = lddz;
     p.out = splits == 1 ? dw : (float *)ws;
     p.M = (int)M;
-    p.ci_tiles = (d->Cin + TI - 1) / TI;
+    const int ti = pick_ti(d);
+    p.ci_tiles = (d->Cin + ti - 1) / ti;
     int pps = (int)((M + splits - 1) / splits);
     p.pix_per_split = ((pps + TP - 1) / TP) * TP;
     p.x_vec = (d->ldx % 4 == 0) && (d->Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
@@ -244,7 +266,8 @@ extern "C" int ds_conv_wgrad(const ds_conv_desc *d, const float *x, const float 
     p.inv_ow = 1.0f / (float)d->OW;
     dim3 grid(d->KH * d->KW * p.ci_tiles, (d->Cout + TJ - 1) / TJ, splits);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, s, p);
+    if (ti == 64) hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, s, p);
     if (splits > 1) {
         const int64_t n = (int64_t)d->KH * d->KW * d->Cin * d->Cout;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ds::stream_grid(n, 256)), dim3(256), 0, s,
