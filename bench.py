@@ -251,6 +251,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
+        barrier()            # rank 0 is still printing / timing the gather: leave together
         dist.destroy_process_group()
 
 
