@@ -129,6 +129,12 @@ int ds_bn_bwd_apply(const float *z, const ds_segments *dy, int64_t M, int32_t C,
 int ds_maxpool_fwd(const float *x, float *y, uint8_t *argmax, int32_t N, int32_t H, int32_t W, int32_t C,
                    int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW,
                    void *stream);
+/* BatchNorm + ReLU + 3x3 max pool of a conv that feeds nothing else (Conv2d_1a_7x7 -> MaxPool_2a_3x3,
+ * Conv2d_2c_3x3 -> MaxPool_3a_3x3, inception_v1.py:63-79): y = relu(rstd*maxpool(z) + shift), identical to
+ * maxpool(relu(bn(z))) because rstd > 0; the full-resolution activation is never materialised.           */
+int ds_maxpool_bn_relu_fwd(const float *z, const float *rstd, const float *shift, float *y, uint8_t *argmax,
+                           int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad_t,
+                           int32_t pad_l, int32_t OH, int32_t OW, void *stream);
 int ds_maxpool_bwd(const float *dy, const uint8_t *argmax, float *dx, int32_t accumulate, int32_t N,
                    int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
                    int32_t OH, int32_t OW, void *stream);

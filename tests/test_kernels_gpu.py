@@ -233,6 +233,35 @@ def test_max_pool_forward_backward(case):
     close(dx, base + dx_ref, 1e-6)
 
 
+@pytest.mark.parametrize("case", [(2, 17, 24, 2), (3, 12, 64, 2), (2, 9, 20, 1)])
+def test_max_pool_with_deferred_batch_norm_relu(case):
+    """ds_maxpool_bn_relu_fwd: relu(rstd*maxpool(z)+shift) == maxpool(relu(rstd*z+shift)) (rstd > 0), and the
+    gradient routed through its arg-max, masked by the ReLU of the pre-pool activation, equals the gradient of
+    the unfused pair BatchNorm-ReLU -> MaxPool."""
+    ops = _ops()
+    N, H, Cc, s = case
+    rng = np.random.RandomState(16)
+    z = rng.normal(size=(N, H, H, Cc))
+    rstd = rng.uniform(0.5, 2.0, size=Cc)
+    shift = rng.normal(size=Cc) * 0.5
+    y_full = np.maximum(z * rstd + shift, 0)
+    ref = S.max_pool(y_full, 3, s, "SAME")
+    OH = ref.shape[1]
+    zd = dev(z)
+    y = torch.empty(N, OH, OH, Cc, device="cuda")
+    am = torch.empty(N, OH, OH, Cc, dtype=torch.uint8, device="cuda")
+    ops.maxpool_bn_relu_fwd(zd, dev(rstd), dev(shift), y, am, N, H, H, Cc, 3, s)
+    torch.cuda.synchronize()
+    close(y, ref)
+    dy = rng.normal(size=ref.shape)
+    dx = torch.zeros(N, H, H, Cc, device="cuda")
+    ops.maxpool_bwd(dev(dy), am, dx, False, N, H, H, Cc, 3, s, "SAME")
+    torch.cuda.synchronize()
+    got = dx.cpu().numpy() * (y_full > 0)               # what BatchNorm backward keeps of it
+    want = S.max_pool_bwd(y_full, dy, 3, s, "SAME") * (y_full > 0)
+    assert np.abs(got - want).max() <= 1e-6
+
+
 def test_avgpool_dropout():
     ops = _ops()
     rng = np.random.RandomState(9)

@@ -130,9 +130,14 @@ __device__ __forceinline__ RowMax row_max3(const float *x, int64_t row_base, int
     return r;
 }
 
+// rstd/shift != nullptr: x is the PRE-BatchNorm conv output z and the pooled value is stored as
+// relu(rstd*max(z) + shift).  With rstd > 0 the affine map and the ReLU are monotone, so this equals the max of
+// relu(bn(z)) over the window (and ties only appear among positions whose ReLU gradient is zero anyway): the
+// full-resolution activation of a conv that only feeds a pool is never written or re-read.
 template <int STRIDE>
 __global__ __launch_bounds__(256) void maxpool3_fwd_rolling(const float *x, float *y, uint8_t *am, int N, int H, int W,
-                                                            int C, int pad_t, int pad_l, int OH, int OW) {
+                                                            int C, int pad_t, int pad_l, int OH, int OW,
+                                                            const float *rstd, const float *shift) {
     const int C4 = C >> 2;
     const int64_t total = (int64_t)N * OW * C4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -157,6 +162,14 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_rolling(const float *x, floa
                 if (r2.v[j] > best[j]) { best[j] = r2.v[j]; arg[j] = 6 + r2.k[j]; }
             }
             const int64_t o = (((int64_t)n * OH + oh) * OW + ow) * C + c;
+            if (rstd) {
+                const float4 r = *reinterpret_cast<const float4 *>(rstd + c);
+                const float4 s = *reinterpret_cast<const float4 *>(shift + c);
+                best[0] = fmaxf(best[0] * r.x + s.x, 0.f);
+                best[1] = fmaxf(best[1] * r.y + s.y, 0.f);
+                best[2] = fmaxf(best[2] * r.z + s.z, 0.f);
+                best[3] = fmaxf(best[3] * r.w + s.w, 0.f);
+            }
             *reinterpret_cast<float4 *>(y + o) = make_float4(best[0], best[1], best[2], best[3]);
             if (am) *reinterpret_cast<uchar4 *>(am + o) = make_uchar4(arg[0], arg[1], arg[2], arg[3]);
             if (STRIDE == 1) {
@@ -368,16 +381,31 @@ extern "C" int ds_maxpool_fwd(const float *x, float *y, uint8_t *argmax, int32_t
         const int64_t cols = (int64_t)N * OW * (C / 4);
         if (stride == 1)
             hipLaunchKernelGGL(maxpool3_fwd_rolling<1>, dim3(ds::stream_grid(cols, 256)), dim3(256), 0,
-                               (hipStream_t)stream, x, y, argmax, N, H, W, C, pad_t, pad_l, OH, OW);
+                               (hipStream_t)stream, x, y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, nullptr, nullptr);
         else
             hipLaunchKernelGGL(maxpool3_fwd_rolling<2>, dim3(ds::stream_grid(cols, 256)), dim3(256), 0,
-                               (hipStream_t)stream, x, y, argmax, N, H, W, C, pad_t, pad_l, OH, OW);
+                               (hipStream_t)stream, x, y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, nullptr, nullptr);
         return ds::check_launch("ds_maxpool_fwd");
     }
     const int64_t total = (int64_t)N * OH * OW * (C / 4);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ds::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
                        argmax, N, H, W, C, k, stride, pad_t, pad_l, OH, OW);
     return ds::check_launch("ds_maxpool_fwd");
+}
+
+extern "C" int ds_maxpool_bn_relu_fwd(const float *z, const float *rstd, const float *shift, float *y, uint8_t *argmax,
+                                      int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride,
+                                      int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW, void *stream) {
+    DS_REQUIRE(z && rstd && shift && y && C % 4 == 0 && k == 3 && (stride == 1 || stride == 2),
+               "ds_maxpool_bn_relu_fwd: bad argument (3x3 pools, stride 1 or 2, C %% 4 == 0)");
+    const int64_t cols = (int64_t)N * OW * (C / 4);
+    if (stride == 1)
+        hipLaunchKernelGGL(maxpool3_fwd_rolling<1>, dim3(ds::stream_grid(cols, 256)), dim3(256), 0, (hipStream_t)stream,
+                           z, y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift);
+    else
+        hipLaunchKernelGGL(maxpool3_fwd_rolling<2>, dim3(ds::stream_grid(cols, 256)), dim3(256), 0, (hipStream_t)stream,
+                           z, y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift);
+    return ds::check_launch("ds_maxpool_bn_relu_fwd");
 }
 
 extern "C" int ds_maxpool_bwd(const float *dy, const uint8_t *argmax, float *dx, int32_t accumulate, int32_t N,

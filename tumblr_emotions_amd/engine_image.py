@@ -117,7 +117,8 @@ class ConvBN:
         k, cin, cout = self.k, self.cin, self.cout
         self.dgrad = ConvPlan(self.B, self.H, self.W, cout, cout, k, k, 1, cin, lddx, cin * cout, cout, 1, flip=1)
 
-    # x_ptr: input activations [B,H,W,ldx]; segs: where relu(bn(conv)) is scattered
+    # x_ptr: input activations [B,H,W,ldx]; segs: where relu(bn(conv)) is scattered (None: the consumer, a max
+    # pool, applies BatchNorm + ReLU to its own output instead -- PoolStage.forward)
     def forward(self, x_ptr, ldx, segs):
         eng = self.eng
         if not self.fold:
@@ -132,7 +133,8 @@ class ConvBN:
             self.fwd.d.flags = 0
             self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z))
             ops.bn_infer_prepare(self.beta, self.mm, self.mv, BN_EPS, self.cout, self.rstd, self.shift)
-        ops.bn_apply_relu(self.z, self.M, self.cout, self.rstd, self.shift, segs)
+        if segs is not None:
+            ops.bn_apply_relu(self.z, self.M, self.cout, self.rstd, self.shift, segs)
 
     def backward(self, dy_segs, x_ptr=None, ldx=0, dx_ptr=None, need_dx=True):
         eng = self.eng
@@ -177,6 +179,7 @@ class ConvStage(Stage):
                             beta_bucket, fold=fold)
         self.H, self.W, self.C = self.layer.OH, self.layer.OW, cout
         self.layers = [self.layer]
+        self.fused_into_pool = False
 
     def alloc(self, B):
         dev = self.eng.device
@@ -189,7 +192,9 @@ class ConvStage(Stage):
             self.layer.make_dgrad(self.prev.C)
 
     def forward(self):
-        self.layer.forward(ops._p(self.prev.out), self.prev.C, self.segs)
+        # fused_into_pool: this conv feeds nothing but the next max pool, which then reads z and applies BN + ReLU
+        # after pooling (a quarter of the elements); `out` is not produced
+        self.layer.forward(ops._p(self.prev.out), self.prev.C, None if self.fused_into_pool else self.segs)
 
     def backward(self, need_dx):
         need_dx = need_dx and not self.layer.fold
@@ -214,7 +219,11 @@ class PoolStage(Stage):
 
     def forward(self):
         p = self.prev
-        ops.maxpool_fwd(p.out, self.out, self.argmax, self.B, p.H, p.W, p.C, self.k, self.stride, "SAME")
+        if getattr(p, "fused_into_pool", False):
+            ops.maxpool_bn_relu_fwd(p.layer.z, p.layer.rstd, p.layer.shift, self.out, self.argmax, self.B, p.H, p.W, p.C,
+                                    self.k, self.stride)
+        else:
+            ops.maxpool_fwd(p.out, self.out, self.argmax, self.B, p.H, p.W, p.C, self.k, self.stride, "SAME")
 
     def backward(self, need_dx):
         if need_dx:
@@ -337,6 +346,10 @@ class InceptionV1Engine:
             self.stages.append(st)
             prev = st
         self.last = prev
+        # BatchNorm + ReLU of a conv whose only consumer is a 3x3 max pool (Conv2d_1a_7x7 -> MaxPool_2a,
+        # Conv2d_2c_3x3 -> MaxPool_3a) moves behind the pool; set fuse_bn_pool = False before the first forward to
+        # get every end point materialised (image_model.inception_v1 does)
+        self.fuse_bn_pool = True
         assert self.last.H == 7 and self.last.W == 7, "AvgPool_0a_7x7 + SpatialSqueeze need a 7x7 map (224x224 input)"
         self.feat = self.last.C
         lg = "InceptionV1/Logits/Conv2d_0c_1x1"
@@ -393,6 +406,9 @@ class InceptionV1Engine:
         internal logits buffer [B,num_classes]."""
         B = images.shape[0]
         self.alloc(B)
+        for a, b in zip(self.stages[:-1], self.stages[1:]):
+            if isinstance(a, ConvStage):
+                a.fused_into_pool = self.fuse_bn_pool and isinstance(b, PoolStage) and b.k == 3
         ops.pad_channels(images, 3, self.input.out, 4, B * self.input.H * self.input.W)
         for s in self.stages:
             s.forward()

@@ -38,6 +38,7 @@ def inception_v1_base(inputs, final_endpoint="Mixed_5c", scope="InceptionV1", ne
         raise ValueError("Unknown final endpoint %s" % final_endpoint)      # :251
     net = net or get_net(scope)
     eng = net.image
+    eng.fuse_bn_pool = False             # callers get every end point materialised
     with torch.no_grad():
         eng.forward(inputs, None, 0)
     end_points = {}
@@ -60,6 +61,7 @@ def inception_v1(inputs, final_endpoint="Mixed_5c", num_classes=1000, is_trainin
     net = net or get_net(scope, num_classes, dropout_keep_prob, reuse)
     if not is_training:
         raise NotImplementedError("inference-mode BatchNorm is not on the training path (SURVEY 8f-3)")
+    net.image.fuse_bn_pool = False       # callers get every end point materialised
     logits = net.forward({"images": inputs}, dropout_mask)
     end_points = {st.name: st.out for st in net.image.stages}
     end_points["Logits"] = logits

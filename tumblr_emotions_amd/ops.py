@@ -189,6 +189,15 @@ def maxpool_fwd(x, y, argmax, N, H, W, C_, k, stride, mode="SAME"):
     return OH, OW
 
 
+def maxpool_bn_relu_fwd(z, rstd, shift, y, argmax, N, H, W, C_, k, stride):
+    """y = maxpool(relu(z*rstd + shift)) computed as relu(rstd*maxpool(z) + shift): SAME padding, 3x3 only."""
+    OH, pt = same_pad(H, k, stride)
+    OW, pl = same_pad(W, k, stride)
+    _lib.check(_lib.load().ds_maxpool_bn_relu_fwd(_p(z), _p(rstd), _p(shift), _p(y), _p(argmax), N, H, W, C_, k, stride,
+                                                  pt, pl, OH, OW, _stream()), "ds_maxpool_bn_relu_fwd")
+    return OH, OW
+
+
 def maxpool_bwd(dy, argmax, dx, accumulate, N, H, W, C_, k, stride, mode="SAME"):
     if mode == "SAME":
         OH, pt = same_pad(H, k, stride)
