@@ -135,6 +135,17 @@ int ds_maxpool_fwd(const float *x, float *y, uint8_t *argmax, int32_t N, int32_t
 int ds_maxpool_bn_relu_fwd(const float *z, const float *rstd, const float *shift, float *y, uint8_t *argmax,
                            int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad_t,
                            int32_t pad_l, int32_t OH, int32_t OW, void *stream);
+/* ... and its backward: BatchNorm(+ReLU) backward of that conv straight from the POOLED gradient (3x3 stride-2
+ * SAME pools).  MaxPoolGrad's full-resolution result is rebuilt per 2x2 input patch on the fly instead of being
+ * written and re-read twice.  reduce -> partials float[2][C][P] (P = ds_bn_pool_bwd_partials), then
+ * ds_bn_bwd_finalize as usual, then apply (dz may alias z).                                                   */
+int ds_bn_pool_bwd_partials(int32_t N, int32_t OH, int32_t OW, int32_t C);
+int ds_bn_pool_bwd_reduce(const float *z, const float *dpool, const uint8_t *argmax, int32_t N, int32_t H, int32_t W,
+                          int32_t C, int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW, const float *mean,
+                          const float *rstd, const float *shift, float *partials, void *stream);
+int ds_bn_pool_bwd_apply(const float *z, const float *dpool, const uint8_t *argmax, int32_t N, int32_t H, int32_t W,
+                         int32_t C, int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW, const float *mean,
+                         const float *rstd, const float *shift, const float *coef, float *dz, void *stream);
 int ds_maxpool_bwd(const float *dy, const uint8_t *argmax, float *dx, int32_t accumulate, int32_t N,
                    int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
                    int32_t OH, int32_t OW, void *stream);

@@ -262,6 +262,50 @@ def test_max_pool_with_deferred_batch_norm_relu(case):
     assert np.abs(got - want).max() <= 1e-6
 
 
+@pytest.mark.parametrize("case", [(2, 17, 24), (3, 12, 64), (1, 30, 192)])
+def test_batch_norm_backward_from_the_pooled_gradient(case):
+    """ds_bn_pool_bwd_reduce/_apply (BN+ReLU backward of a conv behind a 3x3/2 SAME pool, straight from the pool's
+    output gradient) against the oracle's MaxPoolGrad followed by the oracle's BatchNorm backward."""
+    ops = _ops()
+    N, H, Cc = case
+    rng = np.random.RandomState(17)
+    z = rng.normal(0.2, 1.5, size=(N, H, H, Cc))
+    beta = rng.normal(size=Cc) * 0.3
+    M = N * H * H
+    y_bn, mean, var, xhat, rstd = S.batch_norm_train(z.reshape(M, Cc), beta)
+    y = np.maximum(y_bn, 0).reshape(N, H, H, Cc)
+    pooled = S.max_pool(y, 3, 2, "SAME")
+    OH = pooled.shape[1]
+    dpool = rng.normal(size=pooled.shape)
+    dy_full = S.max_pool_bwd(y, dpool, 3, 2, "SAME").reshape(M, Cc)
+    g = dy_full * (y.reshape(M, Cc) > 0)
+    dz_ref, dbeta_ref = S.batch_norm_train_bwd(g, xhat, rstd)
+    # forward through the fused kernel to get the arg-max the backward kernels consume
+    zd = dev(z)
+    shift = beta - mean * rstd
+    rstd_d, shift_d, mean_d = dev(rstd), dev(shift), dev(mean)
+    yp = torch.empty(N, OH, OH, Cc, device="cuda")
+    am = torch.empty(N, OH, OH, Cc, dtype=torch.uint8, device="cuda")
+    ops.maxpool_bn_relu_fwd(zd, rstd_d, shift_d, yp, am, N, H, H, Cc, 3, 2)
+    P = ops.bn_pool_bwd_partials(N, H, H, Cc)
+    part = torch.zeros(2 * Cc * P, device="cuda")
+    dpd = dev(dpool)
+    ops.bn_pool_bwd_reduce(zd, dpd, am, N, H, H, Cc, mean_d, rstd_d, shift_d, part)
+    dbeta = torch.empty(Cc, device="cuda")
+    coef = torch.empty(2, Cc, device="cuda")
+    ops.bn_bwd_finalize(part, P, M, Cc, dbeta, coef)
+    dz = torch.empty(M, Cc, device="cuda")
+    ops.bn_pool_bwd_apply(zd, dpd, am, N, H, H, Cc, mean_d, rstd_d, shift_d, coef, dz)
+    torch.cuda.synchronize()
+    close(yp, pooled)
+    close(dbeta, dbeta_ref, 1e-4)
+    close(dz, dz_ref, 2e-4)
+    again = torch.zeros_like(part)
+    ops.bn_pool_bwd_reduce(zd, dpd, am, N, H, H, Cc, mean_d, rstd_d, shift_d, again)
+    torch.cuda.synchronize()
+    assert torch.equal(part, again)                      # fixed summation order
+
+
 def test_avgpool_dropout():
     ops = _ops()
     rng = np.random.RandomState(9)

@@ -53,6 +53,9 @@ SIGNATURES = {
     "ds_bn_bwd_apply": (C.c_int, [_P, _SG, _i64, _i32, _P, _P, _P, _P, _P, _P]),
     "ds_maxpool_fwd": (C.c_int, [_P, _P, _P] + [_i32] * 10 + [_P]),
     "ds_maxpool_bn_relu_fwd": (C.c_int, [_P, _P, _P, _P, _P] + [_i32] * 10 + [_P]),
+    "ds_bn_pool_bwd_partials": (C.c_int, [_i32, _i32, _i32, _i32]),
+    "ds_bn_pool_bwd_reduce": (C.c_int, [_P, _P, _P] + [_i32] * 8 + [_P, _P, _P, _P, _P]),
+    "ds_bn_pool_bwd_apply": (C.c_int, [_P, _P, _P] + [_i32] * 8 + [_P, _P, _P, _P, _P, _P]),
     "ds_maxpool_bwd": (C.c_int, [_P, _P, _P] + [_i32] * 11 + [_P]),
     "ds_avgpool_dropout_fwd": (C.c_int, [_P, _i32, _i32, _i32, _f32, _u64, _P, _P, _P, _P, _P]),
     "ds_avgpool_dropout_bwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _f32, _P, _P]),

@@ -371,6 +371,167 @@ __global__ __launch_bounds__(256) void avgpool_dropout_bwd_kernel(const float *d
     }
 }
 
+// ---- BatchNorm backward of a conv that feeds only a 3x3/2 max pool, straight from the POOLED gradient -------
+// The pool's gradient w.r.t. its full-resolution input is never written: these two kernels rebuild it per 2x2
+// input patch from the four windows that can name it (same walk as maxpool3s2_bwd_patch) and feed it into the
+// BatchNorm(+ReLU) backward formulas,
+//     g = dy_full * (z*rstd + shift > 0),   dbeta = sum g,   dz = rstd * (g - mean(g) - xhat * mean(g*xhat)).
+// Saves the full-resolution write of MaxPoolGrad and its two re-reads (Conv2d_1a_7x7, Conv2d_2c_3x3).
+struct PatchGrad {
+    float g[2][2][4];      // [row y][col x][channel]: pooled gradient routed to input pixel (2p-pt+1+y, 2q-pl+1+x)
+};
+
+__device__ __forceinline__ PatchGrad patch_grad(const float *dpool, const uint8_t *am, int n, int p, int q, int c, int C,
+                                                int OH, int OW) {
+    float d[2][2][4];
+    unsigned a[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int oh = p + u, ow = q + v;
+            a[u][v] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[u][v][j] = 0.f;
+            if ((unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW) {
+                const int64_t o = (((int64_t)n * OH + oh) * OW + ow) * C + c;
+                a[u][v] = *reinterpret_cast<const unsigned *>(am + o);
+                const float4 t = *reinterpret_cast<const float4 *>(dpool + o);
+                d[u][v][0] = t.x; d[u][v][1] = t.y; d[u][v][2] = t.z; d[u][v][3] = t.w;
+            }
+        }
+    PatchGrad r;
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r.g[y][x][j] = 0.f;
+#pragma unroll
+            for (int u = 0; u <= y; ++u)
+#pragma unroll
+                for (int v = 0; v <= x; ++v) {
+                    const unsigned t = (unsigned)(((y + 1) - 2 * u) * 3 + ((x + 1) - 2 * v));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (((a[u][v] >> (8 * j)) & 0xFFu) == t) r.g[y][x][j] += d[u][v][j];
+                }
+        }
+    return r;
+}
+
+// partials laid out [2][C][P], P = gridDim.x; the launch makes 256*gridDim.x a multiple of C/4 so that a thread
+// keeps its channel group over its whole grid-stride walk
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float *z, const float *dpool, const uint8_t *am,
+                                                                 int N, int H, int W, int C, int pad_t, int pad_l, int OH,
+                                                                 int OW, const float *mean, const float *rstd,
+                                                                 const float *shift, float *partials) {
+    __shared__ float sh[256][8];
+    const int C4 = C >> 2;
+    const int PH = OH + 1, PW = OW + 1;
+    const int64_t total = (int64_t)N * PH * PW * C4;
+    const int64_t first = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(first % C4) * 4;
+    const float4 r4 = *reinterpret_cast<const float4 *>(rstd + c);
+    const float4 s4 = *reinterpret_cast<const float4 *>(shift + c);
+    const float4 m4 = *reinterpret_cast<const float4 *>(mean + c);
+    const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = first; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t r = i / C4;
+        const int q = (int)(r % PW) - 1;
+        r /= PW;
+        const int p = (int)(r % PH) - 1;
+        const int n = (int)(r / PH);
+        const PatchGrad pg = patch_grad(dpool, am, n, p, q, c, C, OH, OW);
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int ih = 2 * p - pad_t + 1 + y;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int iw = 2 * q - pad_l + 1 + x;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const float4 zv = *reinterpret_cast<const float4 *>(z + (((int64_t)n * H + ih) * W + iw) * C + c);
+                const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float g = (zz[j] * rr[j] + ss[j] > 0.f) ? pg.g[y][x][j] : 0.f;
+                    sg[j] += g;
+                    sx[j] += g * ((zz[j] - mm[j]) * rr[j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sh[threadIdx.x][j] = sg[j];
+        sh[threadIdx.x][4 + j] = sx[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < C4) {      // owner of channel group threadIdx.x: add its threads of this block in index order
+        const int cg = threadIdx.x;
+        int t0 = (int)(((int64_t)cg - (int64_t)blockIdx.x * 256) % C4);
+        if (t0 < 0) t0 += C4;
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = t0; t < 256; t += C4)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += sh[t][j];
+        const int P = gridDim.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            partials[(int64_t)(cg * 4 + j) * P + blockIdx.x] = a[j];
+            partials[((int64_t)C + cg * 4 + j) * P + blockIdx.x] = a[4 + j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float *z, const float *dpool, const uint8_t *am,
+                                                                int N, int H, int W, int C, int pad_t, int pad_l, int OH,
+                                                                int OW, const float *mean, const float *rstd,
+                                                                const float *shift, const float *coef, float *dz) {
+    const int C4 = C >> 2;
+    const int PH = OH + 1, PW = OW + 1;
+    const int64_t total = (int64_t)N * PH * PW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        int64_t r = i / C4;
+        const int q = (int)(r % PW) - 1;
+        r /= PW;
+        const int p = (int)(r % PH) - 1;
+        const int n = (int)(r / PH);
+        const PatchGrad pg = patch_grad(dpool, am, n, p, q, c, C, OH, OW);
+        const float4 r4 = *reinterpret_cast<const float4 *>(rstd + c);
+        const float4 s4 = *reinterpret_cast<const float4 *>(shift + c);
+        const float4 m4 = *reinterpret_cast<const float4 *>(mean + c);
+        const float4 k1 = *reinterpret_cast<const float4 *>(coef + c);
+        const float4 k2 = *reinterpret_cast<const float4 *>(coef + C + c);
+        const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+        const float a1[4] = {k1.x, k1.y, k1.z, k1.w}, a2[4] = {k2.x, k2.y, k2.z, k2.w};
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int ih = 2 * p - pad_t + 1 + y;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int iw = 2 * q - pad_l + 1 + x;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const int64_t off = (((int64_t)n * H + ih) * W + iw) * C + c;
+                const float4 zv = *reinterpret_cast<const float4 *>(z + off);
+                const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float g = (zz[j] * rr[j] + ss[j] > 0.f) ? pg.g[y][x][j] : 0.f;
+                    const float xhat = (zz[j] - mm[j]) * rr[j];
+                    o[j] = rr[j] * (g - a1[j] - xhat * a2[j]);
+                }
+                *reinterpret_cast<float4 *>(dz + off) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ds_maxpool_fwd(const float *x, float *y, uint8_t *argmax, int32_t N, int32_t H, int32_t W, int32_t C,
@@ -452,4 +613,43 @@ extern "C" int ds_avgpool_dropout_bwd(const float *dout, const float *mask, int3
     hipLaunchKernelGGL(avgpool_dropout_bwd_kernel, dim3(ds::stream_grid(total, 256)), dim3(256), 0,
                        (hipStream_t)stream, dout, keep >= 1.f ? nullptr : mask, N, HW, C, scale, dx);
     return ds::check_launch("ds_avgpool_dropout_bwd");
+}
+
+namespace {
+int pool_bwd_grid(int N, int OH, int OW, int C) {
+    const int C4 = C / 4;
+    const int64_t total = (int64_t)N * (OH + 1) * (OW + 1) * C4;
+    int g = ds::stream_grid(total, 256 * 4);
+    // 256*g must be a multiple of C4 (a thread keeps its channel group): g multiple of C4 / gcd(256, C4)
+    int a = 256, b = C4;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const int step = C4 / a;
+    g = (g + step - 1) / step * step;
+    return g;
+}
+}  // namespace
+
+extern "C" int ds_bn_pool_bwd_partials(int32_t N, int32_t OH, int32_t OW, int32_t C) { return pool_bwd_grid(N, OH, OW, C); }
+
+extern "C" int ds_bn_pool_bwd_reduce(const float *z, const float *dpool, const uint8_t *argmax, int32_t N, int32_t H,
+                                     int32_t W, int32_t C, int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW,
+                                     const float *mean, const float *rstd, const float *shift, float *partials,
+                                     void *stream) {
+    DS_REQUIRE(z && dpool && argmax && mean && rstd && shift && partials && C % 4 == 0 && C <= 1024 && H <= 2 * OH &&
+                   W <= 2 * OW,
+               "ds_bn_pool_bwd_reduce: bad argument (3x3 stride-2 SAME pools, C %% 4 == 0, C <= 1024)");
+    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(pool_bwd_grid(N, OH, OW, C)), dim3(256), 0, (hipStream_t)stream, z,
+                       dpool, argmax, N, H, W, C, pad_t, pad_l, OH, OW, mean, rstd, shift, partials);
+    return ds::check_launch("ds_bn_pool_bwd_reduce");
+}
+
+extern "C" int ds_bn_pool_bwd_apply(const float *z, const float *dpool, const uint8_t *argmax, int32_t N, int32_t H,
+                                    int32_t W, int32_t C, int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW,
+                                    const float *mean, const float *rstd, const float *shift, const float *coef,
+                                    float *dz, void *stream) {
+    DS_REQUIRE(z && dpool && argmax && mean && rstd && shift && coef && dz && C % 4 == 0 && H <= 2 * OH && W <= 2 * OW,
+               "ds_bn_pool_bwd_apply: bad argument (3x3 stride-2 SAME pools, C %% 4 == 0)");
+    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(pool_bwd_grid(N, OH, OW, C)), dim3(256), 0, (hipStream_t)stream, z,
+                       dpool, argmax, N, H, W, C, pad_t, pad_l, OH, OW, mean, rstd, shift, coef, dz);
+    return ds::check_launch("ds_bn_pool_bwd_apply");
 }

@@ -93,6 +93,8 @@ class ConvBN:
         eng.need_stats(self.fwd.partials * 2 * cout)
         self.bwd_P = ops.bn_bwd_partials(self.M, cout)
         eng.need_bwd_partials(self.bwd_P * 2 * cout)
+        self.pool_P = ops.bn_pool_bwd_partials(B, self.OH, self.OW, cout)      # used when a 3x3/2 pool follows
+        eng.need_bwd_partials(self.pool_P * 2 * cout)
         self.dgrad = None
         self.wgrad = None
         if self.trainable:
@@ -135,6 +137,28 @@ class ConvBN:
             ops.bn_infer_prepare(self.beta, self.mm, self.mv, BN_EPS, self.cout, self.rstd, self.shift)
         if segs is not None:
             ops.bn_apply_relu(self.z, self.M, self.cout, self.rstd, self.shift, segs)
+
+    def backward_pooled(self, pool, x_ptr=None, ldx=0, dx_ptr=None, need_dx=True):
+        """Backward of conv -> BN -> ReLU -> 3x3/2 max pool from the pool's OUTPUT gradient: the pool's
+        full-resolution input gradient is never written (ds_bn_pool_bwd_reduce / _apply rebuild it per patch)."""
+        eng = self.eng
+        M, Cc = self.M, self.cout
+        if self.gbeta is None and not need_dx and not self.trainable:
+            return
+        B, H, W = self.B, self.OH, self.OW
+        ops.bn_pool_bwd_reduce(self.z, pool.dout, pool.argmax, B, H, W, Cc, self.mean, self.rstd, self.shift,
+                               eng.bwd_partials)
+        ops.bn_bwd_finalize(eng.bwd_partials, self.pool_P, M, Cc, self.gbeta if self.gbeta is not None else eng.dummy,
+                            self.coef)
+        if not (need_dx or self.trainable):
+            return
+        ops.bn_pool_bwd_apply(self.z, pool.dout, pool.argmax, B, H, W, Cc, self.mean, self.rstd, self.shift, self.coef,
+                              self.z)
+        if self.trainable:
+            self.wgrad.d.ldx = ldx
+            self.wgrad.run(x_ptr, ops._p(self.z), self.gw_ptr, ops._p(eng.ws), eng.ws_bytes)
+        if need_dx:
+            self.dgrad.run(ops._p(self.z), self.w_ptr, dx_ptr)
 
     def backward(self, dy_segs, x_ptr=None, ldx=0, dx_ptr=None, need_dx=True):
         eng = self.eng
@@ -180,6 +204,7 @@ class ConvStage(Stage):
         self.H, self.W, self.C = self.layer.OH, self.layer.OW, cout
         self.layers = [self.layer]
         self.fused_into_pool = False
+        self.pool = None
 
     def alloc(self, B):
         dev = self.eng.device
@@ -198,8 +223,11 @@ class ConvStage(Stage):
 
     def backward(self, need_dx):
         need_dx = need_dx and not self.layer.fold
-        self.layer.backward(self.dsegs, ops._p(self.prev.out), self.prev.C,
-                            ops._p(self.prev.dout) if need_dx else None, need_dx)
+        dx = ops._p(self.prev.dout) if need_dx else None
+        if self.fused_into_pool and self.pool.stride == 2:
+            self.layer.backward_pooled(self.pool, ops._p(self.prev.out), self.prev.C, dx, need_dx)
+        else:
+            self.layer.backward(self.dsegs, ops._p(self.prev.out), self.prev.C, dx, need_dx)
 
 
 class PoolStage(Stage):
@@ -226,8 +254,10 @@ class PoolStage(Stage):
             ops.maxpool_fwd(p.out, self.out, self.argmax, self.B, p.H, p.W, p.C, self.k, self.stride, "SAME")
 
     def backward(self, need_dx):
+        p = self.prev
+        if getattr(p, "fused_into_pool", False) and self.stride == 2:
+            return          # the conv in front consumes self.dout / self.argmax directly (ConvBN.backward_pooled)
         if need_dx:
-            p = self.prev
             ops.maxpool_bwd(self.dout, self.argmax, p.dout, False, self.B, p.H, p.W, p.C, self.k, self.stride, "SAME")
 
 
@@ -409,6 +439,7 @@ class InceptionV1Engine:
         for a, b in zip(self.stages[:-1], self.stages[1:]):
             if isinstance(a, ConvStage):
                 a.fused_into_pool = self.fuse_bn_pool and isinstance(b, PoolStage) and b.k == 3
+                a.pool = b if a.fused_into_pool else None
         ops.pad_channels(images, 3, self.input.out, 4, B * self.input.H * self.input.W)
         for s in self.stages:
             s.forward()

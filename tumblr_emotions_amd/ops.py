@@ -198,6 +198,27 @@ def maxpool_bn_relu_fwd(z, rstd, shift, y, argmax, N, H, W, C_, k, stride):
     return OH, OW
 
 
+def bn_pool_bwd_partials(N, H, W, C_):
+    OH, _ = same_pad(H, 3, 2)
+    OW, _ = same_pad(W, 3, 2)
+    return _lib.load().ds_bn_pool_bwd_partials(N, OH, OW, C_)
+
+
+def bn_pool_bwd_reduce(z, dpool, argmax, N, H, W, C_, mean, rstd, shift, partials):
+    """BatchNorm(+ReLU) backward sums of a conv behind a 3x3/2 SAME max pool, from the pooled gradient."""
+    OH, pt = same_pad(H, 3, 2)
+    OW, pl = same_pad(W, 3, 2)
+    _lib.check(_lib.load().ds_bn_pool_bwd_reduce(_p(z), _p(dpool), _p(argmax), N, H, W, C_, pt, pl, OH, OW, _p(mean),
+                                                 _p(rstd), _p(shift), _p(partials), _stream()), "ds_bn_pool_bwd_reduce")
+
+
+def bn_pool_bwd_apply(z, dpool, argmax, N, H, W, C_, mean, rstd, shift, coef, dz):
+    OH, pt = same_pad(H, 3, 2)
+    OW, pl = same_pad(W, 3, 2)
+    _lib.check(_lib.load().ds_bn_pool_bwd_apply(_p(z), _p(dpool), _p(argmax), N, H, W, C_, pt, pl, OH, OW, _p(mean),
+                                                _p(rstd), _p(shift), _p(coef), _p(dz), _stream()), "ds_bn_pool_bwd_apply")
+
+
 def maxpool_bwd(dy, argmax, dx, accumulate, N, H, W, C_, k, stride, mode="SAME"):
     if mode == "SAME":
         OH, pt = same_pad(H, k, stride)
