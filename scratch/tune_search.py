@@ -57,13 +57,7 @@ for key, (plan, count) in plans.items():
         gmax = max(1, min(rt, cap//(gy*max(1,splits))))
         tmin = math.ceil(rt/gmax)
         cands = set()
-        for t in list(range(1, 9)) + list(range(tmin, tmin + 3)):
-            g0 = math.ceil(rt/t)
-            if g0 < 1: continue
-            cands.add(g0)
-            g8 = (g0 + 7)//8*8
-            if g8 <= rt: cands.add(g8)
-        cands.add(gmax); cands.add(max(1, gmax & ~7))
+        cands.add(0)      # automatic grid for this nt
         for gx in sorted(cands):
             d.tile_nt = nt; d.grid_x = gx
             t = timeit(run, plan.alg_flops)
