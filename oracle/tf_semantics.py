@@ -143,6 +143,14 @@ def max_pool(x, k, stride, mode="SAME"):
     return win.max(axis=(3, 4))
 
 
+def max_pool_argmax(x, k, stride, mode="SAME"):
+    """Winner of every window as the tap index kh*k+kw inside the (padded) window, first maximum in
+    row-major order -- the element MaxPoolGrad routes the gradient to.  uint8 [N,OH,OW,C]."""
+    n, h, w, c = x.shape
+    win, _, _ = _patches(x, k, k, stride, -np.inf, mode)
+    return win.reshape(n, win.shape[1], win.shape[2], k * k, c).argmax(axis=3).astype(np.uint8)
+
+
 def max_pool_bwd(x, dy, k, stride, mode="SAME"):
     """MaxPoolGrad: the gradient of each window goes to its first (row-major) maximal element."""
     n, h, w, c = x.shape
@@ -268,7 +276,7 @@ def embedding_lookup(table, ids):
     return table[ids]
 
 
-def lstm_forward(x, seq_len, kernel, bias, forget_bias=FORGET_BIAS, keep_cache=False):
+def lstm_forward(x, seq_len, kernel, bias, forget_bias=FORGET_BIAS, keep_cache=False, initial_state=None):
     """x [B,T,D]; kernel [D+H,4H] applied to concat([x_t,h]); gate order i,j,f,o.
     For t >= seq_len[b] the output row is zero and (c,h) are carried.  Returns
     (outputs [B,T,H], h_last [B,H] = outputs[b, seq_len[b]-1])."""
@@ -276,6 +284,8 @@ def lstm_forward(x, seq_len, kernel, bias, forget_bias=FORGET_BIAS, keep_cache=F
     hsz = kernel.shape[1] // 4
     c = np.zeros((b, hsz), dtype=x.dtype)
     h = np.zeros((b, hsz), dtype=x.dtype)
+    if initial_state is not None:          # (c, h); the reference always starts from zeros (dynamic_rnn default)
+        c, h = (np.asarray(a, dtype=x.dtype) for a in initial_state)
     outs = np.zeros((b, t, hsz), dtype=x.dtype)
     cache = []
     for s in range(t):

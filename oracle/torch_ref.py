@@ -37,6 +37,17 @@ def max_pool_same(x, k, s):
     return F.max_pool2d(_same_pad_nchw(x, k, s, float("-inf")), k, s)
 
 
+def max_pool_same_with_argmax(x, k, s, argmax_nhwc):
+    """SAME max pool whose winner per window is GIVEN (tap index kh*k+kw inside the padded window,
+    [N,OH,OW,C]) instead of recomputed: lets a test evaluate the oracle's backward along exactly the
+    arg-max / ReLU decisions another fp32 implementation took (see DeepSentimentRef.inject)."""
+    xp = _same_pad_nchw(x, k, s, 0.0)
+    win = xp.unfold(2, k, s).unfold(3, k, s)                       # [N,C,OH,OW,k,k]
+    win = win.reshape(win.shape[0], win.shape[1], win.shape[2], win.shape[3], k * k)
+    idx = torch.as_tensor(np.asarray(argmax_nhwc), dtype=torch.int64).permute(0, 3, 1, 2).unsqueeze(-1)
+    return torch.gather(win, 4, idx).squeeze(-1)
+
+
 def batch_norm_train(z, beta, eps=S.BN_EPS):
     mean = z.mean(dim=(0, 2, 3))
     var = ((z - mean[None, :, None, None]) ** 2).mean(dim=(0, 2, 3))
@@ -77,6 +88,18 @@ class DeepSentimentRef:
         self.adam_v = {n: torch.zeros_like(self.p[n]) for n in self.trainable}
         self.step = 0
         self.bn_batch_stats = {}
+        # Optional decision injection (tests only).  A deep BatchNorm/ReLU stack evaluated in fp32 takes a
+        # few ReLU / arg-max decisions differently from the same stack in fp64 (pre-activations within
+        # rounding of zero), and each flipped decision moves the upstream gradients by sqrt(flipped
+        # fraction) ~ 1e-2 relative -- for ANY fp32 implementation, this oracle run in fp32 included
+        # (scripts/oracle_fp32_spread.py).  With `inject` set the fp64 oracle follows given decisions:
+        #   "relu/<scope>"   bool [N,H,W,C]: y = bn(z) * mask instead of relu(bn(z))
+        #   "norelu/<scope>" True: no ReLU after this conv (it is applied after the following pool)
+        #   "pool/<name>"    uint8 [N,OH,OW,C] winner tap of every window (+ optional
+        #   "poolrelu/<name>" bool [N,OH,OW,C] ReLU mask applied to the pooled output)
+        # so its gradients are a smooth function of the inputs and can be compared tightly.
+        self.inject = None
+        self.record = None          # dict: filled with this run's own decisions in the `inject` format
 
     @staticmethod
     def _is_trainable(name, trainable_bn_beta):
@@ -100,7 +123,30 @@ class DeepSentimentRef:
         else:
             y = batch_norm_infer(z, beta, self.p[scope + "/BatchNorm/moving_mean"],
                                  self.p[scope + "/BatchNorm/moving_variance"])
+        inj = self.inject
+        if inj is not None:
+            if inj.get("norelu/" + scope):
+                return y
+            m = inj.get("relu/" + scope)
+            if m is not None:
+                return y * torch.as_tensor(np.asarray(m)).permute(0, 3, 1, 2).to(y.dtype)
+        if self.record is not None:
+            self.record["relu/" + scope] = (y.detach() > 0).permute(0, 2, 3, 1).numpy()
         return torch.relu(y)
+
+    def _pool(self, x, k, s, name):
+        inj = self.inject
+        if inj is not None and ("pool/" + name) in inj:
+            y = max_pool_same_with_argmax(x, k, s, inj["pool/" + name])
+            m = inj.get("poolrelu/" + name)
+            if m is not None:
+                y = y * torch.as_tensor(np.asarray(m)).permute(0, 3, 1, 2).to(y.dtype)
+            return y
+        y = max_pool_same(x, k, s)
+        if self.record is not None:
+            self.record["pool/" + name] = S.max_pool_argmax(x.detach().permute(0, 2, 3, 1).numpy(), k, s, "SAME")
+            self.record["poolrelu/" + name] = (y.detach() > 0).permute(0, 2, 3, 1).numpy()
+        return y
 
     def image_tower(self, images_nhwc, dropout_mask=None):
         net = images_nhwc.permute(0, 3, 1, 2)
@@ -109,14 +155,14 @@ class DeepSentimentRef:
             if kind == "conv":
                 net = self._cbr(net, "InceptionV1/" + name, item[3])
             elif kind == "maxpool":
-                net = max_pool_same(net, item[2], item[3])
+                net = self._pool(net, item[2], item[3], name)
             else:
                 pre = "InceptionV1/%s/" % name
                 nm = [n for (n, _, _, _) in S.mixed_conv_names(name)]
                 b0 = self._cbr(net, pre + nm[0])
                 b1 = self._cbr(self._cbr(net, pre + nm[1]), pre + nm[2])
                 b2 = self._cbr(self._cbr(net, pre + nm[3]), pre + nm[4])
-                b3 = self._cbr(max_pool_same(net, 3, 1), pre + nm[5])
+                b3 = self._cbr(self._pool(net, 3, 1, name + "/Branch_3"), pre + nm[5])
                 net = torch.cat([b0, b1, b2, b3], dim=1)
         self.last_mixed_5c = net
         pooled = F.avg_pool2d(net, 7, 1)
@@ -127,7 +173,7 @@ class DeepSentimentRef:
         w = self.p["InceptionV1/Logits/Conv2d_0c_1x1/weights"]
         return pooled @ w.reshape(w.shape[2], w.shape[3]) + self.p["InceptionV1/Logits/Conv2d_0c_1x1/biases"]
 
-    def text_tower(self, texts, seq_lens):
+    def text_tower(self, texts, seq_lens, initial_state=None):
         x = self.embedding[texts]                                   # [B,T,D]
         kernel = self.p["Text/rnn/basic_lstm_cell/kernel"]
         bias = self.p["Text/rnn/basic_lstm_cell/bias"]
@@ -135,6 +181,8 @@ class DeepSentimentRef:
         hsz = kernel.shape[1] // 4
         c = torch.zeros(b, hsz, dtype=self.dtype)
         h = torch.zeros(b, hsz, dtype=self.dtype)
+        if initial_state is not None:      # (c, h); the reference always starts from zeros
+            c, h = (torch.as_tensor(a, dtype=self.dtype) for a in initial_state)
         outs = []
         for s in range(t):
             z = torch.cat([x[:, s, :], h], dim=1) @ kernel + bias

@@ -62,9 +62,30 @@ def test_random_conv_shapes_forward_dgrad_wgrad():
                 torch.cuda.synchronize()
                 ok = ok and np.abs(dw.cpu().numpy() - wref).max() <= 5e-4 * max(1.0, np.abs(wref).max())
             if not ok:
-                bad += 1
-                print("MISMATCH case %d: N=%d H=%d W=%d Ci=%d Co=%d k=%d stride=%d path=%d nt=%d flags=%d" % (case, N, H, W, Ci, Co, k, stride, path, nt, flags), flush=True)
+                failures.append("case %d: N=%d H=%d W=%d Ci=%d Co=%d k=%d stride=%d path=%d nt=%d flags=%d"
+                                % (case, N, H, W, Ci, Co, k, stride, path, nt, flags))
     finally:
         lib.ds_conv_set_path(0)
         lib.ds_conv_set_tile(0, 0)
-    assert not failures, failures
+    assert not failures, "conv parity mismatches:\n" + "\n".join(failures)
+
+
+def test_fuzz_harness_reports_a_planted_mismatch():
+    """The sweep above must be able to fail: the same comparison with a deliberately wrong reference
+    (one weight perturbed) has to be flagged."""
+    from tumblr_emotions_amd import ops
+    rng = np.random.RandomState(7)
+    N, H, W, Ci, Co, k = 2, 9, 9, 16, 32, 3
+    x = rng.normal(size=(N, H, W, Ci)); w = rng.normal(size=(k, k, Ci, Co)) * 0.2
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+    plan = ops.ConvPlan(N, H, W, Ci, Ci, k, k, 1, Co, Co, Ci * Co, 1, Co)
+    z = torch.empty(plan.M, Co, device="cuda")
+    plan.run(ops._p(dev(x)), ops._p(dev(w)), ops._p(z))
+    torch.cuda.synchronize()
+    got = z.cpu().numpy().astype(np.float64)
+    good = S.conv2d_same(x, w, 1).reshape(-1, Co)
+    w_bad = w.copy(); w_bad[1, 1, 3, 5] += 0.05
+    bad = S.conv2d_same(x, w_bad, 1).reshape(-1, Co)
+    tol = 3e-4 * max(1.0, np.abs(good).max())
+    assert np.abs(got - good).max() <= tol
+    assert np.abs(got - bad).max() > tol

@@ -21,22 +21,23 @@ def _dev_batch(b):
 
 
 def _robust_close(got, ref, what, tol=1e-3, frac=0.9, hard=None):
-    """Deep BatchNorm/ReLU stacks at tiny batch are chaotic in the last bits: a pre-activation within
-    fp32 rounding of zero flips its ReLU mask and moves that CHANNEL's gradient by O(1/M).  Two fp32
-    implementations (even the oracle run in fp32 vs fp64) therefore differ by percents on a few
-    channels while agreeing to 1e-5 everywhere else.  So: at least `frac` of the entries within
-    tol*max|ref|, and every entry within `hard`*max|ref| (hard = 3x the oracle's own fp32-vs-fp64
-    spread, measured in the same test)."""
+    """A deep BatchNorm/ReLU stack in fp32 takes a few ReLU / arg-max decisions differently from the same
+    stack in fp64 (pre-activations within rounding of zero); a flipped fraction f of one layer's decisions
+    moves every gradient upstream of it by ~sqrt(f) relative, ~1e-2 for this tower at ANY batch size -- the
+    oracle run in fp32 differs from itself in fp64 by that much (scripts/oracle_fp32_spread.py,
+    profiles/r02_oracle_fp32_spread.txt).  So a plain fp64 comparison cannot be tighter than that spread:
+    `hard` is 3x the spread OF THIS VARIABLE measured in the same test; the tight (1e-3) composition check
+    is test_joint_step_b16_follows_oracle_along_same_decisions, which removes the flips."""
     scale = max(np.abs(ref).max(), 1e-7)
-    e = np.abs(got.reshape(ref.shape) - ref) / scale
-    if hard is None or hard <= tol:          # no chaos in this model (text tower): plain max-norm gate
+    d = got.reshape(ref.shape) - ref
+    e = np.abs(d) / scale
+    if hard is None or hard <= tol:          # no decisions in this model (text tower): plain max-norm gate
         assert e.max() <= tol, "%s: max error %.3e" % (what, e.max())
         return e.max()
-    # variables far from the loss collect every flip downstream of them, so the error is diffuse there:
-    # gate the relative L2 error and the max error by the oracle's own fp32-vs-fp64 spread
-    rel_l2 = np.linalg.norm(got.reshape(ref.shape) - ref) / max(np.linalg.norm(ref), 1e-12)
-    assert rel_l2 <= hard, "%s: relative L2 error %.3e above the fp32-vs-fp64 spread bound %.3e" % (what, rel_l2, hard)
-    assert e.max() <= 2 * hard, "%s: max error %.3e above 2x the spread bound %.3e" % (what, e.max(), hard)
+    rel_l2 = np.linalg.norm(d) / max(np.linalg.norm(ref), 1e-12)
+    assert rel_l2 <= hard, "%s: relative L2 error %.3e above 3x its own fp32-vs-fp64 spread %.3e" % (what, rel_l2, hard)
+    assert (e <= hard).mean() >= frac, "%s: only %.3f of the entries within %.3e" % (what, (e <= hard).mean(), hard)
+    assert e.max() <= 4 * hard, "%s: max error %.3e above 4x the spread bound %.3e" % (what, e.max(), hard)
     return e.max()
 
 
@@ -63,12 +64,17 @@ def _check_step(net, ref, batch, lr, mask_np=None, logit_tol=1e-3, ref32=None, f
     mask_d = None if mask_np is None else torch.tensor(mask_np, dtype=torch.float32).cuda()
     w_before = net.state_dict()
     out = ref.train_step(batch, lr, mask_t)
-    hard = 1e-3
-    if ref32 is not None:          # the oracle's own sensitivity to fp32 rounding on this batch
+    hard = {}
+    if ref32 is not None:          # the oracle's own sensitivity to fp32 rounding on this batch, PER VARIABLE
         out32 = ref32.train_step(batch, lr, None if mask_np is None else torch.tensor(mask_np, dtype=torch.float32))
-        spread = max(float((out32["grads"][n].double() - g).abs().max() / max(float(g.abs().max()), 1e-7))
-                     for n, g in out["grads"].items())
-        hard = max(1e-3, 3 * spread)
+        spread = {n: float((out32["grads"][n].double() - g).norm() / max(float(g.norm()), 1e-30))
+                  for n, g in out["grads"].items()}
+        # flips are rare events: a variable whose downstream saw none in the fp32 oracle may see one on the GPU,
+        # so the tower's median spread is the floor for variables that sit below ReLU/arg-max decisions
+        below = [n for n in spread if n.startswith("InceptionV1/") and "/Logits/" not in n]
+        floor = float(np.median([spread[n] for n in below])) if below else 0.0
+        for n in spread:
+            hard[n] = max(1e-3, 3 * max(spread[n], floor if n in below else 0.0))
     net.train_step(_dev_batch(batch), lr, dropout_mask=mask_d)
     torch.cuda.synchronize()
     logits = net.logits.detach().cpu().numpy()
@@ -77,7 +83,7 @@ def _check_step(net, ref, batch, lr, mask_np=None, logit_tol=1e-3, ref32=None, f
     assert abs(net.total_loss_value() - out["loss"]) <= 1e-3, (net.total_loss_value(), out["loss"])
     grads = net.grads_state_dict()
     for name, g_ref in out["grads"].items():
-        _robust_close(grads[name], g_ref.numpy(), "gradient of " + name, hard=hard)
+        _robust_close(grads[name], g_ref.numpy(), "gradient of " + name, hard=hard.get(name))
     after = net.state_dict()
     for name in ref.trainable:
         w_ref = ref.p[name].detach().numpy()
@@ -239,6 +245,62 @@ def test_joint_step_matches_oracle():
                     ref32.adam_v[k].copy_(ref.adam_v[k])
             ref32.step = ref.step
         _check_step(net, ref, batch, 1e-3, ref32=ref32, first=(i == 0))
+
+
+def test_joint_step_b16_follows_oracle_along_same_decisions():
+    """The tight composition check of the whole backward pass.  B = 16 joint step at 224x224; the fp64 oracle
+    is evaluated along the ReLU masks and max-pool winners the HIP forward pass actually took (read back from
+    its activation buffers, tests/hip_decisions.py), which removes the only ill-conditioned part of the
+    comparison -- so every one of the 71 gradients (all 57 betas, the six Mixed_5c weight tensors, Logits,
+    LSTM, heads) must agree to relative L2 <= 1e-3 and 1e-3 of its largest entry, logits and loss to 1e-3,
+    TF-Adam and the moving statistics as in the other tests.  A dropped AddN term, a wrong segment stride or
+    a mis-routed pool gradient cannot hide below that."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from hip_decisions import hip_decisions
+    rng = np.random.RandomState(41)
+    V, D, H, T, B = 60, 20, 32, 12, 16
+    params = R.make_params("joint", rng, num_classes=15, im_features_size=256, embed_dim=D, rnn_size=H,
+                           fc_size=512, dtype=np.float64)
+    for k in params:
+        if k.endswith("beta"):
+            params[k] = rng.normal(0, 0.1, size=params[k].shape)
+    emb = S.synthetic_embedding(V, D).astype(np.float64)
+    batch = S.synthetic_batch(B, T, V, seed=14)
+    mask = (rng.uniform(size=(B, 1024)) < 0.8).astype(np.float64)
+    net = SentimentNet(mode="joint", nb_emotions=15, im_features_size=256, rnn_size=H, fc_size=512, vocab_size=V,
+                       embedding_dim=D, post_size=T)
+    net.load_state_dict(dict(params, **{"Text/W_embedding": emb}))
+    net.train_step(_dev_batch(batch), 1e-3, dropout_mask=torch.tensor(mask, dtype=torch.float32).cuda())
+    torch.cuda.synchronize()
+    ref = R.DeepSentimentRef(params, emb, "joint", torch.float64)
+    ref.inject = hip_decisions(net)
+    out = ref.train_step(batch, 1e-3, torch.tensor(mask))
+    plain = R.DeepSentimentRef(params, emb, "joint", torch.float64).train_step(batch, 1e-3, torch.tensor(mask))
+    # following the GPU's decisions moves the fp64 forward pass by rounding-size amounts only
+    assert float((out["logits"] - plain["logits"]).abs().max()) <= 1e-4
+    logits = net.logits.detach().cpu().numpy()
+    assert np.abs(logits - out["logits"].numpy()).max() <= 1e-3
+    assert abs(net.total_loss_value() - out["loss"]) <= 1e-3
+    grads = net.grads_state_dict()
+    assert len(out["grads"]) == 71
+    worst = (0.0, "")
+    for name, g_ref in out["grads"].items():
+        g_ref = g_ref.numpy()
+        d = grads[name].reshape(g_ref.shape) - g_ref
+        rel = np.linalg.norm(d) / max(np.linalg.norm(g_ref), 1e-30)
+        emax = np.abs(d).max() / max(np.abs(g_ref).max(), 1e-30)
+        worst = max(worst, (rel, name))
+        assert rel <= 1e-3 and emax <= 1e-3, "gradient of %s: relative L2 %.3e, max-norm %.3e" % (name, rel, emax)
+    print("worst gradient relative L2 along the same decisions: %.3e (%s)" % worst)
+    after = net.state_dict()
+    for name, v in after.items():
+        if name.endswith("moving_mean") or name.endswith("moving_variance"):
+            np.testing.assert_allclose(v, ref.p[name].numpy(), atol=1e-5, err_msg=name)
+    for name in ref.trainable:          # one TF-Adam step: sign-like on tiny gradients, tight on resolved ones
+        w_ref = ref.p[name].detach().numpy()
+        g_ref = out["grads"][name].numpy()
+        big = np.abs(g_ref) > 1e-2 * max(np.abs(g_ref).max(), 1e-12)
+        assert (np.abs(after[name].reshape(w_ref.shape) - w_ref)[big] <= 1e-5).mean() >= 0.99, name
 
 
 def test_frozen_beta_switch_stops_backward_at_mixed_5c():

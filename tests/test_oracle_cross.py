@@ -127,3 +127,46 @@ def test_joint_step_numpy_forward_matches_torch_fp64_small():
     assert len(ref.trainable) == 6 + 57 + 2 + 2 + 4
     n_tr = sum(int(np.prod(ref.p[n].shape)) for n in ref.trainable)
     assert n_tr == 1344512 + 7280 + (1024 * 8 + 8) + ((12 + 16) * 64 + 64) + (24 * 10 + 10 + 10 * 15 + 15)
+
+
+def test_decision_injection_reproduces_the_plain_backward():
+    """DeepSentimentRef.inject (ReLU masks / pool winners given instead of recomputed) is what lets the GPU
+    parity test compare gradients tightly; fed with the oracle's OWN decisions it must reproduce the plain
+    fp64 step exactly, also in the 'ReLU after the pool' form used for the two convs that only feed a pool."""
+    rng = np.random.RandomState(8)
+    params = R.make_params("image", rng, num_classes=15, dtype=np.float64)
+    for k in params:
+        if k.endswith("beta"):
+            params[k] = rng.normal(0, 0.1, size=params[k].shape)
+    batch = S.synthetic_batch(2, 8, 10, seed=2)
+    plain = R.DeepSentimentRef(params, None, "image", torch.float64)
+    plain.record = {}
+    out = plain.train_step(batch, 1e-3)
+    rec = plain.record
+    assert sum(k.startswith("relu/") for k in rec) == 57 and sum(k.startswith("pool/") for k in rec) == 4 + 9
+
+    inj = R.DeepSentimentRef(params, None, "image", torch.float64)
+    inj.inject = {k: v for k, v in rec.items() if not k.startswith("poolrelu/")}
+    out2 = inj.train_step(batch, 1e-3)
+    np.testing.assert_allclose(out2["logits"].numpy(), out["logits"].numpy(), atol=1e-12)
+    for n, g in out["grads"].items():
+        np.testing.assert_allclose(out2["grads"][n].numpy(), g.numpy(), atol=1e-12 * max(1.0, float(g.abs().max())), err_msg=n)
+
+    # conv -> BN -> (no ReLU) -> max pool -> ReLU: winners taken over the pre-ReLU values
+    stem, c2c = "norelu/InceptionV1/Conv2d_1a_7x7", "norelu/InceptionV1/Conv2d_2c_3x3"
+    probe = R.DeepSentimentRef(params, None, "image", torch.float64)
+    probe.inject, probe.record = {stem: True}, {}
+    probe.forward(batch)          # only the first pool's record is meaningful (everything behind it lacks a ReLU)
+    first = {stem: True, "pool/MaxPool_2a_3x3": probe.record["pool/MaxPool_2a_3x3"],
+             "poolrelu/MaxPool_2a_3x3": rec["poolrelu/MaxPool_2a_3x3"]}
+    probe = R.DeepSentimentRef(params, None, "image", torch.float64)
+    probe.inject, probe.record = dict(first, **{c2c: True}), {}
+    probe.forward(batch)          # the stem is right now, so the second pool's pre-ReLU winners are too
+    inj2 = R.DeepSentimentRef(params, None, "image", torch.float64)
+    inj2.inject = dict(inj.inject, **first)
+    inj2.inject.update({c2c: True, "pool/MaxPool_3a_3x3": probe.record["pool/MaxPool_3a_3x3"],
+                        "poolrelu/MaxPool_3a_3x3": rec["poolrelu/MaxPool_3a_3x3"]})
+    out3 = inj2.train_step(batch, 1e-3)
+    np.testing.assert_allclose(out3["logits"].numpy(), out["logits"].numpy(), atol=1e-12)
+    for n, g in out["grads"].items():
+        np.testing.assert_allclose(out3["grads"][n].numpy(), g.numpy(), atol=1e-12 * max(1.0, float(g.abs().max())), err_msg=n)

@@ -125,3 +125,95 @@ def test_numpy_vs_torch_inception_forward_fp64():
     np.testing.assert_allclose(logits_np, logits_t, rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(ep["Mixed_5c"], ref.last_mixed_5c.detach().permute(0, 2, 3, 1).numpy(),
                                rtol=1e-8, atol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------------------
+# [TF-sem] BasicLSTMCell known answer.  NOT under /root/reference (TensorFlow is a third-party dependency
+# of the reference and is not vendored): recalled from TensorFlow 1.x's own unit test
+# tensorflow/python/kernel_tests/rnn_cell_test.py::testBasicLSTMCell -- a 2-layer stack of
+# BasicLSTMCell(2), every kernel entry 0.5, zero bias, x = [1, 1], every state 0.1; that test asserts the
+# state vector [c1, c1, h1, h1, c2, c2, h2, h2] below with assertAllClose (rtol 1e-6; TF computed in fp32).
+# It pins gate order i,j,f,o, forget_bias = 1.0 added before the sigmoid, tanh, and
+# h' = tanh(c') * sigmoid(o) for the restatements of im_text_rnn_model.py:89.
+# ------------------------------------------------------------------------------------------------------
+TF_BASIC_LSTM_EXPECTED = [0.68967271, 0.68967271, 0.44848421, 0.44848421,
+                          0.39897051, 0.39897051, 0.24024698, 0.24024698]
+
+
+def test_basic_lstm_cell_tf_known_answer_numpy():
+    k = np.full((4, 8), 0.5)
+    b = np.zeros(8)
+    st = (np.full((1, 2), 0.1), np.full((1, 2), 0.1))
+    seq = np.array([1])
+    _, h1, cache1 = S.lstm_forward(np.array([[[1.0, 1.0]]]), seq, k, b, keep_cache=True, initial_state=st)
+    c1 = cache1[0]["c_prev"] * cache1[0]["sf"] + cache1[0]["si"] * cache1[0]["tj"]
+    _, h2, cache2 = S.lstm_forward(h1[:, None, :], seq, k, b, keep_cache=True, initial_state=st)
+    c2 = cache2[0]["c_prev"] * cache2[0]["sf"] + cache2[0]["si"] * cache2[0]["tj"]
+    np.testing.assert_allclose(np.concatenate([c1, h1, c2, h2], axis=1)[0], TF_BASIC_LSTM_EXPECTED, rtol=1e-6)
+    np.testing.assert_allclose(np.arctanh(h1 / cache1[0]["so"]), c1, rtol=1e-12)      # h' = tanh(c') * sigmoid(o)
+
+
+def test_basic_lstm_cell_tf_known_answer_torch_ref():
+    k = np.full((4, 8), 0.5)
+    ref = R.DeepSentimentRef({"Text/rnn/basic_lstm_cell/kernel": k, "Text/rnn/basic_lstm_cell/bias": np.zeros(8),
+                              "W_softmax": np.zeros((2, 2)), "b_softmax": np.zeros(2)},
+                             embedding=np.array([[1.0, 1.0]]), mode="text", dtype=torch.float64)
+    st = (np.full((1, 2), 0.1), np.full((1, 2), 0.1))
+    ids, seq = torch.zeros(1, 1, dtype=torch.int64), torch.tensor([1])
+    h1 = ref.text_tower(ids, seq, initial_state=st).detach()
+    ref.embedding = h1.clone()                        # layer 2 reads layer 1's output
+    h2 = ref.text_tower(ids, seq, initial_state=st).detach()
+    np.testing.assert_allclose(torch.cat([h1, h2], dim=1)[0].numpy(),
+                               [TF_BASIC_LSTM_EXPECTED[i] for i in (2, 3, 6, 7)], rtol=1e-6)
+
+
+def test_third_lstm_restatement_torch_nn_lstm_agrees():
+    """An independently authored LSTM -- torch.nn.LSTM (ATen's fused cell, gate order i,f,g,o, separate
+    W_ih / W_hh and two biases) with pack_padded_sequence for dynamic_rnn's length masking -- against both
+    restatements: forward (h at the last valid step) and the gradients of kernel and bias."""
+    rng = np.random.RandomState(17)
+    b, t, d, hsz = 6, 9, 5, 7
+    x = rng.normal(size=(b, t, d))
+    seq = np.array([9, 1, 4, 6, 2, 9])
+    kernel = rng.normal(0, 0.4, size=(d + hsz, 4 * hsz))
+    bias = rng.normal(0, 0.2, size=4 * hsz)
+    dh = rng.normal(size=(b, hsz))
+
+    # TF kernel columns are [i | j | f | o]; torch rows are [i | f | g(=j) | o]; forget_bias joins the f bias
+    def remap(a):            # [..., 4H] in TF order -> torch order
+        i, j, f, o = np.split(a, 4, axis=-1)
+        return np.concatenate([i, f, j, o], axis=-1)
+    lstm = torch.nn.LSTM(d, hsz, batch_first=True).double()
+    fb = np.concatenate([np.zeros(hsz), np.full(hsz, S.FORGET_BIAS), np.zeros(2 * hsz)])
+    with torch.no_grad():
+        lstm.weight_ih_l0.copy_(torch.tensor(remap(kernel[:d]).T))
+        lstm.weight_hh_l0.copy_(torch.tensor(remap(kernel[d:]).T))
+        lstm.bias_ih_l0.copy_(torch.tensor(remap(bias) + fb))
+        lstm.bias_hh_l0.zero_()
+    packed = torch.nn.utils.rnn.pack_padded_sequence(torch.tensor(x), torch.tensor(seq), batch_first=True,
+                                                     enforce_sorted=False)
+    out, (h_n, _) = lstm(packed)
+    h_last_nn = h_n[0]
+    h_last_nn.backward(torch.tensor(dh))
+    padded, _ = torch.nn.utils.rnn.pad_packed_sequence(out, batch_first=True, total_length=t)
+
+    outs, h_last, cache = S.lstm_forward(x, seq, kernel, bias, keep_cache=True)
+    np.testing.assert_allclose(h_last_nn.detach().numpy(), h_last, atol=1e-13)
+    np.testing.assert_allclose(padded.detach().numpy(), outs, atol=1e-13)          # zero rows past seq_len (A8)
+    dk, db = S.lstm_backward(dh, seq, kernel, cache)
+
+    def unmap(a):            # torch order -> TF order
+        i, f, g, o = np.split(a, 4, axis=-1)
+        return np.concatenate([i, g, f, o], axis=-1)
+    dk_nn = np.concatenate([unmap(lstm.weight_ih_l0.grad.numpy().T), unmap(lstm.weight_hh_l0.grad.numpy().T)], axis=0)
+    np.testing.assert_allclose(dk_nn, dk, atol=1e-12)
+    np.testing.assert_allclose(unmap(lstm.bias_ih_l0.grad.numpy()), db, atol=1e-12)
+
+    ref = R.DeepSentimentRef({"Text/rnn/basic_lstm_cell/kernel": kernel, "Text/rnn/basic_lstm_cell/bias": bias,
+                              "W_softmax": np.zeros((hsz, 2)), "b_softmax": np.zeros(2)},
+                             embedding=np.zeros((1, d)), mode="text", dtype=torch.float64)
+    ref.embedding = torch.tensor(x.reshape(b * t, d))
+    ht = ref.text_tower(torch.arange(b * t).reshape(b, t), torch.tensor(seq))
+    ht.backward(torch.tensor(dh))
+    np.testing.assert_allclose(ht.detach().numpy(), h_last_nn.detach().numpy(), atol=1e-13)
+    np.testing.assert_allclose(ref.p["Text/rnn/basic_lstm_cell/kernel"].grad.numpy(), dk_nn, atol=1e-12)
