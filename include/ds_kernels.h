@@ -81,9 +81,13 @@ int ds_conv_set_tile(int mt, int nt);
 int ds_conv_set_path(int path);
 /* Number of row-tile blocks (P) the launch for `d` will use = number of stats partials.   */
 int ds_conv_igemm_partials(const ds_conv_desc *d);
-/* stats (DS_EPI_STATS): float[2][Cout][P] partial column sums / sums of squares.          */
+/* stats (DS_EPI_STATS): float[2][Cout][P] partial column sums of (z - pivot) and (z - pivot)^2.
+ * pivot (nullable = 0): float[Cout], any value near the column mean -- the build passes the previous step's
+ * batch mean (the moving mean after a restore) -- so that the fp32 partial sums carry the spread of z rather
+ * than its offset and the variance E[u^2] - E[u]^2 does not cancel for channels with |mean| >> std
+ * (tf.nn.moments, which slim.batch_norm uses, takes the mean of squared differences).        */
 int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float *w, float *z, const float *bias,
-                  const float *mask, float *stats, void *stream);
+                  const float *mask, float *stats, const float *pivot, void *stream);
 
 /* Conv2DBackpropFilter / MatMul-transposed (wgrad), split over pixels.
  *   dw[tap, ci, co] = sum_m x[pixel(m)+tap, ci] * dz[m, co]
@@ -94,9 +98,10 @@ int ds_conv_wgrad(const ds_conv_desc *d, const float *x, const float *dz, int32_
                   void *ws, size_t ws_bytes, void *stream);
 
 /* slim.batch_norm train mode (center, no scale), slim/nets/inception_utils.py:48-70.
- * finalize: partials -> mean, rstd, scale=rstd, shift=beta-mean*rstd, moving stats update. */
-int ds_bn_finalize(const float *stats, int32_t P, int64_t count, int32_t C, const float *beta, float eps,
-                   float decay, float *mean, float *rstd, float *shift, float *moving_mean,
+ * finalize: partials (about `pivot`, the vector given to ds_conv_igemm; nullable; may alias `mean`) ->
+ * mean, rstd, shift = beta - mean*rstd, moving statistics update.                           */
+int ds_bn_finalize(const float *stats, int32_t P, int64_t count, int32_t C, const float *beta, const float *pivot,
+                   float eps, float decay, float *mean, float *rstd, float *shift, float *moving_mean,
                    float *moving_var, void *stream);
 
 /* y = relu(z*rstd + shift) scattered to up to 4 channel segments (branch outputs written

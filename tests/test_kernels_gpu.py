@@ -210,6 +210,69 @@ def test_batch_norm_forward_backward_with_segments():
     close(zd, dz_ref, 3e-4)
 
 
+@pytest.mark.parametrize("geometry", [(8, 28, 28, 192, 96, 1), (2, 56, 56, 64, 192, 3), (2, 370, 370, 16, 64, 3)])
+def test_batch_norm_statistics_of_channels_with_mean_50_sigma(geometry):
+    """tf.nn.moments (slim.batch_norm, slim/nets/inception_utils.py:48-70) averages squared differences, so it
+    is exact for |mean| >> std; a one-pass E[z^2] - E[z]^2 over fp32 partial sums is not.  Conv outputs with
+    |mean| = 50 std per channel (a constant input plane behind large weights, as a warm-started checkpoint can
+    produce): mean / variance / rstd from the conv epilogue + ds_bn_finalize against the fp64 oracle, with the
+    pivot the engine would pass (the previous step's batch mean: here the true mean off by 0.5 std), and the
+    normalised activations and BN backward on top of those statistics.  The last geometry runs the persistent
+    launch path (one workgroup sums several row tiles)."""
+    ops = _ops()
+    N, H, W, Ci, Co, k = geometry
+    rng = np.random.RandomState(12)
+    x = rng.normal(size=(N, H, W, Ci))
+    x[..., 0] = 1.0                                           # constant plane: carries the channel offsets
+    w = rng.normal(size=(k, k, Ci, Co)) * 0.1
+    w[:, :, 0, :] = 0.0
+    z0 = S.conv2d_same(x, w, 1)
+    sig = z0.reshape(-1, Co).std(axis=0)
+    w[k // 2, k // 2, 0, :] = 50.0 * sig * rng.choice([-1.0, 1.0], size=Co)       # |mean| = 50 sigma
+    x32, w32 = x.astype(np.float32).astype(np.float64), w.astype(np.float32).astype(np.float64)
+    z = S.conv2d_same(x32, w32, 1)
+    M = N * H * W
+    beta = rng.normal(size=Co) * 0.3
+    y_ref, mean, var, xhat, rstd = S.batch_norm_train(z.reshape(M, Co), beta)
+    assert np.abs(mean / np.sqrt(var)).min() > 30
+    xd, wd, bd = dev(x), dev(w), dev(beta)
+    plan = ops.ConvPlan(N, H, W, Ci, Ci, k, k, 1, Co, Co, Ci * Co, 1, Co, flags=ops.DS_EPI_STATS)
+    zd = torch.empty(M, Co, device="cuda")
+    stats = torch.zeros(2, Co, plan.partials, device="cuda")
+    res = {}
+    for label, pivot in (("pivot", dev(mean + 0.5 * np.sqrt(var))), ("no pivot", None)):
+        mean_d, rstd_d, shift_d = (torch.empty(Co, device="cuda") for _ in range(3))
+        mv = torch.zeros(Co, device="cuda")
+        plan.run(ops._p(xd), ops._p(wd), ops._p(zd), stats=ops._p(stats), pivot=ops._p(pivot))
+        ops.bn_finalize(stats, plan.partials, M, Co, bd, S.BN_EPS, 0.0, mean_d, rstd_d, shift_d, None, mv, pivot=pivot)
+        torch.cuda.synchronize()
+        res[label] = (np.abs(rstd_d.cpu().numpy() / rstd - 1).max(), np.abs(mv.cpu().numpy() / var - 1).max())
+        if label == "pivot":
+            keep = (mean_d.clone(), rstd_d.clone(), shift_d.clone())
+            close(mean_d, mean, 1e-6)
+            assert res[label][0] <= 2e-4 and res[label][1] <= 2e-4, res
+    print("rstd / variance relative error, |mean| = 50 sigma:", res)
+    mean_d, rstd_d, shift_d = keep
+    out = torch.empty(M, Co, device="cuda")
+    ops.bn_apply_relu(zd, M, Co, rstd_d, shift_d, ops.make_segments([(0, Co, out.data_ptr(), Co)]))
+    close(out, S.relu(y_ref), 2e-4)
+    dy = rng.normal(size=(M, Co))
+    dz_ref, dbeta_ref = S.batch_norm_train_bwd(dy * (y_ref > 0), xhat, rstd)
+    dyd = dev(dy)
+    dsegs = ops.make_segments([(0, Co, dyd.data_ptr(), Co)])
+    P = ops.bn_bwd_partials(M, Co)
+    part = torch.empty(2, Co, P, device="cuda")
+    dbeta, coef = torch.empty(Co, device="cuda"), torch.empty(2, Co, device="cuda")
+    ops.bn_bwd_reduce(zd, dsegs, M, Co, mean_d, rstd_d, shift_d, part)
+    ops.bn_bwd_finalize(part, P, M, Co, dbeta, coef)
+    ops.bn_bwd_apply(zd, dsegs, M, Co, mean_d, rstd_d, shift_d, coef, zd)
+    torch.cuda.synchronize()
+    # a pre-activation within fp32 rounding of 0 may take the other ReLU branch: compare where |y| is resolved
+    resolved = np.abs(y_ref) > 1e-3
+    err = np.abs(zd.cpu().numpy() - dz_ref) * resolved
+    assert err.max() <= 5e-4 * np.abs(dz_ref).max(), err.max()
+
+
 @pytest.mark.parametrize("case", [(3, 2, 9, "SAME"), (3, 1, 7, "SAME"), (2, 2, 14, "VALID"), (3, 2, 112, "SAME")])
 def test_max_pool_forward_backward(case):
     ops = _ops()

@@ -46,8 +46,9 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 
 // ---- forward ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *stats, int P, double inv_count, int C,
-                                                          const float *beta, float eps, float decay, float *mean,
-                                                          float *rstd, float *shift, float *mm, float *mv) {
+                                                          const float *beta, const float *pivot, float eps,
+                                                          float decay, float *mean, float *rstd, float *shift,
+                                                          float *mm, float *mv) {
     // one workgroup per channel; partials are laid out [2][C][P] so the threads read contiguous floats
     // (P is a few hundred for the persistent conv launches, one per row tile -- up to 2048 -- otherwise);
     // combined in double in a fixed order: strided per thread, butterfly per wave, waves 0..3 (deterministic)
@@ -69,8 +70,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *stats, in
     if (threadIdx.x == 0) {
         s = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
         q = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
-        const double mu = s * inv_count;
-        double var = q * inv_count - mu * mu;          // biased variance (A3)
+        // the partials are sums of (z - pivot) and (z - pivot)^2: with the pivot near the mean the fp32 partial sums
+        // carry the spread of z, not its offset, so E[u^2] - E[u]^2 does not cancel (|mean| >> std channels)
+        const double du = s * inv_count;
+        const double mu = du + (pivot ? (double)pivot[c] : 0.0);      // pivot may alias mean: read before the write below
+        double var = q * inv_count - du * du;          // biased variance (A3)
         if (var < 0.0) var = 0.0;
         const float r = (float)(1.0 / sqrt(var + (double)eps));
         mean[c] = (float)mu;
@@ -261,12 +265,12 @@ int check_segments(const ds_segments *s, int C, const char *who) {
 
 }  // namespace
 
-extern "C" int ds_bn_finalize(const float *stats, int32_t P, int64_t count, int32_t C, const float *beta, float eps,
-                              float decay, float *mean, float *rstd, float *shift, float *moving_mean,
-                              float *moving_var, void *stream) {
+extern "C" int ds_bn_finalize(const float *stats, int32_t P, int64_t count, int32_t C, const float *beta,
+                              const float *pivot, float eps, float decay, float *mean, float *rstd, float *shift,
+                              float *moving_mean, float *moving_var, void *stream) {
     DS_REQUIRE(stats && beta && mean && rstd && shift && P > 0 && count > 0 && C > 0, "ds_bn_finalize: bad argument");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, P,
-                       1.0 / (double)count, C, beta, eps, decay, mean, rstd, shift, moving_mean, moving_var);
+                       1.0 / (double)count, C, beta, pivot, eps, decay, mean, rstd, shift, moving_mean, moving_var);
     return ds::check_launch("ds_bn_finalize");
 }
 

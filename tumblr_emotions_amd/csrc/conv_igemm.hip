@@ -42,6 +42,7 @@ struct ConvParams {
     const float *bias;
     const float *mask;
     float *stats;
+    const float *pivot;   // per-column shift of the statistics (nullable)
     int M;          // N*OH*OW
     int taps;       // KH*KW
     int row_tiles;  // ceil(M/BM)
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
             const int col = n0 + b * 32 + li;
             const bool colok = col < d.Cout;
             const float bv = ((flags & DS_EPI_BIAS) && colok) ? p.bias[col] : 0.f;
+            const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;      // statistics are taken about the pivot
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
@@ -304,8 +306,9 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
                         if (flags & DS_EPI_MASK) v = p.mask[(int64_t)row * d.ldmask + col] > 0.f ? v : 0.f;
                         if (flags & DS_EPI_RELU) v = fmaxf(v, 0.f);
                         zout[off] = v;
-                        s += v;
-                        q += v * v;
+                        const float u = v - pv;
+                        s += u;
+                        q += u * u;
                     }
                 }
             }
@@ -514,6 +517,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
             const int col = n0 + b * 32 + li;
             const bool colok = col < d.Cout;
             const float bv = ((flags & DS_EPI_BIAS) && colok) ? p.bias[col] : 0.f;
+            const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;      // statistics are taken about the pivot
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
@@ -527,8 +531,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
                         if (flags & DS_EPI_MASK) v = p.mask[(int64_t)row * d.ldmask + col] > 0.f ? v : 0.f;
                         if (flags & DS_EPI_RELU) v = fmaxf(v, 0.f);
                         zout[off] = v;
-                        s += v;
-                        q += v * v;
+                        const float u = v - pv;
+                        s += u;
+                        q += u * u;
                     }
                 }
             }
@@ -767,6 +772,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? 3 : 2)) void conv_gld
             const int col = n0 + b * 32 + li;
             const bool colok = col < d.Cout;
             const float bv = ((flags & DS_EPI_BIAS) && colok) ? p.bias[col] : 0.f;
+            const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;      // statistics are taken about the pivot
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -778,8 +784,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? 3 : 2)) void conv_gld
                     if (flags & DS_EPI_MASK) v = p.mask[(int64_t)row * d.ldmask + col] > 0.f ? v : 0.f;
                     if (flags & DS_EPI_RELU) v = fmaxf(v, 0.f);
                     zout[off] = v;
-                    s += v;
-                    q += v * v;
+                    const float u = v - pv;
+                    s += u;
+                    q += u * u;
                 }
             }
             csum[b] += s;
@@ -1021,7 +1028,7 @@ extern "C" int ds_conv_igemm_partials(const ds_conv_desc *d) {
 }
 
 extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float *w, float *z, const float *bias,
-                             const float *mask, float *stats, void *stream) {
+                             const float *mask, float *stats, const float *pivot, void *stream) {
     DS_REQUIRE(d && x && w && z, "ds_conv_igemm: null argument");
     DS_REQUIRE(d->Cin > 0 && d->Cout > 0 && d->N > 0 && d->OH > 0 && d->OW > 0, "ds_conv_igemm: bad dims");
     DS_REQUIRE(d->w_n_stride == 1 || d->w_k_stride == 1, "ds_conv_igemm: one weight stride must be 1");
@@ -1036,6 +1043,7 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     ConvParams p;
     p.d = *d;
     p.x = x; p.w = w; p.z = z; p.bias = bias; p.mask = mask; p.stats = stats;
+    p.pivot = (d->flags & DS_EPI_STATS) ? pivot : nullptr;
     p.M = (int)conv_M(d);
     p.taps = d->KH * d->KW;
     static int prio_mode = -1;

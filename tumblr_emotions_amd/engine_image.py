@@ -110,6 +110,7 @@ class ConvBN:
         self.beta = st.view(self.key + "/BatchNorm/beta")
         self.mm = st.view(self.key + "/BatchNorm/moving_mean")
         self.mv = st.view(self.key + "/BatchNorm/moving_variance")
+        self.mean.copy_(self.mm)          # first pivot of the batch statistics (ConvBN.forward)
         self.gw_ptr = _vp(st.grad_ptr(self.key + "/weights")) if self.trainable else None
         self.gbeta = st.grad_view(self.key + "/BatchNorm/beta") if self.eng.trainable_bn_beta else None
 
@@ -126,11 +127,13 @@ class ConvBN:
         if not self.fold:
             self.fwd.d.ldx = ldx
         if eng.training:       # batch statistics (slim.batch_norm is_training=True)
+            # the column sums are taken about a pivot near the mean -- the previous step's batch mean, the
+            # moving mean before the first step (bind) -- so channels with |mean| >> std keep their variance
             self.fwd.d.flags = DS_EPI_STATS
-            self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z), stats=ops._p(eng.stats))
+            self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z), stats=ops._p(eng.stats), pivot=ops._p(self.mean))
             ops.bn_finalize(eng.stats, self.fwd.partials, self.M, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
                             self.rstd, self.shift, self.mm if eng.update_moving else None,
-                            self.mv if eng.update_moving else None)
+                            self.mv if eng.update_moving else None, pivot=self.mean)
         else:                  # moving statistics (is_training=False: evaluate_* on the validation split)
             self.fwd.d.flags = 0
             self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z))

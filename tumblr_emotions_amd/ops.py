@@ -76,11 +76,12 @@ class ConvPlan:
         k_alg = KH * KW * Cin if not fold_cin else KH * (Cin // fold_cin) * 3
         self.alg_flops = 2.0 * self.M * Cout * k_alg
 
-    def run(self, x, w, z, bias=None, mask=None, stats=None):
+    def run(self, x, w, z, bias=None, mask=None, stats=None, pivot=None):
         t = CONV_TIMER
         if t is not None:
             t.begin()
-        _lib.check(_lib.load().ds_conv_igemm(C.byref(self.d), x, w, z, bias, mask, stats, _stream()), "ds_conv_igemm")
+        _lib.check(_lib.load().ds_conv_igemm(C.byref(self.d), x, w, z, bias, mask, stats, pivot, _stream()),
+                   "ds_conv_igemm")
         if t is not None:
             t.end(self)
 
@@ -144,9 +145,9 @@ class WgradPlan:
                    "ds_conv_wgrad")
 
 
-def bn_finalize(stats, P, count, C_, beta, eps, decay, mean, rstd, shift, mm, mv):
-    _lib.check(_lib.load().ds_bn_finalize(_p(stats), P, count, C_, _p(beta), eps, decay, _p(mean), _p(rstd),
-                                          _p(shift), _p(mm), _p(mv), _stream()), "ds_bn_finalize")
+def bn_finalize(stats, P, count, C_, beta, eps, decay, mean, rstd, shift, mm, mv, pivot=None):
+    _lib.check(_lib.load().ds_bn_finalize(_p(stats), P, count, C_, _p(beta), _p(pivot), eps, decay, _p(mean),
+                                          _p(rstd), _p(shift), _p(mm), _p(mv), _stream()), "ds_bn_finalize")
 
 
 def bn_apply_relu(z, M, C_, rstd, shift, segs):
