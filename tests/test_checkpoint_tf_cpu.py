@@ -103,11 +103,24 @@ def test_get_init_fn_prefers_the_tf_checkpoint(tmp_path):
     fn = get_init_fn(str(tmp_path))
     assert fn is not None and get_init_fn(str(tmp_path / "missing")) is None
 
+    wanted = [k for k in t if k.startswith("InceptionV1/") and "Logits" not in k]
+
+    class FakeStore:
+        def tf_names(self):
+            return wanted + ["InceptionV1/Logits/Conv2d_0c_1x1/weights", "W_fc"]
+
     class FakeNet:
+        store = FakeStore()
+
         def load_state_dict(self, sd, strict=True):
             self.sd, self.strict = sd, strict
+            return set(sd)
     net = FakeNet()
     fn(net)
     assert net.strict is False
+    # a checkpoint that lacks one of the model's InceptionV1 variables must not warm-start silently
+    FakeStore.tf_names = lambda self: wanted + ["InceptionV1/Mixed_9z/weights"]
+    with pytest.raises(KeyError):
+        fn(FakeNet())
     assert sorted(net.sd) == sorted(k for k in t if k.startswith("InceptionV1/") and "Logits" not in k)
     np.testing.assert_array_equal(net.sd["InceptionV1/Conv2d_1a_7x7/weights"], t["InceptionV1/Conv2d_1a_7x7/weights"])

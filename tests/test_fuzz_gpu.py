@@ -80,7 +80,8 @@ def test_fuzz_harness_reports_a_planted_mismatch():
     dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
     plan = ops.ConvPlan(N, H, W, Ci, Ci, k, k, 1, Co, Co, Ci * Co, 1, Co)
     z = torch.empty(plan.M, Co, device="cuda")
-    plan.run(ops._p(dev(x)), ops._p(dev(w)), ops._p(z))
+    xd, wd = dev(x), dev(w)                      # keep the operands alive until the launch has run
+    plan.run(ops._p(xd), ops._p(wd), ops._p(z))
     torch.cuda.synchronize()
     got = z.cpu().numpy().astype(np.float64)
     good = S.conv2d_same(x, w, 1).reshape(-1, Co)

@@ -156,8 +156,12 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float *logits, co
         for (int c = 0; c < C; ++c) m = fmaxf(m, z[c]);
         float s = 0.f;
         for (int c = 0; c < C; ++c) s += expf(z[c] - m);
-        const int y = (int)labels[b];
-        acc += (m + logf(s)) - z[y];
+        // a label outside [0, C) (dataset converted for another class list) must not index out of bounds:
+        // it poisons the loss with NaN so the run stops visibly; one_hot() of such a label is all zeros in TF
+        const int64_t yl = labels[b];
+        const bool yok = yl >= 0 && yl < C;
+        const int y = yok ? (int)yl : -1;
+        acc += yok ? (m + logf(s)) - z[y] : NAN;
         if (dlogits) {
             const float k = grad_scale / (float)B, inv = 1.f / s;
             for (int c = 0; c < C; ++c)

@@ -27,14 +27,19 @@ class Dataset:
         self.data_sources, self.num_samples = data_sources, num_samples
         self.num_classes, self.labels_to_names = num_classes, labels_to_names
 
-    def examples(self, verify_crc=False):
+    def examples(self, verify_crc=False, decode_image=None):
         """Yields dicts: image (uint8 HxWx3), text (int64[50]), seq_len, label, post_id, day
-        (the items_to_handlers of convert_to_dataset.py:163-170)."""
+        (the items_to_handlers of convert_to_dataset.py:163-170).  decode_image(index) -> bool lets a
+        data-parallel reader skip the JPEG decode of records that belong to other ranks (image = None)."""
         from PIL import Image
+        idx = -1
         for path in self.data_sources:
             for rec in read_records(path, verify=verify_crc):
+                idx += 1
                 ex = decode_example(rec)
-                img = np.asarray(Image.open(io.BytesIO(ex['image/encoded'][0])).convert('RGB'))
+                img = None
+                if decode_image is None or decode_image(idx):
+                    img = np.asarray(Image.open(io.BytesIO(ex['image/encoded'][0])).convert('RGB'))
                 text = np.zeros(_POST_SIZE, np.int64)
                 t = ex.get('text', [])
                 text[:len(t)] = t

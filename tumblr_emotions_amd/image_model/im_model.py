@@ -39,7 +39,13 @@ def get_init_fn(checkpoints_dir, model_name=None):
         else:
             from ..checkpoint_tf import read_tf_v1_checkpoint
             sd = read_tf_v1_checkpoint(path, names=lambda n: n.startswith("InceptionV1/") and not n.startswith(exclusions))
-        net.load_state_dict(sd, strict=False)
+        wanted = [e for e in net.store.tf_names() if e.startswith("InceptionV1/") and not e.startswith(exclusions)]
+        seen = set(net.load_state_dict(sd, strict=False))
+        missing = [n for n in wanted if n not in seen]
+        if missing:      # a silent random-init "fine-tune" is worse than stopping (im_model.py:118-137 restores them all)
+            raise KeyError("warm start from %s: %d of %d InceptionV1 variables not found, e.g. %s"
+                           % (path, len(missing), len(wanted), missing[:3]))
+        print("Restored %d variables from %s" % (len(seen), path))
     return init_fn
 
 
@@ -77,13 +83,16 @@ def evaluate_image_model(checkpoint_dir, log_dir, mode, num_evals, *, config=Non
 
 
 def load_batch_with_text(dataset, batch_size=32, shuffle=True, height=299, width=299, is_training=False,
-                         device="cuda", rank=0, world=1, seed=0, loop=True):
+                         device="cuda", rank=0, world=1, seed=0, loop=True, max_token_id=None, num_classes=None):
     """Generator of training batches from a `datasets.convert_to_dataset.Dataset` -- the role of
     load_batch_with_text + tf.train.batch in the reference (im_model.py:78-116): decode the JPEG, apply the
     EVAL preprocessing (is_training=False is what every reference call site uses, :78,102), batch.
     Yields dicts of device tensors: images [B,height,width,3] f32 in [-1,1], texts [B,50] i64, seq_lens,
     labels, post_ids, days.  Under data parallelism every rank reads the same stream and keeps examples
-    rank, rank+world, ... (disjoint shards of one global order)."""
+    rank, rank+world, ... (disjoint shards of one global order; the others are skipped BEFORE the JPEG is
+    decoded).  max_token_id / num_classes: a record whose token ids exceed the embedding table (ids index the
+    vocabulary the dataset was converted with; id == vocabulary size is '<ukn>') or whose label is out of
+    range raises -- the gather would otherwise read zero rows / the loss kernel out of bounds."""
     import torch
     from ..preprocessing.inception_preprocessing import preprocess_image
     rng = np.random.RandomState(seed)
@@ -94,10 +103,15 @@ def load_batch_with_text(dataset, batch_size=32, shuffle=True, height=299, width
             rng.shuffle(sources)
         view = type(dataset)(sources, dataset.num_samples, dataset.num_classes, dataset.labels_to_names)
         n = 0
-        for i, ex in enumerate(view.examples()):
+        for i, ex in enumerate(view.examples(decode_image=lambda idx: idx % world == rank)):
             if i % world != rank:
                 continue
             n += 1
+            if max_token_id is not None and int(np.max(ex["text"])) > max_token_id:
+                raise ValueError("token id %d in the dataset exceeds the embedding table (%d rows + <ukn>): the "
+                                 "dataset was converted with a different vocabulary" % (int(np.max(ex["text"])), max_token_id))
+            if num_classes is not None and not 0 <= int(ex["label"]) < num_classes:
+                raise ValueError("label %d outside [0, %d)" % (int(ex["label"]), num_classes))
             buf["images"].append(preprocess_image(ex["image"], height, width, is_training=is_training))
             buf["texts"].append(ex["text"])
             for k, s in (("seq_lens", "seq_len"), ("labels", "label"), ("post_ids", "post_id"), ("days", "day")):

@@ -52,17 +52,19 @@ def inception_v1_base(inputs, final_endpoint="Mixed_5c", scope="InceptionV1", ne
 def inception_v1(inputs, final_endpoint="Mixed_5c", num_classes=1000, is_training=True, dropout_keep_prob=0.8,
                  prediction_fn=None, spatial_squeeze=True, reuse=None, scope="InceptionV1", net=None,
                  dropout_mask=None):
-    """Returns (logits [B,num_classes], end_points).  Train-mode BatchNorm/dropout only (the
-    reference's training path); `is_training=False` (moving statistics) is served by evaluate_*."""
+    """Returns (logits [B,num_classes], end_points).  is_training=True: batch statistics + dropout (and, as in
+    slim, the moving averages are updated by the training step, not by this call when no step follows);
+    is_training=False: BatchNorm on the moving statistics, dropout off (image_model/inception_v1.py:295-296)."""
     if final_endpoint != "Mixed_5c":
         raise NotImplementedError("the Logits head sits on Mixed_5c (7x7 map); use inception_v1_base for earlier endpoints")
     if not spatial_squeeze:
         raise NotImplementedError("spatial_squeeze=False")
     net = net or get_net(scope, num_classes, dropout_keep_prob, reuse)
-    if not is_training:
-        raise NotImplementedError("inference-mode BatchNorm is not on the training path (SURVEY 8f-3)")
     net.image.fuse_bn_pool = False       # callers get every end point materialised
-    logits = net.forward({"images": inputs}, dropout_mask)
+    if is_training:
+        logits = net.forward({"images": inputs}, dropout_mask)
+    else:
+        logits = net.predict({"images": inputs}, is_training=False)
     end_points = {st.name: st.out for st in net.image.stages}
     end_points["Logits"] = logits
     return logits, end_points

@@ -6,6 +6,7 @@ import torch
 from .. import ops
 from ..image_model.im_model import get_init_fn
 from ..net import SentimentNet
+from ..text_model.text_preprocessing import resolve_embedding
 from ..training import SyntheticInput, run_training
 
 _POST_SIZE = 50
@@ -29,13 +30,9 @@ class DeepSentiment(SyntheticInput):
         if config.get('final_endpoint', 'Mixed_5c') != 'Mixed_5c':
             raise NotImplementedError("final_endpoint must be Mixed_5c")
         self.learning_rate = config['initial_lr']
-        vocab = config.get('vocab_size', 10000)
-        dim = config.get('embedding_dim', 50)
         post = config.get('post_size', _POST_SIZE)
-        if embedding is not None:               # GloVe [V, D] + zero <ukn> row (:75-76)
-            embedding = np.concatenate([np.asarray(embedding, np.float32),
-                                        np.zeros((1, embedding.shape[1]), np.float32)])
-            vocab, dim = embedding.shape[0] - 1, embedding.shape[1]
+        # GloVe file -> [V, D] + zero <ukn> row; V and D come from the file (:71-76)
+        embedding, vocab, dim, self.word_to_id = resolve_embedding(config, embedding)
         self._init_input(config, post, vocab, nb_emotions, True, device)
         self.nb_emotions = self.dataset.num_classes
         for key in ("train_all", "trainable_embedding"):      # optional fine-tuning switches (not in the reference _CONFIG)
@@ -166,10 +163,9 @@ def word_most_relevant(top_words, num_classes, checkpoint_dir, *, config=None, o
     assert model.dataset.num_classes == num_classes or num_classes is None
     cfg = model.config
     if vocabulary is None:
-        try:
-            from ..text_model.text_preprocessing import _load_embedding_weights_glove
-            vocabulary, _ = _load_embedding_weights_glove(cfg['text_dir'], cfg['emb_dir'], cfg['filename'])
-        except (IOError, OSError):
+        if model.word_to_id is not None:      # the GloVe vocabulary the constructor loaded
+            vocabulary = [w for w, _ in sorted(model.word_to_id.items(), key=lambda kv: kv[1]) if w != '<ukn>']
+        else:                                 # synthetic run: ids stand for themselves
             vocabulary = [str(i) for i in range(model.net.text.V - 1)]
     word_to_id = dict(zip(vocabulary, range(len(vocabulary))))
     word_to_id['<ukn>'] = len(vocabulary)

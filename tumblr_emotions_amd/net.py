@@ -189,15 +189,19 @@ class SentimentNet:
                                                   L["b_softmax"])
         return self.logits
 
-    def predict(self, batch, is_training=False):
+    def predict(self, batch, is_training=False, seed=None):
         """Forward only (evaluate_*): is_training=False -> BatchNorm moving statistics, no dropout;
         is_training=True reproduces the reference's evaluation on mode='train' (batch statistics and
         dropout stay on, im_text_rnn_model.py:65) but never touches the moving averages."""
         if self.image is not None:
             self.image.training, self.image.update_moving = is_training, False
+        # evaluation on mode='train' keeps dropout on: every call draws a fresh mask (a fixed seed would apply
+        # the identical mask to every evaluation batch)
+        self._predict_calls = getattr(self, "_predict_calls", 0) + 1
+        seed = (1 << 40) + self._predict_calls if seed is None else seed
         try:
             with torch.no_grad():
-                return self.forward(batch, None, seed=0)
+                return self.forward(batch, None, seed=self._rank_seed(seed))
         finally:
             if self.image is not None:
                 self.image.training, self.image.update_moving = True, True
@@ -214,13 +218,17 @@ class SentimentNet:
             reg = 0.5 * WEIGHT_DECAY * (self.frozen_l2_sumsq + float(self.l2_buf.item()))
         return float(self.loss_buf.item()) + reg
 
+    def _rank_seed(self, seed):
+        return int(seed) * 4096 + self.reducer.rank
+
     # ---- one training step -----------------------------------------------------------------------
     def train_step(self, batch, lr, dropout_mask=None, seed=None):
         st = self.store
         for p in self.leaves.values():
             p.grad = None
         self.step += 1
-        seed = self.step if seed is None else seed
+        # dropout stream: one seed per (step, rank) -- ranks must not share a mask pattern across their shards
+        seed = self._rank_seed(self.step) if seed is None else seed
         logits = self.forward(batch, dropout_mask, seed)
         ce = self.cross_entropy(logits, batch["labels"])
         if st.n_l2 > 0:      # trainable part of the L2 loss, on the pre-update weights

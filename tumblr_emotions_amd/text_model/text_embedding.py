@@ -3,6 +3,7 @@ import numpy as np
 import torch
 
 from ..net import SentimentNet
+from .text_preprocessing import resolve_embedding
 from ..training import SyntheticInput, run_training
 
 _RANDOM_SEED = 0
@@ -22,13 +23,9 @@ class TextModel(SyntheticInput):
     def __init__(self, config, nb_emotions=15, embedding=None, device="cuda", **net_kw):
         self.config = config
         self.learning_rate = config['initial_lr']
-        vocab = config.get('vocab_size', 10000)
-        dim = config.get('embedding_dim', 50)
         post = config.get('post_size', _POST_SIZE)
-        if embedding is not None:               # GloVe matrix [V, D]; a zero <ukn> row is appended (:64-65)
-            embedding = np.concatenate([np.asarray(embedding, np.float32),
-                                        np.zeros((1, embedding.shape[1]), np.float32)])
-            vocab, dim = embedding.shape[0] - 1, embedding.shape[1]
+        # GloVe file -> [V, D] + zero <ukn> row; V and D come from the file (:61-66)
+        embedding, vocab, dim, self.word_to_id = resolve_embedding(config, embedding)
         self._init_input(config, post, vocab, nb_emotions, False, device)
         self.nb_emotions = self.dataset.num_classes
         for key in ("train_all", "trainable_embedding"):      # optional fine-tuning switches (not in the reference _CONFIG)

@@ -31,8 +31,10 @@ def save_checkpoint(model, train_dir, step):
     net = model.net
     torch.cuda.synchronize()
     path = os.path.join(train_dir, "model.ckpt-%d.pt" % step)
-    torch.save({"variables": net.state_dict(), "adam_m": net.store.m.cpu(), "adam_v": net.store.v.cpu(),
-                "global_step": step, "config": model.config}, path)
+    # plain tensors / numbers / strings only, so that the file loads with weights_only=True
+    torch.save({"variables": {k: torch.from_numpy(v) for k, v in net.state_dict().items()},
+                "adam_m": net.store.m.cpu(), "adam_v": net.store.v.cpu(), "global_step": int(step),
+                "config": json.dumps(model.config, default=str)}, path)
     with open(os.path.join(train_dir, "checkpoint"), "w") as f:
         json.dump({"model_checkpoint_path": os.path.basename(path), "global_step": step}, f)
     return path
@@ -56,7 +58,8 @@ def run_training(model, train_dir, num_steps, batch_fn=None, log_every=10, save_
         os.makedirs(train_dir)
     cfg = model.config
     batch_size, initial_lr, decay = cfg["batch_size"], cfg["initial_lr"], cfg["decay_factor"]
-    nb_batches = max(1, model.dataset.num_samples // batch_size)     # python-2 integer division, :140
+    # python-2 integer division, :140; under data parallelism one step consumes batch_size * world samples
+    nb_batches = max(1, model.dataset.num_samples // (batch_size * world))
     net = model.net
     epoch, lr = 0, initial_lr
     last_save = time.time()
@@ -89,8 +92,8 @@ def run_training(model, train_dir, num_steps, batch_fn=None, log_every=10, save_
 
 
 def load_checkpoint(model, path):
-    ck = torch.load(path, map_location="cpu", weights_only=False)
-    model.net.load_state_dict(ck["variables"])
+    ck = torch.load(path, map_location="cpu", weights_only=True)       # never unpickles arbitrary objects
+    model.net.load_state_dict({k: v.numpy() for k, v in ck["variables"].items()})
     model.net.store.m.copy_(ck["adam_m"])
     model.net.store.v.copy_(ck["adam_v"])
     model.net.step = int(ck["global_step"])
@@ -138,11 +141,14 @@ class SyntheticInput:
         self._records = None
         ddir = config.get("dataset_dir")
         split = os.path.join(ddir or "", "photos", "train_valid_split.txt")
-        if ddir and os.path.exists(split) and not config.get("synthetic", False):
+        if config.get("synthetic", False):
+            self.dataset = SyntheticDataset(config.get("num_samples", 50000), nb_emotions)
+        elif ddir and os.path.exists(split):
             from .datasets.convert_to_dataset import get_split_with_text
             self.dataset = get_split_with_text(config.get("mode", "train"), ddir)
-        else:
-            self.dataset = SyntheticDataset(config.get("num_samples", 50000), nb_emotions)
+        else:          # the reference fails in get_split_with_text; never train silently on made-up data
+            raise IOError("no converted dataset under config['dataset_dir'] = %r (expected %s).  Set "
+                          "config['synthetic'] = True for synthetic batches" % (ddir, split))
 
     def next_batch(self, step):
         post_size, vocab, nb, with_images, device = self._in
@@ -151,7 +157,8 @@ class SyntheticInput:
             if self._records is None:
                 from .image_model.im_model import load_batch_with_text
                 self._records = load_batch_with_text(self.dataset, self.config["batch_size"], height=224, width=224,
-                                                     device=device, rank=rank, world=world)
+                                                     device=device, rank=rank, world=world, max_token_id=vocab,
+                                                     num_classes=nb)
             b = next(self._records)
             if not with_images:
                 b.pop("images")
