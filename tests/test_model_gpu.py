@@ -2,9 +2,10 @@
 identical synthetic batches and identical weights (TF variable names on both sides).
 
 Gates (BASELINE.md section 3 / north star): max|dlogits| <= 1e-3, |dloss| <= 1e-3 (loss includes the
-L2 term), gradients of every trainable variable within 1e-3 of the largest gradient entry of that
-variable, one TF-Adam step within 1e-5 on the weights, BatchNorm moving statistics within 1e-5.
-Dropout is either disabled (keep=1) or its mask is injected on both sides.
+L2 term), gradients of every trainable variable within 1e-3 (relative L2 and relative to the largest entry of
+that variable), one TF-Adam step within 1e-5 on the weights, BatchNorm moving statistics within 1e-5.
+Dropout is either disabled (keep=1) or its mask is injected on both sides; for models with an image tower
+the fp64 oracle follows the ReLU / arg-max decisions of the HIP forward pass (see _check_step).
 """
 import numpy as np
 import pytest
@@ -20,25 +21,13 @@ def _dev_batch(b):
     return {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in b.items()}
 
 
-def _robust_close(got, ref, what, tol=1e-3, frac=0.9, hard=None):
-    """A deep BatchNorm/ReLU stack in fp32 takes a few ReLU / arg-max decisions differently from the same
-    stack in fp64 (pre-activations within rounding of zero); a flipped fraction f of one layer's decisions
-    moves every gradient upstream of it by ~sqrt(f) relative, ~1e-2 for this tower at ANY batch size -- the
-    oracle run in fp32 differs from itself in fp64 by that much (scripts/oracle_fp32_spread.py,
-    profiles/r02_oracle_fp32_spread.txt).  So a plain fp64 comparison cannot be tighter than that spread:
-    `hard` is 3x the spread OF THIS VARIABLE measured in the same test; the tight (1e-3) composition check
-    is test_joint_step_b16_follows_oracle_along_same_decisions, which removes the flips."""
-    scale = max(np.abs(ref).max(), 1e-7)
+def _grad_close(got, ref, what, tol=1e-3):
+    """relative L2 AND max-norm (relative to the largest entry) within tol."""
     d = got.reshape(ref.shape) - ref
-    e = np.abs(d) / scale
-    if hard is None or hard <= tol:          # no decisions in this model (text tower): plain max-norm gate
-        assert e.max() <= tol, "%s: max error %.3e" % (what, e.max())
-        return e.max()
-    rel_l2 = np.linalg.norm(d) / max(np.linalg.norm(ref), 1e-12)
-    assert rel_l2 <= hard, "%s: relative L2 error %.3e above 3x its own fp32-vs-fp64 spread %.3e" % (what, rel_l2, hard)
-    assert (e <= hard).mean() >= frac, "%s: only %.3f of the entries within %.3e" % (what, (e <= hard).mean(), hard)
-    assert e.max() <= 4 * hard, "%s: max error %.3e above 4x the spread bound %.3e" % (what, e.max(), hard)
-    return e.max()
+    rel = np.linalg.norm(d) / max(np.linalg.norm(ref), 1e-30)
+    emax = np.abs(d).max() / max(np.abs(ref).max(), 1e-30)
+    assert rel <= tol and emax <= tol, "%s: relative L2 %.3e, max-norm %.3e" % (what, rel, emax)
+    return rel
 
 
 def _sync_from_oracle(net, ref, embedding=None):
@@ -59,31 +48,31 @@ def _sync_from_oracle(net, ref, embedding=None):
     net.step = ref.step
 
 
-def _check_step(net, ref, batch, lr, mask_np=None, logit_tol=1e-3, ref32=None, first=True):
+def _check_step(net, ref, batch, lr, mask_np=None, logit_tol=1e-3, first=True):
+    """One training step on both sides from identical state.  The HIP step runs first; when the model has
+    an image tower the fp64 oracle is then evaluated along the ReLU / max-pool decisions the HIP forward pass
+    took (tests/hip_decisions.py, DeepSentimentRef.inject).  Why: a fp32 forward pass flips a few of those
+    decisions against fp64 (pre-activations within rounding of zero), and a flipped fraction f moves every
+    upstream gradient by ~sqrt(f) -- ~1e-2 for this tower at any batch size, also for the oracle run in fp32
+    against itself (scripts/oracle_fp32_spread.py) -- which would force a percent-level gate.  Along the same
+    decisions the comparison is smooth and every gradient is held to 1e-3 (relative L2 and max-norm)."""
+    from hip_decisions import hip_decisions
     mask_t = None if mask_np is None else torch.tensor(mask_np, dtype=ref.dtype)
     mask_d = None if mask_np is None else torch.tensor(mask_np, dtype=torch.float32).cuda()
     w_before = net.state_dict()
-    out = ref.train_step(batch, lr, mask_t)
-    hard = {}
-    if ref32 is not None:          # the oracle's own sensitivity to fp32 rounding on this batch, PER VARIABLE
-        out32 = ref32.train_step(batch, lr, None if mask_np is None else torch.tensor(mask_np, dtype=torch.float32))
-        spread = {n: float((out32["grads"][n].double() - g).norm() / max(float(g.norm()), 1e-30))
-                  for n, g in out["grads"].items()}
-        # flips are rare events: a variable whose downstream saw none in the fp32 oracle may see one on the GPU,
-        # so the tower's median spread is the floor for variables that sit below ReLU/arg-max decisions
-        below = [n for n in spread if n.startswith("InceptionV1/") and "/Logits/" not in n]
-        floor = float(np.median([spread[n] for n in below])) if below else 0.0
-        for n in spread:
-            hard[n] = max(1e-3, 3 * max(spread[n], floor if n in below else 0.0))
     net.train_step(_dev_batch(batch), lr, dropout_mask=mask_d)
     torch.cuda.synchronize()
+    if net.image is not None:
+        ref.inject = hip_decisions(net)
+    out = ref.train_step(batch, lr, mask_t)
     logits = net.logits.detach().cpu().numpy()
     err = np.abs(logits - out["logits"].numpy()).max()
     assert err <= logit_tol, "logits differ by %.3e" % err
     assert abs(net.total_loss_value() - out["loss"]) <= 1e-3, (net.total_loss_value(), out["loss"])
     grads = net.grads_state_dict()
+    assert set(grads) >= set(out["grads"])
     for name, g_ref in out["grads"].items():
-        _robust_close(grads[name], g_ref.numpy(), "gradient of " + name, hard=hard.get(name))
+        _grad_close(grads[name], g_ref.numpy(), "gradient of " + name)
     after = net.state_dict()
     for name in ref.trainable:
         w_ref = ref.p[name].detach().numpy()
@@ -170,11 +159,10 @@ def test_full_fine_tuning_image_step_matches_oracle():
     batch = S.synthetic_batch(B, 8, 10, seed=9)
     mask = (rng.uniform(size=(B, 1024)) < 0.8).astype(np.float64)
     ref = R.DeepSentimentRef(params, None, "image", torch.float64, train_all=True)
-    ref32 = R.DeepSentimentRef(params, None, "image", torch.float32, train_all=True)
     net = SentimentNet(mode="image", nb_emotions=15, train_all=True)
     net.load_state_dict(params)
     assert net.frozen_l2_sumsq == 0.0
-    out = _check_step(net, ref, batch, 1e-3, mask, ref32=ref32)
+    out = _check_step(net, ref, batch, 1e-3, mask)
     conv_w = [n for n in out["grads"] if n.endswith("/weights")]
     assert len(conv_w) == 58 and "InceptionV1/Conv2d_1a_7x7/weights" in conv_w          # 57 convs + Logits
 
@@ -213,10 +201,9 @@ def test_image_only_step_matches_oracle():
     batch = S.synthetic_batch(B, 8, 10, seed=5)
     mask = (rng.uniform(size=(B, 1024)) < 0.8).astype(np.float64)
     ref = R.DeepSentimentRef(params, None, "image", torch.float64)
-    ref32 = R.DeepSentimentRef(params, None, "image", torch.float32)
     net = SentimentNet(mode="image", nb_emotions=15)
     net.load_state_dict(params)
-    _check_step(net, ref, batch, 1e-3, mask, ref32=ref32)
+    _check_step(net, ref, batch, 1e-3, mask)
 
 
 def test_joint_step_matches_oracle():
@@ -229,7 +216,6 @@ def test_joint_step_matches_oracle():
     emb = S.synthetic_embedding(V, D).astype(np.float64)
     batch = S.synthetic_batch(B, T, V, seed=6)
     ref = R.DeepSentimentRef(params, emb, "joint", torch.float64)
-    ref32 = R.DeepSentimentRef(params, emb, "joint", torch.float32)
     net = SentimentNet(mode="joint", nb_emotions=15, im_features_size=256, rnn_size=H, fc_size=512, vocab_size=V,
                        embedding_dim=D, post_size=T, dropout_keep_prob=1.0)
     net.load_state_dict(dict(params, **{"Text/W_embedding": emb}))
@@ -237,14 +223,7 @@ def test_joint_step_matches_oracle():
     for i in range(2):
         if i:
             _sync_from_oracle(net, ref, emb)
-            with torch.no_grad():            # the fp32 oracle restarts from the fp64 oracle's state too
-                for k in ref.p:
-                    ref32.p[k].copy_(ref.p[k])
-                for k in ref.adam_m:
-                    ref32.adam_m[k].copy_(ref.adam_m[k])
-                    ref32.adam_v[k].copy_(ref.adam_v[k])
-            ref32.step = ref.step
-        _check_step(net, ref, batch, 1e-3, ref32=ref32, first=(i == 0))
+        _check_step(net, ref, batch, 1e-3, first=(i == 0))
 
 
 def test_joint_step_b16_follows_oracle_along_same_decisions():
@@ -311,10 +290,9 @@ def test_frozen_beta_switch_stops_backward_at_mixed_5c():
     params = R.make_params("image", rng, num_classes=15, dtype=np.float64)
     batch = S.synthetic_batch(B, 8, 10, seed=7)
     ref = R.DeepSentimentRef(params, None, "image", torch.float64, trainable_bn_beta=False)
-    ref32 = R.DeepSentimentRef(params, None, "image", torch.float32, trainable_bn_beta=False)
     net = SentimentNet(mode="image", nb_emotions=15, trainable_bn_beta=False, dropout_keep_prob=1.0)
     net.load_state_dict(params)
-    _check_step(net, ref, batch, 1e-3, ref32=ref32)
+    _check_step(net, ref, batch, 1e-3)
 
 
 def test_training_runs_are_bit_reproducible():
