@@ -48,10 +48,38 @@ struct ConvParams {
     int row_tiles;  // ceil(M/BM)
     unsigned x_bytes, w_bytes;   // extents covered by the two buffer descriptors
     int prio_mode;               // 1: staggered static wave priorities (see kernel)
+    int col_tiles;               // > 0: 1-D XCD-aware launch (see TileId); 0: (row, column) = (blockIdx.x, blockIdx.y)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+// Which tile does this workgroup own?  Two launch shapes:
+//   * col_tiles == 0: 2-D grid, blockIdx.x = first row tile (persistent stride gridDim.x), blockIdx.y = column
+//     tile; grid.x is a multiple of 8, so the column tiles of a row tile share an XCD.
+//   * col_tiles > 0 (one workgroup per tile): 1-D grid, XCD-aware.  Workgroup id lands on XCD id % 8
+//     (MI355X_MICROARCH.md, observed placement -- a different one only costs speed).  Consecutive ids of ONE
+//     XCD walk the column tiles of ONE row tile, so the workgroups that read the same A rows run on the same
+//     XCD back to back and the rows come from HBM once per row tile instead of once per column tile (the 1x1
+//     dgrad read its operand 4.6x, profiles/r01h_pmc_traffic.txt).  Row tiles are padded to a multiple of 8;
+//     the surplus workgroups find row >= row_tiles and do nothing.
+struct TileId {
+    int row, col, stride;      // first row tile, column tile, row-tile stride of the persistent loop
+};
+__device__ __forceinline__ TileId tile_id(const ConvParams &p) {
+    TileId t;
+    if (p.col_tiles > 0) {
+        const int id = blockIdx.x, q = id >> 3;
+        t.col = q % p.col_tiles;
+        t.row = (q / p.col_tiles) * 8 + (id & 7);
+        t.stride = p.row_tiles;            // exactly one tile per workgroup
+    } else {
+        t.row = blockIdx.x;
+        t.col = blockIdx.y;
+        t.stride = gridDim.x;
+    }
+    return t;
 }
 
 template <bool VEC>
@@ -87,7 +115,8 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
     const int tid = threadIdx.x, lane = tid & 63;
     const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int li = lane & 31, lk = lane >> 5;
-    const int n0 = blockIdx.y * BN;
+    const TileId tid0 = tile_id(p);
+    const int n0 = tid0.col * BN;
     const int ohw = d.OH * d.OW;
     const int chunks = (d.Cin + BK - 1) / BK;
     // split-K (small-M GEMMs): blockIdx.z owns K-tiles [kt0, kt1) and writes its own output slab
@@ -260,15 +289,15 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
     // first K-tile of the NEXT row tile, so the pipeline never drains between tiles and the epilogue
     // of tile t starts with tile t+1's operands already staged in LDS.
     int par = 0;                                   // LDS buffer holding the K-tile about to be computed
-    if (blockIdx.x < p.row_tiles) {
-        setup_tile(blockIdx.x);
+    if (tid0.row < p.row_tiles) {
+        setup_tile(tid0.row);
         load_tile();
         store_tile(0);
     }
     __syncthreads();
-    for (int tile = blockIdx.x; tile < p.row_tiles; tile += gridDim.x) {
+    for (int tile = tid0.row; tile < p.row_tiles; tile += tid0.stride) {
         const int m0 = tile * BM;
-        const bool has_next = tile + (int)gridDim.x < p.row_tiles;
+        const bool has_next = tile + tid0.stride < p.row_tiles;
 #pragma unroll
         for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -277,7 +306,7 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
         for (int kt = 0; kt < KT; ++kt) {
             const bool last = kt + 1 == KT;
-            if (last && has_next) setup_tile(tile + gridDim.x);
+            if (last && has_next) setup_tile(tile + tid0.stride);
             const bool fetch = !last || has_next;
             if (fetch) load_tile();
             compute(par);
@@ -333,16 +362,16 @@ __global__ __launch_bounds__(256, (MT == 1 && NT == 1) ? 4 : (MT == 1 && NT == 2
             }
         }
         __syncthreads();
-        if (tid < BN && n0 + tid < d.Cout) {
+        if (tid < BN && n0 + tid < d.Cout && tid0.row < p.row_tiles) {
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) {
                 s += red[(w * BN + tid) * 2 + 0];
                 q += red[(w * BN + tid) * 2 + 1];
             }
-            // partials laid out [2][Cout][P] (P = gridDim.x) so ds_bn_finalize reads them contiguously
-            p.stats[(int64_t)(n0 + tid) * gridDim.x + blockIdx.x] = s;
-            p.stats[((int64_t)d.Cout + n0 + tid) * gridDim.x + blockIdx.x] = q;
+            // partials laid out [2][Cout][P] (P = workgroups per column tile) so ds_bn_finalize reads them contiguously
+            p.stats[(int64_t)(n0 + tid) * tid0.stride + tid0.row] = s;
+            p.stats[((int64_t)d.Cout + n0 + tid) * tid0.stride + tid0.row] = q;
         }
     }
 }
@@ -591,7 +620,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? 3 : 2)) void conv_gld
     const int tid = threadIdx.x, lane = tid & 63;
     const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lk = lane >> 5;
-    const int n0 = blockIdx.y * BN;
+    const TileId tid0 = tile_id(p);
+    const int n0 = tid0.col * BN;
     const int ohw = d.OH * d.OW;
     const int chunks = (d.Cin + GK - 1) / GK;
     const int KT_all = p.taps * chunks;
@@ -742,14 +772,14 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? 3 : 2)) void conv_gld
     };
 
     int par = 0;
-    if (blockIdx.x < p.row_tiles) {
-        setup_tile(blockIdx.x);
+    if (tid0.row < p.row_tiles) {
+        setup_tile(tid0.row);
         issue_tile(0);
     }
     __syncthreads();
-    for (int tile = blockIdx.x; tile < p.row_tiles; tile += gridDim.x) {
+    for (int tile = tid0.row; tile < p.row_tiles; tile += tid0.stride) {
         const int m0 = tile * BM;
-        const bool has_next = tile + (int)gridDim.x < p.row_tiles;
+        const bool has_next = tile + tid0.stride < p.row_tiles;
 #pragma unroll
         for (int b = 0; b < NT; ++b)
 #pragma unroll
@@ -757,7 +787,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? 3 : 2)) void conv_gld
         for (int kt = 0; kt < KT; ++kt) {
             const bool last = kt + 1 == KT;
             read_frags(par);
-            if (last && has_next) setup_tile(tile + gridDim.x);
+            if (last && has_next) setup_tile(tile + tid0.stride);
             if (!last || has_next) issue_tile(par ^ 1);
             __builtin_amdgcn_sched_barrier(0);     // DMAs are issued before the MFMAs ...
             mfmas();
@@ -808,15 +838,15 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? 3 : 2)) void conv_gld
             }
         }
         __syncthreads();
-        if (tid < BN && n0 + tid < d.Cout) {
+        if (tid < BN && n0 + tid < d.Cout && tid0.row < p.row_tiles) {
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 s += red[(w * BN + tid) * 2 + 0];
                 q += red[(w * BN + tid) * 2 + 1];
             }
-            p.stats[(int64_t)(n0 + tid) * gridDim.x + blockIdx.x] = s;
-            p.stats[((int64_t)d.Cout + n0 + tid) * gridDim.x + blockIdx.x] = q;
+            p.stats[(int64_t)(n0 + tid) * tid0.stride + tid0.row] = s;
+            p.stats[((int64_t)d.Cout + n0 + tid) * tid0.stride + tid0.row] = q;
         }
     }
 }
@@ -980,23 +1010,29 @@ TileCfg pick_cfg(const ds_conv_desc *d, bool vec) {
 //     hundred partials per channel instead of one per row tile.
 constexpr int kOneTilePerWg = 2048;
 
-void grid_for(const ds_conv_desc *d, TileCfg c, Variant v, int *gx, int *gy, int *row_tiles) {
+void grid_for(const ds_conv_desc *d, TileCfg c, Variant v, int *gx, int *gy, int *row_tiles, bool *one_per_tile = nullptr) {
     const int64_t M = conv_M(d);
     const int bm = (c.direct ? 32 : 128) * (c.glds ? 1 : c.mt), bn = 32 * c.nt;
     *row_tiles = (int)((M + bm - 1) / bm);
     *gy = (d->Cout + bn - 1) / bn;
     const int wg_tiles = c.direct ? (*row_tiles + 3) / 4 : *row_tiles;     // row tiles in units of workgroups
     int x;
+    bool one = false;
     if (wg_tiles <= kOneTilePerWg && !c.direct) {
         x = wg_tiles;
+        one = true;
     } else {
         int target = (resident_per_cu(c, v) * ds::kCUs) / *gy;             // one resident wave of workgroups
         if (target < 8) target = 8;
         x = wg_tiles < target ? wg_tiles : target;
         if (x >= 8) x &= ~7;                  // multiple of 8: column tiles of a row tile share an XCD
     }
-    if (d->grid_x > 0 && !c.direct) x = d->grid_x < wg_tiles ? d->grid_x : wg_tiles;   // per-layer override
+    if (d->grid_x > 0 && !c.direct) {       // per-layer override
+        x = d->grid_x < wg_tiles ? d->grid_x : wg_tiles;
+        one = x == wg_tiles;
+    }
     *gx = x;
+    if (one_per_tile) *one_per_tile = one;
 }
 
 }  // namespace
@@ -1069,8 +1105,20 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     if (splits == 1) p.d.z_split_stride = 0;
     const TileCfg c = pick_cfg(d, v.vec);
     int gx, gy, rt;
-    grid_for(d, c, v, &gx, &gy, &rt);
+    bool one;
+    grid_for(d, c, v, &gx, &gy, &rt, &one);
     p.row_tiles = rt;
-    hipLaunchKernelGGL(kernel_for(c, v), dim3(gx, gy, splits), dim3(256), 0, (hipStream_t)stream, p);
+    static int xcd_remap = -1;
+    if (xcd_remap < 0) {
+        const char *e = getenv("DS_CONV_XCD_REMAP");      // A/B aid; default on
+        xcd_remap = e ? atoi(e) : 1;
+    }
+    dim3 grid(gx, gy, splits);
+    p.col_tiles = 0;
+    if (one && xcd_remap && gy > 1 && !c.direct) {    // one workgroup per tile: 1-D XCD-aware launch (TileId)
+        p.col_tiles = gy;
+        grid = dim3(((rt + 7) / 8 * 8) * gy, 1, splits);
+    }
+    hipLaunchKernelGGL(kernel_for(c, v), grid, dim3(256), 0, (hipStream_t)stream, p);
     return ds::check_launch("ds_conv_igemm");
 }
