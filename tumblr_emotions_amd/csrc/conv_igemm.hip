@@ -59,20 +59,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *p, unsign
 //   * col_tiles == 0: 2-D grid, blockIdx.x = first row tile (persistent stride gridDim.x), blockIdx.y = column
 //     tile; grid.x is a multiple of 8, so the column tiles of a row tile share an XCD.
 //   * col_tiles > 0 (one workgroup per tile): 1-D grid, XCD-aware.  Workgroup id lands on XCD id % 8
-//     (MI355X_MICROARCH.md, observed placement -- a different one only costs speed).  Consecutive ids of ONE
-//     XCD walk the column tiles of ONE row tile, so the workgroups that read the same A rows run on the same
-//     XCD back to back and the rows come from HBM once per row tile instead of once per column tile (the 1x1
-//     dgrad read its operand 4.6x, profiles/r01h_pmc_traffic.txt).  Row tiles are padded to a multiple of 8;
-//     the surplus workgroups find row >= row_tiles and do nothing.
+//     (MI355X_MICROARCH.md, observed placement -- a different one only costs speed).  The row-major list of
+//     (row tile, column tile) pairs is cut into 8 equal contiguous ranges, one per XCD, and consecutive ids of
+//     ONE XCD walk its range: the workgroups that read the same A rows run on the same XCD back to back, so the
+//     rows cross the fabric once per row tile instead of once per column tile (the 1x1 dgrad read its operand
+//     4.6x, profiles/r01h_pmc_traffic.txt), and every XCD gets the same number of tiles whatever the tile
+//     counts are (2 row tiles x 64 column tiles for an LSTM step included).  Up to 7 surplus workgroups find
+//     row >= row_tiles and do nothing.
 struct TileId {
     int row, col, stride;      // first row tile, column tile, row-tile stride of the persistent loop
 };
 __device__ __forceinline__ TileId tile_id(const ConvParams &p) {
     TileId t;
     if (p.col_tiles > 0) {
-        const int id = blockIdx.x, q = id >> 3;
-        t.col = q % p.col_tiles;
-        t.row = (q / p.col_tiles) * 8 + (id & 7);
+        const int id = blockIdx.x;
+        const int lin = (id & 7) * (int)(gridDim.x >> 3) + (id >> 3);      // position in the row-major tile list
+        t.row = lin / p.col_tiles;
+        t.col = lin - t.row * p.col_tiles;
         t.stride = p.row_tiles;            // exactly one tile per workgroup
     } else {
         t.row = blockIdx.x;
@@ -1117,7 +1120,7 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     p.col_tiles = 0;
     if (one && xcd_remap && gy > 1 && !c.direct) {    // one workgroup per tile: 1-D XCD-aware launch (TileId)
         p.col_tiles = gy;
-        grid = dim3(((rt + 7) / 8 * 8) * gy, 1, splits);
+        grid = dim3((rt * gy + 7) / 8 * 8, 1, splits);
     }
     hipLaunchKernelGGL(kernel_for(c, v), grid, dim3(256), 0, (hipStream_t)stream, p);
     return ds::check_launch("ds_conv_igemm");
