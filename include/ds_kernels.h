@@ -193,6 +193,30 @@ int ds_lstm_cell_bwd(const float *acts, const float *c_t, const float *c_prev, c
                      const int64_t *seq_len, int32_t t, int32_t B, int32_t H, float *dgates, float *dc_prev,
                      float *dh_carry, void *stream);
 
+/* The same recurrence for the WHOLE sequence in one launch per direction (lstm_seq: BasicLSTMCell +
+ * tf.nn.dynamic_rnn(sequence_length) + the gather_nd of the last valid output, im_text_rnn_model.py:89-92):
+ * the recurrent weights stay in registers as MFMA fragments partitioned over the workgroups, cell state and
+ * carried gradients stay in registers, h_t / dgates_t are exchanged between the workgroups of a 32-row group
+ * through write-through stores and an arrival counter (no grid-wide barrier: batch rows are independent).
+ *   wh     rows [D, D+H) of the TF kernel: [H, 4H], row stride ldw, gate order i, j, f, o
+ *   gates  [T, B, 4H]   in: x_t Wx + bias for every step (the hoisted input projection); out: activations
+ *   h, c   [T+1, B, H]  slot 0 = initial state (zeros in the reference), slot t+1 = state after step t with
+ *                       dynamic_rnn's copy-through past seq_len, so h[T] is the last valid output
+ *   ws     ds_lstm_seq_workspace(B, H) bytes of device scratch (arrival counters, re-zeroed by every call)
+ * Supported: H in {32, 64, 128, 256, 512, 1024} (ds_lstm_seq_supported); other sizes use the step-wise pair
+ * above.  All workgroups of a row group must become resident for the launch to finish; every wait is bounded
+ * and ds_lstm_seq_status (after the caller synchronised) reports a timeout instead of a hang.            */
+int ds_lstm_seq_supported(int32_t B, int32_t H);
+size_t ds_lstm_seq_workspace(int32_t B, int32_t H);
+int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float *h, float *c, const int64_t *seq_len, int32_t T,
+                    int32_t B, int32_t H, float forget_bias, void *ws, size_t ws_bytes, void *stream);
+/* BPTT: dgates [T, B, 4H] (zero rows past seq_len) from d(loss)/d(h[T]) = dh_last [B, ld_dh]; acts = the
+ * activations ds_lstm_seq_fwd left in `gates`.  The two weight gradients are GEMMs over dgates afterwards. */
+int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, const float *c, const float *dh_last,
+                    int32_t ld_dh, const int64_t *seq_len, int32_t T, int32_t B, int32_t H, float *dgates, void *ws,
+                    size_t ws_bytes, void *stream);
+int ds_lstm_seq_status(const void *ws, int32_t B);
+
 /* slim.losses.softmax_cross_entropy + its gradient (im_text_rnn_model.py:124-125):
  * loss[0] = mean_b(logsumexp(z_b) - z_b[y_b]); dlogits = (softmax - onehot) * grad_scale / B;
  * grad_scale_dev (nullable) is a device scalar multiplied in (autograd's upstream gradient);

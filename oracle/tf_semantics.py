@@ -308,14 +308,16 @@ def lstm_forward(x, seq_len, kernel, bias, forget_bias=FORGET_BIAS, keep_cache=F
     return outs, h_last
 
 
-def lstm_backward(dh_last, seq_len, kernel, cache):
+def lstm_backward(dh_last, seq_len, kernel, cache, return_dz=False):
     """BPTT for lstm_forward given d(loss)/d(h_last).  Returns (dkernel, dbias).  The embedding
-    is frozen (trainable=False, im_text_rnn_model.py:82) so no dx is produced."""
+    is frozen (trainable=False, im_text_rnn_model.py:82) so no dx is produced.  return_dz: also the
+    per-step gradient of the gate pre-activations [T][B,4H] (zero rows past seq_len)."""
     d_in = cache[0]["xh"].shape[1] - dh_last.shape[1]
     dk = np.zeros_like(kernel)
     db = np.zeros(kernel.shape[1], dtype=kernel.dtype)
     dh = np.zeros_like(dh_last)
     dc = np.zeros_like(dh_last)
+    dzs = [None] * len(cache)
     for s in reversed(range(len(cache))):
         q = cache[s]
         last = (s == seq_len - 1)[:, None]
@@ -327,11 +329,14 @@ def lstm_backward(dh_last, seq_len, kernel, cache):
         dj = dct * q["si"] * (1 - q["tj"] ** 2)
         df = dct * q["c_prev"] * q["sf"] * (1 - q["sf"])
         dz = np.where(live, np.concatenate([di, dj, df, do], axis=1), 0)
+        dzs[s] = dz
         dk += q["xh"].T @ dz
         db += dz.sum(axis=0)
         dxh = dz @ kernel.T
         dh = np.where(live, dxh[:, d_in:], dh)
         dc = np.where(live, dct * q["sf"], dc)
+    if return_dz:
+        return dk, db, dzs
     return dk, db
 
 

@@ -164,6 +164,85 @@ def test_gemm_lstm_shape():
     close(dh, dg @ kern[40:].T)
 
 
+@pytest.mark.parametrize("case", [(8, 6, 32), (37, 9, 64), (64, 12, 128), (256, 32, 512), (33, 5, 1024), (5, 50, 256)])
+def test_lstm_sequence_kernels_match_oracle(case):
+    """ds_lstm_seq_fwd / ds_lstm_seq_bwd (whole recurrence in one persistent launch per direction) against the
+    NumPy BasicLSTMCell + dynamic_rnn restatement: every h_t, c_t, the activations, the last valid output, and
+    every per-step gate gradient; ragged batch (B not a multiple of the 32-row groups), sequence lengths 1 and
+    T, every supported hidden size incl. the 8-wave H = 1024 variant and BASELINE's (256, 32, 512)."""
+    ops = _ops()
+    B, T, H = case
+    rng = np.random.RandomState(B + T + H)
+    pre = rng.normal(size=(T, B, 4 * H)) * 0.7                     # x_t Wx + b, already hoisted
+    wh = rng.normal(size=(H, 4 * H)) * (0.5 / np.sqrt(H))
+    seq = rng.randint(1, T + 1, size=B).astype(np.int64)
+    seq[0], seq[-1] = 1, T
+    dh_last = rng.normal(size=(B, H))
+    # oracle: feed the pre-activations through an identity input block of the TF kernel
+    kernel = np.concatenate([np.eye(4 * H), wh], axis=0)
+    outs, h_last, cache = S.lstm_forward(pre.transpose(1, 0, 2), seq, kernel, np.zeros(4 * H), keep_cache=True)
+    _, _, dzs = S.lstm_backward(dh_last, seq, kernel, cache, return_dz=True)
+
+    gates, whd = dev(pre), dev(wh)
+    h = torch.zeros(T + 1, B, H, device="cuda")
+    c = torch.zeros(T + 1, B, H, device="cuda")
+    seqd = torch.from_numpy(seq).cuda()
+    ws = torch.zeros(max(ops.lstm_seq_workspace(B, H) // 4, 4), dtype=torch.int32, device="cuda")
+    assert ops.lstm_seq_supported(B, H)
+    ops.lstm_seq_fwd(gates, ops._p(whd), 4 * H, h, c, seqd, T, B, H, S.FORGET_BIAS, ws)
+    torch.cuda.synchronize()
+    ops.lstm_seq_status(ws, B)
+    close(h[T], h_last)
+    hn, cn, an = h.cpu().numpy(), c.cpu().numpy(), gates.cpu().numpy()
+    for t in range(T):
+        live = t < seq
+        q = cache[t]
+        assert np.abs(hn[t + 1][live] - outs[live, t]).max() <= 2e-4, t
+        c_ref = q["c_prev"] * q["sf"] + q["si"] * q["tj"]
+        assert np.abs(cn[t + 1][live] - c_ref[live]).max() <= 2e-4, t
+        acts = np.concatenate([q["si"], q["tj"], q["sf"], q["so"]], axis=1)
+        assert np.abs(an[t] - acts).max() <= 2e-4, t
+        if (~live).any():            # copy-through past seq_len
+            np.testing.assert_array_equal(hn[t + 1][~live], hn[t][~live])
+            np.testing.assert_array_equal(cn[t + 1][~live], cn[t][~live])
+    dg = torch.full((T, B, 4 * H), float("nan"), device="cuda")
+    dhd = dev(np.pad(dh_last, ((0, 0), (0, 8))))[:, :H]            # a strided view: ld_dh != H
+    ops.lstm_seq_bwd(gates, ops._p(whd), 4 * H, c, dhd, dhd.stride(0), seqd, T, B, H, dg, ws)
+    torch.cuda.synchronize()
+    ops.lstm_seq_status(ws, B)
+    dgn = dg.cpu().numpy()
+    scale = max(np.abs(d).max() for d in dzs)
+    for t in range(T):
+        assert np.abs(dgn[t] - dzs[t]).max() <= 3e-4 * scale, t
+    # two runs are bit-identical (fixed reduction order, no atomics on data)
+    dg2 = torch.empty_like(dg)
+    ops.lstm_seq_bwd(gates, ops._p(whd), 4 * H, c, dhd, dhd.stride(0), seqd, T, B, H, dg2, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(dg, dg2)
+
+
+def test_text_tower_persistent_and_stepwise_paths_agree():
+    """TextTowerEngine with the persistent recurrence against the same engine forced onto the step-wise pair
+    (one GEMM + one cell launch per step): same h_last, same gradients to rounding."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    res = []
+    for persistent in (True, False):
+        net = SentimentNet(mode="text", nb_emotions=15, rnn_size=64, vocab_size=80, embedding_dim=24, post_size=14)
+        net.text.persistent = persistent
+        net.initialize(seed=5)
+        batch = to_device(synthetic_batch_numpy(40, 14, 80, seed=2, with_images=False))
+        net.train_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        assert net.text.use_seq == persistent
+        if persistent:
+            ops = _ops()
+            ops.lstm_seq_status(net.text.seq_ws, 40)
+        res.append((net.logits.clone(), net.store.grad.clone()))
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-5
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * max(1.0, float(res[1][1].abs().max()))
+
+
 def test_batch_norm_forward_backward_with_segments():
     ops = _ops()
     rng = np.random.RandomState(7)

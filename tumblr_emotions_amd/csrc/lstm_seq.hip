@@ -1,0 +1,412 @@
+// BasicLSTMCell under tf.nn.dynamic_rnn for the WHOLE sequence in one launch per direction.
+//
+// Replaces the per-step pair (recurrent GEMM launch + cell launch) of image_text_model/im_text_rnn_model.py:89-92
+// (text_model/text_embedding.py:79-82): at T = 32 that was 31 + 32 dependent launches forward and as many
+// backward, each a 256 x 2048 x 512 GEMM that cannot fill the chip.  Here:
+//   * the recurrent weights Wh [H, 4H] never move: workgroup (cg, rg) owns hidden units [16 cg, 16 cg + 16) for
+//     batch rows [32 rg, 32 rg + 32) and keeps ITS slice of Wh in registers as MFMA B fragments for all T steps
+//     (64 columns x H for the forward gates, 16 rows x 4H for the backward product), split over the waves along K;
+//   * the cell state c (forward) / the carried gradients dc, dh (backward) of those 32 x 16 cells live in
+//     registers for the whole sequence; gates, masking (t >= seq_len copies the state through) and the
+//     last-valid-step capture (h[T] is gather_nd(outputs, seq_len - 1)) are fused into the step;
+//   * per step the only exchange is h_t (forward) / dgates_t (backward) among the H/16 workgroups of ONE row
+//     group -- batch rows are independent -- through the placement-independent protocol of
+//     cdna_hip_programming.md Guideline 16: payload written write-through (sc1 stores), every storing wave
+//     drains (s_waitcnt vmcnt(0)), one lane bumps the row group's arrival counter with a relaxed agent-scope
+//     atomic; consumers poll that one word relaxed from one lane, then read the payload with sc1 loads (served
+//     past the non-coherent L1, so no acquire fence is needed).  Every spin is bounded: on a timeout an error
+//     word is set and the kernel still terminates.
+//   * the input projection x_t Wx + b stays hoisted in one big GEMM in front (ds_conv_igemm), the two weight
+//     gradients in two big wgrad GEMMs behind (ds_conv_wgrad), as before.
+// Numerics: fp32 MFMA (v_mfma_f32_32x32x2_f32 forward, v_mfma_f32_16x16x4_f32 backward), the K reduction split
+// in NW fixed slices summed in a fixed order: deterministic; matches the step-wise path to rounding.
+#include "ds_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kSC1 = 16;                       // buffer-instruction aux bit: sc1 (system-coherent level 1)
+constexpr unsigned kSpinLimit = 1u << 22;      // ~ seconds; a healthy step waits microseconds
+
+struct SeqParams {
+    float *gates;              // [T, B, 4H]  fwd: in x_t Wx + b, out activations (i, j, f, o); bwd: activations (in)
+    const float *wh;           // [H, 4H] row-major with row stride ldw (rows [D, D+H) of the TF kernel)
+    int ldw;
+    float *h;                  // [T+1, B, H]  h[0] = initial state (zeros in the reference)
+    float *c;                  // [T+1, B, H]
+    const float *dh_last;      // bwd: d(loss)/d(h[T])  [B, ld_dh]
+    int ld_dh;
+    float *dgates;             // bwd out [T, B, 4H]
+    const int64_t *seq_len;
+    int T, B, H;
+    float forget_bias;
+    unsigned *sync;            // [row groups] arrival counters, then one error word
+    int nrg;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t srd_of(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// one lane waits until the row group's counter reaches `target`; bounded
+__device__ __forceinline__ void wait_counter(unsigned *cnt, unsigned target, unsigned *err) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+
+// write-through store of 1 or 2 floats (the hand-off payload)
+template <int N>
+__device__ __forceinline__ void store_sc1(float *p, const float *v) {
+    if (N == 2) {
+        unsigned long long x = ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v[0]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ================================================================================================
+// forward: H = 8 * NCH * NW; workgroup tile 32 rows x 64 gate columns (16 units x i,j,f,o), K = H split over NW waves
+// ================================================================================================
+template <int NCH, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const SeqParams p) {
+    constexpr int H = 8 * NCH * NW, KQ = 8 * NCH;
+    constexpr int UPT = 8 / NW;                    // hidden units per thread in the cell phase (512 cells / threads)
+    constexpr int LDR = 68;                        // padded row of the reduction buffer
+    __shared__ __attribute__((aligned(16))) float red[NW * 32 * LDR];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kh = lane >> 5;
+    const int cg = blockIdx.x, rg = blockIdx.y;
+    const int r0 = rg * 32, u0 = cg * 16;
+    const int ncg = gridDim.x;
+    const int B = p.B, T = p.T;
+    unsigned *cnt = p.sync + rg, *err = p.sync + p.nrg;
+
+    // ---- this wave's slice of Wh as MFMA B fragments: column c64 = 16 g + u  <->  Wh column g H + u0 + u ------
+    float bfr[2][NCH][4];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int c64 = 32 * cb + li;
+        const int col = (c64 >> 4) * H + u0 + (c64 & 15);
+#pragma unroll
+        for (int q = 0; q < NCH; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bfr[cb][q][j] = p.wh[(int64_t)(wave * KQ + 8 * q + 4 * kh + j) * p.ldw + col];
+    }
+
+    // ---- cell ownership: thread -> (row, UPT consecutive units) ---------------------------------------------
+    const int crow = tid / (16 / UPT), cu = (tid % (16 / UPT)) * UPT;
+    const int grow = r0 + crow;
+    const bool valid = grow < B;
+    const int64_t sl = valid ? p.seq_len[grow] : 0;
+    float cst[UPT], hst[UPT];
+#pragma unroll
+    for (int e = 0; e < UPT; ++e) {
+        cst[e] = valid ? p.c[(int64_t)grow * H + u0 + cu + e] : 0.f;
+        hst[e] = valid ? p.h[(int64_t)grow * H + u0 + cu + e] : 0.f;
+    }
+
+    const __amdgpu_buffer_rsrc_t srd_h = srd_of(p.h, (unsigned)((int64_t)(T + 1) * B * H * 4));
+    const int arow = (r0 + li < B) ? r0 + li : B - 1;      // rows past the batch read a valid row, results unused
+
+    for (int t = 0; t < T; ++t) {
+        // pre-activations of this thread's cells (hoisted x_t Wx + b): independent of the other workgroups
+        float gp[4][UPT];
+        if (valid) {
+            const float *g = p.gates + ((int64_t)t * B + grow) * 4 * H + u0 + cu;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < UPT; ++e) gp[k][e] = g[k * H + e];
+        }
+        if (t > 0) {                                        // h[t] of the whole row group must have landed
+            if (tid == 0) wait_counter(cnt, (unsigned)t * ncg, err);
+            __syncthreads();
+        }
+        // ---- A fragments straight from h[t] (sc1: past the L1, which other CUs' stores never refresh) --------
+        f32x4 a[NCH];
+        const unsigned abase = (unsigned)((((int64_t)t * B + arow) * H + wave * KQ + 4 * kh) * 4);
+#pragma unroll
+        for (int q = 0; q < NCH; ++q)
+            a[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_h, abase + 32u * q, 0, kSC1));
+        f32x16 acc[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], bfr[cb][q][j], acc[cb], 0, 0, 0);
+        // ---- K slices of the NW waves -> LDS, summed in wave order by the cell threads ------------------------
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * LDR + 32 * cb + li] = acc[cb][r];
+        __syncthreads();
+        if (valid) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < UPT; ++e) gp[k][e] += red[(w * 32 + crow) * LDR + 16 * k + cu + e];
+            const bool live = (int64_t)t < sl;
+            float act[4][UPT], hn[UPT], cn[UPT];
+#pragma unroll
+            for (int e = 0; e < UPT; ++e) {
+                const float si = sigm(gp[0][e]), tj = tanhf(gp[1][e]);
+                const float sf = sigm(gp[2][e] + p.forget_bias), so = sigm(gp[3][e]);
+                const float c_new = cst[e] * sf + si * tj;
+                const float h_new = tanhf(c_new) * so;
+                act[0][e] = si; act[1][e] = tj; act[2][e] = sf; act[3][e] = so;
+                cst[e] = cn[e] = live ? c_new : cst[e];      // dynamic_rnn copies the state through past seq_len
+                hst[e] = hn[e] = live ? h_new : hst[e];
+            }
+            float *g = p.gates + ((int64_t)t * B + grow) * 4 * H + u0 + cu;
+            const int64_t o = ((int64_t)(t + 1) * B + grow) * H + u0 + cu;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < UPT; ++e) g[k * H + e] = act[k][e];
+#pragma unroll
+            for (int e = 0; e < UPT; ++e) p.c[o + e] = cn[e];
+            store_sc1<UPT>(p.h + o, hn);
+        }
+        // ---- publish: every storing wave drains, then one lane counts this workgroup in ----------------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ================================================================================================
+// backward: d(h_t)[rows, own 16 units] = carried part + dgates_{t+1}[rows, :] * Wh[own units, :]^T  (K = 4H)
+// ================================================================================================
+template <int NQ, int NW>       // 4H = 16 * NQ * NW
+__global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const SeqParams p) {
+    constexpr int H4 = 16 * NQ * NW, H = H4 / 4, KQ = 16 * NQ;
+    constexpr int UPT = 8 / NW;
+    constexpr int GQ = NQ < 8 ? NQ : (NW == 8 ? 4 : 8);     // A chunks in flight per register group
+    constexpr int LDR = 20;
+    __shared__ __attribute__((aligned(16))) float red[NW * 32 * LDR];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kb = lane >> 4;
+    const int cg = blockIdx.x, rg = blockIdx.y;
+    const int r0 = rg * 32, u0 = cg * 16;
+    const int ncg = gridDim.x;
+    const int B = p.B, T = p.T;
+    unsigned *cnt = p.sync + rg, *err = p.sync + p.nrg;
+
+    // ---- Wh[u0 + n, this wave's K range] as B fragments of the 16x16x4 MFMA (k-contiguous rows) ----------------
+    f32x4 bfr[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        bfr[q] = *reinterpret_cast<const f32x4 *>(p.wh + (int64_t)(u0 + li) * p.ldw + wave * KQ + 16 * q + 4 * kb);
+
+    const int crow = tid / (16 / UPT), cu = (tid % (16 / UPT)) * UPT;
+    const int grow = r0 + crow;
+    const bool valid = grow < B;
+    const int64_t sl = valid ? p.seq_len[grow] : 0;
+    float dcs[UPT], dhc[UPT];
+#pragma unroll
+    for (int e = 0; e < UPT; ++e) {
+        dcs[e] = 0.f;
+        dhc[e] = valid ? p.dh_last[(int64_t)grow * p.ld_dh + u0 + cu + e] : 0.f;      // gradient of h[T]
+    }
+
+    const __amdgpu_buffer_rsrc_t srd_g = srd_of(p.dgates, (unsigned)((int64_t)T * B * H4 * 4));
+    int arow[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) arow[rb] = (r0 + 16 * rb + li < B) ? r0 + 16 * rb + li : B - 1;
+
+    for (int t = T - 1; t >= 0; --t) {
+        float rec[UPT];
+#pragma unroll
+        for (int e = 0; e < UPT; ++e) rec[e] = 0.f;
+        if (t < T - 1) {
+            if (tid == 0) wait_counter(cnt, (unsigned)(T - 1 - t) * ncg, err);
+            __syncthreads();
+            f32x4 acc[2];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            unsigned abase[2];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+                abase[rb] = (unsigned)((((int64_t)(t + 1) * B + arow[rb]) * H4 + wave * KQ + 4 * kb) * 4);
+            f32x4 a[2][2][GQ];                              // [buffer][row block][chunk]
+            auto load_group = [&](int buf, int g0) {
+#pragma unroll
+                for (int q = 0; q < GQ; ++q)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+                        a[buf][rb][q] = __builtin_bit_cast(
+                            f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_g, abase[rb] + 64u * (g0 + q), 0, kSC1));
+            };
+            load_group(0, 0);
+#pragma unroll
+            for (int g = 0; g < NQ / GQ; ++g) {
+                if (g + 1 < NQ / GQ) load_group((g + 1) & 1, (g + 1) * GQ);
+#pragma unroll
+                for (int q = 0; q < GQ; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb)
+                            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g & 1][rb][q][j], bfr[g * GQ + q][j], acc[rb],
+                                                                           0, 0, 0);
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(wave * 32 + 16 * rb + 4 * kb + r) * LDR + li] = acc[rb][r];
+            __syncthreads();
+            if (valid) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int e = 0; e < UPT; ++e) rec[e] += red[(w * 32 + crow) * LDR + cu + e];
+            }
+        }
+        if (valid) {
+            const bool live = (int64_t)t < sl;
+            const int64_t gi = ((int64_t)t * B + grow) * H4 + u0 + cu;
+            const int64_t ci = ((int64_t)(t + 1) * B + grow) * H + u0 + cu;      // c_t = c[t+1], c_{t-1} = c[t]
+            float dg[4][UPT];
+#pragma unroll
+            for (int e = 0; e < UPT; ++e) {
+                const float dhv = dhc[e] + rec[e];
+                if (live) {
+                    const float si = p.gates[gi + e], tj = p.gates[gi + H + e];
+                    const float sf = p.gates[gi + 2 * H + e], so = p.gates[gi + 3 * H + e];
+                    const float tc = tanhf(p.c[ci + e]);
+                    const float dct = dcs[e] + dhv * so * (1.f - tc * tc);
+                    dg[0][e] = dct * tj * si * (1.f - si);
+                    dg[1][e] = dct * si * (1.f - tj * tj);
+                    dg[2][e] = dct * p.c[ci - (int64_t)B * H + e] * sf * (1.f - sf);
+                    dg[3][e] = dhv * tc * so * (1.f - so);
+                    dcs[e] = dct * sf;
+                    dhc[e] = 0.f;
+                } else {            // past seq_len the state was copied through: so is its gradient
+                    dg[0][e] = dg[1][e] = dg[2][e] = dg[3][e] = 0.f;
+                    dhc[e] = dhv;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) store_sc1<UPT>(p.dgates + gi + k * H, dg[k]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+typedef void (*SeqFn)(const SeqParams);
+
+struct SeqCfg {
+    SeqFn fwd, bwd;
+    int nw;
+};
+
+bool seq_cfg(int H, SeqCfg *c) {
+    switch (H) {
+        case 32: *c = {lstm_seq_fwd_kernel<1, 4>, lstm_seq_bwd_kernel<2, 4>, 4}; return true;
+        case 64: *c = {lstm_seq_fwd_kernel<2, 4>, lstm_seq_bwd_kernel<4, 4>, 4}; return true;
+        case 128: *c = {lstm_seq_fwd_kernel<4, 4>, lstm_seq_bwd_kernel<8, 4>, 4}; return true;
+        case 256: *c = {lstm_seq_fwd_kernel<8, 4>, lstm_seq_bwd_kernel<16, 4>, 4}; return true;
+        case 512: *c = {lstm_seq_fwd_kernel<16, 4>, lstm_seq_bwd_kernel<32, 4>, 4}; return true;
+        case 1024: *c = {lstm_seq_fwd_kernel<16, 8>, lstm_seq_bwd_kernel<32, 8>, 8}; return true;
+        default: return false;
+    }
+}
+
+int common_checks(const char *who, const void *a, const void *b, const void *c, int T, int B, int H, int ldw, void *ws,
+                  size_t ws_bytes) {
+    DS_REQUIRE(a && b && c && ws, "%s: null argument", who);
+    DS_REQUIRE(T > 0 && B > 0 && ds_lstm_seq_supported(B, H), "%s: unsupported size (H must be 32 ... 1024, a power of two)", who);
+    DS_REQUIRE(ldw >= 4 * H && ldw % 4 == 0 && (((uintptr_t)b) & 15) == 0, "%s: Wh must be 16-byte aligned with ldw %% 4 == 0", who);
+    DS_REQUIRE((int64_t)(T + 1) * B * 4 * H * 4 < (1ll << 31), "%s: sequence buffers above 2 GiB (split the batch)", who);
+    DS_REQUIRE(ws_bytes >= ds_lstm_seq_workspace(B, H), "%s: workspace too small", who);
+    return DS_OK;
+}
+
+}  // namespace
+
+extern "C" int ds_lstm_seq_supported(int32_t B, int32_t H) {
+    SeqCfg c;
+    return B > 0 && seq_cfg(H, &c) ? 1 : 0;
+}
+
+extern "C" size_t ds_lstm_seq_workspace(int32_t B, int32_t H) {
+    (void)H;
+    const int nrg = (B + 31) / 32;
+    return (size_t)(nrg + 1 + 3) / 4 * 16;       // arrival counter per row group + error word, 16-byte granules
+}
+
+extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float *h, float *c, const int64_t *seq_len,
+                               int32_t T, int32_t B, int32_t H, float forget_bias, void *ws, size_t ws_bytes,
+                               void *stream) {
+    if (int e = common_checks("ds_lstm_seq_fwd", gates, wh, h, T, B, H, ldw, ws, ws_bytes)) return e;
+    DS_REQUIRE(c && seq_len, "ds_lstm_seq_fwd: null argument");
+    SeqCfg cfg;
+    seq_cfg(H, &cfg);
+    SeqParams p = {};
+    p.gates = gates; p.wh = wh; p.ldw = ldw; p.h = h; p.c = c; p.seq_len = seq_len;
+    p.T = T; p.B = B; p.H = H; p.forget_bias = forget_bias;
+    p.nrg = (B + 31) / 32;
+    p.sync = (unsigned *)ws;
+    // every polled word is re-initialised by a memset node in front of the launch (Guideline 16)
+    if (hipMemsetAsync(ws, 0, ds_lstm_seq_workspace(B, H), (hipStream_t)stream) != hipSuccess)
+        return ds::check_launch("ds_lstm_seq_fwd(memset)");
+    hipLaunchKernelGGL(cfg.fwd, dim3(H / 16, p.nrg), dim3(64 * cfg.nw), 0, (hipStream_t)stream, p);
+    return ds::check_launch("ds_lstm_seq_fwd");
+}
+
+extern "C" int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, const float *c, const float *dh_last,
+                               int32_t ld_dh, const int64_t *seq_len, int32_t T, int32_t B, int32_t H, float *dgates,
+                               void *ws, size_t ws_bytes, void *stream) {
+    if (int e = common_checks("ds_lstm_seq_bwd", acts, wh, c, T, B, H, ldw, ws, ws_bytes)) return e;
+    DS_REQUIRE(dh_last && seq_len && dgates && ld_dh >= H, "ds_lstm_seq_bwd: bad argument");
+    SeqCfg cfg;
+    seq_cfg(H, &cfg);
+    SeqParams p = {};
+    p.gates = const_cast<float *>(acts); p.wh = wh; p.ldw = ldw; p.c = const_cast<float *>(c);
+    p.dh_last = dh_last; p.ld_dh = ld_dh; p.dgates = dgates; p.seq_len = seq_len;
+    p.T = T; p.B = B; p.H = H;
+    p.nrg = (B + 31) / 32;
+    p.sync = (unsigned *)ws;
+    if (hipMemsetAsync(ws, 0, ds_lstm_seq_workspace(B, H), (hipStream_t)stream) != hipSuccess)
+        return ds::check_launch("ds_lstm_seq_bwd(memset)");
+    hipLaunchKernelGGL(cfg.bwd, dim3(H / 16, p.nrg), dim3(64 * cfg.nw), 0, (hipStream_t)stream, p);
+    return ds::check_launch("ds_lstm_seq_bwd");
+}
+
+extern "C" int ds_lstm_seq_status(const void *ws, int32_t B) {
+    // host-side read of the error word of a FINISHED launch (the caller synchronised): 0 = ok, 1 = a hand-off
+    // wait timed out (a workgroup of the row group never became resident) and the results are invalid
+    unsigned v = 0;
+    const int nrg = (B + 31) / 32;
+    if (hipMemcpy(&v, (const unsigned *)ws + nrg, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return DS_ERR_LAUNCH;
+    return (int)v;
+}

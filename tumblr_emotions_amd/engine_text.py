@@ -5,7 +5,10 @@ Reference: image_text_model/im_text_rnn_model.py:71-105, text_model/text_embeddi
 MI355X-first choices:
   * the gather writes time-major rows so every LSTM step reads one contiguous [B, .] slab;
   * the input projection x_t*Wx+b is hoisted out of the recurrence into ONE GEMM over all T*B rows;
-    the recurrence does only h*Wh (accumulated onto the hoisted pre-activations) + the fused cell;
+    the recurrence itself is ONE persistent launch per direction (ds_lstm_seq_fwd / _bwd: Wh partitioned
+    over the workgroups as register-resident MFMA fragments, cell state in registers, h_t / dgates_t handed
+    between the workgroups of a 32-row group through write-through stores and an arrival counter); hidden
+    sizes the persistent kernel does not cover fall back to one GEMM + one cell launch per step;
   * the TF `kernel` [D+H,4H] is read in place: rows [0,D) are Wx, rows [D,D+H) are Wh;
   * h is carried through padded steps, so h[T] IS gather_nd(outputs, seq_len-1) (A8);
   * BPTT keeps dgates for all steps and does the two weight gradients as two big wgrad GEMMs
@@ -48,12 +51,15 @@ class TextTowerEngine:
         store.declare(self.BIAS, (4 * rnn_size,), True, bucket=1)
         self.B = None
         self.reducer = None          # dp.GradientReducer, set by SentimentNet
+        self.persistent = True       # False: force the step-wise recurrence (A/B and tests)
 
     def alloc(self, B):
         if self.B == B:
             return
         dev, T, D, H = self.device, self.T, self.D, self.H
         self.B = B
+        self.use_seq = self.persistent and ops.lstm_seq_supported(B, H)
+        self.seq_ws = torch.zeros(max(ops.lstm_seq_workspace(B, H) // 4, 4), dtype=torch.int32, device=dev)
         self.x = torch.empty(T * B, D, device=dev)                 # time-major embeddings
         self.gates = torch.empty(T, B, 4 * H, device=dev)          # pre-activations, then activations
         self.dgates = torch.empty(T, B, 4 * H, device=dev)
@@ -100,6 +106,9 @@ class TextTowerEngine:
         self.seq_lens, self.texts = seq_lens, texts
         ops.gather_rows(self.table, texts, self.x, B, T, self.D, time_major=True)
         self.xproj.run(ops._p(self.x), self.wx, ops._p(self.gates), bias=self.bias)
+        if self.use_seq:
+            ops.lstm_seq_fwd(self.gates, self.wh, 4 * H, self.h, self.c, seq_lens, T, B, H, FORGET_BIAS, self.seq_ws)
+            return self.h[T]
         slab = B * 4 * H
         for t in range(T):
             ns = 0
@@ -112,6 +121,10 @@ class TextTowerEngine:
 
     def backward(self, dh_last):
         B, T, H = self.B, self.T, self.H
+        if self.use_seq:
+            ops.lstm_seq_bwd(self.gates, self.wh, 4 * H, self.c, dh_last, dh_last.stride(0), self.seq_lens, T, B, H,
+                             self.dgates, self.seq_ws)
+            return self._weight_grads()
         dh, dh2 = self.dh
         ops.copy2d(dh_last, dh_last.stride(0), dh, H, B, H)
         ops.fill(self.dc, B * H, 0.0)
@@ -124,6 +137,10 @@ class TextTowerEngine:
                 self.rec_dgrad.run(ops._p(self.dgates[t]), self.wh, ops._p(self.dh_slabs))
                 ns = self.sb
             dh, dh2 = dh2, dh
+        self._weight_grads()
+
+    def _weight_grads(self):
+        B, T = self.B, self.T
         dg = ops._p(self.dgates)
         self.wgrad_x.run(ops._p(self.x), dg, self.gwx, ops._p(self.ws), self.ws_bytes)
         self.wgrad_h.run(ops._p(self.h), dg, self.gwh, ops._p(self.ws), self.ws_bytes)

@@ -264,6 +264,33 @@ def lstm_cell_bwd(acts, c_t, c_prev, dh, dc, seq_len, t, B, H, dgates, dc_prev, 
                                             _stream()), "ds_lstm_cell_bwd")
 
 
+def lstm_seq_supported(B, H):
+    return bool(_lib.load().ds_lstm_seq_supported(B, H))
+
+
+def lstm_seq_workspace(B, H):
+    return int(_lib.load().ds_lstm_seq_workspace(B, H))
+
+
+def lstm_seq_fwd(gates, wh_ptr, ldw, h, c, seq_len, T, B, H, forget_bias, ws):
+    _lib.check(_lib.load().ds_lstm_seq_fwd(_p(gates), wh_ptr, ldw, _p(h), _p(c), _p(seq_len), T, B, H, forget_bias,
+                                           _p(ws), ws.numel() * ws.element_size(), _stream()), "ds_lstm_seq_fwd")
+
+
+def lstm_seq_bwd(acts, wh_ptr, ldw, c, dh_last, ld_dh, seq_len, T, B, H, dgates, ws):
+    _lib.check(_lib.load().ds_lstm_seq_bwd(_p(acts), wh_ptr, ldw, _p(c), _p(dh_last), ld_dh, _p(seq_len), T, B, H,
+                                           _p(dgates), _p(ws), ws.numel() * ws.element_size(), _stream()),
+               "ds_lstm_seq_bwd")
+
+
+def lstm_seq_status(ws, B):
+    """0 = ok; call after a synchronise.  Raises on a hand-off timeout."""
+    rc = _lib.load().ds_lstm_seq_status(_p(ws), B)
+    if rc != 0:
+        raise RuntimeError("ds_lstm_seq: a workgroup hand-off timed out (status %d): results are invalid" % rc)
+    return rc
+
+
 def softmax_ce(logits, labels, B, C_, grad_scale, grad_scale_dev, loss, dlogits):
     _lib.check(_lib.load().ds_softmax_ce(_p(logits), _p(labels), B, C_, grad_scale, _p(grad_scale_dev), _p(loss),
                                          _p(dlogits), _stream()), "ds_softmax_ce")
