@@ -154,6 +154,10 @@ def main():
     ap.add_argument("--train-all", action="store_true",
                     help="optional full fine-tuning (not the BASELINE workload): every conv weight and the "
                          "embedding trainable; 9.032 GFLOP/sample joint (SURVEY 8d)")
+    ap.add_argument("--stepwise-lstm", action="store_true",
+                    help="A/B aid: one GEMM + one cell launch per LSTM step instead of the persistent ds_lstm_seq kernels")
+    ap.add_argument("--serial-towers", action="store_true",
+                    help="A/B aid: text tower on the main stream instead of concurrently with the image tower")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--cpu-warmup", type=int, default=3)
@@ -185,8 +189,10 @@ def main():
     T, V, D, H = 32, 10000, 300, 512
     net = SentimentNet(mode=args.mode, nb_emotions=15, im_features_size=256, rnn_size=H, fc_size=512, vocab_size=V,
                        embedding_dim=D, post_size=T, dropout_keep_prob=0.8, train_all=args.train_all,
-                       trainable_embedding=args.train_all)
+                       trainable_embedding=args.train_all, concurrent_towers=not args.serial_towers)
     net.initialize(seed=1)
+    if args.stepwise_lstm and net.text is not None:
+        net.text.persistent = False
     strong = args.global_batch > 0
     if strong:
         assert args.global_batch % world == 0, "--global-batch must divide by the number of ranks"

@@ -216,6 +216,9 @@ int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, const float
                     int32_t ld_dh, const int64_t *seq_len, int32_t T, int32_t B, int32_t H, float *dgates, void *ws,
                     size_t ws_bytes, void *stream);
 int ds_lstm_seq_status(const void *ws, int32_t B);
+/* Tuning aid: device buffer of T*8 uint64; workgroup (0,0) of the following ds_lstm_seq_fwd launches stamps
+ * s_memtime at its phase boundaries (scripts/lstm_phase_prof.py).  NULL = off (default).   */
+int ds_lstm_seq_set_profile(void *buf);
 
 /* slim.losses.softmax_cross_entropy + its gradient (im_text_rnn_model.py:124-125):
  * loss[0] = mean_b(logsumexp(z_b) - z_b[y_b]); dlogits = (softmax - onehot) * grad_scale / B;

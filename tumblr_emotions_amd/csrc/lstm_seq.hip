@@ -20,6 +20,7 @@
 //     gradients in two big wgrad GEMMs behind (ds_conv_wgrad), as before.
 // Numerics: fp32 MFMA (v_mfma_f32_32x32x2_f32 forward, v_mfma_f32_16x16x4_f32 backward), the K reduction split
 // in NW fixed slices summed in a fixed order: deterministic; matches the step-wise path to rounding.
+#include <stdlib.h>
 #include "ds_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -45,7 +46,14 @@ struct SeqParams {
     float forget_bias;
     unsigned *sync;            // [row groups] arrival counters, then one error word
     int nrg;
+    unsigned long long *prof;  // tuning aid (ds_lstm_seq_set_profile): workgroup (0,0) stamps its phases, [T][8]
 };
+
+#define DS_STAMP(slot)                                                                  \
+    do {                                                                                \
+        if (p.prof && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)                   \
+            p.prof[(int64_t)t * 8 + (slot)] = __builtin_amdgcn_s_memtime();             \
+    } while (0)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t srd_of(const void *p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
@@ -134,10 +142,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
 #pragma unroll
                 for (int e = 0; e < UPT; ++e) gp[k][e] = g[k * H + e];
         }
+        DS_STAMP(0);
         if (t > 0) {                                        // h[t] of the whole row group must have landed
             if (tid == 0) wait_counter(cnt, (unsigned)t * ncg, err);
             __syncthreads();
         }
+        DS_STAMP(1);
         // ---- A fragments straight from h[t] (sc1: past the L1, which other CUs' stores never refresh) --------
         f32x4 a[NCH];
         const unsigned abase = (unsigned)((((int64_t)t * B + arow) * H + wave * KQ + 4 * kh) * 4);
@@ -162,7 +172,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * LDR + 32 * cb + li] = acc[cb][r];
+        DS_STAMP(2);
         __syncthreads();
+        DS_STAMP(3);
+        float act[4][UPT], hn[UPT];
         if (valid) {
 #pragma unroll
             for (int w = 0; w < NW; ++w)
@@ -171,7 +184,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
 #pragma unroll
                     for (int e = 0; e < UPT; ++e) gp[k][e] += red[(w * 32 + crow) * LDR + 16 * k + cu + e];
             const bool live = (int64_t)t < sl;
-            float act[4][UPT], hn[UPT], cn[UPT];
 #pragma unroll
             for (int e = 0; e < UPT; ++e) {
                 const float si = sigm(gp[0][e]), tj = tanhf(gp[1][e]);
@@ -179,9 +191,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
                 const float c_new = cst[e] * sf + si * tj;
                 const float h_new = tanhf(c_new) * so;
                 act[0][e] = si; act[1][e] = tj; act[2][e] = sf; act[3][e] = so;
-                cst[e] = cn[e] = live ? c_new : cst[e];      // dynamic_rnn copies the state through past seq_len
+                cst[e] = live ? c_new : cst[e];      // dynamic_rnn copies the state through past seq_len
                 hst[e] = hn[e] = live ? h_new : hst[e];
             }
+            const int64_t o = ((int64_t)(t + 1) * B + grow) * H + u0 + cu;
+            store_sc1<UPT>(p.h + o, hn);                     // the hand-off payload goes first ...
+        }
+        DS_STAMP(4);
+        // ---- publish: every storing wave drains, then one lane counts this workgroup in ----------------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DS_STAMP(5);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DS_STAMP(6);
+        if (valid) {                                        // ... what only later kernels read stays off the critical path
             float *g = p.gates + ((int64_t)t * B + grow) * 4 * H + u0 + cu;
             const int64_t o = ((int64_t)(t + 1) * B + grow) * H + u0 + cu;
 #pragma unroll
@@ -189,13 +212,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
 #pragma unroll
                 for (int e = 0; e < UPT; ++e) g[k * H + e] = act[k][e];
 #pragma unroll
-            for (int e = 0; e < UPT; ++e) p.c[o + e] = cn[e];
-            store_sc1<UPT>(p.h + o, hn);
+            for (int e = 0; e < UPT; ++e) p.c[o + e] = cst[e];
         }
-        // ---- publish: every storing wave drains, then one lane counts this workgroup in ----------------------
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -323,6 +341,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
 }
 
 typedef void (*SeqFn)(const SeqParams);
+unsigned long long *g_prof = nullptr;
 
 struct SeqCfg {
     SeqFn fwd, bwd;
@@ -339,6 +358,22 @@ bool seq_cfg(int H, SeqCfg *c) {
         case 1024: *c = {lstm_seq_fwd_kernel<16, 8>, lstm_seq_bwd_kernel<32, 8>, 8}; return true;
         default: return false;
     }
+}
+
+// One workgroup per CU: two co-resident workgroups would share the CU's four matrix pipes and finish their step
+// late, and the whole row group waits for its slowest member (measured: ~3.5 us of a 15 us step was this skew).
+// Residency is limited through the LDS request: static reduction buffer + this dynamic pad > half of 160 KiB.
+// DS_LSTM_SHARED_CU=1 switches the pad off (A/B aid).
+size_t exclusive_lds(int nw, bool fwd) {
+    static int shared_cu = -1;
+    if (shared_cu < 0) {
+        const char *e = getenv("DS_LSTM_SHARED_CU");
+        shared_cu = e ? atoi(e) : 0;
+    }
+    if (shared_cu) return 0;
+    const size_t stat = (size_t)nw * 32 * (fwd ? 68 : 20) * 4;
+    const size_t want = 84 * 1024;
+    return stat >= want ? 0 : want - stat;
 }
 
 int common_checks(const char *who, const void *a, const void *b, const void *c, int T, int B, int H, int ldw, void *ws,
@@ -376,10 +411,11 @@ extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float
     p.T = T; p.B = B; p.H = H; p.forget_bias = forget_bias;
     p.nrg = (B + 31) / 32;
     p.sync = (unsigned *)ws;
+    p.prof = g_prof;
     // every polled word is re-initialised by a memset node in front of the launch (Guideline 16)
     if (hipMemsetAsync(ws, 0, ds_lstm_seq_workspace(B, H), (hipStream_t)stream) != hipSuccess)
         return ds::check_launch("ds_lstm_seq_fwd(memset)");
-    hipLaunchKernelGGL(cfg.fwd, dim3(H / 16, p.nrg), dim3(64 * cfg.nw), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(cfg.fwd, dim3(H / 16, p.nrg), dim3(64 * cfg.nw), exclusive_lds(cfg.nw, true), (hipStream_t)stream, p);
     return ds::check_launch("ds_lstm_seq_fwd");
 }
 
@@ -398,7 +434,7 @@ extern "C" int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, 
     p.sync = (unsigned *)ws;
     if (hipMemsetAsync(ws, 0, ds_lstm_seq_workspace(B, H), (hipStream_t)stream) != hipSuccess)
         return ds::check_launch("ds_lstm_seq_bwd(memset)");
-    hipLaunchKernelGGL(cfg.bwd, dim3(H / 16, p.nrg), dim3(64 * cfg.nw), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(cfg.bwd, dim3(H / 16, p.nrg), dim3(64 * cfg.nw), exclusive_lds(cfg.nw, false), (hipStream_t)stream, p);
     return ds::check_launch("ds_lstm_seq_bwd");
 }
 
@@ -409,4 +445,11 @@ extern "C" int ds_lstm_seq_status(const void *ws, int32_t B) {
     const int nrg = (B + 31) / 32;
     if (hipMemcpy(&v, (const unsigned *)ws + nrg, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return DS_ERR_LAUNCH;
     return (int)v;
+}
+
+// Tuning aid (not part of the product path): device buffer of T*8 uint64 in which workgroup (0,0) of the NEXT
+// ds_lstm_seq_fwd launches stamps s_memtime at its phase boundaries; NULL switches it off.
+extern "C" int ds_lstm_seq_set_profile(void *buf) {
+    g_prof = (unsigned long long *)buf;
+    return DS_OK;
 }

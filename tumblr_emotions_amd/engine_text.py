@@ -140,7 +140,7 @@ class TextTowerEngine:
         self._weight_grads()
 
     def _weight_grads(self):
-        B, T = self.B, self.T
+        B, T, H = self.B, self.T, self.H
         dg = ops._p(self.dgates)
         self.wgrad_x.run(ops._p(self.x), dg, self.gwx, ops._p(self.ws), self.ws_bytes)
         self.wgrad_h.run(ops._p(self.h), dg, self.gwh, ops._p(self.ws), self.ws_bytes)
