@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_SAMPLE = 6.169          # fwd+bwd, reference-faithful freeze (BASELINE.md section 2 / SURVEY 8d)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA, same guide (never the 2:1-sparsity figure)
 
 
 def _physical_cores():
@@ -132,7 +133,7 @@ def pmc_traffic(args):
     FETCH doubled as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the timed
     process, so the figure is null unless a profile of the default workload is present."""
     import glob
-    if args.batch != 256 or args.mode != "joint" or args.gpus != 1 or args.train_all:
+    if args.batch != 256 or args.mode != "joint" or args.gpus != 1 or args.train_all or args.dtype != "f32":
         return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
@@ -154,6 +155,9 @@ def main():
     ap.add_argument("--train-all", action="store_true",
                     help="optional full fine-tuning (not the BASELINE workload): every conv weight and the "
                          "embedding trainable; 9.032 GFLOP/sample joint (SURVEY 8d)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32: the headline (exact fp32 MFMA, 1e-3 parity path).  bf16: SEPARATE, labelled line -- conv "
+                         "forward/dgrad multiplies on the bf16 matrix pipe, fp32 storage/accumulate/statistics/masters")
     ap.add_argument("--stepwise-lstm", action="store_true",
                     help="A/B aid: one GEMM + one cell launch per LSTM step instead of the persistent ds_lstm_seq kernels")
     ap.add_argument("--serial-towers", action="store_true",
@@ -189,7 +193,8 @@ def main():
     T, V, D, H = 32, 10000, 300, 512
     net = SentimentNet(mode=args.mode, nb_emotions=15, im_features_size=256, rnn_size=H, fc_size=512, vocab_size=V,
                        embedding_dim=D, post_size=T, dropout_keep_prob=0.8, train_all=args.train_all,
-                       trainable_embedding=args.train_all, concurrent_towers=not args.serial_towers)
+                       trainable_embedding=args.train_all, concurrent_towers=not args.serial_towers,
+                       dtype=args.dtype)
     net.initialize(seed=1)
     if args.stepwise_lstm and net.text is not None:
         net.text.persistent = False
@@ -262,9 +267,14 @@ def main():
             n, ms, flops = timer.summary()
             ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic, traffic_src = pmc_traffic(args)
-            roof = dict(bound="mfma", kernel="conv_igemm_kernel + conv_glds_kernel (ds_conv_igemm: fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; conv fwd, dgrad, GEMMs)",
-                        achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_unit="HBM bytes per launch",
+            peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
+            kname = ("conv_bf16_kernel (ds_conv_igemm, DS_DTYPE_BF16: v_mfma_f32_32x32x16_bf16 implicit GEMM, fp32 accumulate; conv "
+                     "fwd + dgrad) together with the fp32 GEMMs of the LSTM / heads launched through the same entry point"
+                     if args.dtype == "bf16" else
+                     "conv_igemm_kernel + conv_glds_kernel (ds_conv_igemm: fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; conv fwd, dgrad, GEMMs)")
+            roof = dict(bound="mfma", kernel=kname,
+                        achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
+                        frac=round(ach / peak, 4), traffic=traffic, traffic_unit="HBM bytes per launch",
                         traffic_source=traffic_src, alg_flops_per_launch=round(flops / max(n, 1)),
                         achieved_towers_serialised=isolated,
                         launches_per_step=n // max(args.steps, 1), avg_launch_us=round(1e3 * ms / max(n, 1), 2),
@@ -272,18 +282,20 @@ def main():
                         timing_pass="second pass of the same %d steps with HIP events around every launch "
                                     "(%.3f ms/step with events); the headline pass carries none" % (args.steps, 1e3 * dt_events / args.steps),
                         whole_step_tflops=round(value * flop_per_sample / 1e3, 2),
-                        whole_step_frac=round(value * flop_per_sample / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4))
+                        whole_step_frac=round(value * flop_per_sample / 1e3 / peak, 4))
         out = {
             "metric": "training samples/sec (224x224 img + 32-tok text, batch 256)",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "sec_per_step": round(dt / args.steps, 5), "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "sec_per_step": round(dt / args.steps, 5), "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s train step (fwd+bwd+all-reduce+Adam): Inception-v1 224x224x3 + 300-d embedding + "
                                    "LSTM-512, T=32, V=10000, 15 classes, batch %d per GPU, %s, dropout 0.8, BN train mode"
                                    % (args.mode, args.batch,
                                       "FULL FINE-TUNING (every conv weight and the embedding trainable: NOT the "
                                       "BASELINE workload)" if args.train_all else
-                                      "reference freeze (<=Mixed_5b conv weights frozen, all BN betas trainable)"),
+                                      "reference freeze (<=Mixed_5b conv weights frozen, all BN betas trainable)")
+                                   + (", conv fwd/dgrad multiplies in bf16 (fp32 storage, accumulation, statistics, master "
+                                      "weights; NOT the fp32 parity configuration)" if args.dtype == "bf16" else ""),
                        "global_batch": gb, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
                        "gflop_per_sample": flop_per_sample, "final_loss": round(loss, 5)},
             "roofline": roof,

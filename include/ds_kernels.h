@@ -30,6 +30,11 @@ extern "C" {
 #define DS_ERR_LAUNCH (-2)
 #define DS_ERR_WORKSPACE (-3)
 
+/* arithmetic type of the multiply in ds_conv_igemm (ds_conv_desc.dtype); storage and accumulation stay fp32 */
+#define DS_DTYPE_F32 0     /* v_mfma_f32_32x32x2_f32: exact fp32 (the 1e-3 parity path)                         */
+#define DS_DTYPE_BF16 1    /* v_mfma_f32_32x32x16_bf16: operands rounded to bf16 on the way into LDS, fp32      */
+                           /* accumulate, fp32 z / BatchNorm statistics / master weights (BASELINE configs[4]) */
+
 /* epilogue flags of ds_conv_igemm */
 #define DS_EPI_BIAS 1      /* z += bias[col]                       (BiasAdd)                        */
 #define DS_EPI_RELU 2      /* z = max(z, 0)                        (tf.nn.relu)                     */
@@ -72,6 +77,7 @@ typedef struct ds_conv_desc {
     int32_t tile_nt;          /* 0: automatic.  1..6: workgroup tile is 128 rows x 32*tile_nt columns  */
     int32_t grid_x;           /* 0: automatic.  >0: persistent workgroups per column tile (each walks  */
                               /* row tiles blockIdx.x, +grid_x, ...); also the stats partial count P   */
+    int32_t dtype;            /* DS_DTYPE_F32 (0, default) or DS_DTYPE_BF16                             */
 } ds_conv_desc;
 
 /* Tuning aid: pin the workgroup tile to (128*mt) x (32*nt) rows x columns; 0,0 = automatic.  */

@@ -164,6 +164,96 @@ def test_gemm_lstm_shape():
     close(dh, dg @ kern[40:].T)
 
 
+def _bf16_round(a):
+    """round-to-nearest-even to bfloat16, returned as float64 (what v_cvt_pk_bf16_f32 does to the operands)"""
+    u = np.asarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).astype(np.float64)
+
+
+BF16_CASES = [
+    # (N, H, W, Cin, Cout, k, stride)
+    (2, 9, 9, 16, 32, 1, 1),
+    (3, 14, 14, 24, 64, 3, 1),       # Cin not a multiple of the 32-wide K tile
+    (2, 28, 28, 96, 128, 3, 1),
+    (4, 7, 7, 832, 624, 1, 1),       # several 128-wide column tiles, ragged last one
+    (2, 13, 11, 48, 176, 3, 1),
+    (1, 8, 8, 8, 200, 1, 1),
+    (2, 10, 10, 20, 12, 3, 2),
+    (2, 150, 150, 16, 96, 3, 1),     # 3-wide column tile
+    (2, 370, 370, 8, 64, 3, 1),      # M = 273800: the persistent launch path (one workgroup walks several row tiles)
+]
+
+
+@pytest.mark.parametrize("case", BF16_CASES)
+def test_conv_bf16_forward_dgrad_match_oracle(case):
+    """DS_DTYPE_BF16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate): forward with BatchNorm statistics and the dgrad
+    of the same geometry.  Two gates: (a) against the fp64 oracle evaluated on bf16-ROUNDED operands the result is
+    fp32-accumulation exact (2e-4 of max|ref|) -- layout, transposition, tails, statistics all right; (b) against
+    the oracle on the unrounded operands the documented bf16 tolerance, 1e-2 of max|ref|."""
+    ops = _ops()
+    N, H, W, Ci, Co, k, s = case
+    rng = np.random.RandomState(3)
+    x = rng.normal(size=(N, H, W, Ci))
+    w = rng.normal(size=(k, k, Ci, Co)) * 0.1
+    ref_exact = S.conv2d_same(x, w, s)
+    ref_round = S.conv2d_same(_bf16_round(x), _bf16_round(w), s)
+    xd, wd = dev(x), dev(w)
+    plan = ops.ConvPlan(N, H, W, Ci, Ci, k, k, s, Co, Co, Ci * Co, 1, Co, flags=ops.DS_EPI_STATS, dtype=ops.DS_DTYPE_BF16)
+    M = plan.M
+    z = torch.empty(M, Co, device="cuda")
+    stats = torch.zeros(2, Co, plan.partials, device="cuda")
+    plan.run(ops._p(xd), ops._p(wd), ops._p(z), stats=ops._p(stats))
+    torch.cuda.synchronize()
+    close(z, ref_round.reshape(M, Co), 2e-4)
+    close(z, ref_exact.reshape(M, Co), 1e-2)
+    zz = ref_round.reshape(M, Co)
+    close(stats[0].sum(1), zz.sum(0), 2e-3)
+    close(stats[1].sum(1), (zz ** 2).sum(0), 2e-3)
+    if s == 1:
+        dy = rng.normal(size=ref_exact.shape)
+        g = ops.ConvPlan(N, H, W, Co, Co, k, k, 1, Ci, Ci, Ci * Co, Co, 1, flip=1, dtype=ops.DS_DTYPE_BF16)
+        dx = torch.empty(g.M, Ci, device="cuda")
+        dyd = dev(dy)
+        g.run(ops._p(dyd), ops._p(wd), ops._p(dx))
+        torch.cuda.synchronize()
+        close(dx, S.conv2d_same_bwd_input(_bf16_round(dy), _bf16_round(w), (N, H, W, Ci), 1).reshape(-1, Ci), 2e-4)
+        close(dx, S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1).reshape(-1, Ci), 1e-2)
+
+
+def test_conv_bf16_folded_stem_and_epilogues():
+    """The 7x7/2 stem through its folded 4-channel input, and the bias / relu / accumulate / mask epilogues, on
+    the bf16 matrix pipe."""
+    ops = _ops()
+    rng = np.random.RandomState(4)
+    N, H, Co = 2, 64, 64
+    x = rng.uniform(-1, 1, size=(N, H, H, 3))
+    w = rng.normal(size=(7, 7, 3, Co)) * 0.1
+    ref = S.conv2d_same(_bf16_round(x), _bf16_round(w), 2)
+    x4 = np.zeros((N, H, H, 4)); x4[..., :3] = x
+    w4 = np.zeros((7, 7, 4, Co)); w4[:, :, :3] = w
+    plan = ops.ConvPlan(N, H, H, 7 * 4, 4, 7, 1, 2, Co, Co, 28 * Co, 1, Co, fold_cin=4, dtype=ops.DS_DTYPE_BF16)
+    z = torch.empty(plan.M, Co, device="cuda")
+    xd, wd = dev(x4), dev(w4)
+    plan.run(ops._p(xd), ops._p(wd), ops._p(z))
+    torch.cuda.synchronize()
+    close(z, ref.reshape(plan.M, Co), 2e-4)
+    # GEMM with bias + relu, then accumulate + mask
+    M, K, Nn = 300, 72, 40
+    a, b, bias = rng.normal(size=(M, K)), rng.normal(size=(K, Nn)) * 0.2, rng.normal(size=Nn)
+    prev, mask = rng.normal(size=(M, Nn)), (rng.uniform(size=(M, Nn)) < 0.5).astype(np.float64)
+    ad, bd, biasd, maskd = dev(a), dev(b), dev(bias), dev(mask)
+    core = _bf16_round(a) @ _bf16_round(b)
+    out = torch.empty(M, Nn, device="cuda")
+    ops.gemm_plan(M, K, Nn, K, Nn, Nn, flags=ops.DS_EPI_BIAS | ops.DS_EPI_RELU, dtype=ops.DS_DTYPE_BF16).run(
+        ops._p(ad), ops._p(bd), ops._p(out), bias=ops._p(biasd))
+    close(out, np.maximum(core + bias, 0), 2e-4)
+    acc = dev(prev)
+    ops.gemm_plan(M, K, Nn, K, Nn, Nn, flags=ops.DS_EPI_ACCUM | ops.DS_EPI_MASK, ldmask=Nn, dtype=ops.DS_DTYPE_BF16).run(
+        ops._p(ad), ops._p(bd), ops._p(acc), mask=ops._p(maskd))
+    close(acc, (core + prev) * mask, 2e-4)
+
+
 @pytest.mark.parametrize("case", [(8, 6, 32), (37, 9, 64), (64, 12, 128), (256, 32, 512), (33, 5, 1024), (5, 50, 256)])
 def test_lstm_sequence_kernels_match_oracle(case):
     """ds_lstm_seq_fwd / ds_lstm_seq_bwd (whole recurrence in one persistent launch per direction) against the

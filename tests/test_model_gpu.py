@@ -282,6 +282,39 @@ def test_joint_step_b16_follows_oracle_along_same_decisions():
         assert (np.abs(after[name].reshape(w_ref.shape) - w_ref)[big] <= 1e-5).mean() >= 0.99, name
 
 
+def test_joint_step_bf16_multiply_documented_tolerance():
+    """dtype='bf16' (BASELINE configs[4] groundwork): the 57 convs' forward and dgrad multiplies on the bf16 matrix
+    pipe, everything else fp32.  Not the 1e-3 parity path: against the fp64 oracle (along the HIP decisions) the
+    documented tolerance is 3e-2 on logits and loss and 10 % relative L2 on the gradients (bf16 operand rounding,
+    2^-9 relative per operand, through 22 layers forward and back); the numbers measured on MI355X are printed and
+    recorded in DESIGN.md."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from hip_decisions import hip_decisions
+    rng = np.random.RandomState(61)
+    V, D, H, T, B = 60, 20, 32, 12, 8
+    params = R.make_params("joint", rng, num_classes=15, im_features_size=256, embed_dim=D, rnn_size=H,
+                           fc_size=512, dtype=np.float64)
+    emb = S.synthetic_embedding(V, D).astype(np.float64)
+    batch = S.synthetic_batch(B, T, V, seed=19)
+    net = SentimentNet(mode="joint", nb_emotions=15, im_features_size=256, rnn_size=H, fc_size=512, vocab_size=V,
+                       embedding_dim=D, post_size=T, dropout_keep_prob=1.0, dtype="bf16")
+    net.load_state_dict(dict(params, **{"Text/W_embedding": emb}))
+    net.train_step(_dev_batch(batch), 1e-3)
+    torch.cuda.synchronize()
+    ref = R.DeepSentimentRef(params, emb, "joint", torch.float64)
+    ref.inject = hip_decisions(net)
+    out = ref.train_step(batch, 1e-3)
+    dl = float(np.abs(net.logits.detach().cpu().numpy() - out["logits"].numpy()).max())
+    dloss = abs(net.total_loss_value() - out["loss"])
+    grads = net.grads_state_dict()
+    rels = sorted((float(np.linalg.norm(grads[n].reshape(g.shape) - g.numpy()) / max(float(g.norm()), 1e-30)), n)
+                  for n, g in out["grads"].items())
+    print("bf16 multiply vs fp64 oracle: max|dlogits| %.3e, |dloss| %.3e, gradient relative L2 median %.3e, worst %.3e (%s)"
+          % (dl, dloss, rels[len(rels) // 2][0], rels[-1][0], rels[-1][1]))
+    assert dl <= 3e-2 and dloss <= 3e-2
+    assert rels[-1][0] <= 0.10
+
+
 def test_frozen_beta_switch_stops_backward_at_mixed_5c():
     """trainable_bn_beta=False (SURVEY A4 switch): only Mixed_5c + Logits receive gradients."""
     from tumblr_emotions_amd.net import SentimentNet

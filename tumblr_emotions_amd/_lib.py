@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libds_kernels.so")
 
 DS_EPI_BIAS, DS_EPI_RELU, DS_EPI_ACCUM, DS_EPI_STATS, DS_EPI_MASK = 1, 2, 4, 8, 16
+DS_DTYPE_F32, DS_DTYPE_BF16 = 0, 1
 
 
 class ConvDesc(C.Structure):
@@ -20,7 +21,7 @@ class ConvDesc(C.Structure):
         ("w_tap_stride", C.c_int64), ("w_n_stride", C.c_int32), ("w_k_stride", C.c_int32),
         ("flip", C.c_int32), ("fold_cin", C.c_int32), ("flags", C.c_int32), ("ldmask", C.c_int32),
         ("splits", C.c_int32), ("z_split_stride", C.c_int64),
-        ("tile_nt", C.c_int32), ("grid_x", C.c_int32),
+        ("tile_nt", C.c_int32), ("grid_x", C.c_int32), ("dtype", C.c_int32),
     ]
 
 

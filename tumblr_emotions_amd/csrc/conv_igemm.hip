@@ -26,6 +26,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector (HIP's float4 is a struct)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -854,11 +855,251 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? 3 : 2)) void conv_gld
     }
 }
 
+
+// ================================================================================================
+// bf16-multiply variant (ds_conv_desc.dtype == DS_DTYPE_BF16): v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+//
+// BASELINE configs[4] groundwork.  Storage is unchanged -- activations, weights (masters), BatchNorm statistics
+// and z stay fp32 in HBM -- only the multiply runs on the bf16 matrix pipe (16x the fp32 MFMA rate): operands are
+// rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on their way from the staging registers into LDS.
+// Same implicit GEMM, same SRD loads with hardware zero fill, same epilogue (bias / accumulate / mask / relu /
+// BatchNorm column statistics about the pivot, all in fp32 from the fp32 accumulators).
+//   * K-tile 32 channels of one tap; both tiles live in LDS as [row][k] bf16 rows of 64 B padded to 80 B
+//     (20-bank row stride: the sixteen rows of a ds_read_b128 lane group cover the 64 banks exactly once);
+//   * A fragment of the 32x32x16 MFMA = lane (i, kh) holds A[i][8 kh .. 8 kh + 7] = one ds_read_b128; the B tile is
+//     stored [n][k] for both weight layouts (n-contiguous HWIO weights are transposed on the LDS store by packing
+//     the (k, k+1) pair of each of the four columns of a float4 into one dword);
+//   * at 16x the matrix rate the loop is bound by operand staging, so tiles are 128 x 128 (NT = 4) wherever Cout
+//     allows: 32 KB of fp32 operands staged per 1 MFLOP.
+// Numerics: products of bf16-rounded operands, exact fp32 accumulation in k order; against the fp32 path the
+// relative error is ~2^-9 per operand (documented tolerance of the bf16 parity tests: 1e-2 of max |ref|).
+// ================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int HK = 32;       // K-tile (channels)
+constexpr int HLD = 40;      // LDS row stride in bf16 elements (80 B)
+
+template <int NT, bool BNMAJOR, bool FOLD>
+__global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void conv_bf16_kernel(const ConvParams p) {
+    constexpr int BM = 128, BN = NT * 32;
+    constexpr int AJ = 4;                                                // float4 A loads per thread per K-tile
+    constexpr int BP = BNMAJOR ? (4 * BN + 255) / 256 : 0;               // (k, k+1) x float4(n) pairs per thread
+    constexpr int BJ = BNMAJOR ? 0 : BN / 32;                            // float4(k) loads per thread
+    constexpr int NB = BNMAJOR ? 2 * BP : BJ;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * BM * HLD + 2 * BN * HLD];
+    __bf16 *As = smem;
+    __bf16 *Bs = smem + 2 * BM * HLD;
+
+    const ds_conv_desc &d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kh = lane >> 5;
+    const TileId tid0 = tile_id(p);
+    const int n0 = tid0.col * BN;
+    const int ohw = d.OH * d.OW;
+    const int chunks = (d.Cin + HK - 1) / HK;
+    const int KT = p.taps * chunks;
+    float *const zout = p.z;
+    const int flags = d.flags;
+    const __amdgpu_buffer_rsrc_t srd_x = make_srd(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t srd_w = make_srd(p.w, p.w_bytes);
+
+    float csum[NT], csq[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) csum[j] = csq[j] = 0.f;
+
+    const int srow = tid >> 3, c4 = (tid & 7) * 4;        // A slot: rows srow + 32 j, channels c4 .. c4 + 3 of the K-tile
+    int ih0[AJ], iw0[AJ];
+    unsigned xb[AJ];
+    int tap, c0, dh, dw;
+    f32x4 ra[AJ], rb[NB > 0 ? NB : 1];
+    f32x16 acc[NT];
+
+    auto setup_tile = [&](int tile) {
+        const int m0 = tile * BM;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int m = m0 + srow + 32 * j;
+            const bool rv = m < p.M;
+            const int mm = rv ? m : 0;
+            const int n = mm / ohw;
+            const int r = mm - n * ohw;
+            const int oh = r / d.OW;
+            const int ow = r - oh * d.OW;
+            ih0[j] = rv ? oh * d.stride - d.pad_t : -(1 << 20);
+            iw0[j] = ow * d.stride - d.pad_l;
+            xb[j] = (unsigned)n * (unsigned)(d.H * d.W) * (unsigned)d.ldx;
+        }
+        tap = 0; c0 = 0; dh = 0; dw = 0;                  // channel chunk outer, tap inner (as the fp32 kernels)
+    };
+
+    auto load_tile = [&]() {
+        const int k = c0 + c4;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int ih = ih0[j] + dh;
+            const int iw = iw0[j] + dw;
+            const int iwc = FOLD ? iw + k / d.fold_cin : iw;
+            const bool ok = (unsigned)ih < (unsigned)d.H && (unsigned)iwc < (unsigned)d.W && k < d.Cin;
+            const unsigned off = xb[j] + (unsigned)(ih * d.W + iw) * (unsigned)d.ldx + (unsigned)k;
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, ok ? off * 4u : kOOB, 0, 0));
+        }
+        const int tap_eff = d.flip ? p.taps - 1 - tap : tap;
+        const unsigned wt = (unsigned)tap_eff * (unsigned)d.w_tap_stride;
+        if (BNMAJOR) {
+#pragma unroll
+            for (int i = 0; i < BP; ++i) {
+                const int pi = tid + 256 * i;
+                const int kp = pi / (BN / 4), n4 = pi - kp * (BN / 4);
+                const int kk = c0 + 2 * kp, nn = n0 + 4 * n4;
+                const bool okn = pi < 4 * BN && nn < d.Cout;
+                const unsigned off = wt + (unsigned)kk * (unsigned)d.w_k_stride + (unsigned)nn;
+                rb[2 * i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_w, (okn && kk < d.Cin) ? off * 4u : kOOB, 0, 0));
+                rb[2 * i + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       srd_w, (okn && kk + 1 < d.Cin) ? (off + (unsigned)d.w_k_stride) * 4u : kOOB, 0, 0));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BJ; ++i) {
+                const int nn = n0 + srow + 32 * i;
+                const bool ok = nn < d.Cout && k < d.Cin;
+                const unsigned off = wt + (unsigned)nn * (unsigned)d.w_n_stride + (unsigned)k;
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_w, ok ? off * 4u : kOOB, 0, 0));
+            }
+        }
+        ++tap;
+        if (++dw == d.KW) {
+            dw = 0;
+            if (++dh == d.KH) { dh = 0; tap = 0; c0 += HK; }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        __bf16 *a_s = As + buf * BM * HLD;
+        __bf16 *b_s = Bs + buf * BN * HLD;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j)
+            *reinterpret_cast<bf16x4 *>(a_s + (srow + 32 * j) * HLD + c4) = __builtin_convertvector(ra[j], bf16x4);
+        if (BNMAJOR) {
+#pragma unroll
+            for (int i = 0; i < BP; ++i) {
+                const int pi = tid + 256 * i;
+                const int kp = pi / (BN / 4), n4 = pi - kp * (BN / 4);
+                if (pi < 4 * BN) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const f32x2 pr = {rb[2 * i][jj], rb[2 * i + 1][jj]};
+                        *reinterpret_cast<bf16x2 *>(b_s + (4 * n4 + jj) * HLD + 2 * kp) = __builtin_convertvector(pr, bf16x2);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BJ; ++i)
+                *reinterpret_cast<bf16x4 *>(b_s + (srow + 32 * i) * HLD + c4) = __builtin_convertvector(rb[i], bf16x4);
+        }
+    };
+
+    auto compute = [&](int buf) {
+        const __bf16 *a_s = As + buf * BM * HLD + (wm * 32 + li) * HLD + kh * 8;
+        const __bf16 *b_s = Bs + buf * BN * HLD + li * HLD + kh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(a_s + ks * 16);
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const bf16x8 w = *reinterpret_cast<const bf16x8 *>(b_s + b * 32 * HLD + ks * 16);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, acc[b], 0, 0, 0);
+            }
+        }
+    };
+
+    int par = 0;
+    if (tid0.row < p.row_tiles) {
+        setup_tile(tid0.row);
+        load_tile();
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int tile = tid0.row; tile < p.row_tiles; tile += tid0.stride) {
+        const int m0 = tile * BM;
+        const bool has_next = tile + tid0.stride < p.row_tiles;
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        for (int kt = 0; kt < KT; ++kt) {
+            const bool last = kt + 1 == KT;
+            if (last && has_next) setup_tile(tile + tid0.stride);
+            const bool fetch = !last || has_next;
+            if (fetch) load_tile();
+            compute(par);
+            if (fetch) store_tile(par ^ 1);
+            __syncthreads();
+            par ^= 1;
+        }
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int col = n0 + b * 32 + li;
+            const bool colok = col < d.Cout;
+            const float bv = ((flags & DS_EPI_BIAS) && colok) ? p.bias[col] : 0.f;
+            const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < p.M && colok) {
+                    float v = acc[b][r] + bv;
+                    const int64_t off = (int64_t)row * d.ldz + col;
+                    if (flags & DS_EPI_ACCUM) v += zout[off];
+                    if (flags & DS_EPI_MASK) v = p.mask[(int64_t)row * d.ldmask + col] > 0.f ? v : 0.f;
+                    if (flags & DS_EPI_RELU) v = fmaxf(v, 0.f);
+                    zout[off] = v;
+                    const float u = v - pv;
+                    s += u;
+                    q += u * u;
+                }
+            }
+            csum[b] += s;
+            csq[b] += q;
+        }
+    }
+
+    if (flags & DS_EPI_STATS) {
+        float *red = reinterpret_cast<float *>(smem);   // [4][BN][2] floats; every wave passed the last K-loop barrier
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const float s = csum[b] + __shfl_xor(csum[b], 32);
+            const float q = csq[b] + __shfl_xor(csq[b], 32);
+            if (kh == 0) {
+                const int c = b * 32 + li;
+                red[(wm * BN + c) * 2 + 0] = s;
+                red[(wm * BN + c) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < d.Cout && tid0.row < p.row_tiles) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                s += red[(w * BN + tid) * 2 + 0];
+                q += red[(w * BN + tid) * 2 + 1];
+            }
+            p.stats[(int64_t)(n0 + tid) * tid0.stride + tid0.row] = s;
+            p.stats[((int64_t)d.Cout + n0 + tid) * tid0.stride + tid0.row] = q;
+        }
+    }
+}
+
 // ---- host-side dispatch -----------------------------------------------------------------------
 struct TileCfg {
     int mt, nt;
     bool direct;     // register-direct kernel (tile = per-WAVE 32*mt x 32*nt) instead of the LDS kernel
     bool glds;       // LDS-DMA kernel, K-tile 32 (128 x 32*nt tile)
+    bool bf16;       // bf16-multiply kernel (128 x 32*nt tile, nt <= 4)
 };
 
 typedef void (*KernelFn)(const ConvParams);
@@ -932,7 +1173,25 @@ KernelFn glds_kernel(int nt, Variant v) {
     }
 }
 
+KernelFn bf16_kernel(int nt, Variant v) {
+    if (v.fold) {
+        switch (nt) {
+            case 1: return conv_bf16_kernel<1, true, true>;
+            case 2: return conv_bf16_kernel<2, true, true>;
+            case 3: return conv_bf16_kernel<3, true, true>;
+            default: return conv_bf16_kernel<4, true, true>;
+        }
+    }
+    switch (nt) {
+        case 1: return v.bnmajor ? conv_bf16_kernel<1, true, false> : conv_bf16_kernel<1, false, false>;
+        case 2: return v.bnmajor ? conv_bf16_kernel<2, true, false> : conv_bf16_kernel<2, false, false>;
+        case 3: return v.bnmajor ? conv_bf16_kernel<3, true, false> : conv_bf16_kernel<3, false, false>;
+        default: return v.bnmajor ? conv_bf16_kernel<4, true, false> : conv_bf16_kernel<4, false, false>;
+    }
+}
+
 KernelFn kernel_for(TileCfg c, Variant v) {
+    if (c.bf16) return bf16_kernel(c.nt, v);
     if (c.glds) return glds_kernel(c.nt, v);
     if (c.direct) return c.mt == 2 ? direct_kernel_m<2>(c.nt, v) : direct_kernel_m<1>(c.nt, v);
     return c.mt == 2 ? lds_kernel_m<2>(c.nt, v) : lds_kernel_m<1>(c.nt, v);
@@ -942,8 +1201,8 @@ KernelFn kernel_for(TileCfg c, Variant v) {
 // The persistent grid is sized to exactly one resident wave of workgroups so no CU idles while a
 // partial second wave runs; correctness never depends on it (no inter-workgroup communication).
 int resident_per_cu(TileCfg c, Variant v) {
-    static int cache[3][2][6][2][2][2];
-    int &slot = cache[c.glds ? 2 : (int)c.direct][c.mt - 1][c.nt - 1][v.bnmajor][v.fold][v.vec];
+    static int cache[4][2][6][2][2][2];
+    int &slot = cache[c.bf16 ? 3 : (c.glds ? 2 : (int)c.direct)][c.mt - 1][c.nt - 1][v.bnmajor][v.fold][v.vec];
     if (slot == 0) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kernel_for(c, v), 256, 0) != hipSuccess || n < 1)
@@ -969,7 +1228,20 @@ TileCfg pick_cfg(const ds_conv_desc *d, bool vec) {
     const int64_t M = conv_M(d);
     const int N = d->Cout;
     const int pad32 = (N + 31) / 32 * 32, pad64 = (N + 63) / 64 * 64;
-    TileCfg c = {1, 1, false, false};
+    TileCfg c = {1, 1, false, false, false};
+    if (d->dtype == DS_DTYPE_BF16) {
+        // staging-bound at 16x the matrix rate: the widest tile that does not pad Cout beyond the next 32
+        c.bf16 = true;
+        int best = 4, best_pad = 1 << 30;
+        for (int nt = 4; nt >= 2; --nt) {
+            const int pad = (N + 32 * nt - 1) / (32 * nt) * (32 * nt);
+            if (pad < best_pad) { best_pad = pad; best = nt; }
+        }
+        c.nt = N <= 32 ? 1 : best;
+        if (d->tile_nt > 0) c.nt = d->tile_nt > 4 ? 4 : d->tile_nt;
+        if (force_nt > 0) c.nt = force_nt > 4 ? 4 : force_nt;
+        return c;
+    }
     // Measured (profiles/r01_lds_vs_direct_sweep.txt): the LDS-staged kernel wins on every shape of this
     // model -- fragment-shaped global loads touch 32 cache lines per wave instruction and are TA-bound --
     // so the register-direct family is opt-in only.
@@ -1075,6 +1347,7 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     DS_REQUIRE(!(d->flags & DS_EPI_MASK) || mask, "ds_conv_igemm: DS_EPI_MASK without mask");
     DS_REQUIRE(!(d->flags & DS_EPI_STATS) || stats, "ds_conv_igemm: DS_EPI_STATS without stats buffer");
     DS_REQUIRE(conv_M(d) < (1ll << 31), "ds_conv_igemm: M too large");
+    DS_REQUIRE(d->dtype == DS_DTYPE_F32 || d->dtype == DS_DTYPE_BF16, "ds_conv_igemm: dtype must be DS_DTYPE_F32 or DS_DTYPE_BF16");
     const Variant v = variant_of(d, x, w);
     DS_REQUIRE(!(d->flags & DS_EPI_STATS) || v.vec == dims_vec(d),
                "ds_conv_igemm: DS_EPI_STATS needs 16-byte aligned operand pointers");
@@ -1102,6 +1375,8 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     DS_REQUIRE(!v.fold || (v.bnmajor && v.vec && d->KW == 1 && d->fold_cin % 4 == 0 && d->ldx == d->fold_cin),
                "ds_conv_igemm: fold_cin needs KW=1, n-contiguous 16-byte-aligned weights, ldx==fold_cin");
 
+    DS_REQUIRE(d->dtype != DS_DTYPE_BF16 || (v.vec && d->splits <= 1),
+               "ds_conv_igemm: DS_DTYPE_BF16 needs 16-byte aligned operands with channel counts / strides divisible by 4, no split-K");
     const int splits = d->splits > 1 ? d->splits : 1;
     DS_REQUIRE(splits == 1 || (d->flags == 0 && d->z_split_stride >= (int64_t)(conv_M(d) - 1) * d->ldz + d->Cout),
                "ds_conv_igemm: split-K needs flags == 0 and non-overlapping output slabs");

@@ -86,10 +86,10 @@ class ConvBN:
         if self.fold:
             # Conv2d_1a_7x7: KW folded into the channel axis (28 contiguous floats per kernel row)
             self.fwd = ConvPlan(B, self.H, self.W, 7 * 4, 4, 7, 1, self.stride, cout, cout, 28 * cout, 1, cout,
-                                fold_cin=4, flags=DS_EPI_STATS)
+                                fold_cin=4, flags=DS_EPI_STATS, dtype=eng.conv_dtype)
         else:
             self.fwd = ConvPlan(B, self.H, self.W, cin, 0, k, k, self.stride, cout, cout, cin * cout, 1, cout,
-                                flags=DS_EPI_STATS)
+                                flags=DS_EPI_STATS, dtype=eng.conv_dtype)
         eng.need_stats(self.fwd.partials * 2 * cout)
         self.bwd_P = ops.bn_bwd_partials(self.M, cout)
         eng.need_bwd_partials(self.bwd_P * 2 * cout)
@@ -118,7 +118,8 @@ class ConvBN:
         """Conv2DBackpropInput as a forward conv over dz with flipped taps (stride-1 SAME convs only)."""
         assert self.stride == 1
         k, cin, cout = self.k, self.cin, self.cout
-        self.dgrad = ConvPlan(self.B, self.H, self.W, cout, cout, k, k, 1, cin, lddx, cin * cout, cout, 1, flip=1)
+        self.dgrad = ConvPlan(self.B, self.H, self.W, cout, cout, k, k, 1, cin, lddx, cin * cout, cout, 1, flip=1,
+                              dtype=self.eng.conv_dtype)
 
     # x_ptr: input activations [B,H,W,ldx]; segs: where relu(bn(conv)) is scattered (None: the consumer, a max
     # pool, applies BatchNorm + ReLU to its own output instead -- PoolStage.forward)
@@ -350,8 +351,13 @@ class InceptionV1Engine:
     (image_model/inception_v1.py:254-309) as explicit forward()/backward() over HIP kernels."""
 
     def __init__(self, store, num_classes, image_size=224, dropout_keep_prob=0.8, trainable_bn_beta=True,
-                 device="cuda", train_all=False):
+                 device="cuda", train_all=False, dtype="f32"):
         self.store, self.num_classes, self.keep = store, num_classes, dropout_keep_prob
+        # arithmetic type of the 57 convs' forward and dgrad multiplies: "f32" = exact fp32 MFMA (the parity path),
+        # "bf16" = bf16 MFMA with fp32 accumulation; storage, BatchNorm, wgrad, Logits and master weights stay fp32
+        assert dtype in ("f32", "bf16")
+        self.dtype = dtype
+        self.conv_dtype = ops.DS_DTYPE_BF16 if dtype == "bf16" else ops.DS_DTYPE_F32
         self.trainable_bn_beta = trainable_bn_beta
         # train_all: full-tower fine-tuning (SURVEY row 8f-4) -- every conv weight trainable, i.e. the
         # reference graph with the `trainable=False` of inception_v1.py:57-59 dropped; wgrad then runs for

@@ -29,8 +29,9 @@ class SentimentNet:
     def __init__(self, mode="joint", nb_emotions=15, im_features_size=256, rnn_size=512, fc_size=512,
                  vocab_size=10000, embedding_dim=300, post_size=32, image_size=224, dropout_keep_prob=0.8,
                  trainable_bn_beta=True, device="cuda", process_group=None, overlap_comm=True,
-                 concurrent_towers=True, train_all=False, trainable_embedding=False):
+                 concurrent_towers=True, train_all=False, trainable_embedding=False, dtype="f32"):
         assert mode in ("joint", "image", "text")
+        self.dtype = dtype
         if not torch.cuda.is_available():
             raise RuntimeError("tumblr_emotions_amd needs an MI355X (HIP) device: the training path has no CPU fallback")
         self.mode, self.nb_emotions, self.device = mode, nb_emotions, torch.device(device)
@@ -39,7 +40,7 @@ class SentimentNet:
         if mode in ("joint", "image"):
             nc = im_features_size if mode == "joint" else nb_emotions
             self.image = InceptionV1Engine(self.store, nc, image_size, dropout_keep_prob, trainable_bn_beta, device,
-                                           train_all=train_all)
+                                           train_all=train_all, dtype=dtype)
         if mode in ("joint", "text"):
             self.text = TextTowerEngine(self.store, vocab_size + 1, embedding_dim, rnn_size, post_size, device,
                                         trainable_embedding=trainable_embedding)

@@ -9,7 +9,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, Segments, DS_EPI_ACCUM, DS_EPI_BIAS, DS_EPI_MASK, DS_EPI_RELU, DS_EPI_STATS  # noqa: F401
+from ._lib import (ConvDesc, Segments, DS_EPI_ACCUM, DS_EPI_BIAS, DS_EPI_MASK, DS_EPI_RELU, DS_EPI_STATS,  # noqa: F401
+                   DS_DTYPE_BF16, DS_DTYPE_F32)
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -54,8 +55,9 @@ class ConvPlan:
 
     def __init__(self, N, H, W, Cin, ldx, KH, KW, stride, Cout, ldz, w_tap_stride, w_n_stride, w_k_stride,
                  flip=0, fold_cin=0, flags=0, ldmask=0, pad_t=None, pad_l=None, OH=None, OW=None,
-                 splits=1, z_split_stride=0):
+                 splits=1, z_split_stride=0, dtype=DS_DTYPE_F32):
         d = ConvDesc()
+        d.dtype = dtype
         d.N, d.H, d.W, d.Cin, d.ldx = N, H, W, Cin, ldx
         d.KH, d.KW, d.stride = KH, KW, stride
         if OH is None:
@@ -111,15 +113,16 @@ class ConvTimer:
 CONV_TIMER = None      # set to a ConvTimer to time the dominant kernel
 
 
-def gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=False, flags=0, ldmask=0, splits=1, z_split_stride=0):
+def gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=False, flags=0, ldmask=0, splits=1, z_split_stride=0,
+              dtype=DS_DTYPE_F32):
     """C[M,N] = A[M,K] * W (row-major W[K,N] with row stride w_ld), or * W^T when transposed_w
     (then W is [N,K] row-major): both are read in place.  splits>1: split-K, slab s of partial
     sums at C + s*z_split_stride (the consumer adds the slabs)."""
     if transposed_w:
         return ConvPlan(M, 1, 1, K, lda, 1, 1, 1, N, ldc, 0, w_ld, 1, flags=flags, ldmask=ldmask,
-                        pad_t=0, pad_l=0, OH=1, OW=1, splits=splits, z_split_stride=z_split_stride)
+                        pad_t=0, pad_l=0, OH=1, OW=1, splits=splits, z_split_stride=z_split_stride, dtype=dtype)
     return ConvPlan(M, 1, 1, K, lda, 1, 1, 1, N, ldc, 0, 1, w_ld, flags=flags, ldmask=ldmask,
-                    pad_t=0, pad_l=0, OH=1, OW=1, splits=splits, z_split_stride=z_split_stride)
+                    pad_t=0, pad_l=0, OH=1, OW=1, splits=splits, z_split_stride=z_split_stride, dtype=dtype)
 
 
 class WgradPlan:
