@@ -33,6 +33,35 @@ def conv2d_same(x, w_hwio, stride):
     return F.conv2d(_same_pad_nchw(x, k, stride, 0.0), w_hwio.permute(3, 2, 0, 1), stride=stride)
 
 
+def _bf16(t):
+    """round to bfloat16 the way the HIP path does (fp32 value -> round-to-nearest-even bf16), kept in t's dtype"""
+    return t.float().bfloat16().to(t.dtype)
+
+
+class _ConvBf16Multiply(torch.autograd.Function):
+    """VALID cross-correlation whose forward and input-gradient multiplies see bf16-rounded operands (fp32/fp64
+    accumulation), while the weight gradient is taken on the unrounded operands -- what DS_DTYPE_BF16 of the HIP
+    path computes (conv forward + dgrad on the bf16 matrix pipe, wgrad in fp32)."""
+
+    @staticmethod
+    def forward(ctx, xp, w_oihw, stride):
+        ctx.save_for_backward(xp, w_oihw)
+        ctx.stride = stride
+        return F.conv2d(_bf16(xp), _bf16(w_oihw), stride=stride)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, w = ctx.saved_tensors
+        dx = torch.nn.grad.conv2d_input(xp.shape, _bf16(w), _bf16(dy), stride=ctx.stride)
+        dw = torch.nn.grad.conv2d_weight(xp, w.shape, dy, stride=ctx.stride)
+        return dx, dw, None
+
+
+def conv2d_same_bf16_multiply(x, w_hwio, stride):
+    k = w_hwio.shape[0]
+    return _ConvBf16Multiply.apply(_same_pad_nchw(x, k, stride, 0.0), w_hwio.permute(3, 2, 0, 1), stride)
+
+
 def max_pool_same(x, k, s):
     return F.max_pool2d(_same_pad_nchw(x, k, s, float("-inf")), k, s)
 
@@ -100,6 +129,9 @@ class DeepSentimentRef:
         # so its gradients are a smooth function of the inputs and can be compared tightly.
         self.inject = None
         self.record = None          # dict: filled with this run's own decisions in the `inject` format
+        # "bf16": the 57 BatchNorm convs multiply bf16-rounded operands in forward and dgrad (the build's
+        # dtype='bf16' switch, BASELINE configs[4] groundwork; no reference counterpart -- the reference is fp32)
+        self.conv_multiply = "f32"
 
     @staticmethod
     def _is_trainable(name, trainable_bn_beta):
@@ -115,7 +147,10 @@ class DeepSentimentRef:
 
     # -- towers -------------------------------------------------------------------------------
     def _cbr(self, x, scope, stride=1):
-        z = conv2d_same(x, self.p[scope + "/weights"], stride)
+        if self.conv_multiply == "bf16":
+            z = conv2d_same_bf16_multiply(x, self.p[scope + "/weights"], stride)
+        else:
+            z = conv2d_same(x, self.p[scope + "/weights"], stride)
         beta = self.p[scope + "/BatchNorm/beta"]
         if self.is_training:
             y, mean, var = batch_norm_train(z, beta)
