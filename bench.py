@@ -93,7 +93,9 @@ def cpu_baseline(post_size, vocab, dim, rnn, warmup=3, steps=10):
 def gather_bandwidth():
     """north_star: HBM GB/s on the embedding gather.  The step's own gather moves 19.7 MB (too small to show
     bandwidth), so it is timed at B*T = 2^20 tokens: D = 300 fp32 rows out of the 10 001-row table
-    (12 MB, cache resident) written time-major = 1.26 GB of stores + 8 MB of ids per launch."""
+    written time-major.  What HBM sees: the 1.26 GB of row stores and the 8 MB of ids -- the 12 MB table is
+    cache resident, so its reads are NOT HBM traffic; `hbm_*` count only the former, `alg_*` is SURVEY 8d's
+    algorithmic byte count (row read + row write + id) kept for reference."""
     import torch
     from tumblr_emotions_amd import ops
     V, D, B, T = 10000, 300, 8192, 128
@@ -109,11 +111,12 @@ def gather_bandwidth():
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
-    alg = B * T * (2 * D * 4 + 8)                       # read row + write row + id, SURVEY 8d
-    return dict(kernel="gather_rows_kernel", tokens=B * T, alg_bytes=alg, us=round(us, 1),
-                achieved_GBps=round(alg / us / 1e3, 1), peak_GBps=8000, frac=round(alg / us / 1e3 / 8000, 4),
-                note="algorithmic bytes count the row read although the 12 MB table is L2/MALL resident; "
-                     "HBM sees the 1.26 GB of row writes")
+    hbm = B * T * (D * 4 + 8)                           # row stores + ids
+    alg = B * T * (2 * D * 4 + 8)                       # read row + write row + id
+    return dict(kernel="gather_rows_kernel", tokens=B * T, us=round(us, 1), hbm_bytes=hbm,
+                hbm_GBps=round(hbm / us / 1e3, 1), peak_GBps=8000, frac=round(hbm / us / 1e3 / 8000, 4),
+                alg_bytes=alg, alg_GBps=round(alg / us / 1e3, 1),
+                note="frac = HBM-visible bytes (row stores + ids) / time / 8 TB/s; the table reads are served by the caches")
 
 
 def cpu_model():
@@ -189,6 +192,12 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    rccl_ranks = None
+    if world > 1:          # a real collective before anything is timed: how many ranks does the backend connect?
+        probe = torch.ones(1, device="cuda")
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        rccl_ranks = int(round(float(probe.item())))
 
     T, V, D, H = 32, 10000, 300, 512
     net = SentimentNet(mode=args.mode, nb_emotions=15, im_features_size=256, rnn_size=H, fc_size=512, vocab_size=V,
@@ -224,6 +233,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     loss = net.total_loss_value()
+    dp_report = None
+    if world > 1:          # two more steps with event pairs around the early bucket-1 reduce (not in the timed region)
+        net.reducer.timing = True
+        for _ in range(2):
+            net.train_step(batch, lr)
+        barrier()
+        dp_report = net.reducer.overlap_report() or {}
+        dp_report.update(rccl_ranks=rccl_ranks, backend=dist.get_backend(), world_size=dist.get_world_size(),
+                         overlap_enabled=bool(net.reducer.overlap))
+        net.reducer.timing = False
 
     # Roofline pass: the SAME K steps again, now with a HIP event pair around every conv/GEMM launch on
     # the stream it is launched on.  Kept out of the headline region because the 2 x 148 event records per
@@ -299,6 +318,7 @@ def main():
                        "global_batch": gb, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
                        "gflop_per_sample": flop_per_sample, "final_loss": round(loss, 5)},
             "roofline": roof,
+            "dp": dp_report,
             "gather": gather_bandwidth() if (args.mode != "image" and not args.no_gather) else None,
         }
         if world == 1 and not args.no_cpu_baseline and args.mode == "joint" and not args.train_all:

@@ -7,29 +7,49 @@
 
 namespace {
 
-// ---- embedding gather: one float-vector per lane, rows written in the LSTM's time-major order ----
+// ---- embedding gather: one wavefront per row, rows written in the LSTM's time-major order ----------
+// A wave owns RPW consecutive (b, t) positions.  Per position: the id is a wave-uniform scalar load, the row is
+// VEC-wide vectors handed to lanes 0, 1, ... (D = 300 -> 75 float4: one full and one 11-lane instruction), no
+// per-element integer division.  Four rows are fetched before the first is stored (memory-level parallelism:
+// the 12 MB table is cache resident, the stores are the HBM stream) and the stores are non-temporal -- the
+// rows are next read by the projection GEMM, long after they left the caches at 2^20 tokens.
 template <int VEC>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *table, const int64_t *ids, float *out, int B,
-                                                          int T, int D, int64_t rows, int time_major) {
+                                                          int T, int D, int64_t rows, int time_major, int rpw) {
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t total = (int64_t)B * T;
+    int64_t r = wave * rpw;
+    const int64_t r1 = r + rpw < total ? r + rpw : total;
+    if (r >= r1) return;
     const int DV = D / VEC;
-    const int64_t total = (int64_t)B * T * DV;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int dv = (int)(i % DV);
-        const int64_t r = i / DV;            // r = b*T + t  (ids are batch-major)
-        const int b = (int)(r / T), t = (int)(r - (int64_t)b * T);
-        const int64_t id = ids[r];
-        const int64_t orow = time_major ? (int64_t)t * B + b : r;
-        const bool ok = id >= 0 && id < rows;
-        if (VEC == 4) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) v = *reinterpret_cast<const float4 *>(table + id * D + dv * 4);
-            *reinterpret_cast<float4 *>(out + orow * D + dv * 4) = v;
-        } else if (VEC == 2) {
-            float2 v = make_float2(0.f, 0.f);
-            if (ok) v = *reinterpret_cast<const float2 *>(table + id * D + dv * 2);
-            *reinterpret_cast<float2 *>(out + orow * D + dv * 2) = v;
-        } else {
-            out[orow * D + dv] = ok ? table[id * D + dv] : 0.f;
+    int b = (int)(r / T), t = (int)(r - (int64_t)b * T);           // once per wave; then incremented
+    constexpr int U = 4;                                           // rows in flight
+    for (; r < r1; r += U) {
+        const float *src[U];
+        float *dst[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool in = r + u < r1;
+            const int64_t id = in ? ids[r + u] : -1;               // wave-uniform
+            ok[u] = id >= 0 && id < rows;                          // out-of-range id -> zero row
+            src[u] = table + (ok[u] ? id : 0) * D;
+            dst[u] = in ? out + (time_major ? (int64_t)t * B + b : r + u) * D : nullptr;
+            if (++t == T) { t = 0; ++b; }
+        }
+        for (int v0 = 0; v0 < DV; v0 += 64) {
+            const int v = v0 + lane;
+            vec_t val[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                val[u] = vec_t(0.f);
+                if (v < DV && ok[u]) val[u] = *reinterpret_cast<const vec_t *>(src[u] + v * VEC);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (v < DV && dst[u]) __builtin_nontemporal_store(val[u], reinterpret_cast<vec_t *>(dst[u] + v * VEC));
         }
     }
 }
@@ -279,15 +299,18 @@ extern "C" int ds_gather_rows(const float *table, const int64_t *ids, float *out
     DS_REQUIRE(table && ids && out && B > 0 && T > 0 && D > 0 && table_rows > 0, "ds_gather_rows: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const bool a16 = (((uintptr_t)table | (uintptr_t)out) & 15) == 0, a8 = (((uintptr_t)table | (uintptr_t)out) & 7) == 0;
+    const int64_t total = (int64_t)B * T;
+    // rows per wave: enough waves to fill the chip several times over, at most 16 rows each
+    int rpw = (int)((total + (int64_t)ds::kCUs * 32 * 4 - 1) / ((int64_t)ds::kCUs * 32 * 4));
+    rpw = rpw < 4 ? 4 : (rpw > 16 ? 16 : rpw);
+    const int64_t waves = (total + rpw - 1) / rpw;
+    const dim3 grid((unsigned)((waves + 3) / 4));
     if (D % 4 == 0 && a16) {
-        hipLaunchKernelGGL(gather_rows_kernel<4>, dim3(ds::stream_grid((int64_t)B * T * (D / 4), 256)), dim3(256), 0, s,
-                           table, ids, out, B, T, D, table_rows, time_major);
+        hipLaunchKernelGGL(gather_rows_kernel<4>, grid, dim3(256), 0, s, table, ids, out, B, T, D, table_rows, time_major, rpw);
     } else if (D % 2 == 0 && a8) {
-        hipLaunchKernelGGL(gather_rows_kernel<2>, dim3(ds::stream_grid((int64_t)B * T * (D / 2), 256)), dim3(256), 0, s,
-                           table, ids, out, B, T, D, table_rows, time_major);
+        hipLaunchKernelGGL(gather_rows_kernel<2>, grid, dim3(256), 0, s, table, ids, out, B, T, D, table_rows, time_major, rpw);
     } else {
-        hipLaunchKernelGGL(gather_rows_kernel<1>, dim3(ds::stream_grid((int64_t)B * T * D, 256)), dim3(256), 0, s, table,
-                           ids, out, B, T, D, table_rows, time_major);
+        hipLaunchKernelGGL(gather_rows_kernel<1>, grid, dim3(256), 0, s, table, ids, out, B, T, D, table_rows, time_major, rpw);
     }
     return ds::check_launch("ds_gather_rows");
 }

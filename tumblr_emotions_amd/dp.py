@@ -46,6 +46,10 @@ class GradientReducer:
         self._ready = set()
         self._needed = set()
         self._events = []
+        # timing=True (bench.py): event pairs around the early bucket-1 reduce on the side stream and at the end of
+        # the backward pass on the main stream, so the first multi-GPU run says whether the overlap is real
+        self.timing = False
+        self._t = None
 
     # -- early launch of bucket 1 ----------------------------------------------------------------
     def expect(self, *names):
@@ -70,6 +74,9 @@ class GradientReducer:
             for ev in self._events:
                 self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
+                if self.timing:
+                    self._t = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                    self._t[0].record(self.stream)          # bucket-1 reduce enters the side stream
                 self._pending = dist.all_reduce(self.g[:self.n1], op=dist.ReduceOp.SUM, group=self.group,
                                                 async_op=True)
 
@@ -80,12 +87,28 @@ class GradientReducer:
         if self.world == 1:
             return 1.0
         if self._pending is not None:
-            self._pending.wait()
-            if self.stream is not None:
-                torch.cuda.current_stream().wait_stream(self.stream)
+            main = torch.cuda.current_stream()
+            if self.timing and self._t is not None:
+                self._t[2].record(main)                     # the backward pass has been enqueued up to here
+            with torch.cuda.stream(self.stream):
+                self._pending.wait()                        # side stream waits for RCCL's stream
+                if self.timing and self._t is not None:
+                    self._t[1].record(self.stream)          # bucket-1 reduce complete
+            main.wait_stream(self.stream)
         else:
             dist.all_reduce(self.g[:self.n1], op=dist.ReduceOp.SUM, group=self.group)
         if self.g.numel() > self.n1:
             dist.all_reduce(self.g[self.n1:], op=dist.ReduceOp.SUM, group=self.group)
         self._pending = None
         return 1.0 / self.world
+
+    def overlap_report(self):
+        """After a synchronise, for the last step run with timing=True: how long bucket 1's all-reduce took on the
+        side stream and how much of it was still outstanding when the backward pass ended (exposed = not hidden)."""
+        if not self._t:
+            return None
+        t0, t1, t2 = self._t
+        return dict(bucket1_bytes=int(self.n1) * 4, bucket2_bytes=int(self.g.numel() - self.n1) * 4,
+                    bucket1_allreduce_ms=round(t0.elapsed_time(t1), 3),
+                    backward_after_launch_ms=round(t0.elapsed_time(t2), 3),
+                    bucket1_exposed_ms=round(max(0.0, t2.elapsed_time(t1)), 3))
