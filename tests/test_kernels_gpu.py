@@ -583,6 +583,28 @@ def test_gather_rows_is_bit_exact(D):
     assert np.array_equal(out2.cpu().numpy(), table[ids])
 
 
+def test_gather_rows_long_list_is_bit_exact():
+    """2^17 positions out of a 10 001 x 300 table: Zipf-like ids, out-of-range ids (zero rows), a ragged last wave,
+    both output orders."""
+    ops = _ops()
+    rng = np.random.RandomState(16)
+    B, T, V, D = 1031, 127, 10000, 300
+    table = rng.normal(size=(V + 1, D)).astype(np.float32)
+    table[V] = 0
+    ids = np.minimum(rng.zipf(1.3, size=(B, T)) - 1, V).astype(np.int64)
+    ids[5, 7], ids[900, 3] = V + 5, -2                       # outside the table: zero rows
+    want = np.where(((ids >= 0) & (ids <= V))[..., None], table[np.clip(ids, 0, V)], 0).astype(np.float32)
+    td, idd = dev(table), dev(ids, torch.int64)
+    out = torch.full((T, B, D), float("nan"), device="cuda")
+    ops.gather_rows(td, idd, out, B, T, D, True)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want.transpose(1, 0, 2))
+    out2 = torch.full((B, T, D), float("nan"), device="cuda")
+    ops.gather_rows(td, idd, out2, B, T, D, False)
+    torch.cuda.synchronize()
+    assert np.array_equal(out2.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("D,B,T,V", [(300, 6, 9, 40), (50, 5, 70, 30), (7, 3, 5, 200), (512, 2, 3, 4)])
 def test_embedding_grad_scatter_add(D, B, T, V):
     """dtable[v] = sum of the dx rows whose id is v (np.add.at), collisions, unused rows (zeros), the pad row,

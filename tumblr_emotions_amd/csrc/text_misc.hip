@@ -3,6 +3,7 @@
 //   LSTM cell         BasicLSTMCell + dynamic_rnn mask  im_text_rnn_model.py:89-90 (A7/A8)
 //   softmax CE        slim.losses.softmax_cross_entropy im_text_rnn_model.py:124-125 (A9)
 //   Adam              tf.train.AdamOptimizer            im_text_rnn_model.py:134-135 (A10)
+#include <stdlib.h>
 #include "ds_common.h"
 
 namespace {
@@ -13,7 +14,7 @@ namespace {
 // per-element integer division.  Four rows are fetched before the first is stored (memory-level parallelism:
 // the 12 MB table is cache resident, the stores are the HBM stream) and the stores are non-temporal -- the
 // rows are next read by the projection GEMM, long after they left the caches at 2^20 tokens.
-template <int VEC>
+template <int VEC, bool NT = true>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *table, const int64_t *ids, float *out, int B,
                                                           int T, int D, int64_t rows, int time_major, int rpw) {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
@@ -49,7 +50,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *table, co
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (v < DV && dst[u]) __builtin_nontemporal_store(val[u], reinterpret_cast<vec_t *>(dst[u] + v * VEC));
+                if (v < DV && dst[u]) {
+                    if (NT) __builtin_nontemporal_store(val[u], reinterpret_cast<vec_t *>(dst[u] + v * VEC));
+                    else *reinterpret_cast<vec_t *>(dst[u] + v * VEC) = val[u];
+                }
         }
     }
 }
@@ -305,7 +309,14 @@ extern "C" int ds_gather_rows(const float *table, const int64_t *ids, float *out
     rpw = rpw < 4 ? 4 : (rpw > 16 ? 16 : rpw);
     const int64_t waves = (total + rpw - 1) / rpw;
     const dim3 grid((unsigned)((waves + 3) / 4));
-    if (D % 4 == 0 && a16) {
+    static int plain = -1;
+    if (plain < 0) {
+        const char *e = getenv("DS_GATHER_PLAIN_STORES");      // A/B aid
+        plain = e ? atoi(e) : 0;
+    }
+    if (D % 4 == 0 && a16 && plain) {
+        hipLaunchKernelGGL((gather_rows_kernel<4, false>), grid, dim3(256), 0, s, table, ids, out, B, T, D, table_rows, time_major, rpw);
+    } else if (D % 4 == 0 && a16) {
         hipLaunchKernelGGL(gather_rows_kernel<4>, grid, dim3(256), 0, s, table, ids, out, B, T, D, table_rows, time_major, rpw);
     } else if (D % 2 == 0 && a8) {
         hipLaunchKernelGGL(gather_rows_kernel<2>, grid, dim3(256), 0, s, table, ids, out, B, T, D, table_rows, time_major, rpw);
