@@ -124,3 +124,28 @@ def test_get_init_fn_prefers_the_tf_checkpoint(tmp_path):
         fn(FakeNet())
     assert sorted(net.sd) == sorted(k for k in t if k.startswith("InceptionV1/") and "Logits" not in k)
     np.testing.assert_array_equal(net.sd["InceptionV1/Conv2d_1a_7x7/weights"], t["InceptionV1/Conv2d_1a_7x7/weights"])
+
+
+def test_handmade_v1_checkpoint_fixture():
+    """tests/golden/handmade_v1.ckpt: a complete table assembled byte by byte by tests/golden/make_handmade_fixtures.py
+    (independent of checkpoint_tf.py): a snappy data block with real back-reference copies, restart interval 2 with
+    shared key prefixes, separator index keys, SavedSlice fields in reverse order, unpacked float_val / int64_val,
+    tensor_content, packed int_val with a negative, a full extent written as an empty message, the VersionDef and
+    per-tensor slice lists real TF files carry, a rank-0 tensor."""
+    path = os.path.join(os.path.dirname(__file__), "golden", "handmade_v1.ckpt")
+    got = C.read_tf_v1_checkpoint(path, verify_checksums=True)
+    assert sorted(got) == ["a/weights", "b/step", "c/idx"]
+    np.testing.assert_array_equal(got["a/weights"], np.array([[1.5, -2.0, 3.25], [4.0, 5.0, -6.5]], np.float32))
+    assert got["a/weights"].dtype == np.float32
+    assert got["b/step"].shape == () and got["b/step"].dtype == np.int64 and int(got["b/step"]) == 123456789012
+    np.testing.assert_array_equal(got["c/idx"], np.array([7, -3, 0, 2 ** 31 - 1], np.int32))
+    data = open(path, "rb").read()
+    footer = data[-48:]
+    _, pos = C._handle(footer, 0)
+    index, _ = C._handle(footer, pos)
+    handles = [C._handle(v, 0)[0] for _, v in C._block_entries(C._read_block(data, index, True))]
+    assert data[handles[0][0] + handles[0][1]] == 1 and data[handles[1][0] + handles[1][1]] == 0     # snappy, raw
+    raw0 = C._read_block(data, handles[0], True)
+    assert len(raw0) > handles[0][1]                                # the compressed block really is smaller
+    only = C.read_tf_v1_checkpoint(path, names=lambda n: n.startswith("c/"))
+    assert list(only) == ["c/idx"]

@@ -103,3 +103,37 @@ def test_preprocess_for_eval_geometry_and_range():
     ref = (x[y0][:, x0] * (1 - fy) * (1 - fx) + x[y0][:, x1] * (1 - fy) * fx + x[y1][:, x0] * fy * (1 - fx)
            + x[y1][:, x1] * fy * fx)
     np.testing.assert_allclose(up, ref, atol=1e-6)
+
+
+def test_crc32c_rfc3720_vectors_and_mask():
+    """CRC-32C against the iSCSI test vectors (RFC 3720 appendix B.4), for the table-driven implementation of the
+    package AND the bit-wise one the fixture generator uses; the TFRecord mask is rot-right-15 + 0xa282ead8."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_handmade_fixtures import crc32c_bitwise, masked
+    vectors = [(bytes(32), 0x8A9136AA), (b"\xff" * 32, 0x62A8AB43), (bytes(range(32)), 0x46DD794E),
+               (bytes(range(31, -1, -1)), 0x113FDB5C), (b"123456789", 0xE3069283)]
+    for data, want in vectors:
+        assert T.crc32c(data) == want and crc32c_bitwise(data) == want
+    c = T.crc32c(b"foo")
+    assert T.masked_crc(b"foo") == masked(b"foo") == (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def test_handmade_tf_example_records_decode():
+    """tests/golden/handmade_examples.tfrecord: two framed tf.train.Example records assembled byte by byte by
+    tests/golden/make_handmade_fixtures.py (independent of this package) in encodings our writer never produces."""
+    path = os.path.join(os.path.dirname(__file__), "golden", "handmade_examples.tfrecord")
+    recs = list(T.read_records(path, verify=True))
+    assert len(recs) == 2 and recs[1] == b""
+    ex = T.decode_example(recs[0])
+    assert ex["text"] == [5, 300, 70000, -1]                       # unpacked Int64List, 10-byte negative varint
+    assert ex["image/encoded"] == [b"\x89PNG-not-really", b"second"]
+    assert ex["image/format"] == [b"png"]                          # value before key, unknown field skipped
+    assert ex["seq_len"] == [300, 2]
+    assert ex["weights"] == [0.5, -2.25]                           # unpacked FloatList
+    assert ex["k" * 200] == [1]
+    assert len(ex) == 6
+    assert T.decode_example(recs[1]) == {}
+    # our own writer's encoding of the same content decodes to the same dict (packed, sorted)
+    again = T.decode_example(T.encode_example({k: v for k, v in ex.items()}))
+    assert again == ex

@@ -10,8 +10,11 @@ is not available here, so both directions are restated from the published format
   Example = { 1: Features { 1: repeated MapEntry { 1: key string, 2: Feature } } }
   Feature = oneof { 1: BytesList{1: repeated bytes}, 2: FloatList{1: packed float}, 3: Int64List{1: packed varint} }
 
-Pinned by the CRC-32C check value (0xE3069283 for b"123456789") and by write/read round trips; there
-is no TensorFlow-written file in the reference tree to pin the framing against (parity unpinned).
+Pinned by the CRC-32C check values (0xE3069283 for b"123456789", the RFC 3720 B.4 vectors), by write/read round
+trips, and by tests/golden/handmade_examples.tfrecord -- records assembled byte by byte from the published
+specs by an independent script, in encodings this module's writer never emits (unsorted map, unpacked lists,
+value-before-key entries, unknown fields, zero-length record).  There is no TensorFlow-WRITTEN file in the
+reference tree to pin the framing against: parity unpinned.
 """
 import struct
 
@@ -144,11 +147,11 @@ def encode_example(features):
 def decode_example(buf):
     """serialized tf.train.Example -> {name: list of bytes | floats | ints}."""
     out = {}
-    for f1, _, features in _fields(buf):
-        if f1 != 1:
+    for f1, w1, features in _fields(buf):
+        if f1 != 1 or w1 != 2:
             continue
-        for f2, _, entry in _fields(features):
-            if f2 != 1:
+        for f2, w2, entry in _fields(features):
+            if f2 != 1 or w2 != 2:
                 continue
             key, feat = None, b""
             for f3, _, v in _fields(entry):
@@ -157,7 +160,9 @@ def decode_example(buf):
                 elif f3 == 2:
                     feat = v
             vals = []
-            for kind, _, lst in _fields(feat):
+            for kind, kwt, lst in _fields(feat):
+                if kind not in (1, 2, 3) or kwt != 2:        # unknown fields are skipped, as protobuf parsers do
+                    continue
                 for f5, wt, v in _fields(lst):
                     if f5 != 1:
                         continue
