@@ -163,6 +163,9 @@ def main():
                          "forward/dgrad multiplies on the bf16 matrix pipe, fp32 storage/accumulate/statistics/masters")
     ap.add_argument("--stepwise-lstm", action="store_true",
                     help="A/B aid: one GEMM + one cell launch per LSTM step instead of the persistent ds_lstm_seq kernels")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the training step as one captured hipGraph (single rank; what bounds small per-GPU batches "
+                         "is host launch cost)")
     ap.add_argument("--serial-towers", action="store_true",
                     help="A/B aid: text tower on the main stream instead of concurrently with the image tower")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -220,6 +223,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    graphed = bool(args.graph and world == 1 and net.capture_step(batch))
     for _ in range(args.warmup):
         net.train_step(batch, lr)
     barrier()
@@ -249,6 +253,8 @@ def main():
     # step cost 2-3 % of the step (measured); everything else is identical (towers concurrent, all-reduce).
     timer = None
     dt_events = None
+    if graphed:
+        net.release_graph()      # the roofline passes time individual launches: eager
     if not args.no_conv_timing:
         timer = ops.ConvTimer()
         ops.CONV_TIMER = timer
@@ -316,7 +322,8 @@ def main():
                                    + (", conv fwd/dgrad multiplies in bf16 (fp32 storage, accumulation, statistics, master "
                                       "weights; NOT the fp32 parity configuration)" if args.dtype == "bf16" else ""),
                        "global_batch": gb, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
-                       "gflop_per_sample": flop_per_sample, "final_loss": round(loss, 5)},
+                       "gflop_per_sample": flop_per_sample, "final_loss": round(loss, 5),
+                       "launch": "hipGraph replay" if graphed else "eager"},
             "roofline": roof,
             "dp": dp_report,
             "gather": gather_bandwidth() if (args.mode != "image" and not args.no_gather) else None,

@@ -367,6 +367,7 @@ class InceptionV1Engine:
         self.update_moving = True
         self.training = True         # False: BatchNorm uses moving statistics, dropout is the identity
         self.reducer = None          # dp.GradientReducer, set by SentimentNet
+        self.seed_dev = None         # device int64 added to the dropout seed (hipGraph replay draws fresh masks)
         self._stats_n = self._bwdp_n = self._ws_bytes = 0
         self.B = None
         self.input = InputStage(self, image_size)
@@ -454,7 +455,7 @@ class InceptionV1Engine:
             s.forward()
         last = self.last
         ops.avgpool_dropout_fwd(last.out, B, last.H * last.W, self.feat, self.keep if self.training else 1.0, seed,
-                                dropout_mask, self.mask, self.pooled)
+                                dropout_mask, self.mask, self.pooled, seed_dev=self.seed_dev)
         self.fc.run(ops._p(self.pooled), self.w_fc, ops._p(self.logits), bias=self.b_fc)
         return self.logits
 

@@ -74,6 +74,8 @@ class SentimentNet:
             if e is not None:
                 e.reducer = self.reducer
         self.logits = None
+        self._graph = None           # captured training step (capture_step)
+        self._graph_key = None
 
     # ---- variables --------------------------------------------------------------------------------
     def initialize(self, seed=1):
@@ -225,11 +227,19 @@ class SentimentNet:
     # ---- one training step -----------------------------------------------------------------------
     def train_step(self, batch, lr, dropout_mask=None, seed=None):
         st = self.store
-        for p in self.leaves.values():
-            p.grad = None
         self.step += 1
+        t = self.step
+        lr_t = lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
         # dropout stream: one seed per (step, rank) -- ranks must not share a mask pattern across their shards
         seed = self._rank_seed(self.step) if seed is None else seed
+        if self._graph is not None and self._graph_key == self._batch_key(batch, dropout_mask):
+            # replay of the captured step: only the two per-step scalars change, and they live on the device
+            self.seed_dev.fill_(seed)
+            self.lr_t_dev.fill_(lr_t)
+            self._graph.replay()
+            return self.loss_buf.view(())
+        for p in self.leaves.values():
+            p.grad = None
         logits = self.forward(batch, dropout_mask, seed)
         ce = self.cross_entropy(logits, batch["labels"])
         if st.n_l2 > 0:      # trainable part of the L2 loss, on the pre-update weights
@@ -237,8 +247,94 @@ class SentimentNet:
         self.reducer.begin_step()
         ce.backward()          # engines call reducer.stage_done(...): bucket 1 is all-reduced under the backward
         grad_scale = self.reducer.finish()
-        t = self.step
-        lr_t = lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
         ops.adam_tf(st.theta, st.grad, st.m, st.v, st.n_trainable_padded, st.n_l2, WEIGHT_DECAY, grad_scale, lr_t,
                     ADAM_B1, ADAM_B2, ADAM_EPS)
         return ce
+
+    # ---- the same step as one hipGraph ---------------------------------------------------------------
+    @staticmethod
+    def _batch_key(batch, dropout_mask):
+        return tuple(sorted((k, v.data_ptr(), tuple(v.shape)) for k, v in batch.items())) + (
+            None if dropout_mask is None else dropout_mask.data_ptr(),)
+
+    def _step_kernels(self, batch, dropout_mask):
+        """Everything train_step enqueues between the batch and Adam -- forward, CE, L2 term, backward -- with the
+        engines driven directly (the autograd nodes of functions.py are thin wrappers around exactly these calls,
+        in this order, on these streams)."""
+        st = self.store
+        main = torch.cuda.current_stream()
+        side = self.text_stream if (self.image is not None and self.text is not None) else None
+        im = tx = None
+        if side is not None:
+            ready = torch.cuda.Event()
+            ready.record(main)
+        if self.image is not None:
+            im = self.image.forward(batch["images"], dropout_mask, 0)
+        if self.text is not None:
+            if side is not None:
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    tx = self.text.forward(batch["texts"], batch["seq_lens"])
+                main.wait_stream(side)
+            else:
+                tx = self.text.forward(batch["texts"], batch["seq_lens"])
+        if self.mode == "image":
+            logits = im
+        elif self.mode == "text":
+            logits = self.head.forward(tx)
+        else:
+            logits = self.head.forward(im, tx)
+        self.logits = logits
+        if self.dlogits is None or self.dlogits.shape != logits.shape:
+            raise RuntimeError("capture_step: run one eager train_step with this batch size first")
+        B, C_ = logits.shape
+        ops.softmax_ce(logits, batch["labels"], B, C_, 1.0, None, self.loss_buf, self.dlogits)
+        if st.n_l2 > 0:
+            ops.sumsq(st.theta, st.n_l2, self.l2_scratch, self.l2_buf)
+        if self.mode == "image":
+            self.image.backward(self.dlogits)
+        elif self.mode == "text":
+            self.text.backward(self.head.backward(self.dlogits))
+        else:
+            d_im, d_tx = self.head.backward(self.dlogits)
+            if side is not None:              # BPTT next to the Inception backward, as in the eager step
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self.text.backward(d_tx)
+                self.image.backward(d_im)
+                main.wait_stream(side)
+            else:
+                self.text.backward(d_tx)
+                self.image.backward(d_im)
+
+    def capture_step(self, batch, dropout_mask=None):
+        """Capture one whole training step on `batch`'s tensors (static addresses: refill them in place between
+        steps) into a hipGraph; later train_step calls with the same tensors replay it -- one graph launch instead
+        of ~900 kernel launches, which is what bounds the step below ~64 samples per GPU.  Per-step scalars (Adam's
+        lr_t, the dropout seed) are read from device memory.  Single rank only: with data parallelism the RCCL
+        all-reduce stays outside a graph and the eager step is used."""
+        if self.world != 1:
+            return False
+        st = self.store
+        # eager warm-up (allocates every buffer, builds every plan) on a snapshot of the optimiser state, so that
+        # capturing has no side effect on the variables, the Adam slots or the BatchNorm moving statistics
+        keep = [b.clone() for b in (st.theta, st.m, st.v, st.frozen)]
+        self.train_step(batch, 0.0, dropout_mask)
+        self.step -= 1
+        for b, k in zip((st.theta, st.m, st.v, st.frozen), keep):
+            b.copy_(k)
+        if self.image is not None:
+            self.image.seed_dev = self.seed_dev
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step_kernels(batch, dropout_mask)
+            ops.adam_tf(st.theta, st.grad, st.m, st.v, st.n_trainable_padded, st.n_l2, WEIGHT_DECAY, 1.0, 0.0,
+                        ADAM_B1, ADAM_B2, ADAM_EPS, lr_t_dev=self.lr_t_dev)
+        self._graph, self._graph_key = g, self._batch_key(batch, dropout_mask)
+        return True
+
+    def release_graph(self):
+        self._graph = self._graph_key = None
+        if self.image is not None:
+            self.image.seed_dev = None
