@@ -95,6 +95,21 @@ int ds_conv_igemm_partials(const ds_conv_desc *d);
 int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float *w, float *z, const float *bias,
                   const float *mask, float *stats, const float *pivot, void *stream);
 
+/* 3x3 stride-1 SAME convolution as fused Winograd F(2x2, 3x3) on fp32 MFMA: 2.25x fewer matrix passes than the
+ * implicit GEMM for Conv2d_2c_3x3 and the Branch_1 / Branch_2 Conv2d_0b_3x3 of every Mixed block
+ * (image_model/inception_v1.py:74-75, 86-247), forward and Conv2DBackpropInput alike.
+ *   u      = G g G^T of the filter, [16][Cout][Cin] floats, made by ds_wino_transform_weights from the TF HWIO
+ *            tensor w [3][3][Cin_w][Cout_w] whenever w changes.  dgrad = 0: forward (Cin = Cin_w, Cout = Cout_w);
+ *            dgrad = 1: input gradient -- flipped taps, channel roles swapped (the conv then runs over dz with
+ *            Cin = Cout_w, Cout = Cin_w).  ds_wino_transform_weights takes (Cin_w, Cout_w) either way.
+ *   x, z   NHWC with pixel strides ldx / ldz; Cin % 8 == 0; flags: 0 or DS_EPI_STATS (partials float[2][Cout][P],
+ *          P = ds_conv_wino_partials, about `pivot` like ds_conv_igemm).
+ * Results equal the direct kernels' to ~1e-6 relative (the transforms round differently), deterministically.   */
+int ds_wino_transform_weights(const float *w, float *u, int32_t Cin, int32_t Cout, int32_t dgrad, void *stream);
+int ds_conv_wino_partials(int32_t N, int32_t H, int32_t W);
+int ds_conv_wino(const float *x, const float *u, float *z, float *stats, const float *pivot, int32_t N, int32_t H,
+                 int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz, int32_t flags, void *stream);
+
 /* Conv2DBackpropFilter / MatMul-transposed (wgrad), split over pixels.
  *   dw[tap, ci, co] = sum_m x[pixel(m)+tap, ci] * dz[m, co]
  * only reached for the trainable scope image_model/inception_v1.py:229-250,302-303 and the

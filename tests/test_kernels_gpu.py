@@ -164,6 +164,47 @@ def test_gemm_lstm_shape():
     close(dh, dg @ kern[40:].T)
 
 
+@pytest.mark.parametrize("case", [(2, 8, 8, 16, 32), (3, 14, 14, 24, 64), (2, 28, 28, 96, 128), (5, 7, 7, 160, 320),
+                                  (2, 13, 11, 48, 176), (1, 9, 10, 8, 40), (2, 56, 56, 64, 192)])
+def test_winograd_conv_forward_and_dgrad_match_oracle(case):
+    """ds_conv_wino (fused Winograd F(2x2,3x3), fp32 MFMA) against the fp64 direct-convolution oracle: forward with
+    BatchNorm statistics about a pivot, and the input gradient through the flipped / transposed transformed filter;
+    odd map sizes (half-empty border tiles), Cout not a multiple of 32, a ragged last tile group."""
+    ops = _ops()
+    N, H, W, Ci, Co = case
+    rng = np.random.RandomState(5)
+    x = rng.normal(size=(N, H, W, Ci))
+    w = rng.normal(size=(3, 3, Ci, Co)) * 0.1
+    ref = S.conv2d_same(x, w, 1)
+    xd, wd = dev(x), dev(w)
+    u = torch.empty(16, Co, Ci, device="cuda")
+    ops.wino_transform_weights(ops._p(wd), u, Ci, Co, dgrad=False)
+    plan = ops.WinoPlan(N, H, W, Ci, Ci, Co, Co, flags=ops.DS_EPI_STATS)
+    M = plan.M
+    z = torch.full((M, Co), float("nan"), device="cuda")
+    stats = torch.zeros(2, Co, plan.partials, device="cuda")
+    pivot = dev(rng.normal(size=Co) * 0.1)
+    plan.run(ops._p(xd), ops._p(u), ops._p(z), stats=ops._p(stats), pivot=ops._p(pivot))
+    torch.cuda.synchronize()
+    zz = ref.reshape(M, Co)
+    close(z, zz, 2e-4)
+    pv = pivot.cpu().numpy().astype(np.float64)
+    close(stats[0].sum(1), (zz - pv).sum(0), 2e-3)
+    close(stats[1].sum(1), ((zz - pv) ** 2).sum(0), 2e-3)
+    # dgrad: correlation over dz with the flipped, channel-transposed filter
+    dy = rng.normal(size=ref.shape)
+    ud = torch.empty(16, Ci, Co, device="cuda")
+    ops.wino_transform_weights(ops._p(wd), ud, Ci, Co, dgrad=True)
+    g = ops.WinoPlan(N, H, W, Co, Co, Ci, Ci + 4)                 # strided output rows (ldz > Cout)
+    dx = torch.zeros(M, Ci + 4, device="cuda")
+    dyd = dev(dy)
+    if Co % 8 == 0:
+        g.run(ops._p(dyd), ops._p(ud), ops._p(dx))
+        torch.cuda.synchronize()
+        close(dx[:, :Ci], S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1).reshape(-1, Ci), 2e-4)
+        assert float(dx[:, Ci:].abs().max()) == 0.0
+
+
 def _bf16_round(a):
     """round-to-nearest-even to bfloat16, returned as float64 (what v_cvt_pk_bf16_f32 does to the operands)"""
     u = np.asarray(a, np.float32).view(np.uint32).astype(np.uint64)

@@ -1,0 +1,286 @@
+// 3x3 stride-1 SAME convolution (forward and dgrad) as fused Winograd F(2x2, 3x3) on the fp32 matrix cores.
+//
+// The 3x3 layers are 2/3 of Inception-v1's multiplies (image_model/inception_v1.py: Conv2d_2c_3x3 :74-75 and the
+// Branch_1 / Branch_2 Conv2d_0b_3x3 of all nine Mixed blocks :86-247) and fp32 MFMA runs at the fp32 vector rate, so
+// the direct implicit GEMM is bound by the matrix pipe even when everything else is hidden.  Winograd's minimal
+// filtering trades 36 multiplies per 2x2 output tile and channel pair for 16:
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A            (Lavin & Gray, F(2x2, 3x3); cross-correlation form)
+// i.e. sixteen independent GEMMs  M_xi[tile, co] = sum_ci V_xi[tile, ci] U_xi[ci, co]  over the sixteen positions
+// xi of the transformed 4x4 patch -- 2.25x fewer MFMA passes for the same convolution.
+//
+// Fused form (nothing but x, the pre-transformed weights U and z touches memory):
+//   * a wave owns 32 output tiles x 32 output channels and ALL sixteen positions: sixteen 32x32 fp32 accumulators
+//     = 256 accumulator registers (gfx950's unified 512-register file at one wave per SIMD);
+//   * lane (i, kh) of the 32x32x2 MFMA's A operand is tile i and channels 4 kh .. 4 kh + 3 of the 8-channel K step:
+//     the lane loads the 16 pixels of its own 4x4 input patch as float4 (SRD loads, padding pixels and tiles past
+//     the end read zeros from an out-of-range offset), runs B^T d B on them in registers (32 adds per channel) and
+//     the sixteen results ARE its A fragments -- no LDS round trip, no im2col, no transformed-input tensor;
+//   * the transformed weights U [16][Cout][Cin] (ci contiguous; made once per weight update by
+//     ds_wino_transform_weights) are the B operand: the workgroup's [16][32][8] slice of a K step goes global -> LDS
+//     by LDS-DMA (lane-linear = exactly this layout), double buffered, shared by the four waves (four different
+//     32-tile groups, same 32 channels);
+//   * the matrix pipe needs 64 cycles per MFMA, so between two MFMAs the wave has issue slots for the next
+//     position's ds_read_b128 and for the loads of the next K step: per K step 64 MFMAs (4096 cycles) against
+//     ~128 transform adds, 16 + 4 loads, 16 LDS reads and one barrier;
+//   * epilogue: A^T M A per lane across the sixteen accumulators (the C layout is position independent), 2x2
+//     outputs stored as 128-byte channel runs, BatchNorm column statistics about the pivot as in conv_igemm.hip.
+// dgrad of a 3x3 stride-1 SAME conv is the same correlation over dz with the taps flipped and the channel roles
+// swapped, so it is this kernel with U built from the flipped, transposed filter.
+// Numerics: fp32 throughout; the transforms add ~1e-7-level rounding of their own (inputs are combined before the
+// multiply), so results match the direct kernels to ~1e-6 relative, not bit for bit; reductions are ordered and
+// deterministic.
+#include <stdlib.h>
+#include "ds_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr unsigned kOOB = 0x80000000u;
+
+struct WinoParams {
+    const float *x;         // [N, H, W, ldx]
+    const float *u;         // [16][Cout][Cin]
+    float *z;               // [N, H, W, ldz]
+    float *stats;           // [2][Cout][P], P = gridDim.x
+    const float *pivot;
+    int N, H, W, Cin, ldx, Cout, ldz;
+    int TH, TW, Mt;         // output tiles per column / row / in total
+    unsigned x_bytes, u_bytes;
+    int flags;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wsrd(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+typedef __attribute__((address_space(3))) void *lds_ptr;
+
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
+    // B tile of one K step: [16 positions][32 channels][8 ci] floats = 16 KB, two buffers
+    __shared__ __attribute__((aligned(128))) float smem[2 * 16 * 32 * 8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kh = lane >> 5;
+    const int co0 = blockIdx.y * 32;
+    const int tile0 = (blockIdx.x * 4 + wave) * 32;
+    const __amdgpu_buffer_rsrc_t srd_x = wsrd(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t srd_u = wsrd(p.u, p.u_bytes);
+
+    // ---- this lane's tile: byte offsets of the 16 pixels of its 4x4 input patch (channel 4 kh) -------------
+    const int m = tile0 + li;
+    const bool tv = m < p.Mt;
+    const int tpi = p.TH * p.TW;
+    const int n = (tv ? m : 0) / tpi;
+    const int r = (tv ? m : 0) - n * tpi;
+    const int th = r / p.TW, tw = r - th * p.TW;
+    unsigned voff[16];
+#pragma unroll
+    for (int py = 0; py < 4; ++py)
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const int ih = 2 * th - 1 + py, iw = 2 * tw - 1 + px;
+            const bool ok = tv && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            voff[py * 4 + px] = ok ? (unsigned)(((n * p.H + ih) * p.W + iw) * p.ldx + 4 * kh) * 4u : kOOB;
+        }
+    // ---- B tile DMA slots: instruction i of wave w fills floats [(i*256 + w*64 + lane) * 4, +4) of the buffer ---
+    unsigned uoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 256 + tid;                  // (xi, co, half) = (idx / 64, (idx / 2) % 32, idx % 2)
+        const int xi = idx >> 6, co = (idx >> 1) & 31, half = idx & 1;
+        uoff[i] = (co0 + co < p.Cout) ? (unsigned)(((xi * p.Cout + co0 + co) * p.Cin) + 4 * half) * 4u : kOOB;
+    }
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[xi][e] = 0.f;
+
+    f32x4 raw[16];
+    auto load_raw = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            raw[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff[q], c0 * 4, 0));
+    };
+    auto dma_u = [&](int buf, int c0) {
+        float *dst = smem + buf * 4096 + wave * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_u, (lds_ptr)(dst + i * 1024), 16, uoff[i], c0 * 4, 0, 0);
+    };
+
+    const int ksteps = p.Cin >> 3;
+    load_raw(0);
+    dma_u(0, 0);
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        // ---- V = B^T d B on the 16 pixels, per channel component: the results are the A fragments ---------------
+        f32x4 v[16];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const f32x4 d0 = raw[px], d1 = raw[4 + px], d2 = raw[8 + px], d3 = raw[12 + px];
+            v[px] = d0 - d2;
+            v[4 + px] = d1 + d2;
+            v[8 + px] = d2 - d1;
+            v[12 + px] = d1 - d3;
+        }
+#pragma unroll
+        for (int py = 0; py < 4; ++py) {
+            const f32x4 t0 = v[py * 4], t1 = v[py * 4 + 1], t2 = v[py * 4 + 2], t3 = v[py * 4 + 3];
+            v[py * 4] = t0 - t2;
+            v[py * 4 + 1] = t1 + t2;
+            v[py * 4 + 2] = t2 - t1;
+            v[py * 4 + 3] = t1 - t3;
+        }
+        if (ks + 1 < ksteps) {          // operands of the next K step: in flight under this step's MFMAs
+            load_raw((ks + 1) * 8);
+            dma_u((ks + 1) & 1, (ks + 1) * 8);
+        }
+        const float *b_s = smem + (ks & 1) * 4096 + li * 8 + kh * 4;
+        f32x4 b = *reinterpret_cast<const f32x4 *>(b_s);
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            // the next position's weights are read while this position's four MFMAs occupy the matrix pipe
+            const f32x4 bn = *reinterpret_cast<const f32x4 *>(b_s + (xi < 15 ? xi + 1 : 15) * 256);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[xi][j], b[j], acc[xi], 0, 0, 0);
+            b = bn;
+        }
+        __syncthreads();
+    }
+
+    // ---- output transform Y = A^T M A, per lane across the sixteen accumulators; store; statistics ---------------
+    // accumulator element e of every position is the same (tile row, channel column): row = (e&3) + 8 (e>>2) + 4 kh
+    const int col = co0 + li;
+    const bool colok = col < p.Cout;
+    const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
+    // pixel base (floats) of the tile each row of the C layout belongs to, fetched from the lane that owns that tile
+    const int obase = tv ? ((n * p.H + 2 * th) * p.W + 2 * tw) : -1;
+    const int oh_ok = tv ? ((2 * th + 1 < p.H) ? 1 : 0) : 0, ow_ok = tv ? ((2 * tw + 1 < p.W) ? 1 : 0) : 0;
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int ob = __shfl(obase, row);
+        const int okh = __shfl(oh_ok, row), okw = __shfl(ow_ok, row);
+        float mm[16];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) mm[xi] = acc[xi][e];
+        // rows of A^T M: a0 = m0 + m1 + m2, a1 = m1 - m2 - m3 (over the first index), then the same over the second
+        float a0[4], a1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a0[j] = mm[j] + mm[4 + j] + mm[8 + j];
+            a1[j] = mm[4 + j] - mm[8 + j] - mm[12 + j];
+        }
+        const float y00 = a0[0] + a0[1] + a0[2], y01 = a0[1] - a0[2] - a0[3];
+        const float y10 = a1[0] + a1[1] + a1[2], y11 = a1[1] - a1[2] - a1[3];
+        if (ob >= 0 && colok) {
+            float *o = p.z + (int64_t)ob * p.ldz + col;
+            o[0] = y00;
+            float u = y00 - pv;
+            s += u; q += u * u;
+            if (okw) { o[p.ldz] = y01; u = y01 - pv; s += u; q += u * u; }
+            if (okh) {
+                o[(int64_t)p.W * p.ldz] = y10; u = y10 - pv; s += u; q += u * u;
+                if (okw) { o[(int64_t)(p.W + 1) * p.ldz] = y11; u = y11 - pv; s += u; q += u * u; }
+            }
+        }
+    }
+    if (p.flags & DS_EPI_STATS) {
+        float *red = smem;        // [4 waves][32][2]; every wave passed the last K-loop barrier, no DMA in flight
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+        if (kh == 0) {
+            red[(wave * 32 + li) * 2 + 0] = s;
+            red[(wave * 32 + li) * 2 + 1] = q;
+        }
+        __syncthreads();
+        if (tid < 32 && co0 + tid < p.Cout) {
+            float ss = 0.f, qq = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                ss += red[(w * 32 + tid) * 2 + 0];
+                qq += red[(w * 32 + tid) * 2 + 1];
+            }
+            p.stats[(int64_t)(co0 + tid) * gridDim.x + blockIdx.x] = ss;
+            p.stats[((int64_t)p.Cout + co0 + tid) * gridDim.x + blockIdx.x] = qq;
+        }
+    }
+}
+
+// U = G g G^T for every (ci, co) pair.  w is the TF HWIO filter [3][3][Cin][Cout].
+//   dgrad == 0: U[xi][co][ci] from g = w[:, :, ci, co]                       (forward)
+//   dgrad == 1: U[xi][ci][co] from g = w[2 - kh, 2 - kw, ci, co]             (Conv2DBackpropInput: flipped taps,
+//               output channel = ci, reduction channel = co)
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float *w, float *u, int Cin, int Cout, int dgrad) {
+    const int64_t total = (int64_t)Cin * Cout;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ci = (int)(i / Cout), co = (int)(i - (int64_t)ci * Cout);
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                g[a][b] = w[((int64_t)((dgrad ? 2 - a : a) * 3 + (dgrad ? 2 - b : b)) * Cin + ci) * Cout + co];
+        float t[4][3];          // G g
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+            t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+        const int64_t plane = total;
+        const int64_t o = dgrad ? (int64_t)ci * Cout + co : (int64_t)co * Cin + ci;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            u[(a * 4 + 0) * plane + o] = t[a][0];
+            u[(a * 4 + 1) * plane + o] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+            u[(a * 4 + 2) * plane + o] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+            u[(a * 4 + 3) * plane + o] = t[a][2];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ds_wino_transform_weights(const float *w, float *u, int32_t Cin, int32_t Cout, int32_t dgrad, void *stream) {
+    DS_REQUIRE(w && u && Cin > 0 && Cout > 0, "ds_wino_transform_weights: bad argument");
+    hipLaunchKernelGGL(wino_weights_kernel, dim3(ds::stream_grid((int64_t)Cin * Cout, 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, u, Cin, Cout, dgrad);
+    return ds::check_launch("ds_wino_transform_weights");
+}
+
+extern "C" int ds_conv_wino_partials(int32_t N, int32_t H, int32_t W) {
+    const int64_t mt = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2);
+    return (int)((mt + 127) / 128);
+}
+
+extern "C" int ds_conv_wino(const float *x, const float *u, float *z, float *stats, const float *pivot, int32_t N,
+                            int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz, int32_t flags,
+                            void *stream) {
+    DS_REQUIRE(x && u && z && N > 0 && H > 0 && W > 0, "ds_conv_wino: bad argument");
+    DS_REQUIRE(Cin > 0 && Cin % 8 == 0 && ldx % 4 == 0 && ldx >= Cin && Cout > 0 && ldz >= Cout &&
+                   ((((uintptr_t)x | (uintptr_t)u) & 15) == 0),
+               "ds_conv_wino: needs Cin %% 8 == 0, ldx %% 4 == 0 and 16-byte aligned operands");
+    DS_REQUIRE((flags & ~DS_EPI_STATS) == 0 && (!(flags & DS_EPI_STATS) || stats), "ds_conv_wino: only DS_EPI_STATS is supported");
+    WinoParams p;
+    p.x = x; p.u = u; p.z = z; p.stats = stats; p.pivot = (flags & DS_EPI_STATS) ? pivot : nullptr;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.ldz = ldz;
+    p.TH = (H + 1) / 2; p.TW = (W + 1) / 2;
+    const int64_t mt = (int64_t)N * p.TH * p.TW;
+    const int64_t xb = ((int64_t)N * H * W - 1) * ldx + Cin, ub = (int64_t)16 * Cin * Cout;
+    DS_REQUIRE(mt < (1ll << 30) && xb * 4 < (1ll << 31) && ub * 4 < (1ll << 31), "ds_conv_wino: operand larger than 2 GiB");
+    p.Mt = (int)mt;
+    p.x_bytes = (unsigned)(xb * 4);
+    p.u_bytes = (unsigned)(ub * 4);
+    p.flags = flags;
+    const dim3 grid((unsigned)((mt + 127) / 128), (unsigned)((Cout + 31) / 32));
+    hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return ds::check_launch("ds_conv_wino");
+}

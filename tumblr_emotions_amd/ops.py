@@ -125,6 +125,32 @@ def gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=False, flags=0, ldmask=0, sp
                     pad_t=0, pad_l=0, OH=1, OW=1, splits=splits, z_split_stride=z_split_stride, dtype=dtype)
 
 
+class WinoPlan:
+    """3x3 stride-1 SAME conv through ds_conv_wino (fused Winograd F(2x2,3x3)); `u` is the transformed filter."""
+
+    def __init__(self, N, H, W, Cin, ldx, Cout, ldz, flags=0):
+        self.args = (N, H, W, Cin, ldx, Cout, ldz)
+        self.flags = flags
+        self.M = N * H * W
+        self.partials = _lib.load().ds_conv_wino_partials(N, H, W) if flags & DS_EPI_STATS else 0
+        self.alg_flops = 2.0 * self.M * Cout * 9 * Cin          # the convolution's FLOPs, not Winograd's
+
+    def run(self, x, u, z, stats=None, pivot=None):
+        t = CONV_TIMER
+        if t is not None:
+            t.begin()
+        N, H, W, Cin, ldx, Cout, ldz = self.args
+        _lib.check(_lib.load().ds_conv_wino(x, u, z, stats, pivot, N, H, W, Cin, ldx, Cout, ldz, self.flags, _stream()),
+                   "ds_conv_wino")
+        if t is not None:
+            t.end(self)
+
+
+def wino_transform_weights(w_ptr, u, Cin, Cout, dgrad):
+    _lib.check(_lib.load().ds_wino_transform_weights(w_ptr, _p(u), Cin, Cout, int(dgrad), _stream()),
+               "ds_wino_transform_weights")
+
+
 class WgradPlan:
     """dw[tap, ci, co] = sum_m x[pixel(m)+tap, ci] * dz[m, co]; geometry given by a forward ConvPlan-like desc."""
 
