@@ -163,6 +163,8 @@ def main():
                          "forward/dgrad multiplies on the bf16 matrix pipe, fp32 storage/accumulate/statistics/masters")
     ap.add_argument("--stepwise-lstm", action="store_true",
                     help="A/B aid: one GEMM + one cell launch per LSTM step instead of the persistent ds_lstm_seq kernels")
+    ap.add_argument("--no-winograd", action="store_true",
+                    help="A/B aid: implicit GEMM for every 3x3 layer instead of the fused Winograd F(2x2,3x3) kernel")
     ap.add_argument("--graph", action="store_true",
                     help="replay the training step as one captured hipGraph (single rank; what bounds small per-GPU batches "
                          "is host launch cost)")
@@ -210,6 +212,8 @@ def main():
     net.initialize(seed=1)
     if args.stepwise_lstm and net.text is not None:
         net.text.persistent = False
+    if args.no_winograd and net.image is not None:
+        net.image.winograd = False
     strong = args.global_batch > 0
     if strong:
         assert args.global_batch % world == 0, "--global-batch must divide by the number of ranks"
@@ -296,7 +300,9 @@ def main():
             kname = ("conv_bf16_kernel (ds_conv_igemm, DS_DTYPE_BF16: v_mfma_f32_32x32x16_bf16 implicit GEMM, fp32 accumulate; conv "
                      "fwd + dgrad) together with the fp32 GEMMs of the LSTM / heads launched through the same entry point"
                      if args.dtype == "bf16" else
-                     "conv_igemm_kernel + conv_glds_kernel (ds_conv_igemm: fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; conv fwd, dgrad, GEMMs)")
+                     "conv_igemm_kernel + conv_glds_kernel + conv_wino_kernel (fp32 v_mfma_f32_32x32x2_f32: implicit GEMM for conv fwd / "
+                     "dgrad / GEMMs through ds_conv_igemm, fused Winograd F(2x2,3x3) for the 3x3 layers through ds_conv_wino; FLOPs "
+                     "counted are the convolution's 2*M*N*K, so the Winograd launches can exceed the matrix peak)")
             roof = dict(bound="mfma", kernel=kname,
                         achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
                         frac=round(ach / peak, 4), traffic=traffic, traffic_unit="HBM bytes per launch",

@@ -18,7 +18,7 @@ import ctypes as C
 import torch
 
 from . import ops
-from .ops import ConvPlan, WgradPlan, gemm_plan, make_segments, same_pad, DS_EPI_BIAS, DS_EPI_STATS
+from .ops import ConvPlan, WgradPlan, WinoPlan, gemm_plan, make_segments, same_pad, DS_EPI_BIAS, DS_EPI_STATS
 
 BN_EPS = 0.001         # slim/nets/inception_utils.py:35
 BN_DECAY = 0.9997      # slim/nets/inception_utils.py:34
@@ -90,6 +90,19 @@ class ConvBN:
         else:
             self.fwd = ConvPlan(B, self.H, self.W, cin, 0, k, k, self.stride, cout, cout, cin * cout, 1, cout,
                                 flags=DS_EPI_STATS, dtype=eng.conv_dtype)
+        # 3x3 stride-1 layers: fused Winograd F(2x2,3x3) where it beats the implicit GEMM (measured per shape,
+        # profiles/r02_wino_layers.txt): needs 8-channel K steps, loses on <= 32 output channels (one 32-wide
+        # column block, most of it padding) and on the short-K 7x7 maps
+        def wino_ok(H, cin_k, cout_k):
+            return (eng.winograd and eng.conv_dtype == ops.DS_DTYPE_F32 and k == 3 and self.stride == 1 and
+                    cin_k % 8 == 0 and cout_k >= 48 and (H >= 14 or cin_k >= 192))
+        self.wino_fwd = self.wino_dgrad = None
+        if wino_ok(self.H, cin, cout):
+            self.wino_fwd = WinoPlan(B, self.H, self.W, cin, 0, cout, cout, flags=DS_EPI_STATS)
+            self.u_fwd = torch.empty(16, cout, cin, device=dev)
+            eng.need_stats(self.wino_fwd.partials * 2 * cout)
+        self._wino_dgrad_ok = wino_ok(self.H, cout, cin)
+        self.u_version = -1
         eng.need_stats(self.fwd.partials * 2 * cout)
         self.bwd_P = ops.bn_bwd_partials(self.M, cout)
         eng.need_bwd_partials(self.bwd_P * 2 * cout)
@@ -120,6 +133,23 @@ class ConvBN:
         k, cin, cout = self.k, self.cin, self.cout
         self.dgrad = ConvPlan(self.B, self.H, self.W, cout, cout, k, k, 1, cin, lddx, cin * cout, cout, 1, flip=1,
                               dtype=self.eng.conv_dtype)
+        if self._wino_dgrad_ok:
+            self.wino_dgrad = WinoPlan(self.B, self.H, self.W, cout, cout, cin, lddx)
+            self.u_dgrad = torch.empty(16, cin, cout, device=self.eng.device)
+
+    def _refresh_wino(self):
+        """G g G^T of the filter for the Winograd kernels: redone when the weights changed -- every step for a
+        trainable layer (Adam moves them), once per load for a frozen one."""
+        eng = self.eng
+        if self.wino_fwd is None and self.wino_dgrad is None:
+            return
+        if not self.trainable and self.u_version == eng.weights_version:
+            return
+        if self.wino_fwd is not None:
+            ops.wino_transform_weights(self.w_ptr, self.u_fwd, self.cin, self.cout, False)
+        if self.wino_dgrad is not None:
+            ops.wino_transform_weights(self.w_ptr, self.u_dgrad, self.cin, self.cout, True)
+        self.u_version = eng.weights_version
 
     # x_ptr: input activations [B,H,W,ldx]; segs: where relu(bn(conv)) is scattered (None: the consumer, a max
     # pool, applies BatchNorm + ReLU to its own output instead -- PoolStage.forward)
@@ -127,17 +157,31 @@ class ConvBN:
         eng = self.eng
         if not self.fold:
             self.fwd.d.ldx = ldx
+        self._refresh_wino()
+        wino = self.wino_fwd
+        if wino is not None:
+            wino.args = wino.args[:4] + (ldx,) + wino.args[5:]
         if eng.training:       # batch statistics (slim.batch_norm is_training=True)
             # the column sums are taken about a pivot near the mean -- the previous step's batch mean, the
             # moving mean before the first step (bind) -- so channels with |mean| >> std keep their variance
-            self.fwd.d.flags = DS_EPI_STATS
-            self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z), stats=ops._p(eng.stats), pivot=ops._p(self.mean))
-            ops.bn_finalize(eng.stats, self.fwd.partials, self.M, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
+            if wino is not None:
+                wino.flags = DS_EPI_STATS
+                wino.run(x_ptr, ops._p(self.u_fwd), ops._p(self.z), stats=ops._p(eng.stats), pivot=ops._p(self.mean))
+                P = wino.partials
+            else:
+                self.fwd.d.flags = DS_EPI_STATS
+                self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z), stats=ops._p(eng.stats), pivot=ops._p(self.mean))
+                P = self.fwd.partials
+            ops.bn_finalize(eng.stats, P, self.M, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
                             self.rstd, self.shift, self.mm if eng.update_moving else None,
                             self.mv if eng.update_moving else None, pivot=self.mean)
         else:                  # moving statistics (is_training=False: evaluate_* on the validation split)
-            self.fwd.d.flags = 0
-            self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z))
+            if wino is not None:
+                wino.flags = 0
+                wino.run(x_ptr, ops._p(self.u_fwd), ops._p(self.z))
+            else:
+                self.fwd.d.flags = 0
+                self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z))
             ops.bn_infer_prepare(self.beta, self.mm, self.mv, BN_EPS, self.cout, self.rstd, self.shift)
         if segs is not None:
             ops.bn_apply_relu(self.z, self.M, self.cout, self.rstd, self.shift, segs)
@@ -162,6 +206,12 @@ class ConvBN:
             self.wgrad.d.ldx = ldx
             self.wgrad.run(x_ptr, ops._p(self.z), self.gw_ptr, ops._p(eng.ws), eng.ws_bytes)
         if need_dx:
+            self._run_dgrad(dx_ptr)
+
+    def _run_dgrad(self, dx_ptr):
+        if self.wino_dgrad is not None:
+            self.wino_dgrad.run(ops._p(self.z), ops._p(self.u_dgrad), dx_ptr)
+        else:
             self.dgrad.run(ops._p(self.z), self.w_ptr, dx_ptr)
 
     def backward(self, dy_segs, x_ptr=None, ldx=0, dx_ptr=None, need_dx=True):
@@ -179,7 +229,7 @@ class ConvBN:
             self.wgrad.d.ldx = ldx
             self.wgrad.run(x_ptr, ops._p(self.z), self.gw_ptr, ops._p(eng.ws), eng.ws_bytes)
         if need_dx:
-            self.dgrad.run(ops._p(self.z), self.w_ptr, dx_ptr)
+            self._run_dgrad(dx_ptr)
 
 
 class Stage:
@@ -368,6 +418,8 @@ class InceptionV1Engine:
         self.training = True         # False: BatchNorm uses moving statistics, dropout is the identity
         self.reducer = None          # dp.GradientReducer, set by SentimentNet
         self.seed_dev = None         # device int64 added to the dropout seed (hipGraph replay draws fresh masks)
+        self.winograd = True         # 3x3 layers through ds_conv_wino where it wins (False: implicit GEMM everywhere)
+        self.weights_version = 0     # bumped by SentimentNet.after_load(): frozen layers redo their G g G^T
         self._stats_n = self._bwdp_n = self._ws_bytes = 0
         self.B = None
         self.input = InputStage(self, image_size)

@@ -154,6 +154,8 @@ class SentimentNet:
                 ops.sumsq(self.store.view(e.name), e.numel, self.l2_scratch, self.l2_buf)
                 tot += float(self.l2_buf.item())
         self.frozen_l2_sumsq = tot
+        if self.image is not None:
+            self.image.weights_version += 1      # Winograd-transformed copies of the frozen filters are stale
 
     # ---- forward / loss ---------------------------------------------------------------------------
     def forward(self, batch, dropout_mask=None, seed=0):
