@@ -47,7 +47,7 @@ struct WinoParams {
     const float *pivot;
     int N, H, W, Cin, ldx, Cout, ldz;
     int TH, TW, Mt;         // output tiles per column / row / in total
-    unsigned x_bytes, u_bytes;
+    unsigned x_bytes, u_bytes, z_bytes;
     int flags;
 };
 
@@ -135,20 +135,39 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
             v[py * 4 + 2] = t2 - t1;
             v[py * 4 + 3] = t1 - t3;
         }
-        if (ks + 1 < ksteps) {          // operands of the next K step: in flight under this step's MFMAs
-            load_raw((ks + 1) * 8);
-            dma_u((ks + 1) & 1, (ks + 1) * 8);
-        }
+        // Operands of the next K step are requested BETWEEN the MFMA groups, two patch pixels (and one weight DMA) per
+        // pair of positions: each pixel-scattered load occupies the texture-address path for a while, and issued in one
+        // burst at the top of the step they stall the wave's in-order issue with the matrix pipe idle (measured
+        // +0.8 us per step); spread out, they sit in the shadow of the eight MFMAs in front of them.
+        const bool more = ks + 1 < ksteps;
+        const int cn = (ks + 1) * 8;
+        float *dma_dst = smem + ((ks + 1) & 1) * 4096 + wave * 256;
         const float *b_s = smem + (ks & 1) * 4096 + li * 8 + kh * 4;
-        f32x4 b = *reinterpret_cast<const f32x4 *>(b_s);
+        // positions in pairs: consecutive MFMAs alternate between two accumulators, and the next pair's weights are
+        // read while this pair's eight MFMAs run
+        f32x4 b0 = *reinterpret_cast<const f32x4 *>(b_s), b1 = *reinterpret_cast<const f32x4 *>(b_s + 256);
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            // the next position's weights are read while this position's four MFMAs occupy the matrix pipe
-            const f32x4 bn = *reinterpret_cast<const f32x4 *>(b_s + (xi < 15 ? xi + 1 : 15) * 256);
+        for (int xi = 0; xi < 16; xi += 2) {
+            const int nx = xi + 2 < 16 ? xi + 2 : 14;
+            const f32x4 n0 = *reinterpret_cast<const f32x4 *>(b_s + nx * 256);
+            const f32x4 n1 = *reinterpret_cast<const f32x4 *>(b_s + (nx + 1) * 256);
+            if (more) {
+                if (!(p.flags & 256)) {
+                    raw[xi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff[xi], cn * 4, 0));
+                    raw[xi + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff[xi + 1], cn * 4, 0));
+                }
+                if (xi < 8 && !(p.flags & 512))
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_u, (lds_ptr)(dma_dst + (xi >> 1) * 1024), 16, uoff[xi >> 1], cn * 4, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[xi][j], b[j], acc[xi], 0, 0, 0);
-            b = bn;
+            for (int j = 0; j < 4; ++j) {
+                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[xi][j], b0[j], acc[xi], 0, 0, 0);
+                acc[xi + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[xi + 1][j], b1[j], acc[xi + 1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            b0 = n0;
+            b1 = n1;
         }
         __syncthreads();
     }
@@ -158,15 +177,22 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     const int col = co0 + li;
     const bool colok = col < p.Cout;
     const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
-    // pixel base (floats) of the tile each row of the C layout belongs to, fetched from the lane that owns that tile
-    const int obase = tv ? ((n * p.H + 2 * th) * p.W + 2 * tw) : -1;
-    const int oh_ok = tv ? ((2 * th + 1 < p.H) ? 1 : 0) : 0, ow_ok = tv ? ((2 * tw + 1 < p.W) ? 1 : 0) : 0;
+    const __amdgpu_buffer_rsrc_t srd_z = wsrd(p.z, p.z_bytes);
+    // byte offset of the tile's top-left output pixel (channel 0), or out of range; bit 0 / 1 = the tile has a
+    // right column / a bottom row inside the image (odd H, W).  Read from the lane that owns the tile with
+    // v_readlane (the row of an accumulator element is a compile-time constant plus 4 kh).
+    const unsigned obase = tv ? (unsigned)(((n * p.H + 2 * th) * p.W + 2 * tw) * p.ldz) * 4u : kOOB;
+    const int oflags = tv ? ((2 * tw + 1 < p.W ? 1 : 0) | (2 * th + 1 < p.H ? 2 : 0)) : 0;
+    const unsigned right = (unsigned)p.ldz * 4u, below = (unsigned)(p.W * p.ldz) * 4u;
+    const unsigned cbyte = colok ? (unsigned)col * 4u : kOOB;
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
-        const int ob = __shfl(obase, row);
-        const int okh = __shfl(oh_ok, row), okw = __shfl(ow_ok, row);
+        const int row0 = (e & 3) + 8 * (e >> 2);
+        const unsigned ob0 = __builtin_amdgcn_readlane(obase, row0), ob1 = __builtin_amdgcn_readlane(obase, row0 + 4);
+        const int of0 = __builtin_amdgcn_readlane(oflags, row0), of1 = __builtin_amdgcn_readlane(oflags, row0 + 4);
+        const unsigned ob = kh ? ob1 : ob0;
+        const int of = kh ? of1 : of0;
         float mm[16];
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) mm[xi] = acc[xi][e];
@@ -177,18 +203,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
             a0[j] = mm[j] + mm[4 + j] + mm[8 + j];
             a1[j] = mm[4 + j] - mm[8 + j] - mm[12 + j];
         }
-        const float y00 = a0[0] + a0[1] + a0[2], y01 = a0[1] - a0[2] - a0[3];
-        const float y10 = a1[0] + a1[1] + a1[2], y11 = a1[1] - a1[2] - a1[3];
-        if (ob >= 0 && colok) {
-            float *o = p.z + (int64_t)ob * p.ldz + col;
-            o[0] = y00;
-            float u = y00 - pv;
-            s += u; q += u * u;
-            if (okw) { o[p.ldz] = y01; u = y01 - pv; s += u; q += u * u; }
-            if (okh) {
-                o[(int64_t)p.W * p.ldz] = y10; u = y10 - pv; s += u; q += u * u;
-                if (okw) { o[(int64_t)(p.W + 1) * p.ldz] = y11; u = y11 - pv; s += u; q += u * u; }
-            }
+        const float y[4] = {a0[0] + a0[1] + a0[2], a0[1] - a0[2] - a0[3], a1[0] + a1[1] + a1[2], a1[1] - a1[2] - a1[3]};
+        // branch-free stores: a pixel outside the image or a column past Cout gets an out-of-range offset, which the
+        // buffer store drops
+        const bool live = ob != kOOB && colok;
+        const bool ok[4] = {live, live && (of & 1), live && (of & 2), live && (of & 3) == 3};
+        const unsigned off[4] = {ob, ob + right, ob + below, ob + below + right};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!(p.flags & 1024))
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[k]), srd_z, ok[k] ? off[k] + cbyte : kOOB, 0, 0);
+            const float u = ok[k] ? y[k] - pv : 0.f;
+            s += u;
+            q += u * u;
         }
     }
     if (p.flags & DS_EPI_STATS) {
@@ -268,7 +295,7 @@ extern "C" int ds_conv_wino(const float *x, const float *u, float *z, float *sta
     DS_REQUIRE(Cin > 0 && Cin % 8 == 0 && ldx % 4 == 0 && ldx >= Cin && Cout > 0 && ldz >= Cout &&
                    ((((uintptr_t)x | (uintptr_t)u) & 15) == 0),
                "ds_conv_wino: needs Cin %% 8 == 0, ldx %% 4 == 0 and 16-byte aligned operands");
-    DS_REQUIRE((flags & ~DS_EPI_STATS) == 0 && (!(flags & DS_EPI_STATS) || stats), "ds_conv_wino: only DS_EPI_STATS is supported");
+    DS_REQUIRE((flags & ~(DS_EPI_STATS | 256 | 512 | 1024 | 2048)) == 0 && (!(flags & DS_EPI_STATS) || stats), "ds_conv_wino: only DS_EPI_STATS is supported");
     WinoParams p;
     p.x = x; p.u = u; p.z = z; p.stats = stats; p.pivot = (flags & DS_EPI_STATS) ? pivot : nullptr;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.ldz = ldz;
@@ -279,6 +306,9 @@ extern "C" int ds_conv_wino(const float *x, const float *u, float *z, float *sta
     p.Mt = (int)mt;
     p.x_bytes = (unsigned)(xb * 4);
     p.u_bytes = (unsigned)(ub * 4);
+    const int64_t zb = ((int64_t)N * H * W - 1) * ldz + Cout;
+    DS_REQUIRE(zb * 4 < (1ll << 31), "ds_conv_wino: output larger than 2 GiB");
+    p.z_bytes = (unsigned)(zb * 4);
     p.flags = flags;
     const dim3 grid((unsigned)((mt + 127) / 128), (unsigned)((Cout + 31) / 32));
     hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);

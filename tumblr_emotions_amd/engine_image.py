@@ -91,11 +91,11 @@ class ConvBN:
             self.fwd = ConvPlan(B, self.H, self.W, cin, 0, k, k, self.stride, cout, cout, cin * cout, 1, cout,
                                 flags=DS_EPI_STATS, dtype=eng.conv_dtype)
         # 3x3 stride-1 layers: fused Winograd F(2x2,3x3) where it beats the implicit GEMM (measured per shape,
-        # profiles/r02_wino_layers.txt): needs 8-channel K steps, loses on <= 32 output channels (one 32-wide
-        # column block, most of it padding) and on the short-K 7x7 maps
+        # profiles/r02_wino_layers.txt: 1.3-1.8x on every 56x56 / 28x28 / 14x14 layer): needs 8-channel K steps;
+        # on the 7x7 maps (half-empty border tiles, 16 tiles per image) only the wide layers gain
         def wino_ok(H, cin_k, cout_k):
             return (eng.winograd and eng.conv_dtype == ops.DS_DTYPE_F32 and k == 3 and self.stride == 1 and
-                    cin_k % 8 == 0 and cout_k >= 48 and (H >= 14 or cin_k >= 192))
+                    cin_k % 8 == 0 and (H >= 14 or cout_k >= 128))
         self.wino_fwd = self.wino_dgrad = None
         if wino_ok(self.H, cin, cout):
             self.wino_fwd = WinoPlan(B, self.H, self.W, cin, 0, cout, cout, flags=DS_EPI_STATS)
