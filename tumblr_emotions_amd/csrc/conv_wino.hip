@@ -43,10 +43,11 @@ struct WinoParams {
     const float *x;         // [N, H, W, ldx]
     const float *u;         // [16][Cout][Cin]
     float *z;               // [N, H, W, ldz]
-    float *stats;           // [2][Cout][P], P = gridDim.x
+    float *stats;           // [2][Cout][P], P = groups
     const float *pivot;
     int N, H, W, Cin, ldx, Cout, ldz;
     int TH, TW, Mt;         // output tiles per column / row / in total
+    int groups, ncol;       // 128-tile groups, 32-channel blocks
     unsigned x_bytes, u_bytes, z_bytes;
     int flags;
 };
@@ -63,8 +64,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
-    const int co0 = blockIdx.y * 32;
-    const int tile0 = (blockIdx.x * 4 + wave) * 32;
+    // 1-D XCD-aware launch (as conv_igemm.hip's TileId): the row-major list of (tile group, channel block) pairs is
+    // cut into 8 contiguous ranges, one per XCD (workgroup id % 8, observed placement; a different one only costs
+    // speed), so the channel blocks of a tile group -- which read the same input patches -- run back to back on one
+    // XCD and the patches cross the fabric once per tile group instead of once per channel block.
+    const int id = blockIdx.x;
+    const int lin = (id & 7) * (int)(gridDim.x >> 3) + (id >> 3);
+    const int group = lin / p.ncol, cblk = lin - group * p.ncol;
+    const int co0 = cblk * 32;
+    const int tile0 = group < p.groups ? (group * 4 + wave) * 32 : p.Mt;      // surplus workgroups own no tile
     const __amdgpu_buffer_rsrc_t srd_x = wsrd(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t srd_u = wsrd(p.u, p.u_bytes);
 
@@ -234,8 +242,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                 ss += red[(w * 32 + tid) * 2 + 0];
                 qq += red[(w * 32 + tid) * 2 + 1];
             }
-            p.stats[(int64_t)(co0 + tid) * gridDim.x + blockIdx.x] = ss;
-            p.stats[((int64_t)p.Cout + co0 + tid) * gridDim.x + blockIdx.x] = qq;
+            if (group < p.groups) {
+                p.stats[(int64_t)(co0 + tid) * p.groups + group] = ss;
+                p.stats[((int64_t)p.Cout + co0 + tid) * p.groups + group] = qq;
+            }
         }
     }
 }
@@ -310,7 +320,9 @@ extern "C" int ds_conv_wino(const float *x, const float *u, float *z, float *sta
     DS_REQUIRE(zb * 4 < (1ll << 31), "ds_conv_wino: output larger than 2 GiB");
     p.z_bytes = (unsigned)(zb * 4);
     p.flags = flags;
-    const dim3 grid((unsigned)((mt + 127) / 128), (unsigned)((Cout + 31) / 32));
+    p.groups = (int)((mt + 127) / 128);
+    p.ncol = (Cout + 31) / 32;
+    const dim3 grid((unsigned)(((int64_t)p.groups * p.ncol + 7) / 8 * 8));
     hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     return ds::check_launch("ds_conv_wino");
 }
