@@ -85,6 +85,9 @@ int ds_conv_set_tile(int mt, int nt);
 /* Tuning aid: 0 = automatic, 1 = register-staged LDS kernel (K-tile 16), 2 = register-direct (LDS-free)
  * kernel, 3 = LDS-DMA kernel (buffer_load ... lds, K-tile 32; falls back to 1 where it does not apply). */
 int ds_conv_set_path(int path);
+/* Tuning aid: the wide-tile register-direct kernel for plain 1x1 / GEMM shapes (flags within DS_EPI_STATS):
+ * 0 = never, 1 = automatic (default), 2 = wherever the shape allows.                                      */
+int ds_conv_set_wide(int mode);
 /* Number of row-tile blocks (P) the launch for `d` will use = number of stats partials.   */
 int ds_conv_igemm_partials(const ds_conv_desc *d);
 /* stats (DS_EPI_STATS): float[2][Cout][P] partial column sums of (z - pivot) and (z - pivot)^2.

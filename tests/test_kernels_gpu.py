@@ -205,6 +205,49 @@ def test_winograd_conv_forward_and_dgrad_match_oracle(case):
         assert float(dx[:, Ci:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("case", [(300, 64, 64), (1000, 192, 176), (777, 480, 304), (513, 296, 512), (260, 40, 96),
+                                  (4096, 832, 624), (129, 280, 528)])
+def test_wide_1x1_kernel_forward_and_dgrad_match_oracle(case):
+    """The wide-tile register-direct kernel for plain 1x1 / GEMM shapes (gemm_wide_kernel), forced on for every
+    shape: forward (n-contiguous HWIO weights, BatchNorm statistics about a pivot) and dgrad (the same tensor read
+    k-contiguous); K not a multiple of the 16-channel step (296, 280, 40), N not a multiple of the column tile,
+    ragged last row group, strided input rows."""
+    ops = _ops()
+    from tumblr_emotions_amd import _lib
+    lib = _lib.load()
+    M, K, N = case
+    rng = np.random.RandomState(M + K + N)
+    x = rng.normal(size=(M, K + 8))[:, :K]                       # row stride K + 8
+    w = rng.normal(size=(K, N)) * 0.1
+    xd = dev(np.ascontiguousarray(np.pad(x, ((0, 0), (0, 8)), constant_values=np.nan)))   # NaN in the row padding
+    xd = torch.nan_to_num(xd, nan=7.0)                            # (finite garbage: the kernel may read it against zero weights)
+    wd = dev(w)
+    lib.ds_conv_set_wide(2)
+    try:
+        plan = ops.ConvPlan(M, 1, 1, K, K + 8, 1, 1, 1, N, N, 0, 1, N, flags=ops.DS_EPI_STATS, pad_t=0, pad_l=0, OH=1, OW=1)
+        z = torch.full((M, N), float("nan"), device="cuda")
+        stats = torch.zeros(2, N, plan.partials, device="cuda")
+        pivot = dev(rng.normal(size=N) * 0.2)
+        plan.run(ops._p(xd), ops._p(wd), ops._p(z), stats=ops._p(stats), pivot=ops._p(pivot))
+        torch.cuda.synchronize()
+        ref = x @ w
+        close(z, ref)
+        pv = pivot.cpu().numpy().astype(np.float64)
+        close(stats[0].sum(1), (ref - pv).sum(0), 2e-3)
+        close(stats[1].sum(1), ((ref - pv) ** 2).sum(0), 2e-3)
+        # dgrad: dx[M, K] = dz[M, N] * w^T, w read in place k(=n here)-contiguous
+        if N % 8 == 0 and N >= 32:
+            dz = rng.normal(size=(M, N))
+            g = ops.gemm_plan(M, N, K, N, K, N, transposed_w=True)
+            dx = torch.full((M, K), float("nan"), device="cuda")
+            dzd = dev(dz)
+            g.run(ops._p(dzd), ops._p(wd), ops._p(dx))
+            torch.cuda.synchronize()
+            close(dx, dz @ w.T)
+    finally:
+        lib.ds_conv_set_wide(1)
+
+
 def _bf16_round(a):
     """round-to-nearest-even to bfloat16, returned as float64 (what v_cvt_pk_bf16_f32 does to the operands)"""
     u = np.asarray(a, np.float32).view(np.uint32).astype(np.uint64)

@@ -41,6 +41,7 @@ SIGNATURES = {
     "ds_last_error": (C.c_char_p, []),
     "ds_conv_set_tile": (C.c_int, [C.c_int, C.c_int]),
     "ds_conv_set_path": (C.c_int, [C.c_int]),
+    "ds_conv_set_wide": (C.c_int, [C.c_int]),
     "ds_conv_igemm_partials": (C.c_int, [_CD]),
     "ds_conv_igemm": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ds_wino_transform_weights": (C.c_int, [_P, _P, _i32, _i32, _i32, _P]),

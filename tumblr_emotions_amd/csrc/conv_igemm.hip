@@ -28,6 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector (HIP's float4 is a struct)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void *lds_ptr;
 
 namespace {
 
@@ -689,8 +690,6 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? 3 : 2)) void conv_gld
         dw = tap - dh * d.KW;
     };
 
-    typedef __attribute__((address_space(3))) void *lds_ptr;
-
     auto issue_tile = [&](int buf) {       // DMA the K-tile the loader points at into buffer `buf`, then advance
         float *a_s = As + buf * ASZ + wm * 256;                  // this wave's 1 KiB window of pass j = 0
         const int ka = c0 + slc4;
@@ -1094,12 +1093,176 @@ __global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void conv_bf16_kernel(const C
     }
 }
 
+
+// ================================================================================================
+// Wide-tile 1x1 / GEMM variant: one wave per 32 rows x (NB * 32) columns, A operand register-direct.
+//
+// The 1x1 layers (Branch_0/1/2 Conv2d_0a_1x1 fused, Branch_3 Conv2d_0b_1x1, Conv2d_2b_1x1 and their dgrads) have no
+// spatial footprint: row m of the A operand IS pixel m.  So the structure that made the Winograd kernel fast applies
+// without the transform: lane (i, kh) of the 32x32x2 MFMA loads channels 4 kh .. 4 kh + 3 of row i as one float4 and
+// that IS its A fragment -- no LDS round trip for A, no barrier on its account -- and every A fragment is used for
+// NB * 4 MFMAs (NB up to 8: 256 columns, 128 accumulator registers) instead of 2 * 4 in the 128 x 64 LDS tile.  The B
+// operand (a [16 k][NB*32] slice of the weights per K step, read in place from the HWIO tensor) goes global -> LDS by
+// LDS-DMA, double buffered, shared by the workgroup's four waves (four 32-row groups); its fragments are read
+// position by position in the shadow of the MFMAs, and the loads / DMAs of the next K step are issued BETWEEN the
+// MFMA groups (conv_wino.hip: a burst of row-scattered loads stalls the in-order wave behind the texture path).
+// Epilogue: plain stores + BatchNorm column statistics about the pivot (flags 0 or DS_EPI_STATS only).
+// ================================================================================================
+template <int NB, bool BNMAJOR>
+__global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const ConvParams p) {
+    constexpr int BN = NB * 32, WK = 16;                       // K step: 16 channels = two float4 per lane
+    constexpr int BSZ = WK * BN;                               // floats per B buffer
+    constexpr int DJ = BSZ / 4 / 256;                          // 16-byte DMA slots per thread per K step (NB / 2 ... )
+    static_assert(BSZ % 1024 == 0, "B tile must be a whole number of DMA instructions per thread");
+    __shared__ __attribute__((aligned(128))) float smem[2 * BSZ + 256];
+    const ds_conv_desc &d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kh = lane >> 5;
+    const TileId t0 = tile_id(p);
+    const int n0 = t0.col * BN;
+    const bool item = t0.row < p.row_tiles;
+    const int m = t0.row * 128 + wave * 32 + li;
+    const __amdgpu_buffer_rsrc_t srd_x = make_srd(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t srd_w = make_srd(p.w, p.w_bytes);
+    const int K = d.Cin;
+    const unsigned voff = (item && m < p.M) ? ((unsigned)m * (unsigned)d.ldx + 4u * kh) * 4u : kOOB;
+
+    // B DMA slots.  n-contiguous weights (forward): buffer layout [k][n], slot -> (k = idx / (BN/4), n4 = idx % (BN/4)).
+    // k-contiguous weights (dgrad): buffer layout [n][16 k] with the four 16-byte chunks of a row XOR-swizzled by
+    // (n >> 2) & 3 on the SOURCE side (the DMA destination is lane-linear), conflict-free for ds_read_b128.
+    unsigned uoff[DJ];
+    int ukq[DJ];
+#pragma unroll
+    for (int i = 0; i < DJ; ++i) {
+        const int idx = i * 256 + tid;
+        if (BNMAJOR) {
+            const int k = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+            ukq[i] = k;
+            uoff[i] = n < d.Cout ? ((unsigned)k * (unsigned)d.w_k_stride + (unsigned)n) * 4u : kOOB;
+        } else {
+            const int nl = idx >> 2, pc = idx & 3, kq = pc ^ ((nl >> 2) & 3);
+            ukq[i] = kq * 4;
+            uoff[i] = n0 + nl < d.Cout ? ((unsigned)(n0 + nl) * (unsigned)d.w_n_stride + 4u * kq) * 4u : kOOB;
+        }
+    }
+    auto dma_b = [&](int buf, int c0, int i) {
+        // past the end of the reduction the weights must read as zeros (the A operand there is whatever follows in
+        // the row): out-of-range offset
+        const bool ok = c0 + ukq[i] < K;
+        const unsigned off = BNMAJOR ? uoff[i] + (unsigned)c0 * (unsigned)d.w_k_stride * 4u : uoff[i] + (unsigned)c0 * 4u;
+        // (written as an if: hipcc's host pass silently dropped this kernel's stub with a `cond ? off : kOOB` here)
+        unsigned o = off;
+        if (!ok || uoff[i] == 0x80000000u) o = 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr)(smem + buf * BSZ + wave * 256 + i * 1024), 16, o, 0, 0, 0);
+    };
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+
+    f32x4 a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, 0, 0));
+    f32x4 a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, 32, 0));
+#pragma unroll
+    for (int i = 0; i < DJ; ++i) dma_b(0, 0, i);
+    __syncthreads();
+    const int ksteps = (K + WK - 1) / WK;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const bool more = ks + 1 < ksteps;
+        const int cn = (ks + 1) * WK;
+        const float *b_s = smem + (ks & 1) * BSZ;
+        f32x4 n0v = a0, n1v = a1;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            // B fragments of column block b: lane (n, kh) needs B[k = 4 kh + j (+ 8)][32 b + n]
+            float bf[8];
+            if (BNMAJOR) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bf[j] = b_s[(4 * kh + j) * BN + 32 * b + li];
+                    bf[4 + j] = b_s[(8 + 4 * kh + j) * BN + 32 * b + li];
+                }
+            } else {
+                const int nl = 32 * b + li, sw = (nl >> 2) & 3;
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(b_s + nl * 16 + ((kh ^ sw) * 4));
+                const f32x4 hi = *reinterpret_cast<const f32x4 *>(b_s + nl * 16 + (((2 + kh) ^ sw) * 4));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bf[j] = lo[j]; bf[4 + j] = hi[j]; }
+            }
+            if (more) {                                    // next K step's operands, spread over the column blocks
+                if (b == 0) n0v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, cn * 4, 0));
+                if (b == (NB > 1 ? 1 : 0)) n1v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, cn * 4 + 32, 0));
+                if (b < DJ) dma_b((ks + 1) & 1, cn, b);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bf[j], acc[b], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bf[4 + j], acc[b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more && DJ > NB) {
+#pragma unroll
+            for (int i = NB; i < DJ; ++i) dma_b((ks + 1) & 1, cn, i);
+        }
+        a0 = n0v;
+        a1 = n1v;
+        __syncthreads();
+    }
+
+    // ---- epilogue: store, BatchNorm column statistics ---------------------------------------------------------------
+    const int flags = d.flags;
+    float *red = smem + 2 * BSZ;
+    const int mrow0 = t0.row * 128 + wave * 32;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int col = n0 + 32 * b + li;
+        const bool colok = item && col < d.Cout;
+        const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row < p.M && colok) {
+                const float v = acc[b][r];
+                p.z[(int64_t)row * d.ldz + col] = v;
+                const float u = v - pv;
+                s += u;
+                q += u * u;
+            }
+        }
+        if (flags & DS_EPI_STATS) {
+            s += __shfl_xor(s, 32);
+            q += __shfl_xor(q, 32);
+            __syncthreads();
+            if (kh == 0) {
+                red[(wave * 32 + li) * 2 + 0] = s;
+                red[(wave * 32 + li) * 2 + 1] = q;
+            }
+            __syncthreads();
+            if (tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
+                float ss = 0.f, qq = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    ss += red[(w * 32 + tid) * 2 + 0];
+                    qq += red[(w * 32 + tid) * 2 + 1];
+                }
+                p.stats[(int64_t)(n0 + 32 * b + tid) * t0.stride + t0.row] = ss;
+                p.stats[((int64_t)d.Cout + n0 + 32 * b + tid) * t0.stride + t0.row] = qq;
+            }
+        }
+    }
+}
+
 // ---- host-side dispatch -----------------------------------------------------------------------
 struct TileCfg {
     int mt, nt;
     bool direct;     // register-direct kernel (tile = per-WAVE 32*mt x 32*nt) instead of the LDS kernel
     bool glds;       // LDS-DMA kernel, K-tile 32 (128 x 32*nt tile)
     bool bf16;       // bf16-multiply kernel (128 x 32*nt tile, nt <= 4)
+    int wide;        // > 0: wide 1x1 kernel, 128 rows x 32*wide columns per workgroup
 };
 
 typedef void (*KernelFn)(const ConvParams);
@@ -1190,6 +1353,48 @@ KernelFn bf16_kernel(int nt, Variant v) {
     }
 }
 
+void launch_wide(int nb, bool bnmajor, dim3 grid, hipStream_t st, const ConvParams &p) {
+#define DS_WIDE(NBV)                                                                                   \
+    case NBV:                                                                                          \
+        if (bnmajor) hipLaunchKernelGGL((gemm_wide_kernel<NBV, true>), grid, dim3(256), 0, st, p);     \
+        else hipLaunchKernelGGL((gemm_wide_kernel<NBV, false>), grid, dim3(256), 0, st, p);            \
+        break;
+    switch (nb) {
+        DS_WIDE(2)
+        DS_WIDE(4)
+        DS_WIDE(6)
+        default:
+        DS_WIDE(8)
+    }
+#undef DS_WIDE
+}
+
+// Column blocks per wave of the wide 1x1 kernel for `d`, or 0 when the layer stays on the LDS-tile kernels:
+// plain 1x1 stride-1 GEMM shape, flags within {STATS}, vector-aligned, no split-K, enough workgroups to fill the chip.
+int force_wide = -1;
+int wide_nb(const ds_conv_desc *d, bool vec) {
+    if (force_wide < 0) {
+        const char *e = getenv("DS_CONV_WIDE");          // A/B aid: 0 = never
+        force_wide = e ? atoi(e) : 1;
+    }
+    if (!force_wide || !vec || d->dtype != DS_DTYPE_F32) return 0;
+    if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->fold_cin || d->splits > 1) return 0;
+    if (d->flags & ~DS_EPI_STATS) return 0;
+    if (d->Cin % 8 != 0 || d->Cin < 32) return 0;
+    const int64_t M = conv_M(d);
+    const int N = d->Cout;
+    int best = 0, best_pad = 1 << 30;
+    for (int nb = 8; nb >= 2; nb -= 2) {
+        const int pad = (N + 32 * nb - 1) / (32 * nb) * (32 * nb);
+        if (pad < best_pad) { best_pad = pad; best = nb; }
+    }
+    const int64_t wgs = (M + 127) / 128 * ((N + 32 * best - 1) / (32 * best));
+    // measured per shape (profiles/r02_wide_layers.txt): wins 1.1-1.4x except with one mostly padded column tile or too
+    // few workgroups to cover the CUs (7x7 maps with N <= 128)
+    if (force_wide < 2 && (wgs * 10 < 12 * ds::kCUs || best_pad * 100 > N * 125)) return 0;
+    return best;
+}
+
 KernelFn kernel_for(TileCfg c, Variant v) {
     if (c.bf16) return bf16_kernel(c.nt, v);
     if (c.glds) return glds_kernel(c.nt, v);
@@ -1201,7 +1406,7 @@ KernelFn kernel_for(TileCfg c, Variant v) {
 // The persistent grid is sized to exactly one resident wave of workgroups so no CU idles while a
 // partial second wave runs; correctness never depends on it (no inter-workgroup communication).
 int resident_per_cu(TileCfg c, Variant v) {
-    static int cache[4][2][6][2][2][2];
+    static int cache[4][2][8][2][2][2];
     int &slot = cache[c.bf16 ? 3 : (c.glds ? 2 : (int)c.direct)][c.mt - 1][c.nt - 1][v.bnmajor][v.fold][v.vec];
     if (slot == 0) {
         int n = 0;
@@ -1228,7 +1433,12 @@ TileCfg pick_cfg(const ds_conv_desc *d, bool vec) {
     const int64_t M = conv_M(d);
     const int N = d->Cout;
     const int pad32 = (N + 31) / 32 * 32, pad64 = (N + 63) / 64 * 64;
-    TileCfg c = {1, 1, false, false, false};
+    TileCfg c = {1, 1, false, false, false, 0};
+    if (int nb = wide_nb(d, vec)) {
+        c.wide = nb;
+        c.nt = nb;
+        return c;
+    }
     if (d->dtype == DS_DTYPE_BF16) {
         // staging-bound at 16x the matrix rate: the widest tile that does not pad Cout beyond the next 32
         c.bf16 = true;
@@ -1293,7 +1503,10 @@ void grid_for(const ds_conv_desc *d, TileCfg c, Variant v, int *gx, int *gy, int
     const int wg_tiles = c.direct ? (*row_tiles + 3) / 4 : *row_tiles;     // row tiles in units of workgroups
     int x;
     bool one = false;
-    if (wg_tiles <= kOneTilePerWg && !c.direct) {
+    if (c.wide) {                       // wide 1x1 kernel: always one workgroup per (row group, column tile)
+        x = wg_tiles;
+        one = true;
+    } else if (wg_tiles <= kOneTilePerWg && !c.direct) {
         x = wg_tiles;
         one = true;
     } else {
@@ -1316,6 +1529,12 @@ extern "C" int ds_conv_set_tile(int mt, int nt) {
     DS_REQUIRE((mt == 0 && nt == 0) || ((mt == 1 || mt == 2) && nt >= 1 && nt <= 6), "ds_conv_set_tile: mt in {1,2}, nt in 1..6, or 0,0 = automatic");
     force_mt = mt;
     force_nt = nt;
+    return DS_OK;
+}
+
+extern "C" int ds_conv_set_wide(int mode) {
+    DS_REQUIRE(mode >= 0 && mode <= 2, "ds_conv_set_wide: 0 = never, 1 = automatic, 2 = wherever the shape allows");
+    force_wide = mode;
     return DS_OK;
 }
 
@@ -1393,10 +1612,11 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     }
     dim3 grid(gx, gy, splits);
     p.col_tiles = 0;
-    if (one && xcd_remap && gy > 1 && !c.direct) {    // one workgroup per tile: 1-D XCD-aware launch (TileId)
+    if (one && (c.wide || (xcd_remap && gy > 1)) && !c.direct) {    // one workgroup per tile: 1-D XCD-aware launch (TileId)
         p.col_tiles = gy;
         grid = dim3((rt * gy + 7) / 8 * 8, 1, splits);
     }
-    hipLaunchKernelGGL(kernel_for(c, v), grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (c.wide) launch_wide(c.wide, v.bnmajor, grid, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(kernel_for(c, v), grid, dim3(256), 0, (hipStream_t)stream, p);
     return ds::check_launch("ds_conv_igemm");
 }
