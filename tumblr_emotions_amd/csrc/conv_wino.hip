@@ -125,57 +125,61 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     dma_u(0, 0);
     __syncthreads();
     for (int ks = 0; ks < ksteps; ++ks) {
-        // ---- V = B^T d B on the 16 pixels, per channel component: the results are the A fragments ---------------
-        f32x4 v[16];
+        // ---- V = B^T d B on the 16 pixels, per channel component: the results are the A fragments.  The row pass
+        // (B^T d) needs all 16 pixels and runs first; the column pass of patch row py+1 is issued behind the MFMAs of
+        // row py, in the shadow of the last of them ----------------------------------------------------------------------
+        f32x4 t[16];
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
             const f32x4 d0 = raw[px], d1 = raw[4 + px], d2 = raw[8 + px], d3 = raw[12 + px];
-            v[px] = d0 - d2;
-            v[4 + px] = d1 + d2;
-            v[8 + px] = d2 - d1;
-            v[12 + px] = d1 - d3;
+            t[px] = d0 - d2;
+            t[4 + px] = d1 + d2;
+            t[8 + px] = d2 - d1;
+            t[12 + px] = d1 - d3;
         }
-#pragma unroll
-        for (int py = 0; py < 4; ++py) {
-            const f32x4 t0 = v[py * 4], t1 = v[py * 4 + 1], t2 = v[py * 4 + 2], t3 = v[py * 4 + 3];
-            v[py * 4] = t0 - t2;
-            v[py * 4 + 1] = t1 + t2;
-            v[py * 4 + 2] = t2 - t1;
-            v[py * 4 + 3] = t1 - t3;
-        }
-        // Operands of the next K step are requested BETWEEN the MFMA groups, two patch pixels (and one weight DMA) per
-        // pair of positions: each pixel-scattered load occupies the texture-address path for a while, and issued in one
-        // burst at the top of the step they stall the wave's in-order issue with the matrix pipe idle (measured
-        // +0.8 us per step); spread out, they sit in the shadow of the eight MFMAs in front of them.
+        // Operands of the next K step are requested BETWEEN the MFMA groups, four patch pixels and one weight DMA per
+        // patch row: each pixel-scattered load occupies the texture-address path for a while, and issued in one burst at
+        // the top of the step they stall the wave's in-order issue with the matrix pipe idle (measured +0.8 us per
+        // step); spread out, they sit in the shadow of the MFMAs in front of them.
         const bool more = ks + 1 < ksteps;
         const int cn = (ks + 1) * 8;
         float *dma_dst = smem + ((ks + 1) & 1) * 4096 + wave * 256;
         const float *b_s = smem + (ks & 1) * 4096 + li * 8 + kh * 4;
-        // positions in pairs: consecutive MFMAs alternate between two accumulators, and the next pair's weights are
-        // read while this pair's eight MFMAs run
-        f32x4 b0 = *reinterpret_cast<const f32x4 *>(b_s), b1 = *reinterpret_cast<const f32x4 *>(b_s + 256);
+        f32x4 v[4], vn[4], b[4], bn[4];
+        vn[0] = t[0] - t[2]; vn[1] = t[1] + t[2]; vn[2] = t[2] - t[1]; vn[3] = t[1] - t[3];
 #pragma unroll
-        for (int xi = 0; xi < 16; xi += 2) {
-            const int nx = xi + 2 < 16 ? xi + 2 : 14;
-            const f32x4 n0 = *reinterpret_cast<const f32x4 *>(b_s + nx * 256);
-            const f32x4 n1 = *reinterpret_cast<const f32x4 *>(b_s + (nx + 1) * 256);
+        for (int px = 0; px < 4; ++px) bn[px] = *reinterpret_cast<const f32x4 *>(b_s + px * 256);
+#pragma unroll
+        for (int py = 0; py < 4; ++py) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = vn[j]; b[j] = bn[j]; }
+            if (py < 3) {       // the next row's weights are read while this row's sixteen MFMAs run
+#pragma unroll
+                for (int px = 0; px < 4; ++px) bn[px] = *reinterpret_cast<const f32x4 *>(b_s + (py * 4 + 4 + px) * 256);
+            }
             if (more) {
                 if (!(p.flags & 256)) {
-                    raw[xi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff[xi], cn * 4, 0));
-                    raw[xi + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff[xi + 1], cn * 4, 0));
-                }
-                if (xi < 8 && !(p.flags & 512))
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_u, (lds_ptr)(dma_dst + (xi >> 1) * 1024), 16, uoff[xi >> 1], cn * 4, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[xi][j], b0[j], acc[xi], 0, 0, 0);
-                acc[xi + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[xi + 1][j], b1[j], acc[xi + 1], 0, 0, 0);
+                    for (int px = 0; px < 4; ++px)
+                        raw[py * 4 + px] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff[py * 4 + px], cn * 4, 0));
+                }
+                if (!(p.flags & 512))
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_u, (lds_ptr)(dma_dst + py * 1024), 16, uoff[py], cn * 4, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            b0 = n0;
-            b1 = n1;
+            // positions of this patch row, two at a time: consecutive MFMAs alternate between two accumulators
+#pragma unroll
+            for (int pp = 0; pp < 4; pp += 2)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[py * 4 + pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[pp][j], b[pp][j], acc[py * 4 + pp], 0, 0, 0);
+                    acc[py * 4 + pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[pp + 1][j], b[pp + 1][j], acc[py * 4 + pp + 1], 0, 0, 0);
+                }
+            if (py < 3) {       // column pass of the next patch row, behind this row's MFMAs
+                const f32x4 t0 = t[py * 4 + 4], t1 = t[py * 4 + 5], t2 = t[py * 4 + 6], t3 = t[py * 4 + 7];
+                vn[0] = t0 - t2; vn[1] = t1 + t2; vn[2] = t2 - t1; vn[3] = t1 - t3;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
