@@ -163,6 +163,8 @@ def main():
                          "forward/dgrad multiplies on the bf16 matrix pipe, fp32 storage/accumulate/statistics/masters")
     ap.add_argument("--stepwise-lstm", action="store_true",
                     help="A/B aid: one GEMM + one cell launch per LSTM step instead of the persistent ds_lstm_seq kernels")
+    ap.add_argument("--bf16-staged", action="store_true",
+                    help="--dtype bf16: the LDS-staged bf16 kernel for every conv (default: ds_conv_bf16 where it wins)")
     ap.add_argument("--no-winograd", action="store_true",
                     help="A/B aid: implicit GEMM for every 3x3 layer instead of the fused Winograd F(2x2,3x3) kernel")
     ap.add_argument("--graph", action="store_true",
@@ -214,6 +216,8 @@ def main():
         net.text.persistent = False
     if args.no_winograd and net.image is not None:
         net.image.winograd = False
+    if args.bf16_staged and net.image is not None:
+        net.image.bf16_direct = False
     strong = args.global_batch > 0
     if strong:
         assert args.global_batch % world == 0, "--global-batch must divide by the number of ranks"

@@ -98,6 +98,19 @@ int ds_conv_igemm_partials(const ds_conv_desc *d);
 int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float *w, float *z, const float *bias,
                   const float *mask, float *stats, const float *pivot, void *stream);
 
+/* DS_DTYPE_BF16, second generation: register-direct implicit GEMM on v_mfma_f32_32x32x16_bf16 for the 1x1 and 3x3
+ * convs (forward and Conv2DBackpropInput), fp32 accumulation and storage.  wb = the filter converted once per
+ * weight update by ds_weights_to_bf16 into the kernel's own order ([channel chunk x tap][column][16 k] bf16, zero
+ * padded; ds_weights_bf16_bytes gives its size; dgrad = 1: flipped taps, channel roles swapped -- the conv then
+ * runs over dz with Cin = Cout_w, Cout = Cin_w).  `d` as for ds_conv_igemm (geometry, ldx, ldz, flags 0 or
+ * DS_EPI_STATS; the weight strides are ignored); partials float[2][Cout][ds_conv_bf16_partials(d)].          */
+size_t ds_weights_bf16_bytes(int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad);
+int ds_weights_to_bf16(const float *w, void *wb, int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad, void *stream);
+int ds_conv_bf16_supported(const ds_conv_desc *d);
+int ds_conv_bf16_partials(const ds_conv_desc *d);
+int ds_conv_bf16(const ds_conv_desc *d, const float *x, const void *wb, float *z, float *stats, const float *pivot,
+                 void *stream);
+
 /* 3x3 stride-1 SAME convolution as fused Winograd F(2x2, 3x3) on fp32 MFMA: 2.25x fewer matrix passes than the
  * implicit GEMM for Conv2d_2c_3x3 and the Branch_1 / Branch_2 Conv2d_0b_3x3 of every Mixed block
  * (image_model/inception_v1.py:74-75, 86-247), forward and Conv2DBackpropInput alike.

@@ -305,6 +305,68 @@ def test_conv_bf16_forward_dgrad_match_oracle(case):
         close(dx, S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1).reshape(-1, Ci), 1e-2)
 
 
+BF16D_CASES = [
+    # (N, H, W, Cin, Cout, k, stride)
+    (2, 9, 9, 16, 32, 1, 1),
+    (3, 14, 14, 24, 64, 3, 1),       # Cin not a multiple of the 16-wide channel chunk
+    (2, 28, 28, 96, 128, 3, 1),
+    (4, 7, 7, 832, 624, 1, 1),       # ragged last column tile
+    (2, 13, 11, 48, 176, 3, 1),      # odd extents, rows past M in the last tile
+    (1, 8, 8, 8, 200, 1, 1),         # one half-empty channel chunk
+    (2, 10, 10, 24, 40, 3, 2),       # stride 2
+    (2, 56, 56, 64, 192, 3, 1),
+    (2, 14, 14, 512, 296, 1, 1),
+    (1, 5, 5, 8, 8, 3, 1),           # fewer columns than one block
+]
+
+
+@pytest.mark.parametrize("case", BF16D_CASES)
+def test_conv_bf16_register_direct_forward_dgrad_match_oracle(case):
+    """ds_conv_bf16 (register-direct A, pre-converted weights): forward with BatchNorm statistics about a pivot and
+    the dgrad of the same geometry; same two gates as the LDS-staged bf16 kernel.  The converted weight tensor
+    itself is checked element for element against numpy's rounding."""
+    ops = _ops()
+    N, H, W, Ci, Co, k, s = case
+    rng = np.random.RandomState(5)
+    x = rng.normal(size=(N, H, W, Ci))
+    w = rng.normal(size=(k, k, Ci, Co)) * 0.1
+    ref_exact = S.conv2d_same(x, w, s)
+    ref_round = S.conv2d_same(_bf16_round(x), _bf16_round(w), s)
+    xd, wd = dev(x), dev(w)
+    wb = torch.empty(ops.weights_bf16_bytes(Ci, Co, k * k, 0), dtype=torch.uint8, device="cuda")
+    ops.weights_to_bf16(ops._p(wd), wb, Ci, Co, k * k, 0)
+    # layout check: wb[it][col][16], it = chunk * taps + tap
+    chunks, ncols = (Ci + 15) // 16, (Co + 31) // 32 * 32
+    got = wb.view(torch.bfloat16).float().cpu().numpy().reshape(chunks, k * k, ncols, 16)
+    want = np.zeros((chunks * 16, k * k, ncols))
+    want[:Ci, :, :Co] = _bf16_round(w).reshape(k * k, Ci, Co).transpose(1, 0, 2)
+    want = want.reshape(chunks, 16, k * k, ncols).transpose(0, 2, 3, 1)
+    assert np.array_equal(got, want.astype(np.float32))
+    plan = ops.Bf16Plan(N, H, W, Ci, Ci, k, s, Co, Co, flags=ops.DS_EPI_STATS)
+    M = plan.M
+    z = torch.empty(M, Co, device="cuda")
+    stats = torch.zeros(2, Co, plan.partials, device="cuda")
+    pivot = dev(rng.normal(size=Co))
+    plan.run(ops._p(xd), ops._p(wb), ops._p(z), stats=ops._p(stats), pivot=ops._p(pivot))
+    torch.cuda.synchronize()
+    close(z, ref_round.reshape(M, Co), 2e-4)
+    close(z, ref_exact.reshape(M, Co), 1e-2)
+    u = ref_round.reshape(M, Co) - pivot.double().cpu().numpy()
+    close(stats[0].sum(1), u.sum(0), 2e-3)
+    close(stats[1].sum(1), (u ** 2).sum(0), 2e-3)
+    if s == 1 and Co % 8 == 0:
+        dy = rng.normal(size=ref_exact.shape)
+        wbt = torch.empty(ops.weights_bf16_bytes(Ci, Co, k * k, 1), dtype=torch.uint8, device="cuda")
+        ops.weights_to_bf16(ops._p(wd), wbt, Ci, Co, k * k, 1)
+        g = ops.Bf16Plan(N, H, W, Co, Co, k, 1, Ci, Ci)
+        dx = torch.empty(g.M, Ci, device="cuda")
+        dyd = dev(dy)
+        g.run(ops._p(dyd), ops._p(wbt), ops._p(dx))
+        torch.cuda.synchronize()
+        close(dx, S.conv2d_same_bwd_input(_bf16_round(dy), _bf16_round(w), (N, H, W, Ci), 1).reshape(-1, Ci), 2e-4)
+        close(dx, S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1).reshape(-1, Ci), 1e-2)
+
+
 def test_conv_bf16_folded_stem_and_epilogues():
     """The 7x7/2 stem through its folded 4-channel input, and the bias / relu / accumulate / mask epilogues, on
     the bf16 matrix pipe."""

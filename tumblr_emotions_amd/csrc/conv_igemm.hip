@@ -51,6 +51,7 @@ struct ConvParams {
     unsigned x_bytes, w_bytes;   // extents covered by the two buffer descriptors
     int prio_mode;               // 1: staggered static wave priorities (see kernel)
     int col_tiles;               // > 0: 1-D XCD-aware launch (see TileId); 0: (row, column) = (blockIdx.x, blockIdx.y)
+    int col_total;               // conv_bf16d_kernel: columns of the converted weight tensor (Cout rounded up to 32)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *p, unsigned bytes) {
@@ -1256,6 +1257,194 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
     }
 }
 
+
+// ================================================================================================
+// bf16 register-direct implicit GEMM (ds_conv_bf16): v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 storage.
+//
+// Second generation of the DS_DTYPE_BF16 path (conv_bf16_kernel above stages both operands through registers AND
+// LDS one K-tile ahead: 184 TFLOP/s, every fetch latency exposed against 256 matrix cycles).  Here:
+//   * the weights are converted ONCE per weight update into the kernel's own order (ds_weights_to_bf16):
+//     wb[it][column][16 k] bf16 with it = channel chunk * taps + tap -- exactly the K-loop order -- zero padded in k, so
+//     the B operand of a step (four (chunk, tap) iterations x NB*32 columns x 16 k = NB * 4 KB) is a linear run that
+//     LDS-DMA drops into LDS in fragment layout; no conversion, no transpose, no K-tail logic in the loop;
+//   * the A operand is register-direct: lane (i, kh) of the 32x32x16 MFMA loads channels 8 kh .. 8 kh + 7 of ITS
+//     pixel at the current tap as two float4 (SRD loads; padding pixels and rows past M read zeros from an
+//     out-of-range offset), rounds them to bf16 (v_cvt_pk_bf16_f32, RNE) and that IS its A fragment;
+//   * a wave owns 32 pixels x NB*32 columns (NB <= 8: 128 accumulator registers, two waves per SIMD); each A
+//     fragment feeds NB MFMAs; the next step's eight A loads and NB weight DMAs are issued between the MFMA groups.
+// Epilogue: fp32 stores + BatchNorm column statistics about the pivot (flags 0 or DS_EPI_STATS).
+// ================================================================================================
+template <int NB, int KS>      // KS x KS taps (1 or 3)
+__global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) {
+    constexpr int BN = NB * 32, SI = 4, TAPS = KS * KS;
+    constexpr int BSZ = SI * BN * 16;                          // bf16 elements per B buffer
+    __shared__ __attribute__((aligned(128))) __bf16 smem[2 * BSZ + 512];
+    const ds_conv_desc &d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kh = lane >> 5;
+    const TileId t0 = tile_id(p);
+    const int n0 = t0.col * BN;
+    const bool item = t0.row < p.row_tiles;
+    const __amdgpu_buffer_rsrc_t srd_x = make_srd(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t srd_w = make_srd(p.w, p.w_bytes);
+    const int chunks = (d.Cin + 15) >> 4;
+    const int iters = chunks * TAPS;
+    const int nsteps = (iters + SI - 1) / SI;
+
+    // ---- this lane's pixel and the byte offset of its input pixel at every tap (channel 8 kh) -----------------------
+    const int m = t0.row * 128 + wave * 32 + li;
+    const bool rv = item && m < p.M;
+    const int ohw = d.OH * d.OW;
+    const int n = (rv ? m : 0) / ohw;
+    const int r = (rv ? m : 0) - n * ohw;
+    const int oh = r / d.OW, ow = r - oh * d.OW;
+    unsigned voff[TAPS];
+#pragma unroll
+    for (int a = 0; a < KS; ++a)
+#pragma unroll
+        for (int b = 0; b < KS; ++b) {
+            const int ih = oh * d.stride - d.pad_t + a, iw = ow * d.stride - d.pad_l + b;
+            const bool ok = rv && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+            voff[a * KS + b] = ok ? ((unsigned)((n * d.H + ih) * d.W + iw) * (unsigned)d.ldx + 8u * kh) * 4u : kOOB;
+        }
+    // ---- B DMA slots of a step: slot -> (local iteration, column, 8-k half); source is linear in wb ---------------
+    const int ncols = p.col_total;                              // columns of wb (Cout rounded up to 32)
+    unsigned uoff[NB];
+    int uit[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int sl = i * 256 + tid;
+        const int itl = sl / (BN * 2), nn = (sl >> 1) % BN, half = sl & 1;
+        uit[i] = itl;
+        uoff[i] = (n0 + nn < ncols) ? ((unsigned)((itl * ncols + n0 + nn) * 16 + 8 * half)) * 2u : kOOB;
+    }
+    const unsigned it_bytes = (unsigned)ncols * 32u;            // bytes of one iteration's weights
+    auto dma_b = [&](int buf, int step, int i) {
+        unsigned o = uoff[i] + (unsigned)(step * SI) * it_bytes;
+        if (step * SI + uit[i] >= iters || uoff[i] == 0x80000000u) o = 0x80000000u;     // past the reduction: zeros
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr)(smem + buf * BSZ + wave * 512 + i * 2048), 16, o, 0, 0, 0);
+    };
+    // A loads of one (chunk, tap) iteration
+    auto load_a = [&](int it, f32x4 &lo, f32x4 &hi) {
+        const int chunk = it / TAPS, tap = it - chunk * TAPS;
+        unsigned vo = voff[0];
+#pragma unroll
+        for (int k = 1; k < TAPS; ++k) vo = tap == k ? voff[k] : vo;
+        lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vo, chunk * 64, 0));
+        hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vo, chunk * 64 + 16, 0));
+    };
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+
+    f32x4 alo[SI], ahi[SI];
+#pragma unroll
+    for (int j = 0; j < SI; ++j) load_a(j, alo[j], ahi[j]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) dma_b(0, 0, i);
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+        const bool more = st + 1 < nsteps;
+        const __bf16 *b_s = smem + (st & 1) * BSZ + li * 16 + kh * 8;
+        f32x4 nlo[SI], nhi[SI];
+#pragma unroll
+        for (int j = 0; j < SI; ++j) {
+            // A fragment: 8 consecutive channels rounded to bf16
+            bf16x8 af;
+            {
+                const bf16x4 l4 = __builtin_convertvector(alo[j], bf16x4), h4 = __builtin_convertvector(ahi[j], bf16x4);
+                af = __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            if (more) {             // next step's operands between the MFMA groups
+                load_a((st + 1) * SI + j, nlo[j], nhi[j]);
+#pragma unroll
+                for (int i = j; i < NB; i += SI) dma_b((st + 1) & 1, st + 1, i);
+            }
+            bf16x8 bfr[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) bfr[b] = *reinterpret_cast<const bf16x8 *>(b_s + (j * BN + b * 32) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[b], acc[b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < SI; ++j) { alo[j] = nlo[j]; ahi[j] = nhi[j]; }
+        __syncthreads();
+    }
+
+    // ---- epilogue: store, BatchNorm column statistics ---------------------------------------------------------------
+    const int flags = d.flags;
+    float *red = reinterpret_cast<float *>(smem + 2 * BSZ);
+    const int mrow0 = t0.row * 128 + wave * 32;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int col = n0 + 32 * b + li;
+        const bool colok = item && col < d.Cout;
+        const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row < p.M && colok) {
+                const float v = acc[b][r];
+                p.z[(int64_t)row * d.ldz + col] = v;
+                const float u = v - pv;
+                s += u;
+                q += u * u;
+            }
+        }
+        if (flags & DS_EPI_STATS) {
+            s += __shfl_xor(s, 32);
+            q += __shfl_xor(q, 32);
+            __syncthreads();
+            if (kh == 0) {
+                red[(wave * 32 + li) * 2 + 0] = s;
+                red[(wave * 32 + li) * 2 + 1] = q;
+            }
+            __syncthreads();
+            if (tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
+                float ss = 0.f, qq = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    ss += red[(w * 32 + tid) * 2 + 0];
+                    qq += red[(w * 32 + tid) * 2 + 1];
+                }
+                p.stats[(int64_t)(n0 + 32 * b + tid) * t0.stride + t0.row] = ss;
+                p.stats[((int64_t)d.Cout + n0 + 32 * b + tid) * t0.stride + t0.row] = qq;
+            }
+        }
+    }
+}
+
+// wb[it][column][16] bf16, it = chunk * taps + tap, from the TF HWIO filter w [taps][Cin][Cout] (fp32).
+//   dgrad == 0: column = co, k = ci (forward);  dgrad == 1: column = ci, k = co, taps flipped (Conv2DBackpropInput).
+// Columns are padded to a multiple of 32 and k to a multiple of 16 with zeros.
+__global__ __launch_bounds__(256) void weights_to_bf16_kernel(const float *w, __bf16 *wb, int Cin, int Cout, int taps,
+                                                              int dgrad) {
+    const int K = dgrad ? Cout : Cin, Ncol = dgrad ? Cin : Cout;
+    const int chunks = (K + 15) >> 4, ncols = (Ncol + 31) / 32 * 32;
+    const int64_t total = (int64_t)chunks * taps * ncols * 16;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int j = (int)(i & 15);
+        const int64_t rest = i >> 4;
+        const int col = (int)(rest % ncols);
+        const int it = (int)(rest / ncols);
+        const int chunk = it / taps, tap = it - chunk * taps;
+        const int k = chunk * 16 + j;
+        float v = 0.f;
+        if (col < Ncol && k < K) {
+            const int ci = dgrad ? col : k, co = dgrad ? k : col, tp = dgrad ? taps - 1 - tap : tap;
+            v = w[((int64_t)tp * Cin + ci) * Cout + co];
+        }
+        wb[i] = (__bf16)v;
+    }
+}
+
 // ---- host-side dispatch -----------------------------------------------------------------------
 struct TileCfg {
     int mt, nt;
@@ -1619,4 +1808,83 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     if (c.wide) launch_wide(c.wide, v.bnmajor, grid, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(kernel_for(c, v), grid, dim3(256), 0, (hipStream_t)stream, p);
     return ds::check_launch("ds_conv_igemm");
+}
+
+// ---- bf16 register-direct path -------------------------------------------------------------------------------------
+namespace {
+int bf16d_nb(int Cout) {
+    // a workgroup's cost per K step ~ (A fetch + NB MFMAs); minimise column tiles x (c + NB), c ~ 4, ties to wider
+    int best = 8, best_cost = 1 << 30;
+    for (int nb = 8; nb >= 1; --nb) {
+        const int tiles = (Cout + 32 * nb - 1) / (32 * nb);
+        const int cost = tiles * (4 + nb);
+        if (cost < best_cost) { best_cost = cost; best = nb; }
+    }
+    return best;
+}
+bool bf16d_ok(const ds_conv_desc *d) {
+    return (d->KH == d->KW) && (d->KH == 1 || d->KH == 3) && d->fold_cin == 0 && d->Cin % 8 == 0 && d->ldx % 4 == 0 &&
+           !(d->flags & ~DS_EPI_STATS) && d->splits <= 1;
+}
+}  // namespace
+
+extern "C" size_t ds_weights_bf16_bytes(int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad) {
+    const int K = dgrad ? Cout : Cin, Ncol = dgrad ? Cin : Cout;
+    return (size_t)((K + 15) / 16) * taps * ((Ncol + 31) / 32 * 32) * 16 * 2;
+}
+
+extern "C" int ds_weights_to_bf16(const float *w, void *wb, int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad,
+                                  void *stream) {
+    DS_REQUIRE(w && wb && Cin > 0 && Cout > 0 && taps > 0, "ds_weights_to_bf16: bad argument");
+    const int64_t total = (int64_t)ds_weights_bf16_bytes(Cin, Cout, taps, dgrad) / 2;
+    hipLaunchKernelGGL(weights_to_bf16_kernel, dim3(ds::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (__bf16 *)wb, Cin, Cout, taps, dgrad);
+    return ds::check_launch("ds_weights_to_bf16");
+}
+
+extern "C" int ds_conv_bf16_supported(const ds_conv_desc *d) { return d && bf16d_ok(d) ? 1 : 0; }
+
+extern "C" int ds_conv_bf16_partials(const ds_conv_desc *d) { return (int)((conv_M(d) + 127) / 128); }
+
+extern "C" int ds_conv_bf16(const ds_conv_desc *d, const float *x, const void *wb, float *z, float *stats,
+                            const float *pivot, void *stream) {
+    DS_REQUIRE(d && x && wb && z, "ds_conv_bf16: null argument");
+    DS_REQUIRE(bf16d_ok(d), "ds_conv_bf16: needs a 1x1 or 3x3 conv, Cin %% 8 == 0, ldx %% 4 == 0, flags within DS_EPI_STATS");
+    DS_REQUIRE(((((uintptr_t)x | (uintptr_t)wb) & 15) == 0) && conv_M(d) < (1ll << 31), "ds_conv_bf16: operands must be 16-byte aligned");
+    DS_REQUIRE(!(d->flags & DS_EPI_STATS) || stats, "ds_conv_bf16: DS_EPI_STATS without stats buffer");
+    ConvParams p = {};
+    p.d = *d;
+    p.x = x; p.w = (const float *)wb; p.z = z; p.stats = stats;
+    p.pivot = (d->flags & DS_EPI_STATS) ? pivot : nullptr;
+    p.M = (int)conv_M(d);
+    p.taps = d->KH * d->KW;
+    const int64_t x_elems = ((int64_t)d->N * d->H * d->W - 1) * d->ldx + d->Cin;
+    const int64_t wb_bytes = (int64_t)((d->Cin + 15) / 16) * p.taps * ((d->Cout + 31) / 32 * 32) * 32;
+    DS_REQUIRE(x_elems * 4 < (1ll << 31) && wb_bytes < (1ll << 31), "ds_conv_bf16: operand larger than 2 GiB");
+    p.x_bytes = (unsigned)(x_elems * 4);
+    p.w_bytes = (unsigned)wb_bytes;
+    p.col_total = (d->Cout + 31) / 32 * 32;
+    const int nb = bf16d_nb(d->Cout);
+    p.row_tiles = (int)((conv_M(d) + 127) / 128);
+    p.col_tiles = (d->Cout + 32 * nb - 1) / (32 * nb);
+    const dim3 grid((unsigned)(((int64_t)p.row_tiles * p.col_tiles + 7) / 8 * 8));
+    hipStream_t st = (hipStream_t)stream;
+#define DS_B16(NBV)                                                                                        \
+    case NBV:                                                                                              \
+        if (d->KH == 1) hipLaunchKernelGGL((conv_bf16d_kernel<NBV, 1>), grid, dim3(256), 0, st, p);        \
+        else hipLaunchKernelGGL((conv_bf16d_kernel<NBV, 3>), grid, dim3(256), 0, st, p);                   \
+        break;
+    switch (nb) {
+        DS_B16(1)
+        DS_B16(2)
+        DS_B16(3)
+        DS_B16(4)
+        DS_B16(5)
+        DS_B16(6)
+        DS_B16(7)
+        default:
+        DS_B16(8)
+    }
+#undef DS_B16
+    return ds::check_launch("ds_conv_bf16");
 }

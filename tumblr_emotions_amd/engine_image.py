@@ -102,6 +102,15 @@ class ConvBN:
             self.u_fwd = torch.empty(16, cout, cin, device=dev)
             eng.need_stats(self.wino_fwd.partials * 2 * cout)
         self._wino_dgrad_ok = wino_ok(self.H, cout, cin)
+        # bf16: the register-direct kernel (ds_conv_bf16, pre-converted weights) where it beats the LDS-staged one
+        # (profiles/r02_bf16_layers.txt): forward from 48 output columns up, dgrad for the 1x1 layers and from 160
+        # columns up; it rides the same alternative-plan slots as the Winograd kernel (u_* = its converted weights)
+        bf16 = eng.conv_dtype == ops.DS_DTYPE_BF16 and not self.fold and k in (1, 3) and eng.bf16_direct
+        self._bf16_dgrad_ok = bf16 and cout % 8 == 0 and (k == 1 or cin >= 160)
+        if bf16 and cin % 8 == 0 and cout >= 48:
+            self.wino_fwd = ops.Bf16Plan(B, self.H, self.W, cin, cin, k, self.stride, cout, cout, flags=DS_EPI_STATS)
+            self.u_fwd = torch.empty(ops.weights_bf16_bytes(cin, cout, k * k, False), dtype=torch.uint8, device=dev)
+            eng.need_stats(self.wino_fwd.partials * 2 * cout)
         self.u_version = -1
         eng.need_stats(self.fwd.partials * 2 * cout)
         self.bwd_P = ops.bn_bwd_partials(self.M, cout)
@@ -136,6 +145,10 @@ class ConvBN:
         if self._wino_dgrad_ok:
             self.wino_dgrad = WinoPlan(self.B, self.H, self.W, cout, cout, cin, lddx)
             self.u_dgrad = torch.empty(16, cin, cout, device=self.eng.device)
+        elif self._bf16_dgrad_ok:
+            self.wino_dgrad = ops.Bf16Plan(self.B, self.H, self.W, cout, cout, k, 1, cin, lddx)
+            self.u_dgrad = torch.empty(ops.weights_bf16_bytes(cin, cout, k * k, True), dtype=torch.uint8,
+                                       device=self.eng.device)
 
     def _refresh_wino(self):
         """G g G^T of the filter for the Winograd kernels: redone when the weights changed -- every step for a
@@ -145,10 +158,13 @@ class ConvBN:
             return
         if not self.trainable and self.u_version == eng.weights_version:
             return
-        if self.wino_fwd is not None:
-            ops.wino_transform_weights(self.w_ptr, self.u_fwd, self.cin, self.cout, False)
-        if self.wino_dgrad is not None:
-            ops.wino_transform_weights(self.w_ptr, self.u_dgrad, self.cin, self.cout, True)
+        taps = self.k * self.k
+        for plan, u, dgrad in ((self.wino_fwd, getattr(self, "u_fwd", None), False),
+                               (self.wino_dgrad, getattr(self, "u_dgrad", None), True)):
+            if isinstance(plan, ops.Bf16Plan):
+                ops.weights_to_bf16(self.w_ptr, u, self.cin, self.cout, taps, dgrad)
+            elif plan is not None:
+                ops.wino_transform_weights(self.w_ptr, u, self.cin, self.cout, dgrad)
         self.u_version = eng.weights_version
 
     # x_ptr: input activations [B,H,W,ldx]; segs: where relu(bn(conv)) is scattered (None: the consumer, a max
@@ -160,7 +176,7 @@ class ConvBN:
         self._refresh_wino()
         wino = self.wino_fwd
         if wino is not None:
-            wino.args = wino.args[:4] + (ldx,) + wino.args[5:]
+            wino.set_ldx(ldx)
         if eng.training:       # batch statistics (slim.batch_norm is_training=True)
             # the column sums are taken about a pivot near the mean -- the previous step's batch mean, the
             # moving mean before the first step (bind) -- so channels with |mean| >> std keep their variance
@@ -418,6 +434,7 @@ class InceptionV1Engine:
         self.training = True         # False: BatchNorm uses moving statistics, dropout is the identity
         self.reducer = None          # dp.GradientReducer, set by SentimentNet
         self.seed_dev = None         # device int64 added to the dropout seed (hipGraph replay draws fresh masks)
+        self.bf16_direct = True      # dtype bf16: ds_conv_bf16 where it wins (False: the LDS-staged bf16 kernel everywhere)
         self.winograd = True         # 3x3 layers through ds_conv_wino where it wins (False: implicit GEMM everywhere)
         self.weights_version = 0     # bumped by SentimentNet.after_load(): frozen layers redo their G g G^T
         self._stats_n = self._bwdp_n = self._ws_bytes = 0

@@ -135,6 +135,9 @@ class WinoPlan:
         self.partials = _lib.load().ds_conv_wino_partials(N, H, W) if flags & DS_EPI_STATS else 0
         self.alg_flops = 2.0 * self.M * Cout * 9 * Cin          # the convolution's FLOPs, not Winograd's
 
+    def set_ldx(self, ldx):
+        self.args = self.args[:4] + (ldx,) + self.args[5:]
+
     def run(self, x, u, z, stats=None, pivot=None):
         t = CONV_TIMER
         if t is not None:
@@ -149,6 +152,60 @@ class WinoPlan:
 def wino_transform_weights(w_ptr, u, Cin, Cout, dgrad):
     _lib.check(_lib.load().ds_wino_transform_weights(w_ptr, _p(u), Cin, Cout, int(dgrad), _stream()),
                "ds_wino_transform_weights")
+
+
+class Bf16Plan:
+    """1x1 / 3x3 conv (or its dgrad) through ds_conv_bf16: register-direct bf16 MFMA, weights pre-converted by
+    `weights_to_bf16` into the kernel's K-loop order.  Geometry arguments as ConvPlan's."""
+
+    def __init__(self, N, H, W, Cin, ldx, k, stride, Cout, ldz, flags=0, pad_t=None, pad_l=None, OH=None, OW=None):
+        d = ConvDesc()
+        d.dtype = DS_DTYPE_BF16
+        d.N, d.H, d.W, d.Cin, d.ldx = N, H, W, Cin, ldx
+        d.KH, d.KW, d.stride = k, k, stride
+        if OH is None:
+            OH, pt = same_pad(H, k, stride)
+            OW, pl = same_pad(W, k, stride)
+            pad_t = pt if pad_t is None else pad_t
+            pad_l = pl if pad_l is None else pad_l
+        d.pad_t, d.pad_l, d.OH, d.OW = pad_t, pad_l, OH, OW
+        d.Cout, d.ldz, d.flags, d.splits = Cout, ldz, flags, 1
+        self.d = d
+        lib = _lib.load()
+        if not lib.ds_conv_bf16_supported(C.byref(d)):
+            raise ValueError("ds_conv_bf16 does not take this geometry")
+        self.M = N * OH * OW
+        self.partials = lib.ds_conv_bf16_partials(C.byref(d)) if flags & DS_EPI_STATS else 0
+        self.alg_flops = 2.0 * self.M * Cout * k * k * Cin
+
+    def set_ldx(self, ldx):
+        self.d.ldx = ldx
+
+    @property
+    def flags(self):
+        return self.d.flags
+
+    @flags.setter
+    def flags(self, v):
+        self.d.flags = v
+
+    def run(self, x, wb, z, stats=None, pivot=None):
+        t = CONV_TIMER
+        if t is not None:
+            t.begin()
+        _lib.check(_lib.load().ds_conv_bf16(C.byref(self.d), x, wb, z, stats, pivot, _stream()), "ds_conv_bf16")
+        if t is not None:
+            t.end(self)
+
+
+def weights_bf16_bytes(Cin, Cout, taps, dgrad):
+    return int(_lib.load().ds_weights_bf16_bytes(Cin, Cout, taps, int(dgrad)))
+
+
+def weights_to_bf16(w_ptr, wb, Cin, Cout, taps, dgrad):
+    """HWIO fp32 filter -> ds_conv_bf16's weight tensor (`wb`: a uint8/bf16 device tensor of weights_bf16_bytes)."""
+    _lib.check(_lib.load().ds_weights_to_bf16(w_ptr, _p(wb), Cin, Cout, taps, int(dgrad), _stream()),
+               "ds_weights_to_bf16")
 
 
 class WgradPlan:
