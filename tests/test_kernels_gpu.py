@@ -117,6 +117,42 @@ def test_conv_wgrad(case):
     close(dw, ref, 3e-4)
 
 
+WGRAD_DIRECT_CASES = [
+    # (N, H, W, Cin, Cout, k, stride, ldx_extra): M >= 512 takes the register-direct kernel
+    (16, 7, 7, 48, 128, 3, 1, 0),        # 2-wide x 4-wide vectors
+    (16, 7, 7, 832, 624, 1, 1, 0),       # Mixed_5c fused 1x1
+    (4, 14, 14, 100, 36, 3, 1, 0),       # 4-wide x 2-wide, ragged blocks
+    (8, 15, 15, 16, 24, 3, 2, 0),        # stride 2, odd extent
+    (8, 9, 9, 15, 33, 3, 1, 0),          # odd channel counts: scalar loads on both sides
+    (8, 14, 14, 64, 96, 3, 1, 32),       # x is a channel slice of a wider buffer (ldx > Cin)
+    (3, 14, 14, 192, 384, 3, 1, 0),      # M = 588: waves with ragged quarters
+    (8192, 1, 1, 300, 64, 1, 1, 0),      # the text tower's transposed MatMul (H = W = 1)
+    (600, 1, 1, 52, 15, 1, 1, 0),        # Logits-like: 15 columns
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_DIRECT_CASES)
+def test_conv_wgrad_register_direct(case):
+    """wgrad_direct_kernel (coalesced k-major operands straight into the MFMA, four waves summed through LDS,
+    split-K slabs): Conv2DBackpropFilter against the fp64 oracle."""
+    ops = _ops()
+    N, H, W, Ci, Co, k, s, extra = case
+    rng = np.random.RandomState(6)
+    ld = Ci + extra
+    xfull = rng.normal(size=(N, H, W, ld))
+    x = xfull[..., extra:]
+    OH, OW = -(-H // s), -(-W // s)
+    dy = rng.normal(size=(N, OH, OW, Co))
+    ref = S.conv2d_same_bwd_filter(x, dy, (k, k, Ci, Co), s)
+    plan = ops.WgradPlan(N, H, W, Ci, ld, k, k, s, Co, Co)
+    ws = torch.empty(max(plan.ws_bytes // 4, 1), device="cuda")
+    dw = torch.full((k, k, Ci, Co), float("nan"), device="cuda")
+    xd, dyd = dev(xfull), dev(dy)
+    plan.run(C.c_void_p(xd.data_ptr() + 4 * extra), ops._p(dyd), ops._p(dw), ops._p(ws), plan.ws_bytes)
+    torch.cuda.synchronize()
+    close(dw, ref, 3e-4)
+
+
 def test_gemm_variants_bias_relu_accum_mask_and_unaligned():
     ops = _ops()
     rng = np.random.RandomState(5)

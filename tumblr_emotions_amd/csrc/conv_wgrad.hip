@@ -8,6 +8,7 @@
 // exactly as they lie in HBM (NHWC rows), fragments are read with ds_read_b32 (32 consecutive
 // channels per half-wave: conflict-free), and the reduction over pixels is cut into `splits`
 // slabs that a second kernel sums in a fixed order (deterministic, no atomics).
+#include <stdio.h>
 #include <stdlib.h>
 #include "ds_common.h"
 
@@ -32,6 +33,7 @@ struct WgradParams {
     int x_vec, z_vec;
     unsigned x_bytes, z_bytes;   // extents covered by the two buffer descriptors
     float inv_ohw, inv_ow;
+    int slabs;          // wgrad_direct_kernel: split-K slabs (see the id -> slab mapping there)
 };
 
 constexpr unsigned kOOB = 0x80000000u;   // byte offset beyond any descriptor: the load returns 0
@@ -193,6 +195,218 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         }
 }
 
+
+// ================================================================================================
+// Register-direct wgrad (round 2): no LDS in the main loop, one wave = one (32 AI) x (32 BJ) block of dw.
+//
+// For C[ci, co] = sum_m x[m, ci] dz[m, co] both MFMA operands are "k-major": lane (i, kh) of v_mfma_f32_32x32x2_f32
+// needs x[m0 + kh][channel i] and dz[m0 + kh][column i] -- 32 consecutive lanes read 32 consecutive channels of ONE
+// pixel row, i.e. the operands are coalesced exactly as they lie in HBM.  Which physical channel plays "row i" of a
+// block is free, so lane i takes AI consecutive channels (AI*i .. AI*i + AI - 1) with ONE 4*AI-byte load and uses
+// component a as the A operand of block a (block a = channels {AI*i + a}); the same for dz with BJ.  A K step (two
+// pixels) is therefore two loads (at AI = BJ = 4: two coalesced 512-byte rows per half-wave) for AI*BJ MFMAs (16
+// at 4x4 = 1024 matrix cycles) -- the load path is idle and four steps of prefetch hide the latency.
+// Taps: the lane walks its own pixel (n, oh, ow) incrementally, the tap shift and the SAME padding are folded into
+// the byte offset (out-of-range offset -> zeros).  The four waves of a workgroup take four quarters of the
+// workgroup's pixel range and are summed through LDS at the end; workgroups along gridDim.y are the split-K slabs
+// summed by splitk_reduce_kernel in a fixed order (deterministic, no atomics).
+// The transposed stores put component b back next to its neighbours: out[ci][co0 + BJ*li + 0..BJ-1] is one store.
+// ================================================================================================
+template <int W>
+__device__ __forceinline__ f32x4 loadw(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (W == 4) {
+        v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    } else if constexpr (W == 2) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+        v[0] = t[0]; v[1] = t[1];
+    } else {
+        v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    }
+    return v;
+}
+
+template <int AI, int BJ>
+__global__ __launch_bounds__(256, (AI * BJ > 8) ? 1 : 2) void wgrad_direct_kernel(const WgradParams p) {
+    constexpr int NACC = AI * BJ, U = 4;
+    __shared__ __attribute__((aligned(16))) float red[2 * NACC * 16 * 64];
+    const ds_conv_desc &d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    const int co_tiles = (d.Cout + 32 * BJ - 1) / (32 * BJ);
+    // slab = id % slabs with slabs in {1, 2, 4} or a multiple of 8: the hardware deals workgroup ids round-robin to the
+    // 8 XCDs, so every workgroup of a slab runs on the same XCD(s) and the tiles resident there at any time (a run of
+    // consecutive tile ids, co fastest) walk the slab's pixel rows in step -- x and dz cross the fabric about once
+    const int split = (int)(blockIdx.x % (unsigned)p.slabs);
+    int bid = (int)(blockIdx.x / (unsigned)p.slabs);
+    const int jt = bid % co_tiles; bid /= co_tiles;
+    const int itile = bid % p.ci_tiles;
+    const int tap = bid / p.ci_tiles;
+    const int dh = tap / d.KW, dw = tap % d.KW;
+    const int ci0 = itile * 32 * AI, co0 = jt * 32 * BJ;
+    const int ci = ci0 + AI * li, co = co0 + BJ * li;
+    const bool ci_ok = ci < d.Cin, co_ok = co < d.Cout;
+    const __amdgpu_buffer_rsrc_t srd_x = make_srd(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t srd_z = make_srd(p.dz, p.z_bytes);
+
+    // pixel range: workgroup's slab, then this wave's quarter (even length so the two k lanes stay paired)
+    const int m_begin = split * p.pix_per_split;
+    int m_end = m_begin + p.pix_per_split;
+    if (m_end > p.M) m_end = p.M;
+    int q = (m_end - m_begin + 3) / 4;
+    q = (q + 1) & ~1;
+    const int wb = m_begin + wave * q;
+    int we = wb + q;
+    if (we > m_end) we = m_end;
+    const int steps = we > wb ? (we - wb + 1) / 2 : 0;
+
+    // The lane walks pixels m, m + 2, m + 4, ... of its wave's quarter.  Everything per step is an add or a select:
+    // the input pixel of (n, oh, ow) at this tap is a byte offset that advances by a constant per step, plus a
+    // constant when ow wraps to the next row and another when oh wraps to the next image (unsigned arithmetic, the
+    // intermediate values of padding pixels may wrap around); the padding test is one unsigned compare per axis
+    // against the tap's valid [lo, hi] output range.
+    int m = wb + lk;
+    const int ohw = d.OH * d.OW;
+    int oh = 0, ow = 0;
+    unsigned offx, offz;
+    {
+        const int mm = m < p.M ? m : 0;
+        const int n = mm / ohw;
+        const int r = mm - n * ohw;
+        oh = r / d.OW;
+        ow = r - oh * d.OW;
+        const int ih = oh * d.stride - d.pad_t + dh, iw = ow * d.stride - d.pad_l + dw;
+        offx = ((unsigned)((n * d.H + ih) * d.W + iw) * (unsigned)d.ldx + (unsigned)ci) * 4u;
+        offz = ((unsigned)mm * (unsigned)p.lddz + (unsigned)co) * 4u;
+    }
+    const unsigned ldx4 = (unsigned)d.ldx * 4u;
+    const unsigned step_x = 2u * (unsigned)d.stride * ldx4;
+    const unsigned row_x = (unsigned)((d.W - d.OW) * d.stride) * ldx4;                // ow -= OW, oh += 1
+    const unsigned img_x = (unsigned)((d.H - d.OH * d.stride) * d.W) * ldx4;          // oh -= OH, n += 1
+    const unsigned step_z = 2u * (unsigned)p.lddz * 4u;
+    // valid output coordinates for this tap: 0 <= o * stride - pad + tap < extent
+    auto lo_of = [](int pad, int tap, int stride) { const int v = pad - tap; return v <= 0 ? 0 : (v + stride - 1) / stride; };
+    auto hi_of = [](int pad, int tap, int stride, int ext, int oext) {
+        const int v = ext - 1 + pad - tap;          // o * stride <= v
+        const int h = v < 0 ? -1 : v / stride;
+        return h > oext - 1 ? oext - 1 : h;
+    };
+    const int lo_h = lo_of(d.pad_t, dh, d.stride), lo_w = lo_of(d.pad_l, dw, d.stride);
+    const unsigned span_h = (unsigned)(hi_of(d.pad_t, dh, d.stride, d.H, d.OH) - lo_h);
+    const unsigned span_w = (unsigned)(hi_of(d.pad_l, dw, d.stride, d.W, d.OW) - lo_w);
+    const int OWc = d.OW, OHc = d.OH;
+    auto offsets = [&](unsigned &ox, unsigned &oz) {
+        const bool mv = m < we;
+        const bool in = (unsigned)(oh - lo_h) <= span_h && (unsigned)(ow - lo_w) <= span_w;
+        oz = (mv && co_ok) ? offz : kOOB;
+        ox = (mv && ci_ok && in) ? offx : kOOB;
+        m += 2;
+        offz += step_z;
+        offx += step_x;
+        ow += 2;
+        // up to two row wraps per step when OW == 1 (the GEMM case H = W = 1 has OH = 1 too: both wrap every step)
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            if (rep == 1 && OWc > 1) break;
+            const bool wrap = ow >= OWc;
+            ow = wrap ? ow - OWc : ow;
+            oh += wrap ? 1 : 0;
+            offx += wrap ? row_x : 0u;
+            const bool wrap2 = oh >= OHc;
+            oh = wrap2 ? oh - OHc : oh;
+            offx += wrap2 ? img_x : 0u;
+        }
+    };
+
+    f32x16 acc[AI][BJ];
+#pragma unroll
+    for (int a = 0; a < AI; ++a)
+#pragma unroll
+        for (int b = 0; b < BJ; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    f32x4 xa[U], zb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        unsigned ox, oz;
+        offsets(ox, oz);
+        xa[u] = loadw<AI>(srd_x, ox);
+        zb[u] = loadw<BJ>(srd_z, oz);
+    }
+    for (int s = 0; s < steps; s += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const f32x4 a4 = xa[u], b4 = zb[u];
+            unsigned ox, oz;
+            offsets(ox, oz);                  // step s + u + U (past the range: zeros)
+            xa[u] = loadw<AI>(srd_x, ox);
+            zb[u] = loadw<BJ>(srd_z, oz);
+#pragma unroll
+            for (int a = 0; a < AI; ++a)
+#pragma unroll
+                for (int b = 0; b < BJ; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[a], b4[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // ---- sum the four waves: 2,3 -> 0,1 then 1 -> 0 ------------------------------------------------------------
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int a = 0; a < AI; ++a)
+#pragma unroll
+            for (int b = 0; b < BJ; ++b)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
+                    *reinterpret_cast<f32x4 *>(red + ((slot * NACC + a * BJ + b) * 4 + r4) * 256 + lane * 4) = v;
+                }
+    };
+    auto get = [&](int slot) {
+#pragma unroll
+        for (int a = 0; a < AI; ++a)
+#pragma unroll
+            for (int b = 0; b < BJ; ++b)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(red + ((slot * NACC + a * BJ + b) * 4 + r4) * 256 + lane * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[a][b][4 * r4 + e] += v[e];
+                }
+    };
+    if (wave >= 2) put(wave - 2);
+    __syncthreads();
+    if (wave < 2) get(wave);
+    __syncthreads();
+    if (wave == 1) put(0);
+    __syncthreads();
+    if (wave != 0) return;
+    get(0);
+
+    float *out = p.out + (int64_t)split * (d.KH * d.KW) * d.Cin * d.Cout + (int64_t)tap * d.Cin * d.Cout;
+    if (!co_ok) return;
+#pragma unroll
+    for (int a = 0; a < AI; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = ci0 + AI * ((r & 3) + 8 * (r >> 2) + 4 * lk) + a;
+            if (row < d.Cin) {
+                float *o = out + (int64_t)row * d.Cout + co;
+                if constexpr (BJ == 4) {
+                    *reinterpret_cast<f32x4 *>(o) = f32x4{acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+                } else if constexpr (BJ == 2) {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<f32x2 *>(o) = f32x2{acc[a][0][r], acc[a][1][r]};
+                } else {
+                    *o = acc[a][0][r];
+                }
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *ws, float *dw, int64_t n, int splits) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float s = 0.f;
@@ -224,11 +438,96 @@ int pick_splits(const ds_conv_desc *d, int64_t M) {
     return splits;
 }
 
+// ---- which kernel, which tile, how many slabs ---------------------------------------------------------------
+struct WgradPlan {
+    int direct;      // 1: wgrad_direct_kernel<ai, bj>
+    int ai, bj;
+    int splits;
+};
+
+int max_width(int C, int ld, uintptr_t ptr) {
+    for (int w = 4; w > 1; w >>= 1)
+        if (C % w == 0 && ld % w == 0 && (ptr & (4 * w - 1)) == 0) return w;
+    return 1;
+}
+
+bool direct_ok(const ds_conv_desc *d, int64_t M) {
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("DS_WGRAD_DIRECT");
+        mode = e ? atoi(e) : 1;
+    }
+    return mode && d->fold_cin == 0 && M >= 512;
+}
+
+// Tile shape and slab count by a cycle model of the launch: rounds of resident workgroups x (K steps x MFMA cycles
+// + epilogue), plus the split-K reduction's traffic.  Slabs are 1, 2, 4 or a multiple of 8 (XCD-aligned, see the
+// kernel); a slab keeps >= 64 pixels per wave.
+WgradPlan plan_direct(const ds_conv_desc *d, int64_t M, int wx, int wz) {
+    WgradPlan best = {};
+    double best_cost = 1e30;
+    static const int kSlabs[] = {1, 2, 4, 8, 16, 24, 32, 40, 48, 56, 64};
+    const double wbytes = (double)d->KH * d->KW * d->Cin * d->Cout * 4.0;
+    for (int ai = 1; ai <= wx; ai *= 2)
+        for (int bj = 1; bj <= wz; bj *= 2) {
+            const int nacc = ai * bj;
+            const int occ = nacc > 8 ? 1 : (nacc > 4 ? 2 : 3);
+            const int tiles = d->KH * d->KW * ((d->Cin + 32 * ai - 1) / (32 * ai)) * ((d->Cout + 32 * bj - 1) / (32 * bj));
+            for (int slabs : kSlabs) {
+                if (slabs > 1 && M / slabs < 256) break;
+                const int xcds = slabs >= 8 ? 8 : slabs;                    // XCDs' worth of slots a slab group spans
+                const double per_xcd = (double)tiles * slabs / 8.0;        // workgroups per XCD
+                const double slots = 32.0 * occ;
+                double rounds = (double)(int64_t)(per_xcd / slots);
+                if (rounds * slots < per_xcd) rounds += 1.0;
+                const double steps = (double)M / slabs / 8.0;              // K steps per wave
+                // narrow blocks issue a load pair per few MFMAs: charge the address path too
+                const double step_cycles = nacc * 64.0 > 160.0 ? nacc * 64.0 : 160.0;
+                const double t_wg = steps * step_cycles + 1500.0 + nacc * 350.0;
+                const double t_red = slabs > 1 ? 6000.0 + slabs * wbytes / 1500.0 : 0.0;
+                const double cost = rounds * t_wg + t_red;
+                (void)xcds;
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best.direct = 1; best.ai = ai; best.bj = bj; best.splits = slabs;
+                }
+            }
+        }
+    return best;
+}
+
+WgradPlan plan_wgrad(const ds_conv_desc *d, int64_t M, const float *x, const float *dz, int lddz) {
+    if (direct_ok(d, M)) {
+        WgradPlan pl = plan_direct(d, M, max_width(d->Cin, d->ldx, (uintptr_t)x), max_width(d->Cout, lddz, (uintptr_t)dz));
+        if (const char *e = getenv("DS_WGRAD_FORCE")) {          // "ai,bj,slabs" (tuning aid; the caller sizes the workspace)
+            int a = 0, b = 0, sl = 0;
+            if (sscanf(e, "%d,%d,%d", &a, &b, &sl) == 3) {
+                if (a) pl.ai = a;
+                if (b) pl.bj = b;
+                if (sl) pl.splits = sl;
+            }
+        }
+        return pl;
+    }
+    WgradPlan pl = {};
+    pl.splits = pick_splits(d, M);
+    return pl;
+}
+
 }  // namespace
 
 extern "C" size_t ds_conv_wgrad_workspace(const ds_conv_desc *d) {
     const int64_t M = (int64_t)d->N * d->OH * d->OW;
-    const int splits = pick_splits(d, M);
+    // the vector widths depend on the run-time pointers and leading dimensions: size for the worst of them
+    int splits = pick_splits(d, M);
+    if (direct_ok(d, M)) {
+        splits = 1;
+        for (int wx = 1; wx <= 4; wx *= 2)
+            for (int wz = 1; wz <= 4; wz *= 2) {
+                const int sp = plan_direct(d, M, wx, wz).splits;
+                splits = sp > splits ? sp : splits;
+            }
+    }
     if (splits == 1) return 0;
     return (size_t)splits * d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
 }
@@ -240,8 +539,12 @@ extern "C" int ds_conv_wgrad(const ds_conv_desc *d, const float *x, const float 
     DS_REQUIRE(M < (1ll << 31), "ds_conv_wgrad: M too large");
     DS_REQUIRE(d->fold_cin == 0 || (d->KW == 1 && d->ldx == d->fold_cin && d->fold_cin % 4 == 0 && d->Cin % d->fold_cin == 0),
                "ds_conv_wgrad: fold_cin needs KW=1, ldx==fold_cin, fold_cin %% 4 == 0");
-    const int splits = pick_splits(d, M);
-    const size_t need = ds_conv_wgrad_workspace(d);
+    const WgradPlan pl = plan_wgrad(d, M, x, dz, lddz);
+    if (getenv("DS_WGRAD_DEBUG"))
+        fprintf(stderr, "wgrad M=%lld Cin=%d Cout=%d k=%d: direct=%d ai=%d bj=%d slabs=%d\n", (long long)M, d->Cin, d->Cout, d->KH,
+                pl.direct, pl.ai, pl.bj, pl.splits);
+    const int splits = pl.splits;
+    const size_t need = splits == 1 ? 0 : (size_t)splits * d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
     if (need > 0 && (ws == nullptr || ws_bytes < need)) {
         ds::set_error("ds_conv_wgrad: workspace %zu bytes < required %zu", ws_bytes, need);
         return DS_ERR_WORKSPACE;
@@ -251,12 +554,6 @@ extern "C" int ds_conv_wgrad(const ds_conv_desc *d, const float *x, const float 
     p.x = x; p.dz = dz; p.lddz = lddz;
     p.out = splits == 1 ? dw : (float *)ws;
     p.M = (int)M;
-    const int ti = pick_ti(d);
-    p.ci_tiles = (d->Cin + ti - 1) / ti;
-    int pps = (int)((M + splits - 1) / splits);
-    p.pix_per_split = ((pps + TP - 1) / TP) * TP;
-    p.x_vec = (d->ldx % 4 == 0) && (d->Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
-    p.z_vec = (lddz % 4 == 0) && (d->Cout % 4 == 0) && (((uintptr_t)dz & 15) == 0);
     const int64_t x_elems = ((int64_t)d->N * d->H * d->W - 1) * d->ldx + d->Cin;
     const int64_t z_elems = (M - 1) * lddz + d->Cout;
     DS_REQUIRE(x_elems * 4 < (1ll << 31) && z_elems * 4 < (1ll << 31), "ds_conv_wgrad: operand larger than 2 GiB (split the batch)");
@@ -264,10 +561,27 @@ extern "C" int ds_conv_wgrad(const ds_conv_desc *d, const float *x, const float 
     p.z_bytes = (unsigned)(z_elems * 4);
     p.inv_ohw = 1.0f / (float)(d->OH * d->OW);
     p.inv_ow = 1.0f / (float)d->OW;
-    dim3 grid(d->KH * d->KW * p.ci_tiles, (d->Cout + TJ - 1) / TJ, splits);
+    p.x_vec = (d->ldx % 4 == 0) && (d->Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    p.z_vec = (lddz % 4 == 0) && (d->Cout % 4 == 0) && (((uintptr_t)dz & 15) == 0);
     hipStream_t s = (hipStream_t)stream;
-    if (ti == 64) hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, s, p);
+    int pps = (int)((M + splits - 1) / splits);
+    if (pl.direct) {
+        p.ci_tiles = (d->Cin + 32 * pl.ai - 1) / (32 * pl.ai);
+        p.pix_per_split = (pps + 7) / 8 * 8;
+        const int co_tiles = (d->Cout + 32 * pl.bj - 1) / (32 * pl.bj);
+        p.slabs = splits;
+        const dim3 grid((unsigned)(d->KH * d->KW * p.ci_tiles * co_tiles * splits));
+#define DS_WG(A, B) if (pl.ai == A && pl.bj == B) hipLaunchKernelGGL((wgrad_direct_kernel<A, B>), grid, dim3(256), 0, s, p);
+        DS_WG(4, 4) DS_WG(4, 2) DS_WG(4, 1) DS_WG(2, 4) DS_WG(2, 2) DS_WG(2, 1) DS_WG(1, 4) DS_WG(1, 2) DS_WG(1, 1)
+#undef DS_WG
+    } else {
+        const int ti = pick_ti(d);
+        p.ci_tiles = (d->Cin + ti - 1) / ti;
+        p.pix_per_split = ((pps + TP - 1) / TP) * TP;
+        dim3 grid(d->KH * d->KW * p.ci_tiles, (d->Cout + TJ - 1) / TJ, splits);
+        if (ti == 64) hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, s, p);
+    }
     if (splits > 1) {
         const int64_t n = (int64_t)d->KH * d->KW * d->Cin * d->Cout;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ds::stream_grid(n, 256)), dim3(256), 0, s,
