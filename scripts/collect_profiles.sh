@@ -9,13 +9,17 @@ mkdir -p $R/gpurun_out
 cd $R
 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp && export PYTHONPATH=$R
-rocprofv3 --kernel-trace -d $R/gpurun_out/_kt -o kt -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gather > /dev/null 2>&1
+rocprofv3 --kernel-trace -d $R/gpurun_out/_kt -o kt -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gather --no-conv-timing > /dev/null 2>&1
 python $R/scripts/rocpd_summary.py $(ls $R/gpurun_out/_kt/*.db | head -1) > $R/gpurun_out/${TAG}_kernel_stats.txt
+# the same with the Mixed-block branches on one stream: a kernel's begin..end is then its own duration (this is the
+# mode bench.py's roofline timing pass runs in)
+rocprofv3 --kernel-trace -d $R/gpurun_out/_ks -o ks -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gather --no-conv-timing --no-branch-streams > /dev/null 2>&1
+python $R/scripts/rocpd_summary.py $(ls $R/gpurun_out/_ks/*.db | head -1) > $R/gpurun_out/${TAG}_kernel_stats_serial.txt
 # HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes, kernel trace only (MI355X_MICROARCH.md)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/_pf -o pf -- python $R/bench.py --steps 3 --warmup 0 --no-cpu-baseline --no-conv-timing --no-gather > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/_pw -o pw -- python $R/bench.py --steps 3 --warmup 0 --no-cpu-baseline --no-conv-timing --no-gather > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/_pf -o pf -- python $R/bench.py --steps 3 --warmup 0 --no-cpu-baseline --no-conv-timing --no-gather --no-branch-streams > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/_pw -o pw -- python $R/bench.py --steps 3 --warmup 0 --no-cpu-baseline --no-conv-timing --no-gather --no-branch-streams > /dev/null 2>&1
 python $R/scripts/pmc_summary.py $(ls $R/gpurun_out/_pf/*.db | head -1) $(ls $R/gpurun_out/_pw/*.db | head -1) 3 $R/gpurun_out/${TAG}_pmc.json > $R/gpurun_out/${TAG}_pmc_traffic.txt
-rm -rf $R/gpurun_out/_kt $R/gpurun_out/_pf $R/gpurun_out/_pw
+rm -rf $R/gpurun_out/_kt $R/gpurun_out/_ks $R/gpurun_out/_pf $R/gpurun_out/_pw
 cat $R/gpurun_out/${TAG}_bench.json
 head -8 $R/gpurun_out/${TAG}_kernel_stats.txt
 head -8 $R/gpurun_out/${TAG}_pmc_traffic.txt

@@ -59,6 +59,7 @@ class ConvBN:
         self.eng, self.scopes, self.k, self.stride = eng, scopes, k, stride
         self.cin, self.cout, self.H, self.W = cin, cout, H, W
         self.trainable, self.fold = trainable, fold
+        self.slot = 0          # which of the engine's scratch sets (one per branch stream) this layer uses
         self.OH, _ = same_pad(H, k, stride)
         self.OW, _ = same_pad(W, k, stride)
         st = eng.store
@@ -133,6 +134,8 @@ class ConvBN:
         self.mm = st.view(self.key + "/BatchNorm/moving_mean")
         self.mv = st.view(self.key + "/BatchNorm/moving_variance")
         self.mean.copy_(self.mm)          # first pivot of the batch statistics (ConvBN.forward)
+        eng = self.eng
+        self.stats_buf, self.bwdp_buf, self.ws_buf = eng.stats_set[self.slot], eng.bwdp_set[self.slot], eng.ws_set[self.slot]
         self.gw_ptr = _vp(st.grad_ptr(self.key + "/weights")) if self.trainable else None
         self.gbeta = st.grad_view(self.key + "/BatchNorm/beta") if self.eng.trainable_bn_beta else None
 
@@ -182,13 +185,13 @@ class ConvBN:
             # moving mean before the first step (bind) -- so channels with |mean| >> std keep their variance
             if wino is not None:
                 wino.flags = DS_EPI_STATS
-                wino.run(x_ptr, ops._p(self.u_fwd), ops._p(self.z), stats=ops._p(eng.stats), pivot=ops._p(self.mean))
+                wino.run(x_ptr, ops._p(self.u_fwd), ops._p(self.z), stats=ops._p(self.stats_buf), pivot=ops._p(self.mean))
                 P = wino.partials
             else:
                 self.fwd.d.flags = DS_EPI_STATS
-                self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z), stats=ops._p(eng.stats), pivot=ops._p(self.mean))
+                self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z), stats=ops._p(self.stats_buf), pivot=ops._p(self.mean))
                 P = self.fwd.partials
-            ops.bn_finalize(eng.stats, P, self.M, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
+            ops.bn_finalize(self.stats_buf, P, self.M, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
                             self.rstd, self.shift, self.mm if eng.update_moving else None,
                             self.mv if eng.update_moving else None, pivot=self.mean)
         else:                  # moving statistics (is_training=False: evaluate_* on the validation split)
@@ -211,8 +214,8 @@ class ConvBN:
             return
         B, H, W = self.B, self.OH, self.OW
         ops.bn_pool_bwd_reduce(self.z, pool.dout, pool.argmax, B, H, W, Cc, self.mean, self.rstd, self.shift,
-                               eng.bwd_partials)
-        ops.bn_bwd_finalize(eng.bwd_partials, self.pool_P, M, Cc, self.gbeta if self.gbeta is not None else eng.dummy,
+                               self.bwdp_buf)
+        ops.bn_bwd_finalize(self.bwdp_buf, self.pool_P, M, Cc, self.gbeta if self.gbeta is not None else eng.dummy,
                             self.coef)
         if not (need_dx or self.trainable):
             return
@@ -220,7 +223,7 @@ class ConvBN:
                               self.z)
         if self.trainable:
             self.wgrad.d.ldx = ldx
-            self.wgrad.run(x_ptr, ops._p(self.z), self.gw_ptr, ops._p(eng.ws), eng.ws_bytes)
+            self.wgrad.run(x_ptr, ops._p(self.z), self.gw_ptr, ops._p(self.ws_buf), eng.ws_bytes)
         if need_dx:
             self._run_dgrad(dx_ptr)
 
@@ -235,15 +238,15 @@ class ConvBN:
         M, Cc = self.M, self.cout
         if self.gbeta is None and not need_dx and not self.trainable:
             return
-        ops.bn_bwd_reduce(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, eng.bwd_partials)
-        ops.bn_bwd_finalize(eng.bwd_partials, self.bwd_P, M, Cc, self.gbeta if self.gbeta is not None else eng.dummy,
+        ops.bn_bwd_reduce(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.bwdp_buf)
+        ops.bn_bwd_finalize(self.bwdp_buf, self.bwd_P, M, Cc, self.gbeta if self.gbeta is not None else eng.dummy,
                             self.coef)
         if not (need_dx or self.trainable):
             return
         ops.bn_bwd_apply(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.coef, self.z)   # dz over z
         if self.trainable:
             self.wgrad.d.ldx = ldx
-            self.wgrad.run(x_ptr, ops._p(self.z), self.gw_ptr, ops._p(eng.ws), eng.ws_bytes)
+            self.wgrad.run(x_ptr, ops._p(self.z), self.gw_ptr, ops._p(self.ws_buf), eng.ws_bytes)
         if need_dx:
             self._run_dgrad(dx_ptr)
 
@@ -354,6 +357,8 @@ class MixedStage(Stage):
         self.c3 = ConvBN(eng, [(pre + "Branch_3/Conv2d_0b_1x1", 0, b3)], 1, 1, cin, b3, self.H, self.W, trainable,
                          beta_bucket)
         self.layers = [self.fused, self.c1, self.c2, self.c3]
+        self.c2.slot, self.c3.slot = 1, 2
+        self.ev = None
 
     def alloc(self, B):
         dev = self.eng.device
@@ -390,23 +395,71 @@ class MixedStage(Stage):
         self.c2.make_dgrad(b2a)
         self.c3.make_dgrad(cin)
 
+    # The three chains behind the block input -- [fused 1x1 -> Branch_1 3x3], [... -> Branch_2 3x3] and
+    # [3x3/1 pool -> Branch_3 1x1] -- are independent: Branch_2 and Branch_3 are issued on two side streams (fork /
+    # join by events, each with its own scratch set), so one chain's single-workgroup finalize kernels and the
+    # partly filled last round of its conv launches run under another chain's kernels.
+    def _events(self):
+        if self.ev is None:
+            self.ev = [torch.cuda.Event() for _ in range(4)]
+        return self.ev
+
     def forward(self):
         p = self.prev
         b0, b1a, b1b, b2a, b2b, b3 = self.b
         x = ops._p(p.out)
+        eng = self.eng
+        if not (eng.branch_streams and eng.side):
+            self.fused.forward(x, p.C, self.seg_f)
+            self.c1.forward(ops._p(self.r1), b1a, self.seg_1)
+            self.c2.forward(ops._p(self.r2), b2a, self.seg_2)
+            ops.maxpool_fwd(p.out, self.pooled, self.argmax, self.B, p.H, p.W, p.C, 3, 1, "SAME")
+            self.c3.forward(ops._p(self.pooled), p.C, self.seg_3)
+            return
+        main = torch.cuda.current_stream()
+        s1, s2 = eng.side
+        e_in, e_f, e_2, e_3 = self._events()
+        e_in.record(main)
+        with torch.cuda.stream(s2):
+            s2.wait_event(e_in)
+            ops.maxpool_fwd(p.out, self.pooled, self.argmax, self.B, p.H, p.W, p.C, 3, 1, "SAME")
+            self.c3.forward(ops._p(self.pooled), p.C, self.seg_3)
+            e_3.record(s2)
         self.fused.forward(x, p.C, self.seg_f)
+        e_f.record(main)
+        with torch.cuda.stream(s1):
+            s1.wait_event(e_f)
+            self.c2.forward(ops._p(self.r2), b2a, self.seg_2)
+            e_2.record(s1)
         self.c1.forward(ops._p(self.r1), b1a, self.seg_1)
-        self.c2.forward(ops._p(self.r2), b2a, self.seg_2)
-        ops.maxpool_fwd(p.out, self.pooled, self.argmax, self.B, p.H, p.W, p.C, 3, 1, "SAME")
-        self.c3.forward(ops._p(self.pooled), p.C, self.seg_3)
+        main.wait_event(e_2)
+        main.wait_event(e_3)
 
     def backward(self, need_dx):
         p = self.prev
         b0, b1a, b1b, b2a, b2b, b3 = self.b
         x = ops._p(p.out)
-        self.c3.backward(self.dseg_3, ops._p(self.pooled), p.C, ops._p(self.dpooled), need_dx)
-        self.c1.backward(self.dseg_1, ops._p(self.r1), b1a, ops._p(self.dr1), True)
-        self.c2.backward(self.dseg_2, ops._p(self.r2), b2a, ops._p(self.dr2), True)
+        eng = self.eng
+        if not (eng.branch_streams and eng.side):
+            self.c3.backward(self.dseg_3, ops._p(self.pooled), p.C, ops._p(self.dpooled), need_dx)
+            self.c1.backward(self.dseg_1, ops._p(self.r1), b1a, ops._p(self.dr1), True)
+            self.c2.backward(self.dseg_2, ops._p(self.r2), b2a, ops._p(self.dr2), True)
+        else:
+            main = torch.cuda.current_stream()
+            s1, s2 = eng.side
+            e_in, e_f, e_2, e_3 = self._events()
+            e_in.record(main)
+            with torch.cuda.stream(s2):
+                s2.wait_event(e_in)
+                self.c3.backward(self.dseg_3, ops._p(self.pooled), p.C, ops._p(self.dpooled), need_dx)
+                e_3.record(s2)
+            with torch.cuda.stream(s1):
+                s1.wait_event(e_in)
+                self.c2.backward(self.dseg_2, ops._p(self.r2), b2a, ops._p(self.dr2), True)
+                e_2.record(s1)
+            self.c1.backward(self.dseg_1, ops._p(self.r1), b1a, ops._p(self.dr1), True)
+            main.wait_event(e_2)
+            main.wait_event(e_3)
         self.fused.backward(self.dseg_f, x, p.C, ops._p(p.dout) if need_dx else None, need_dx)
         if need_dx:      # AddN of the two paths into the block input: fused dgrad wrote, the pool path adds
             ops.maxpool_bwd(self.dpooled, self.argmax, p.dout, True, self.B, p.H, p.W, p.C, 3, 1, "SAME")
@@ -434,6 +487,8 @@ class InceptionV1Engine:
         self.training = True         # False: BatchNorm uses moving statistics, dropout is the identity
         self.reducer = None          # dp.GradientReducer, set by SentimentNet
         self.seed_dev = None         # device int64 added to the dropout seed (hipGraph replay draws fresh masks)
+        self.branch_streams = True   # Mixed blocks: Branch_2 and Branch_3 on side streams next to Branch_0/1 (False: one stream)
+        self.side = None
         self.bf16_direct = True      # dtype bf16: ds_conv_bf16 where it wins (False: the LDS-staged bf16 kernel everywhere)
         self.winograd = True         # 3x3 layers through ds_conv_wino where it wins (False: implicit GEMM everywhere)
         self.weights_version = 0     # bumped by SentimentNet.after_load(): frozen layers redo their G g G^T
@@ -496,9 +551,13 @@ class InceptionV1Engine:
         self.fc_wgrad = WgradPlan(B, 1, 1, F, F, 1, 1, 1, nc, nc, pad_t=0, pad_l=0, OH=1, OW=1)
         self.need_ws(self.fc_wgrad.ws_bytes)
         self.colsum_scratch = torch.empty(64 * max(nc, 4), device=dev)
-        self.stats = torch.empty(max(self._stats_n, 4), device=dev)
-        self.bwd_partials = torch.empty(max(self._bwdp_n, 4), device=dev)
-        self.ws = torch.empty(max(self._ws_bytes // 4, 4), device=dev)
+        # three scratch sets: the branches of a Mixed block run on three streams (MixedStage.forward)
+        self.stats_set = [torch.empty(max(self._stats_n, 4), device=dev) for _ in range(3)]
+        self.bwdp_set = [torch.empty(max(self._bwdp_n, 4), device=dev) for _ in range(3)]
+        self.ws_set = [torch.empty(max(self._ws_bytes // 4, 4), device=dev) for _ in range(3)]
+        self.stats, self.bwd_partials, self.ws = self.stats_set[0], self.bwdp_set[0], self.ws_set[0]
+        if self.side is None and self.device.type == "cuda":
+            self.side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         self.ws_bytes = self._ws_bytes
         self.dummy = torch.empty(1024, device=dev)
         for l in self.layers:
