@@ -111,6 +111,14 @@ int ds_conv_bf16_partials(const ds_conv_desc *d);
 int ds_conv_bf16(const ds_conv_desc *d, const float *x, const void *wb, float *z, float *stats, const float *pivot,
                  void *stream);
 
+/* Conv2d_1a_7x7 (inception_v1.py:63): 7x7 stride-2 SAME conv 3 -> 64 read from the PACKED RGB images
+ * x [N, H, W, 3] (no 4-channel copy), w = HWIO [7][7][cin_store][64] (cin_store 3 or 4: the store keeps the stem
+ * filter zero-padded to 4 input channels), z [N*OH*OW, ldz].  stats != NULL: BatchNorm column sums about `pivot`
+ * as float[2][64][ds_conv_stem_partials(N, OH, OW)].                                                         */
+int ds_conv_stem_partials(int32_t N, int32_t OH, int32_t OW);
+int ds_conv_stem(const float *x, const float *w, float *z, float *stats, const float *pivot, int32_t N, int32_t H,
+                 int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream);
+
 /* 3x3 stride-1 SAME convolution as fused Winograd F(2x2, 3x3) on fp32 MFMA: 2.25x fewer matrix passes than the
  * implicit GEMM for Conv2d_2c_3x3 and the Branch_1 / Branch_2 Conv2d_0b_3x3 of every Mixed block
  * (image_model/inception_v1.py:74-75, 86-247), forward and Conv2DBackpropInput alike.

@@ -83,6 +83,33 @@ def test_conv_stem_7x7_stride2_folded():
     close(z, ref.reshape(-1, 64))
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 4), (3, 37, 29, 3), (5, 64, 64, 4), (1, 224, 224, 4)])
+def test_conv_stem_packed_rgb(case):
+    """ds_conv_stem: the 7x7/2 stem straight from the packed [N, H, W, 3] images (register-direct, 12-byte loads,
+    K order built in LDS), with the BatchNorm statistics about a pivot; odd extents exercise both SAME-padding
+    sides and the ragged last tile."""
+    ops = _ops()
+    N, H, W, cs = case
+    rng = np.random.RandomState(12)
+    x = rng.uniform(-1, 1, size=(N, H, W, 3))
+    w = rng.normal(size=(7, 7, 3, 64)) * 0.1
+    ref = S.conv2d_same(x, w, 2)
+    ws = np.zeros((7, 7, cs, 64))
+    ws[:, :, :3] = w
+    plan = ops.StemPlan(N, H, W, cs, 64, 64)
+    assert plan.M == ref.shape[0] * ref.shape[1] * ref.shape[2]
+    z = torch.full((plan.M, 64), float("nan"), device="cuda")
+    stats = torch.zeros(2, 64, plan.partials, device="cuda")
+    pivot = dev(rng.normal(size=64))
+    xd, wd = dev(x), dev(ws)
+    plan.run(ops._p(xd), ops._p(wd), ops._p(z), stats=ops._p(stats), pivot=ops._p(pivot))
+    torch.cuda.synchronize()
+    close(z, ref.reshape(plan.M, 64))
+    u = ref.reshape(plan.M, 64) - pivot.double().cpu().numpy()
+    close(stats[0].sum(1), u.sum(0), 1e-3)
+    close(stats[1].sum(1), (u ** 2).sum(0), 1e-3)
+
+
 @pytest.mark.parametrize("case", [(2, 14, 14, 24, 64, 3), (2, 7, 7, 192, 384, 3), (3, 9, 9, 32, 176, 1)])
 def test_conv_dgrad_reads_hwio_weights_in_place(case):
     ops = _ops()

@@ -1,0 +1,202 @@
+// Conv2d_1a_7x7 (image_model/inception_v1.py:63: 7x7, stride 2, SAME, 3 -> 64 channels) on fp32 MFMA, reading the
+// packed RGB images as the caller hands them over.
+//
+// The generic kernel runs this layer through a zero-padded 4-channel copy of the input with KW folded into the
+// channel axis: K = 7 x 28 = 196 (147 real), both operands staged through LDS, ~60 TFLOP/s -- the slowest conv of the
+// step.  This one is register-direct like gemm_wide_kernel:
+//   * which physical k plays "k = 2 s + kh" of a v_mfma_f32_32x32x2_f32 step is free as long as A and B agree, so
+//     lane (i, kh) loads the THREE channels of input pixel (2 j + kh) of kernel row dh with one 12-byte load
+//     (buffer_load_dwordx3 straight from the [N, H, W, 3] image) and feeds them to three K steps: K = 7 rows x 4 pixel
+//     pairs x 3 channels = 84 steps (168 k, 147 real: the eighth pixel of a row is a zero weight row and is not
+//     loaded);
+//   * the whole filter, reordered to that K order ([dh][j][c][kh][64]: 43 KB), is built in LDS once per workgroup
+//     from the HWIO weights -- no separate packed copy to keep fresh; a B fragment is one conflict-free ds_read_b32;
+//   * a wave owns 64 output pixels (two 32-row blocks) x 64 channels: every B fragment feeds two MFMAs, 64
+//     accumulator registers, two workgroups per CU; the 8 loads of the next kernel row are issued ahead of the 48
+//     MFMAs of the current one;
+//   * workgroups are persistent (grid = 2 per CU) and keep the BatchNorm column sums about the pivot in registers
+//     across their tiles: one partial per workgroup.
+// SAME padding (pad 2 top/left for 224 -> 112) and rows past the end come back as zeros from an out-of-range offset.
+#include "ds_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+
+namespace {
+
+constexpr unsigned kOOB = 0x80000000u;
+constexpr int CO = 64;
+
+struct StemParams {
+    const float *x;      // [N, H, W, 3]
+    const float *w;      // HWIO [7][7][cin_store][64]
+    float *z;            // [N*OH*OW, ldz]
+    float *stats;        // [2][64][P], P = gridDim.x
+    const float *pivot;
+    int N, H, W, OH, OW, pad_t, pad_l, cin_store, ldz;
+    int M, tiles;        // output pixels, 256-pixel tiles
+    unsigned x_bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemParams p) {
+    __shared__ float wl[7 * 4 * 3 * 2 * CO];          // [dh][j][c][kh][co]
+    __shared__ float red[4 * CO * 2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kh = lane >> 5;
+    for (int i = tid; i < 7 * 4 * 3 * 2 * CO; i += 256) {
+        const int co = i & 63, k2 = (i >> 6) & 1, c = (i >> 7) % 3, j = ((i >> 7) / 3) & 3, dh = (i >> 7) / 12;
+        const int px = 2 * j + k2;
+        wl[i] = px < 7 ? p.w[((dh * 7 + px) * p.cin_store + c) * CO + co] : 0.f;
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const float pv0 = p.pivot ? p.pivot[li] : 0.f, pv1 = p.pivot ? p.pivot[32 + li] : 0.f;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    const int ohw = p.OH * p.OW;
+
+    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+        // ---- the lane's two output pixels (row blocks a = 0, 1) ------------------------------------------------
+        int ih0[2], iw0[2], nb[2];
+        bool rv[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int m = tile * 256 + wave * 64 + a * 32 + li;
+            rv[a] = m < p.M;
+            const int mm = rv[a] ? m : 0;
+            const int n = mm / ohw, r = mm - n * ohw;
+            const int oh = r / p.OW, ow = r - oh * p.OW;
+            ih0[a] = 2 * oh - p.pad_t;
+            iw0[a] = 2 * ow - p.pad_l + kh;             // pixel 2 j + kh of the kernel row
+            nb[a] = n * p.H;
+        }
+        auto row_offsets = [&](int dh, unsigned (&vo)[2][4]) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int ih = ih0[a] + dh;
+                const bool rok = rv[a] && (unsigned)ih < (unsigned)p.H;
+                const int base = (nb[a] + ih) * p.W;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int iw = iw0[a] + 2 * j;
+                    const bool ok = rok && (unsigned)iw < (unsigned)p.W && (2 * j + kh) < 7;
+                    vo[a][j] = ok ? (unsigned)(base + iw) * 12u : kOOB;
+                }
+            }
+        };
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+        f32x3 cur[2][4], nxt[2][4];
+        {
+            unsigned vo[2][4];
+            row_offsets(0, vo);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    cur[a][j] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(srd, vo[a][j], 0, 0));
+        }
+#pragma unroll 1
+        for (int dh = 0; dh < 7; ++dh) {
+            if (dh < 6) {
+                unsigned vo[2][4];
+                row_offsets(dh + 1, vo);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        nxt[a][j] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(srd, vo[a][j], 0, 0));
+            }
+            const float *wr = wl + dh * (4 * 3 * 2 * CO) + kh * CO + li;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float b0 = wr[(j * 3 + c) * 2 * CO], b1 = wr[(j * 3 + c) * 2 * CO + 32];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][j][c], b0, acc[0][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[1][j][c], b0, acc[1][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][j][c], b1, acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[1][j][c], b1, acc[1][1], 0, 0, 0);
+                }
+            if (dh < 6) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cur[a][j] = nxt[a][j];
+            }
+        }
+        // ---- store + statistics: element e of a block is output row (e&3) + 8 (e>>2) + 4 kh, column li ---------------
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int row0 = tile * 256 + wave * 64 + a * 32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                if (row < p.M) {
+                    const float v0 = acc[a][0][e], v1 = acc[a][1][e];
+                    p.z[(int64_t)row * p.ldz + li] = v0;
+                    p.z[(int64_t)row * p.ldz + 32 + li] = v1;
+                    const float u0 = v0 - pv0, u1 = v1 - pv1;
+                    s0 += u0; q0 += u0 * u0;
+                    s1 += u1; q1 += u1 * u1;
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32);
+        s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
+        if (kh == 0) {
+            red[(wave * CO + li) * 2] = s0;       red[(wave * CO + li) * 2 + 1] = q0;
+            red[(wave * CO + 32 + li) * 2] = s1;  red[(wave * CO + 32 + li) * 2 + 1] = q1;
+        }
+        __syncthreads();
+        if (tid < CO) {
+            float ss = 0.f, qq = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                ss += red[(w * CO + tid) * 2];
+                qq += red[(w * CO + tid) * 2 + 1];
+            }
+            p.stats[(int64_t)tid * gridDim.x + blockIdx.x] = ss;
+            p.stats[((int64_t)CO + tid) * gridDim.x + blockIdx.x] = qq;
+        }
+    }
+}
+
+int stem_grid(int64_t M) {
+    const int64_t tiles = (M + 255) / 256;
+    const int64_t g = 2 * ds::kCUs;
+    return (int)(tiles < g ? tiles : g);
+}
+
+}  // namespace
+
+extern "C" int ds_conv_stem_partials(int32_t N, int32_t OH, int32_t OW) { return stem_grid((int64_t)N * OH * OW); }
+
+extern "C" int ds_conv_stem(const float *x, const float *w, float *z, float *stats, const float *pivot, int32_t N, int32_t H,
+                            int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream) {
+    DS_REQUIRE(x && w && z, "ds_conv_stem: null argument");
+    DS_REQUIRE(Cout == CO && (cin_store == 3 || cin_store == 4) && ldz >= CO, "ds_conv_stem: the 7x7/2 stem has 3 input and 64 output channels");
+    StemParams p = {};
+    p.x = x; p.w = w; p.z = z; p.stats = stats; p.pivot = stats ? pivot : nullptr;
+    p.N = N; p.H = H; p.W = W;
+    p.OH = (H + 1) / 2; p.OW = (W + 1) / 2;
+    const int ph = (p.OH - 1) * 2 + 7 - H, pw = (p.OW - 1) * 2 + 7 - W;     // TF SAME: the smaller half in front
+    p.pad_t = (ph > 0 ? ph : 0) / 2; p.pad_l = (pw > 0 ? pw : 0) / 2;
+    p.cin_store = cin_store; p.ldz = ldz;
+    const int64_t M = (int64_t)N * p.OH * p.OW;
+    const int64_t xb = (int64_t)N * H * W * 12;
+    DS_REQUIRE(M < (1ll << 31) && xb < (1ll << 31), "ds_conv_stem: input larger than 2 GiB (split the batch)");
+    p.M = (int)M; p.tiles = (int)((M + 255) / 256);
+    p.x_bytes = (unsigned)xb;
+    hipLaunchKernelGGL(conv_stem_kernel, dim3(stem_grid(M)), dim3(256), 0, (hipStream_t)stream, p);
+    return ds::check_launch("ds_conv_stem");
+}

@@ -98,6 +98,12 @@ class ConvBN:
             return (eng.winograd and eng.conv_dtype == ops.DS_DTYPE_F32 and k == 3 and self.stride == 1 and
                     cin_k % 8 == 0 and (H >= 14 or cout_k >= 128))
         self.wino_fwd = self.wino_dgrad = None
+        # the stem straight from the packed RGB batch (ds_conv_stem); rides the alternative-plan slot, its "u" is
+        # the HWIO filter itself
+        self.stem_direct = self.fold and eng.stem_direct and eng.conv_dtype == ops.DS_DTYPE_F32 and cout == 64
+        if self.stem_direct:
+            self.wino_fwd = ops.StemPlan(B, self.H, self.W, 4, cout, cout)
+            eng.need_stats(self.wino_fwd.partials * 2 * cout)
         if wino_ok(self.H, cin, cout):
             self.wino_fwd = WinoPlan(B, self.H, self.W, cin, 0, cout, cout, flags=DS_EPI_STATS)
             self.u_fwd = torch.empty(16, cout, cin, device=dev)
@@ -157,7 +163,7 @@ class ConvBN:
         """G g G^T of the filter for the Winograd kernels: redone when the weights changed -- every step for a
         trainable layer (Adam moves them), once per load for a frozen one."""
         eng = self.eng
-        if self.wino_fwd is None and self.wino_dgrad is None:
+        if (self.wino_fwd is None and self.wino_dgrad is None) or self.stem_direct:
             return
         if not self.trainable and self.u_version == eng.weights_version:
             return
@@ -178,14 +184,17 @@ class ConvBN:
             self.fwd.d.ldx = ldx
         self._refresh_wino()
         wino = self.wino_fwd
-        if wino is not None:
+        if self.stem_direct:
+            x_ptr, u_ptr = ops._p(eng.images), self.w_ptr
+        elif wino is not None:
             wino.set_ldx(ldx)
+            u_ptr = ops._p(self.u_fwd)
         if eng.training:       # batch statistics (slim.batch_norm is_training=True)
             # the column sums are taken about a pivot near the mean -- the previous step's batch mean, the
             # moving mean before the first step (bind) -- so channels with |mean| >> std keep their variance
             if wino is not None:
                 wino.flags = DS_EPI_STATS
-                wino.run(x_ptr, ops._p(self.u_fwd), ops._p(self.z), stats=ops._p(self.stats_buf), pivot=ops._p(self.mean))
+                wino.run(x_ptr, u_ptr, ops._p(self.z), stats=ops._p(self.stats_buf), pivot=ops._p(self.mean))
                 P = wino.partials
             else:
                 self.fwd.d.flags = DS_EPI_STATS
@@ -197,7 +206,7 @@ class ConvBN:
         else:                  # moving statistics (is_training=False: evaluate_* on the validation split)
             if wino is not None:
                 wino.flags = 0
-                wino.run(x_ptr, ops._p(self.u_fwd), ops._p(self.z))
+                wino.run(x_ptr, u_ptr, ops._p(self.z))
             else:
                 self.fwd.d.flags = 0
                 self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z))
@@ -487,6 +496,7 @@ class InceptionV1Engine:
         self.training = True         # False: BatchNorm uses moving statistics, dropout is the identity
         self.reducer = None          # dp.GradientReducer, set by SentimentNet
         self.seed_dev = None         # device int64 added to the dropout seed (hipGraph replay draws fresh masks)
+        self.stem_direct = True      # Conv2d_1a_7x7 from the packed RGB batch (ds_conv_stem; False: generic kernel on a 4-channel copy)
         self.branch_streams = True   # Mixed blocks: Branch_2 and Branch_3 on side streams next to Branch_0/1 (False: one stream)
         self.side = None
         self.bf16_direct = True      # dtype bf16: ds_conv_bf16 where it wins (False: the LDS-staged bf16 kernel everywhere)
@@ -578,7 +588,11 @@ class InceptionV1Engine:
             if isinstance(a, ConvStage):
                 a.fused_into_pool = self.fuse_bn_pool and isinstance(b, PoolStage) and b.k == 3
                 a.pool = b if a.fused_into_pool else None
-        ops.pad_channels(images, 3, self.input.out, 4, B * self.input.H * self.input.W)
+        self.images = images
+        stem = self.stages[0].layer
+        if not stem.stem_direct or (stem.trainable and self.training):
+            # the generic stem kernel and the stem's wgrad (train_all) read a zero-padded 4-channel copy
+            ops.pad_channels(images, 3, self.input.out, 4, B * self.input.H * self.input.W)
         for s in self.stages:
             s.forward()
         last = self.last

@@ -321,10 +321,18 @@ class SentimentNet:
         # eager warm-up (allocates every buffer, builds every plan) on a snapshot of the optimiser state, so that
         # capturing has no side effect on the variables, the Adam slots or the BatchNorm moving statistics
         keep = [b.clone() for b in (st.theta, st.m, st.v, st.frozen)]
+        if self.image is not None and self.image.B != batch["images"].shape[0]:
+            self.image.alloc(batch["images"].shape[0])
+        # ... and of the BatchNorm pivots (each layer's previous batch mean), so that the first replayed step rounds
+        # exactly like the eager step it replaces
+        pivots = [] if self.image is None else [l.mean for l in self.image.layers]
+        keep_pivots = [m.clone() for m in pivots]
         self.train_step(batch, 0.0, dropout_mask)
         self.step -= 1
         for b, k in zip((st.theta, st.m, st.v, st.frozen), keep):
             b.copy_(k)
+        for m, k in zip(pivots, keep_pivots):
+            m.copy_(k)
         if self.image is not None:
             self.image.seed_dev = self.seed_dev
         torch.cuda.synchronize()

@@ -154,6 +154,27 @@ def wino_transform_weights(w_ptr, u, Cin, Cout, dgrad):
                "ds_wino_transform_weights")
 
 
+class StemPlan:
+    """Conv2d_1a_7x7 through ds_conv_stem: packed RGB input [N, H, W, 3], HWIO weights with `cin_store` input rows."""
+
+    def __init__(self, N, H, W, cin_store, Cout, ldz):
+        self.args = (N, H, W, cin_store, Cout, ldz)
+        self.flags = DS_EPI_STATS      # kept for the common plan interface: statistics are on iff `stats` is passed
+        OH, OW = (H + 1) // 2, (W + 1) // 2
+        self.M = N * OH * OW
+        self.partials = _lib.load().ds_conv_stem_partials(N, OH, OW)
+        self.alg_flops = 2.0 * self.M * Cout * 147
+
+    def run(self, x, w, z, stats=None, pivot=None):
+        t = CONV_TIMER
+        if t is not None:
+            t.begin()
+        N, H, W, cs, Cout, ldz = self.args
+        _lib.check(_lib.load().ds_conv_stem(x, w, z, stats, pivot, N, H, W, cs, Cout, ldz, _stream()), "ds_conv_stem")
+        if t is not None:
+            t.end(self)
+
+
 class Bf16Plan:
     """1x1 / 3x3 conv (or its dgrad) through ds_conv_bf16: register-direct bf16 MFMA, weights pre-converted by
     `weights_to_bf16` into the kernel's K-loop order.  Geometry arguments as ConvPlan's."""
