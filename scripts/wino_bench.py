@@ -6,7 +6,10 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from tumblr_emotions_amd import ops
+from tumblr_emotions_amd import _lib, ops
+
+if os.environ.get("DS_LIB"):        # A/B runs of kernel variants on one box
+    _lib.LIB_PATH = os.environ["DS_LIB"]
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 SHAPES = [(56, 64, 192), (28, 96, 128), (28, 128, 192), (28, 16, 32), (28, 32, 96), (14, 96, 208), (14, 112, 224),

@@ -58,6 +58,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wsrd(const void *p, unsigned b
 
 typedef __attribute__((address_space(3))) void *lds_ptr;
 
+// a - b on four floats as two v_pk_add_f32 with the second operand negated.  hipcc packs fp32 adds into
+// v_pk_add_f32 by itself but leaves subtractions as four v_sub_f32, and with one wave per SIMD every VALU issue
+// slot of the transform is a slot the matrix pipe idles (scratch/mfma_mix.hip: 64 MFMAs alone 1.73 us, with the K
+// step's 128 VALU ops, 16 LDS reads and barrier 2.15 us): 112 -> 64 VALU instructions per K step, -4 % kernel time.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
+    f32x2 lo, hi;
+    const f32x2 alo = {a[0], a[1]}, ahi = {a[2], a[3]}, blo = {b[0], b[1]}, bhi = {b[2], b[3]};
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(alo), "v"(blo));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(ahi), "v"(bhi));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     // B tile of one K step: [16 positions][32 channels][8 ci] floats = 16 KB, two buffers
     __shared__ __attribute__((aligned(128))) float smem[2 * 16 * 32 * 8];
@@ -132,10 +145,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
             const f32x4 d0 = raw[px], d1 = raw[4 + px], d2 = raw[8 + px], d3 = raw[12 + px];
-            t[px] = d0 - d2;
+            t[px] = sub4(d0, d2);
             t[4 + px] = d1 + d2;
-            t[8 + px] = d2 - d1;
-            t[12 + px] = d1 - d3;
+            t[8 + px] = sub4(d2, d1);
+            t[12 + px] = sub4(d1, d3);
         }
         // Operands of the next K step are requested BETWEEN the MFMA groups, four patch pixels and one weight DMA per
         // patch row: each pixel-scattered load occupies the texture-address path for a while, and issued in one burst at
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
         float *dma_dst = smem + ((ks + 1) & 1) * 4096 + wave * 256;
         const float *b_s = smem + (ks & 1) * 4096 + li * 8 + kh * 4;
         f32x4 v[4], vn[4], b[4], bn[4];
-        vn[0] = t[0] - t[2]; vn[1] = t[1] + t[2]; vn[2] = t[2] - t[1]; vn[3] = t[1] - t[3];
+        vn[0] = sub4(t[0], t[2]); vn[1] = t[1] + t[2]; vn[2] = sub4(t[2], t[1]); vn[3] = sub4(t[1], t[3]);
 #pragma unroll
         for (int px = 0; px < 4; ++px) bn[px] = *reinterpret_cast<const f32x4 *>(b_s + px * 256);
 #pragma unroll
@@ -158,6 +171,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                 for (int px = 0; px < 4; ++px) bn[px] = *reinterpret_cast<const f32x4 *>(b_s + (py * 4 + 4 + px) * 256);
             }
             if (more) {
+                // (flags 256 / 512 / 1024 switch the pixel loads / weight DMAs / stores off for timing experiments.  The
+                // uniform branches also keep hipcc from regrouping the requests: with them removed the same kernel
+                // measured 5.7 % slower, with the loads made unconditional 2 % slower -- scratch A/B on one box.)
                 if (!(p.flags & 256)) {
 #pragma unroll
                     for (int px = 0; px < 4; ++px)
@@ -177,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                 }
             if (py < 3) {       // column pass of the next patch row, behind this row's MFMAs
                 const f32x4 t0 = t[py * 4 + 4], t1 = t[py * 4 + 5], t2 = t[py * 4 + 6], t3 = t[py * 4 + 7];
-                vn[0] = t0 - t2; vn[1] = t1 + t2; vn[2] = t2 - t1; vn[3] = t1 - t3;
+                vn[0] = sub4(t0, t2); vn[1] = t1 + t2; vn[2] = sub4(t2, t1); vn[3] = sub4(t1, t3);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
