@@ -28,7 +28,7 @@ def timeit(f, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-tot = [0.0, 0.0, 0.0]
+tot = [0.0, 0.0, 0.0, 0.0]
 print("%4s %5s %5s %6s | %9s %7s | %9s %7s | %6s" % ("HW", "K", "N", "", "lds us", "TF", "wide us", "TF", "ratio"))
 for (hw, ci, co) in SHAPES:
     M = B * hw * hw
@@ -40,7 +40,7 @@ for (hw, ci, co) in SHAPES:
         w = torch.randn(ci, co, device="cuda") * 0.05
         z = torch.empty(M, N, device="cuda")
         res = []
-        for mode in (0, 2):
+        for mode in (0, 2, 1):
             lib.ds_conv_set_wide(mode)
             if dgrad:
                 plan = ops.gemm_plan(M, K, N, K, N, co, transposed_w=True)
@@ -53,8 +53,9 @@ for (hw, ci, co) in SHAPES:
         auto = ops.ConvPlan(M, 1, 1, K, K, 1, 1, 1, N, N, 0, 1, N, pad_t=0, pad_l=0, OH=1, OW=1) if not dgrad else None
         tot[0] += res[0]
         tot[1] += res[1]
-        tot[2] += min(res)
+        tot[2] += min(res[:2])
+        tot[3] += res[2]
         print("%4d %5d %5d %6s | %9.1f %7.1f | %9.1f %7.1f | %6.2f" % (hw, K, N, "dgrad" if dgrad else "", res[0], fl / res[0] / 1e6,
                                                                      res[1], fl / res[1] / 1e6, res[0] / res[1]))
 lib.ds_conv_set_wide(1)
-print("sum: lds %.1f us, wide %.1f us, best of both %.1f us" % tuple(tot))
+print("sum: lds %.1f us, wide %.1f us, best of both %.1f us, library's own choice %.1f us" % tuple(tot))

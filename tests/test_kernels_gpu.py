@@ -269,7 +269,7 @@ def test_winograd_conv_forward_and_dgrad_match_oracle(case):
 
 
 @pytest.mark.parametrize("case", [(300, 64, 64), (1000, 192, 176), (777, 480, 304), (513, 296, 512), (260, 40, 96),
-                                  (4096, 832, 624), (129, 280, 528)])
+                                  (4096, 832, 624), (129, 280, 528), (300, 64, 224), (300, 96, 288), (400, 448, 160)])
 def test_wide_1x1_kernel_forward_and_dgrad_match_oracle(case):
     """The wide-tile register-direct kernel for plain 1x1 / GEMM shapes (gemm_wide_kernel), forced on for every
     shape: forward (n-contiguous HWIO weights, BatchNorm statistics about a pivot) and dgrad (the same tensor read

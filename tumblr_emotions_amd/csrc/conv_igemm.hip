@@ -1112,9 +1112,8 @@ __global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void conv_bf16_kernel(const C
 template <int NB, bool BNMAJOR>
 __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const ConvParams p) {
     constexpr int BN = NB * 32, WK = 16;                       // K step: 16 channels = two float4 per lane
-    constexpr int BSZ = WK * BN;                               // floats per B buffer
-    constexpr int DJ = BSZ / 4 / 256;                          // 16-byte DMA slots per thread per K step (NB / 2 ... )
-    static_assert(BSZ % 1024 == 0, "B tile must be a whole number of DMA instructions per thread");
+    constexpr int DJ = (WK * BN / 4 + 255) / 256;              // 16-byte DMA slots per thread per K step: ceil(NB / 2)
+    constexpr int BSZ = DJ * 1024;                             // floats per B buffer (odd NB: the last DMA is half used)
     __shared__ __attribute__((aligned(128))) float smem[2 * BSZ + 256];
     const ds_conv_desc &d = p.d;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1140,11 +1139,11 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
         if (BNMAJOR) {
             const int k = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
             ukq[i] = k;
-            uoff[i] = n < d.Cout ? ((unsigned)k * (unsigned)d.w_k_stride + (unsigned)n) * 4u : kOOB;
+            uoff[i] = (n < d.Cout && k < WK) ? ((unsigned)k * (unsigned)d.w_k_stride + (unsigned)n) * 4u : kOOB;
         } else {
             const int nl = idx >> 2, pc = idx & 3, kq = pc ^ ((nl >> 2) & 3);
             ukq[i] = kq * 4;
-            uoff[i] = n0 + nl < d.Cout ? ((unsigned)(n0 + nl) * (unsigned)d.w_n_stride + 4u * kq) * 4u : kOOB;
+            uoff[i] = (n0 + nl < d.Cout && nl < BN) ? ((unsigned)(n0 + nl) * (unsigned)d.w_n_stride + 4u * kq) * 4u : kOOB;
         }
     }
     auto dma_b = [&](int buf, int c0, int i) {
@@ -1549,9 +1548,13 @@ void launch_wide(int nb, bool bnmajor, dim3 grid, hipStream_t st, const ConvPara
         else hipLaunchKernelGGL((gemm_wide_kernel<NBV, false>), grid, dim3(256), 0, st, p);            \
         break;
     switch (nb) {
+        DS_WIDE(1)
         DS_WIDE(2)
+        DS_WIDE(3)
         DS_WIDE(4)
+        DS_WIDE(5)
         DS_WIDE(6)
+        DS_WIDE(7)
         default:
         DS_WIDE(8)
     }
@@ -1572,15 +1575,32 @@ int wide_nb(const ds_conv_desc *d, bool vec) {
     if (d->Cin % 8 != 0 || d->Cin < 32) return 0;
     const int64_t M = conv_M(d);
     const int N = d->Cout;
-    int best = 0, best_pad = 1 << 30;
-    for (int nb = 8; nb >= 2; nb -= 2) {
-        const int pad = (N + 32 * nb - 1) / (32 * nb) * (32 * nb);
-        if (pad < best_pad) { best_pad = pad; best = nb; }
+    // Every workgroup puts one wave on each SIMD of its CU and the resident waves of a SIMD share its matrix pipe, so a
+    // launch takes ceil(workgroups / CUs) x (one wave's work): NB blocks of MFMAs per K step plus about half a block
+    // for the A fetch it does not share.  Pick the NB with the least of that (ties to the wider tile).
+    int best = 0, best_pad = 0;
+    int64_t best_cost = (int64_t)1 << 60;
+    static int cA = -1;
+    if (cA < 0) {
+        const char *e = getenv("DS_WIDE_COST");
+        cA = e ? atoi(e) : 0;                                    // in halves of a block
+    }
+    const int64_t row_tiles = (M + 127) / 128;
+    for (int nb = 8; nb >= (N <= 32 ? 1 : 2); --nb) {      // one block per wave only where two would be half padding
+        const int tiles = (N + 32 * nb - 1) / (32 * nb);
+        const int64_t rounds = (row_tiles * tiles + ds::kCUs - 1) / ds::kCUs;
+        const int64_t cost = rounds * (2 * nb + cA);
+        if (cost < best_cost) { best_cost = cost; best = nb; best_pad = tiles * 32 * nb; }
     }
     const int64_t wgs = (M + 127) / 128 * ((N + 32 * best - 1) / (32 * best));
     // measured per shape (profiles/r02_wide_layers.txt): wins 1.1-1.4x except with one mostly padded column tile or too
     // few workgroups to cover the CUs (7x7 maps with N <= 128)
-    if (force_wide < 2 && (wgs * 10 < 12 * ds::kCUs || best_pad * 100 > N * 125)) return 0;
+    static int min_wgs = -1;
+    if (min_wgs < 0) {
+        const char *e = getenv("DS_WIDE_MINWGS");
+        min_wgs = e ? atoi(e) : 128;
+    }
+    if (force_wide < 2 && (wgs < min_wgs || best_pad * 100 > N * 125)) return 0;
     return best;
 }
 
