@@ -163,6 +163,8 @@ def main():
                          "forward/dgrad multiplies on the bf16 matrix pipe, fp32 storage/accumulate/statistics/masters")
     ap.add_argument("--stepwise-lstm", action="store_true",
                     help="A/B aid: one GEMM + one cell launch per LSTM step instead of the persistent ds_lstm_seq kernels")
+    ap.add_argument("--no-pool-first", action="store_true",
+                    help="Mixed backward: fused 1x1 dgrad writes the block-input gradient and the Branch_3 pool adds (default: the reverse)")
     ap.add_argument("--no-stem-direct", action="store_true",
                     help="Conv2d_1a_7x7 through the generic kernel on a 4-channel copy (default: ds_conv_stem on the packed RGB batch)")
     ap.add_argument("--no-branch-streams", action="store_true",
@@ -222,6 +224,8 @@ def main():
         net.image.winograd = False
     if args.no_branch_streams and net.image is not None:
         net.image.branch_streams = False
+    if args.no_pool_first and net.image is not None:
+        net.image.pool_first = False
     if args.no_stem_direct and net.image is not None:
         net.image.stem_direct = False
     if args.bf16_staged and net.image is not None:

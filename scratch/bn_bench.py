@@ -8,7 +8,7 @@ def timeit(fn, n=20):
     e0.record()
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1)/n
-for M, C in [(802816, 192), (802816, 64), (200704, 256), (200704, 480), (50176, 512), (50176, 832), (12544, 832)]:
+for M, C in [(802816, 192), (802816, 64), (200704, 176), (200704, 128), (200704, 32), (200704, 288), (200704, 192), (200704, 96), (200704, 64), (50176, 304), (50176, 208), (50176, 48), (50176, 64), (50176, 296), (50176, 224), (50176, 448), (50176, 320), (50176, 128), (12544, 448), (12544, 320), (12544, 128), (12544, 624), (12544, 384)]:
     z = torch.randn(M, C, device='cuda'); dy = torch.randn(M, C, device='cuda'); y = torch.empty_like(z)
     mean = torch.zeros(C, device='cuda'); rstd = torch.ones(C, device='cuda'); shift = torch.zeros(C, device='cuda')
     coef = torch.zeros(2, C, device='cuda'); dbeta = torch.zeros(C, device='cuda')

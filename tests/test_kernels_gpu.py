@@ -307,6 +307,13 @@ def test_wide_1x1_kernel_forward_and_dgrad_match_oracle(case):
             g.run(ops._p(dzd), ops._p(wd), ops._p(dx))
             torch.cuda.synchronize()
             close(dx, dz @ w.T)
+            # DS_EPI_ACCUM: dx += dz * w^T (the fused 1x1 dgrad adding onto the pool path's gradient)
+            g.d.flags = ops.DS_EPI_ACCUM
+            prev = rng.normal(size=(M, K))
+            dx.copy_(dev(prev))
+            g.run(ops._p(dzd), ops._p(wd), ops._p(dx))
+            torch.cuda.synchronize()
+            close(dx, prev + dz @ w.T)
     finally:
         lib.ds_conv_set_wide(1)
 

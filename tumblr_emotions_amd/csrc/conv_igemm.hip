@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void conv_bf16_kernel(const C
 // LDS-DMA, double buffered, shared by the workgroup's four waves (four 32-row groups); its fragments are read
 // position by position in the shadow of the MFMAs, and the loads / DMAs of the next K step are issued BETWEEN the
 // MFMA groups (conv_wino.hip: a burst of row-scattered loads stalls the in-order wave behind the texture path).
-// Epilogue: plain stores + BatchNorm column statistics about the pivot (flags 0 or DS_EPI_STATS only).
+// Epilogue: stores (DS_EPI_ACCUM: z += result) + BatchNorm column statistics about the pivot (DS_EPI_STATS).
 // ================================================================================================
 template <int NB, bool BNMAJOR>
 __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const ConvParams p) {
@@ -1226,7 +1226,8 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
         for (int r = 0; r < 16; ++r) {
             const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             if (row < p.M && colok) {
-                const float v = acc[b][r];
+                float v = acc[b][r];
+                if (flags & DS_EPI_ACCUM) v += p.z[(int64_t)row * d.ldz + col];
                 p.z[(int64_t)row * d.ldz + col] = v;
                 const float u = v - pv;
                 s += u;
@@ -1571,7 +1572,7 @@ int wide_nb(const ds_conv_desc *d, bool vec) {
     }
     if (!force_wide || !vec || d->dtype != DS_DTYPE_F32) return 0;
     if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->fold_cin || d->splits > 1) return 0;
-    if (d->flags & ~DS_EPI_STATS) return 0;
+    if (d->flags & ~(DS_EPI_STATS | DS_EPI_ACCUM)) return 0;
     if (d->Cin % 8 != 0 || d->Cin < 32) return 0;
     const int64_t M = conv_M(d);
     const int N = d->Cout;

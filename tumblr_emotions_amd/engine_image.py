@@ -449,8 +449,19 @@ class MixedStage(Stage):
         b0, b1a, b1b, b2a, b2b, b3 = self.b
         x = ops._p(p.out)
         eng = self.eng
-        if not (eng.branch_streams and eng.side):
+        # AddN of the two paths into the block input.  pool_first: the pool path WRITES p.dout inside the Branch_3 chain
+        # (9 B/element, under the other chains' convs) and the fused 1x1 dgrad accumulates onto it in its epilogue;
+        # otherwise (dgrad kernels without an accumulate epilogue) the dgrad writes and the pool path adds afterwards.
+        pool_first = need_dx and self.fused.wino_dgrad is None and eng.pool_first
+        self.fused.dgrad.d.flags = ops.DS_EPI_ACCUM if pool_first else 0
+
+        def branch3():
             self.c3.backward(self.dseg_3, ops._p(self.pooled), p.C, ops._p(self.dpooled), need_dx)
+            if pool_first:
+                ops.maxpool_bwd(self.dpooled, self.argmax, p.dout, False, self.B, p.H, p.W, p.C, 3, 1, "SAME")
+
+        if not (eng.branch_streams and eng.side):
+            branch3()
             self.c1.backward(self.dseg_1, ops._p(self.r1), b1a, ops._p(self.dr1), True)
             self.c2.backward(self.dseg_2, ops._p(self.r2), b2a, ops._p(self.dr2), True)
         else:
@@ -460,7 +471,7 @@ class MixedStage(Stage):
             e_in.record(main)
             with torch.cuda.stream(s2):
                 s2.wait_event(e_in)
-                self.c3.backward(self.dseg_3, ops._p(self.pooled), p.C, ops._p(self.dpooled), need_dx)
+                branch3()
                 e_3.record(s2)
             with torch.cuda.stream(s1):
                 s1.wait_event(e_in)
@@ -470,7 +481,7 @@ class MixedStage(Stage):
             main.wait_event(e_2)
             main.wait_event(e_3)
         self.fused.backward(self.dseg_f, x, p.C, ops._p(p.dout) if need_dx else None, need_dx)
-        if need_dx:      # AddN of the two paths into the block input: fused dgrad wrote, the pool path adds
+        if need_dx and not pool_first:
             ops.maxpool_bwd(self.dpooled, self.argmax, p.dout, True, self.B, p.H, p.W, p.C, 3, 1, "SAME")
 
 
@@ -496,6 +507,7 @@ class InceptionV1Engine:
         self.training = True         # False: BatchNorm uses moving statistics, dropout is the identity
         self.reducer = None          # dp.GradientReducer, set by SentimentNet
         self.seed_dev = None         # device int64 added to the dropout seed (hipGraph replay draws fresh masks)
+        self.pool_first = True       # Mixed backward: Branch_3's pool gradient written first, fused dgrad accumulates (False: the reverse)
         self.stem_direct = True      # Conv2d_1a_7x7 from the packed RGB batch (ds_conv_stem; False: generic kernel on a 4-channel copy)
         self.branch_streams = True   # Mixed blocks: Branch_2 and Branch_3 on side streams next to Branch_0/1 (False: one stream)
         self.side = None
