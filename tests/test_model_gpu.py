@@ -372,6 +372,29 @@ def test_captured_step_matches_eager_step(mode):
     assert torch.equal(z0, z1) and torch.equal(th0, th1) and torch.equal(fr0, fr1)
 
 
+@pytest.mark.parametrize("B", [16, 96])
+def test_branch_streams_and_pool_order_do_not_change_a_bit(B):
+    """The Mixed-block branches on three streams (fork/join by events, one scratch set per stream) and the
+    pool-first order of the block-input gradient are scheduling choices: two training steps give the same bits with
+    them on and off.  A missing event wait or a shared scratch buffer between the concurrent chains shows up here as
+    a difference (and as run-to-run differences in the three concurrent repetitions)."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    batch = to_device(synthetic_batch_numpy(B, 10, 50, seed=2))
+    outs = []
+    for streams, pool_first in ((False, False), (True, True), (True, True), (True, True), (True, False), (False, True)):
+        net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10)
+        net.initialize(seed=3)
+        net.image.branch_streams, net.image.pool_first = streams, pool_first
+        for _ in range(2):
+            net.train_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        outs.append((net.logits.clone(), net.store.grad.clone(), net.store.theta.clone(), net.store.frozen.clone()))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
+
+
 def test_training_runs_are_bit_reproducible():
     """Deterministic reductions everywhere: two runs from the same state give identical bits."""
     from tumblr_emotions_amd.net import SentimentNet
