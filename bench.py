@@ -163,6 +163,8 @@ def main():
                          "forward/dgrad multiplies on the bf16 matrix pipe, fp32 storage/accumulate/statistics/masters")
     ap.add_argument("--stepwise-lstm", action="store_true",
                     help="A/B aid: one GEMM + one cell launch per LSTM step instead of the persistent ds_lstm_seq kernels")
+    ap.add_argument("--lstm-rows", type=int, default=0,
+                    help="row groups per workgroup of the persistent LSTM kernels (1, 2, 4, 8; default: the net's choice)")
     ap.add_argument("--no-pool-first", action="store_true",
                     help="Mixed backward: fused 1x1 dgrad writes the block-input gradient and the Branch_3 pool adds (default: the reverse)")
     ap.add_argument("--no-stem-direct", action="store_true",
@@ -218,6 +220,8 @@ def main():
                        trainable_embedding=args.train_all, concurrent_towers=not args.serial_towers,
                        dtype=args.dtype)
     net.initialize(seed=1)
+    if args.lstm_rows and net.text is not None:
+        net.text.seq_rows = args.lstm_rows
     if args.stepwise_lstm and net.text is not None:
         net.text.persistent = False
     if args.no_winograd and net.image is not None:

@@ -263,6 +263,7 @@ int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, const float
 int ds_lstm_seq_status(const void *ws, int32_t B);
 /* Tuning aid: device buffer of T*8 uint64; workgroup (0,0) of the following ds_lstm_seq_fwd launches stamps
  * s_memtime at its phase boundaries (scripts/lstm_phase_prof.py).  NULL = off (default).   */
+int ds_lstm_seq_set_rows(int32_t rows);   /* row groups per workgroup: 1 (default), 2, 4, 8 -- fewer, longer-running workgroups */
 int ds_lstm_seq_set_profile(void *buf);
 
 /* slim.losses.softmax_cross_entropy + its gradient (im_text_rnn_model.py:124-125):

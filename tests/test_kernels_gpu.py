@@ -525,6 +525,23 @@ def test_lstm_sequence_kernels_match_oracle(case):
     ops.lstm_seq_bwd(gates, ops._p(whd), 4 * H, c, dhd, dhd.stride(0), seqd, T, B, H, dg2, ws)
     torch.cuda.synchronize()
     assert torch.equal(dg, dg2)
+    # ds_lstm_seq_set_rows: R row groups per workgroup (fewer, longer workgroups) changes scheduling only: the forward
+    # pass gives the same bits, the backward pass the same values to the last bit or two (hipcc contracts the gate
+    # derivatives' multiply-adds differently in the R > 1 instantiations of the small hidden sizes); a last workgroup
+    # with fewer than R row groups is included
+    try:
+        for rows in (2, 4, 8):
+            ops.lstm_seq_set_rows(rows)
+            g2, h2, c2 = dev(pre), torch.zeros_like(h), torch.zeros_like(c)
+            ops.lstm_seq_fwd(g2, ops._p(whd), 4 * H, h2, c2, seqd, T, B, H, S.FORGET_BIAS, ws)
+            dg3 = torch.empty_like(dg)
+            ops.lstm_seq_bwd(g2, ops._p(whd), 4 * H, c2, dhd, dhd.stride(0), seqd, T, B, H, dg3, ws)
+            torch.cuda.synchronize()
+            ops.lstm_seq_status(ws, B)
+            assert torch.equal(h2, h) and torch.equal(c2, c) and torch.equal(g2, gates), rows
+            assert float((dg3 - dg).abs().max()) <= 4e-7 * float(dg.abs().max()), rows
+    finally:
+        ops.lstm_seq_set_rows(1)
 
 
 def test_text_tower_persistent_and_stepwise_paths_agree():

@@ -88,7 +88,7 @@ __device__ __forceinline__ void store_sc1(float *p, const float *v) {
 // ================================================================================================
 // forward: H = 8 * NCH * NW; workgroup tile 32 rows x 64 gate columns (16 units x i,j,f,o), K = H split over NW waves
 // ================================================================================================
-template <int NCH, int NW>
+template <int NCH, int NW, int R>      // R row groups per workgroup (see ds_lstm_seq_set_rows)
 __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const SeqParams p) {
     constexpr int H = 8 * NCH * NW, KQ = 8 * NCH;
     constexpr int UPT = 8 / NW;                    // hidden units per thread in the cell phase (512 cells / threads)
@@ -98,11 +98,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
-    const int cg = blockIdx.x, rg = blockIdx.y;
-    const int r0 = rg * 32, u0 = cg * 16;
+    const int cg = blockIdx.x, rg0 = blockIdx.y * R;
+    const int u0 = cg * 16;
     const int ncg = gridDim.x;
     const int B = p.B, T = p.T;
-    unsigned *cnt = p.sync + rg, *err = p.sync + p.nrg;
+    unsigned *err = p.sync + p.nrg;
 
     // ---- this wave's slice of Wh as MFMA B fragments: column c64 = 16 g + u  <->  Wh column g H + u0 + u ------
     float bfr[2][NCH][4];
@@ -117,102 +117,114 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
                 bfr[cb][q][j] = p.wh[(int64_t)(wave * KQ + 8 * q + 4 * kh + j) * p.ldw + col];
     }
 
-    // ---- cell ownership: thread -> (row, UPT consecutive units) ---------------------------------------------
+    // ---- cell ownership: thread -> (row, UPT consecutive units), for each of the R row groups ----------------
     const int crow = tid / (16 / UPT), cu = (tid % (16 / UPT)) * UPT;
-    const int grow = r0 + crow;
-    const bool valid = grow < B;
-    const int64_t sl = valid ? p.seq_len[grow] : 0;
-    float cst[UPT], hst[UPT];
+    int grow[R], arow[R];
+    bool valid[R];
+    int64_t sl[R];
+    float cst[R][UPT], hst[R][UPT];
 #pragma unroll
-    for (int e = 0; e < UPT; ++e) {
-        cst[e] = valid ? p.c[(int64_t)grow * H + u0 + cu + e] : 0.f;
-        hst[e] = valid ? p.h[(int64_t)grow * H + u0 + cu + e] : 0.f;
+    for (int rr = 0; rr < R; ++rr) {
+        const int r0 = (rg0 + rr) * 32;
+        grow[rr] = r0 + crow;
+        valid[rr] = grow[rr] < B;
+        sl[rr] = valid[rr] ? p.seq_len[grow[rr]] : 0;
+#pragma unroll
+        for (int e = 0; e < UPT; ++e) {
+            cst[rr][e] = valid[rr] ? p.c[(int64_t)grow[rr] * H + u0 + cu + e] : 0.f;
+            hst[rr][e] = valid[rr] ? p.h[(int64_t)grow[rr] * H + u0 + cu + e] : 0.f;
+        }
+        arow[rr] = (r0 + li < B) ? r0 + li : B - 1;        // rows past the batch read a valid row, results unused
     }
 
     const __amdgpu_buffer_rsrc_t srd_h = srd_of(p.h, (unsigned)((int64_t)(T + 1) * B * H * 4));
-    const int arow = (r0 + li < B) ? r0 + li : B - 1;      // rows past the batch read a valid row, results unused
 
     for (int t = 0; t < T; ++t) {
-        // pre-activations of this thread's cells (hoisted x_t Wx + b): independent of the other workgroups
-        float gp[4][UPT];
-        if (valid) {
-            const float *g = p.gates + ((int64_t)t * B + grow) * 4 * H + u0 + cu;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int e = 0; e < UPT; ++e) gp[k][e] = g[k * H + e];
-        }
-        DS_STAMP(0);
-        if (t > 0) {                                        // h[t] of the whole row group must have landed
-            if (tid == 0) wait_counter(cnt, (unsigned)t * ncg, err);
-            __syncthreads();
-        }
-        DS_STAMP(1);
-        // ---- A fragments straight from h[t] (sc1: past the L1, which other CUs' stores never refresh) --------
-        f32x4 a[NCH];
-        const unsigned abase = (unsigned)((((int64_t)t * B + arow) * H + wave * KQ + 4 * kh) * 4);
-#pragma unroll
-        for (int q = 0; q < NCH; ++q)
-            a[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_h, abase + 32u * q, 0, kSC1));
-        f32x16 acc[2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
-#pragma unroll
-        for (int q = 0; q < NCH; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], bfr[cb][q][j], acc[cb], 0, 0, 0);
-        // ---- K slices of the NW waves -> LDS, summed in wave order by the cell threads ------------------------
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * LDR + 32 * cb + li] = acc[cb][r];
-        DS_STAMP(2);
-        __syncthreads();
-        DS_STAMP(3);
-        float act[4][UPT], hn[UPT];
-        if (valid) {
-#pragma unroll
-            for (int w = 0; w < NW; ++w)
+        for (int rr = 0; rr < R; ++rr) {
+            if (rg0 + rr >= p.nrg) continue;                    // (uniform) a last workgroup with fewer row groups
+            unsigned *cnt = p.sync + rg0 + rr;
+            // pre-activations of this thread's cells (hoisted x_t Wx + b): independent of the other workgroups
+            float gp[4][UPT];
+            if (valid[rr]) {
+                const float *g = p.gates + ((int64_t)t * B + grow[rr]) * 4 * H + u0 + cu;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
-                    for (int e = 0; e < UPT; ++e) gp[k][e] += red[(w * 32 + crow) * LDR + 16 * k + cu + e];
-            const bool live = (int64_t)t < sl;
-#pragma unroll
-            for (int e = 0; e < UPT; ++e) {
-                const float si = sigm(gp[0][e]), tj = tanhf(gp[1][e]);
-                const float sf = sigm(gp[2][e] + p.forget_bias), so = sigm(gp[3][e]);
-                const float c_new = cst[e] * sf + si * tj;
-                const float h_new = tanhf(c_new) * so;
-                act[0][e] = si; act[1][e] = tj; act[2][e] = sf; act[3][e] = so;
-                cst[e] = live ? c_new : cst[e];      // dynamic_rnn copies the state through past seq_len
-                hst[e] = hn[e] = live ? h_new : hst[e];
+                    for (int e = 0; e < UPT; ++e) gp[k][e] = g[k * H + e];
             }
-            const int64_t o = ((int64_t)(t + 1) * B + grow) * H + u0 + cu;
-            store_sc1<UPT>(p.h + o, hn);                     // the hand-off payload goes first ...
-        }
-        DS_STAMP(4);
-        // ---- publish: every storing wave drains, then one lane counts this workgroup in ----------------------
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        DS_STAMP(5);
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        DS_STAMP(6);
-        if (valid) {                                        // ... what only later kernels read stays off the critical path
-            float *g = p.gates + ((int64_t)t * B + grow) * 4 * H + u0 + cu;
-            const int64_t o = ((int64_t)(t + 1) * B + grow) * H + u0 + cu;
+            if (rr == 0) DS_STAMP(0);
+            if (t > 0) {                                        // h[t] of the whole row group must have landed
+                if (tid == 0) wait_counter(cnt, (unsigned)t * ncg, err);
+                __syncthreads();
+            }
+            if (rr == 0) DS_STAMP(1);
+            // ---- A fragments straight from h[t] (sc1: past the L1, which other CUs' stores never refresh) --------
+            f32x4 a[NCH];
+            const unsigned abase = (unsigned)((((int64_t)t * B + arow[rr]) * H + wave * KQ + 4 * kh) * 4);
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int q = 0; q < NCH; ++q)
+                a[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_h, abase + 32u * q, 0, kSC1));
+            f32x16 acc[2];
 #pragma unroll
-                for (int e = 0; e < UPT; ++e) g[k * H + e] = act[k][e];
+            for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int e = 0; e < UPT; ++e) p.c[o + e] = cst[e];
+                for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < NCH; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], bfr[cb][q][j], acc[cb], 0, 0, 0);
+            // ---- K slices of the NW waves -> LDS, summed in wave order by the cell threads ------------------------
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * LDR + 32 * cb + li] = acc[cb][r];
+            if (rr == 0) DS_STAMP(2);
+            __syncthreads();
+            if (rr == 0) DS_STAMP(3);
+            float act[4][UPT], hn[UPT];
+            if (valid[rr]) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int e = 0; e < UPT; ++e) gp[k][e] += red[(w * 32 + crow) * LDR + 16 * k + cu + e];
+                const bool live = (int64_t)t < sl[rr];
+#pragma unroll
+                for (int e = 0; e < UPT; ++e) {
+                    const float si = sigm(gp[0][e]), tj = tanhf(gp[1][e]);
+                    const float sf = sigm(gp[2][e] + p.forget_bias), so = sigm(gp[3][e]);
+                    const float c_new = cst[rr][e] * sf + si * tj;
+                    const float h_new = tanhf(c_new) * so;
+                    act[0][e] = si; act[1][e] = tj; act[2][e] = sf; act[3][e] = so;
+                    cst[rr][e] = live ? c_new : cst[rr][e];      // dynamic_rnn copies the state through past seq_len
+                    hst[rr][e] = hn[e] = live ? h_new : hst[rr][e];
+                }
+                const int64_t o = ((int64_t)(t + 1) * B + grow[rr]) * H + u0 + cu;
+                store_sc1<UPT>(p.h + o, hn);                     // the hand-off payload goes first ...
+            }
+            if (rr == 0) DS_STAMP(4);
+            // ---- publish: every storing wave drains, then one lane counts this workgroup in ----------------------
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (rr == 0) DS_STAMP(5);
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rr == 0) DS_STAMP(6);
+            if (valid[rr]) {                                    // ... what only later kernels read stays off the critical path
+                float *g = p.gates + ((int64_t)t * B + grow[rr]) * 4 * H + u0 + cu;
+                const int64_t o = ((int64_t)(t + 1) * B + grow[rr]) * H + u0 + cu;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < UPT; ++e) g[k * H + e] = act[k][e];
+#pragma unroll
+                for (int e = 0; e < UPT; ++e) p.c[o + e] = cst[rr][e];
+            }
         }
     }
 }
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
 // ================================================================================================
 // backward: d(h_t)[rows, own 16 units] = carried part + dgates_{t+1}[rows, :] * Wh[own units, :]^T  (K = 4H)
 // ================================================================================================
-template <int NQ, int NW>       // 4H = 16 * NQ * NW
+template <int NQ, int NW, int R>       // 4H = 16 * NQ * NW; R row groups per workgroup
 __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const SeqParams p) {
     constexpr int H4 = 16 * NQ * NW, H = H4 / 4, KQ = 16 * NQ;
     constexpr int UPT = 8 / NW;
@@ -231,11 +243,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kb = lane >> 4;
-    const int cg = blockIdx.x, rg = blockIdx.y;
-    const int r0 = rg * 32, u0 = cg * 16;
+    const int cg = blockIdx.x, rg0 = blockIdx.y * R;
+    const int u0 = cg * 16;
     const int ncg = gridDim.x;
     const int B = p.B, T = p.T;
-    unsigned *cnt = p.sync + rg, *err = p.sync + p.nrg;
+    unsigned *err = p.sync + p.nrg;
 
     // ---- Wh[u0 + n, this wave's K range] as B fragments of the 16x16x4 MFMA (k-contiguous rows) ----------------
     f32x4 bfr[NQ];
@@ -244,99 +256,110 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
         bfr[q] = *reinterpret_cast<const f32x4 *>(p.wh + (int64_t)(u0 + li) * p.ldw + wave * KQ + 16 * q + 4 * kb);
 
     const int crow = tid / (16 / UPT), cu = (tid % (16 / UPT)) * UPT;
-    const int grow = r0 + crow;
-    const bool valid = grow < B;
-    const int64_t sl = valid ? p.seq_len[grow] : 0;
-    float dcs[UPT], dhc[UPT];
+    int grow[R], arow[R][2];
+    bool valid[R];
+    int64_t sl[R];
+    float dcs[R][UPT], dhc[R][UPT];
 #pragma unroll
-    for (int e = 0; e < UPT; ++e) {
-        dcs[e] = 0.f;
-        dhc[e] = valid ? p.dh_last[(int64_t)grow * p.ld_dh + u0 + cu + e] : 0.f;      // gradient of h[T]
+    for (int rr = 0; rr < R; ++rr) {
+        const int r0 = (rg0 + rr) * 32;
+        grow[rr] = r0 + crow;
+        valid[rr] = grow[rr] < B;
+        sl[rr] = valid[rr] ? p.seq_len[grow[rr]] : 0;
+#pragma unroll
+        for (int e = 0; e < UPT; ++e) {
+            dcs[rr][e] = 0.f;
+            dhc[rr][e] = valid[rr] ? p.dh_last[(int64_t)grow[rr] * p.ld_dh + u0 + cu + e] : 0.f;      // gradient of h[T]
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) arow[rr][rb] = (r0 + 16 * rb + li < B) ? r0 + 16 * rb + li : B - 1;
     }
 
     const __amdgpu_buffer_rsrc_t srd_g = srd_of(p.dgates, (unsigned)((int64_t)T * B * H4 * 4));
-    int arow[2];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) arow[rb] = (r0 + 16 * rb + li < B) ? r0 + 16 * rb + li : B - 1;
 
     for (int t = T - 1; t >= 0; --t) {
-        float rec[UPT];
 #pragma unroll
-        for (int e = 0; e < UPT; ++e) rec[e] = 0.f;
-        if (t < T - 1) {
-            if (tid == 0) wait_counter(cnt, (unsigned)(T - 1 - t) * ncg, err);
-            __syncthreads();
-            f32x4 acc[2];
+        for (int rr = 0; rr < R; ++rr) {
+            if (rg0 + rr >= p.nrg) continue;
+            unsigned *cnt = p.sync + rg0 + rr;
+            float rec[UPT];
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            unsigned abase[2];
+            for (int e = 0; e < UPT; ++e) rec[e] = 0.f;
+            if (t < T - 1) {
+                if (tid == 0) wait_counter(cnt, (unsigned)(T - 1 - t) * ncg, err);
+                __syncthreads();
+                f32x4 acc[2];
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-                abase[rb] = (unsigned)((((int64_t)(t + 1) * B + arow[rb]) * H4 + wave * KQ + 4 * kb) * 4);
-            f32x4 a[2][2][GQ];                              // [buffer][row block][chunk]
-            auto load_group = [&](int buf, int g0) {
+                for (int rb = 0; rb < 2; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                unsigned abase[2];
 #pragma unroll
-                for (int q = 0; q < GQ; ++q)
+                for (int rb = 0; rb < 2; ++rb)
+                    abase[rb] = (unsigned)((((int64_t)(t + 1) * B + arow[rr][rb]) * H4 + wave * KQ + 4 * kb) * 4);
+                f32x4 a[2][2][GQ];                              // [buffer][row block][chunk]
+                auto load_group = [&](int buf, int g0) {
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
-                        a[buf][rb][q] = __builtin_bit_cast(
-                            f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_g, abase[rb] + 64u * (g0 + q), 0, kSC1));
-            };
-            load_group(0, 0);
-#pragma unroll
-            for (int g = 0; g < NQ / GQ; ++g) {
-                if (g + 1 < NQ / GQ) load_group((g + 1) & 1, (g + 1) * GQ);
-#pragma unroll
-                for (int q = 0; q < GQ; ++q)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int q = 0; q < GQ; ++q)
 #pragma unroll
                         for (int rb = 0; rb < 2; ++rb)
-                            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g & 1][rb][q][j], bfr[g * GQ + q][j], acc[rb],
-                                                                           0, 0, 0);
-            }
+                            a[buf][rb][q] = __builtin_bit_cast(
+                                f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_g, abase[rb] + 64u * (g0 + q), 0, kSC1));
+                };
+                load_group(0, 0);
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+                for (int g = 0; g < NQ / GQ; ++g) {
+                    if (g + 1 < NQ / GQ) load_group((g + 1) & 1, (g + 1) * GQ);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[(wave * 32 + 16 * rb + 4 * kb + r) * LDR + li] = acc[rb][r];
-            __syncthreads();
-            if (valid) {
+                    for (int q = 0; q < GQ; ++q)
 #pragma unroll
-                for (int w = 0; w < NW; ++w)
+                        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int e = 0; e < UPT; ++e) rec[e] += red[(w * 32 + crow) * LDR + cu + e];
-            }
-        }
-        if (valid) {
-            const bool live = (int64_t)t < sl;
-            const int64_t gi = ((int64_t)t * B + grow) * H4 + u0 + cu;
-            const int64_t ci = ((int64_t)(t + 1) * B + grow) * H + u0 + cu;      // c_t = c[t+1], c_{t-1} = c[t]
-            float dg[4][UPT];
+                            for (int rb = 0; rb < 2; ++rb)
+                                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g & 1][rb][q][j], bfr[g * GQ + q][j], acc[rb],
+                                                                               0, 0, 0);
+                }
 #pragma unroll
-            for (int e = 0; e < UPT; ++e) {
-                const float dhv = dhc[e] + rec[e];
-                if (live) {
-                    const float si = p.gates[gi + e], tj = p.gates[gi + H + e];
-                    const float sf = p.gates[gi + 2 * H + e], so = p.gates[gi + 3 * H + e];
-                    const float tc = tanhf(p.c[ci + e]);
-                    const float dct = dcs[e] + dhv * so * (1.f - tc * tc);
-                    dg[0][e] = dct * tj * si * (1.f - si);
-                    dg[1][e] = dct * si * (1.f - tj * tj);
-                    dg[2][e] = dct * p.c[ci - (int64_t)B * H + e] * sf * (1.f - sf);
-                    dg[3][e] = dhv * tc * so * (1.f - so);
-                    dcs[e] = dct * sf;
-                    dhc[e] = 0.f;
-                } else {            // past seq_len the state was copied through: so is its gradient
-                    dg[0][e] = dg[1][e] = dg[2][e] = dg[3][e] = 0.f;
-                    dhc[e] = dhv;
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[(wave * 32 + 16 * rb + 4 * kb + r) * LDR + li] = acc[rb][r];
+                __syncthreads();
+                if (valid[rr]) {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w)
+#pragma unroll
+                        for (int e = 0; e < UPT; ++e) rec[e] += red[(w * 32 + crow) * LDR + cu + e];
                 }
             }
+            if (valid[rr]) {
+                const bool live = (int64_t)t < sl[rr];
+                const int64_t gi = ((int64_t)t * B + grow[rr]) * H4 + u0 + cu;
+                const int64_t ci = ((int64_t)(t + 1) * B + grow[rr]) * H + u0 + cu;      // c_t = c[t+1], c_{t-1} = c[t]
+                float dg[4][UPT];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) store_sc1<UPT>(p.dgates + gi + k * H, dg[k]);
+                for (int e = 0; e < UPT; ++e) {
+                    const float dhv = dhc[rr][e] + rec[e];
+                    if (live) {
+                        const float si = p.gates[gi + e], tj = p.gates[gi + H + e];
+                        const float sf = p.gates[gi + 2 * H + e], so = p.gates[gi + 3 * H + e];
+                        const float tc = tanhf(p.c[ci + e]);
+                        const float dct = dcs[rr][e] + dhv * so * (1.f - tc * tc);
+                        dg[0][e] = dct * tj * si * (1.f - si);
+                        dg[1][e] = dct * si * (1.f - tj * tj);
+                        dg[2][e] = dct * p.c[ci - (int64_t)B * H + e] * sf * (1.f - sf);
+                        dg[3][e] = dhv * tc * so * (1.f - so);
+                        dcs[rr][e] = dct * sf;
+                        dhc[rr][e] = 0.f;
+                    } else {            // past seq_len the state was copied through: so is its gradient
+                        dg[0][e] = dg[1][e] = dg[2][e] = dg[3][e] = 0.f;
+                        dhc[rr][e] = dhv;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) store_sc1<UPT>(p.dgates + gi + k * H, dg[k]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -348,16 +371,40 @@ struct SeqCfg {
     int nw;
 };
 
-bool seq_cfg(int H, SeqCfg *c) {
+// Row groups per workgroup (ds_lstm_seq_set_rows).  1: every (unit block, row group) pair is a workgroup -- the
+// shortest sequence time, but at B = 256, H = 512 that is 256 workgroups of 256-register waves which spend ~40 % of a
+// step waiting for their row group: nothing that needs a whole SIMD (the Winograd conv of the image tower) can run
+// beside them.  R > 1: a workgroup walks R row groups per time step with the same register-resident Wh slice; the
+// hand-off wait of one row group is covered by the work on the others and the launch occupies 1/R of the CUs.
+int g_rows = 1;
+
+template <int R>
+bool seq_cfg_r(int H, SeqCfg *c) {
     switch (H) {
-        case 32: *c = {lstm_seq_fwd_kernel<1, 4>, lstm_seq_bwd_kernel<2, 4>, 4}; return true;
-        case 64: *c = {lstm_seq_fwd_kernel<2, 4>, lstm_seq_bwd_kernel<4, 4>, 4}; return true;
-        case 128: *c = {lstm_seq_fwd_kernel<4, 4>, lstm_seq_bwd_kernel<8, 4>, 4}; return true;
-        case 256: *c = {lstm_seq_fwd_kernel<8, 4>, lstm_seq_bwd_kernel<16, 4>, 4}; return true;
-        case 512: *c = {lstm_seq_fwd_kernel<16, 4>, lstm_seq_bwd_kernel<32, 4>, 4}; return true;
-        case 1024: *c = {lstm_seq_fwd_kernel<16, 8>, lstm_seq_bwd_kernel<32, 8>, 8}; return true;
+        case 32: *c = {lstm_seq_fwd_kernel<1, 4, R>, lstm_seq_bwd_kernel<2, 4, R>, 4}; return true;
+        case 64: *c = {lstm_seq_fwd_kernel<2, 4, R>, lstm_seq_bwd_kernel<4, 4, R>, 4}; return true;
+        case 128: *c = {lstm_seq_fwd_kernel<4, 4, R>, lstm_seq_bwd_kernel<8, 4, R>, 4}; return true;
+        case 256: *c = {lstm_seq_fwd_kernel<8, 4, R>, lstm_seq_bwd_kernel<16, 4, R>, 4}; return true;
+        case 512: *c = {lstm_seq_fwd_kernel<16, 4, R>, lstm_seq_bwd_kernel<32, 4, R>, 4}; return true;
+        case 1024: *c = {lstm_seq_fwd_kernel<16, 8, R>, lstm_seq_bwd_kernel<32, 8, R>, 8}; return true;
         default: return false;
     }
+}
+
+bool seq_cfg(int H, SeqCfg *c, int rows = 1) {
+    switch (rows) {
+        case 2: return seq_cfg_r<2>(H, c);
+        case 4: return seq_cfg_r<4>(H, c);
+        case 8: return seq_cfg_r<8>(H, c);
+        default: return seq_cfg_r<1>(H, c);
+    }
+}
+
+// the R in use for a batch of nrg row groups: never more than there are row groups
+int rows_for(int nrg) {
+    int r = g_rows;
+    while (r > 1 && r > nrg) r >>= 1;
+    return r;
 }
 
 // One workgroup per CU: two co-resident workgroups would share the CU's four matrix pipes and finish their step
@@ -405,7 +452,8 @@ extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float
     if (int e = common_checks("ds_lstm_seq_fwd", gates, wh, h, T, B, H, ldw, ws, ws_bytes)) return e;
     DS_REQUIRE(c && seq_len, "ds_lstm_seq_fwd: null argument");
     SeqCfg cfg;
-    seq_cfg(H, &cfg);
+    const int rows = rows_for((B + 31) / 32);
+    seq_cfg(H, &cfg, rows);
     SeqParams p = {};
     p.gates = gates; p.wh = wh; p.ldw = ldw; p.h = h; p.c = c; p.seq_len = seq_len;
     p.T = T; p.B = B; p.H = H; p.forget_bias = forget_bias;
@@ -415,7 +463,7 @@ extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float
     // every polled word is re-initialised by a memset node in front of the launch (Guideline 16)
     if (hipMemsetAsync(ws, 0, ds_lstm_seq_workspace(B, H), (hipStream_t)stream) != hipSuccess)
         return ds::check_launch("ds_lstm_seq_fwd(memset)");
-    hipLaunchKernelGGL(cfg.fwd, dim3(H / 16, p.nrg), dim3(64 * cfg.nw), exclusive_lds(cfg.nw, true), (hipStream_t)stream, p);
+    hipLaunchKernelGGL(cfg.fwd, dim3(H / 16, (p.nrg + rows - 1) / rows), dim3(64 * cfg.nw), exclusive_lds(cfg.nw, true), (hipStream_t)stream, p);
     return ds::check_launch("ds_lstm_seq_fwd");
 }
 
@@ -425,7 +473,8 @@ extern "C" int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, 
     if (int e = common_checks("ds_lstm_seq_bwd", acts, wh, c, T, B, H, ldw, ws, ws_bytes)) return e;
     DS_REQUIRE(dh_last && seq_len && dgates && ld_dh >= H, "ds_lstm_seq_bwd: bad argument");
     SeqCfg cfg;
-    seq_cfg(H, &cfg);
+    const int rows = rows_for((B + 31) / 32);
+    seq_cfg(H, &cfg, rows);
     SeqParams p = {};
     p.gates = const_cast<float *>(acts); p.wh = wh; p.ldw = ldw; p.c = const_cast<float *>(c);
     p.dh_last = dh_last; p.ld_dh = ld_dh; p.dgates = dgates; p.seq_len = seq_len;
@@ -434,7 +483,7 @@ extern "C" int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, 
     p.sync = (unsigned *)ws;
     if (hipMemsetAsync(ws, 0, ds_lstm_seq_workspace(B, H), (hipStream_t)stream) != hipSuccess)
         return ds::check_launch("ds_lstm_seq_bwd(memset)");
-    hipLaunchKernelGGL(cfg.bwd, dim3(H / 16, p.nrg), dim3(64 * cfg.nw), exclusive_lds(cfg.nw, false), (hipStream_t)stream, p);
+    hipLaunchKernelGGL(cfg.bwd, dim3(H / 16, (p.nrg + rows - 1) / rows), dim3(64 * cfg.nw), exclusive_lds(cfg.nw, false), (hipStream_t)stream, p);
     return ds::check_launch("ds_lstm_seq_bwd");
 }
 
@@ -449,6 +498,15 @@ extern "C" int ds_lstm_seq_status(const void *ws, int32_t B) {
 
 // Tuning aid (not part of the product path): device buffer of T*8 uint64 in which workgroup (0,0) of the NEXT
 // ds_lstm_seq_fwd launches stamps s_memtime at its phase boundaries; NULL switches it off.
+// Row groups per workgroup for the following ds_lstm_seq_fwd / _bwd launches: 1, 2, 4 or 8 (see g_rows).  Scheduling only:
+// every cell's arithmetic and summation order are the same (results agree to the last bit or two -- the compiler
+// contracts a few multiply-adds differently per instantiation).
+extern "C" int ds_lstm_seq_set_rows(int32_t rows) {
+    DS_REQUIRE(rows == 1 || rows == 2 || rows == 4 || rows == 8, "ds_lstm_seq_set_rows: 1, 2, 4 or 8");
+    g_rows = rows;
+    return DS_OK;
+}
+
 extern "C" int ds_lstm_seq_set_profile(void *buf) {
     g_prof = (unsigned long long *)buf;
     return DS_OK;

@@ -52,6 +52,7 @@ class TextTowerEngine:
         self.B = None
         self.reducer = None          # dp.GradientReducer, set by SentimentNet
         self.persistent = True       # False: force the step-wise recurrence (A/B and tests)
+        self.seq_rows = 1            # row groups per workgroup of the persistent kernels (ds_lstm_seq_set_rows)
 
     def alloc(self, B):
         if self.B == B:
@@ -107,6 +108,7 @@ class TextTowerEngine:
         ops.gather_rows(self.table, texts, self.x, B, T, self.D, time_major=True)
         self.xproj.run(ops._p(self.x), self.wx, ops._p(self.gates), bias=self.bias)
         if self.use_seq:
+            ops.lstm_seq_set_rows(self.seq_rows)
             ops.lstm_seq_fwd(self.gates, self.wh, 4 * H, self.h, self.c, seq_lens, T, B, H, FORGET_BIAS, self.seq_ws)
             return self.h[T]
         slab = B * 4 * H
@@ -122,6 +124,7 @@ class TextTowerEngine:
     def backward(self, dh_last):
         B, T, H = self.B, self.T, self.H
         if self.use_seq:
+            ops.lstm_seq_set_rows(self.seq_rows)
             ops.lstm_seq_bwd(self.gates, self.wh, 4 * H, self.c, dh_last, dh_last.stride(0), self.seq_lens, T, B, H,
                              self.dgates, self.seq_ws)
             return self._weight_grads()

@@ -65,6 +65,11 @@ class SentimentNet:
         self.dlogits = None
         self.pg = process_group
         self.text_stream = torch.cuda.Stream() if (mode == "joint" and concurrent_towers) else None
+        if self.text_stream is not None:
+            # beside the image tower the persistent LSTM runs four row groups per workgroup: a quarter of the CUs for a
+            # longer time instead of a 256-register wave on every SIMD that mostly waits -- the Winograd conv needs
+            # whole SIMDs and could not run beside it (joint step 18.5 -> 17.9 ms; text-only keeps 1: shortest sequence)
+            self.text.seq_rows = 4
         self.reducer = GradientReducer(st.grad, st.n_bucket1, process_group, overlap_comm)
         self.world = self.reducer.world
         # bucket 1 of the flat gradient is complete once these backward stages have run

@@ -375,6 +375,11 @@ def lstm_seq_supported(B, H):
     return bool(_lib.load().ds_lstm_seq_supported(B, H))
 
 
+def lstm_seq_set_rows(rows):
+    """Row groups per workgroup of the following persistent-LSTM launches (1, 2, 4, 8): scheduling only."""
+    _lib.check(_lib.load().ds_lstm_seq_set_rows(int(rows)), "ds_lstm_seq_set_rows")
+
+
 def lstm_seq_workspace(B, H):
     return int(_lib.load().ds_lstm_seq_workspace(B, H))
 
