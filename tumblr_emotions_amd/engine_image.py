@@ -600,6 +600,10 @@ class InceptionV1Engine:
             if isinstance(a, ConvStage):
                 a.fused_into_pool = self.fuse_bn_pool and isinstance(b, PoolStage) and b.k == 3
                 a.pool = b if a.fused_into_pool else None
+        if images.dtype != torch.float32 or images.dim() != 4 or images.shape[-1] != 3:
+            raise ValueError("images must be float32 NHWC [B, H, W, 3], got %s %s" % (images.dtype, tuple(images.shape)))
+        if not images.is_contiguous():      # the stem kernel reads the packed batch through a raw pointer
+            images = images.contiguous()
         self.images = images
         stem = self.stages[0].layer
         if not stem.stem_direct or (stem.trainable and self.training):
