@@ -285,6 +285,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
             float rec[UPT];
 #pragma unroll
             for (int e = 0; e < UPT; ++e) rec[e] = 0.f;
+            // this thread's saved activations and cell states (written by the forward launch): requested before the
+            // hand-off wait, they arrive under it
+            const int64_t gi = ((int64_t)t * B + grow[rr]) * H4 + u0 + cu;
+            const int64_t ci = ((int64_t)(t + 1) * B + grow[rr]) * H + u0 + cu;      // c_t = c[t+1], c_{t-1} = c[t]
+            float a_si[UPT], a_tj[UPT], a_sf[UPT], a_so[UPT], a_ct[UPT], a_cp[UPT];
+#pragma unroll
+            for (int e = 0; e < UPT; ++e) {
+                a_si[e] = valid[rr] ? p.gates[gi + e] : 0.f;
+                a_tj[e] = valid[rr] ? p.gates[gi + H + e] : 0.f;
+                a_sf[e] = valid[rr] ? p.gates[gi + 2 * H + e] : 0.f;
+                a_so[e] = valid[rr] ? p.gates[gi + 3 * H + e] : 0.f;
+                a_ct[e] = valid[rr] ? p.c[ci + e] : 0.f;
+                a_cp[e] = valid[rr] ? p.c[ci - (int64_t)B * H + e] : 0.f;
+            }
             if (t < T - 1) {
                 if (tid == 0) wait_counter(cnt, (unsigned)(T - 1 - t) * ncg, err);
                 __syncthreads();
@@ -331,20 +345,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
             }
             if (valid[rr]) {
                 const bool live = (int64_t)t < sl[rr];
-                const int64_t gi = ((int64_t)t * B + grow[rr]) * H4 + u0 + cu;
-                const int64_t ci = ((int64_t)(t + 1) * B + grow[rr]) * H + u0 + cu;      // c_t = c[t+1], c_{t-1} = c[t]
                 float dg[4][UPT];
 #pragma unroll
                 for (int e = 0; e < UPT; ++e) {
                     const float dhv = dhc[rr][e] + rec[e];
                     if (live) {
-                        const float si = p.gates[gi + e], tj = p.gates[gi + H + e];
-                        const float sf = p.gates[gi + 2 * H + e], so = p.gates[gi + 3 * H + e];
-                        const float tc = tanhf(p.c[ci + e]);
+                        const float si = a_si[e], tj = a_tj[e];
+                        const float sf = a_sf[e], so = a_so[e];
+                        const float tc = tanhf(a_ct[e]);
                         const float dct = dcs[rr][e] + dhv * so * (1.f - tc * tc);
                         dg[0][e] = dct * tj * si * (1.f - si);
                         dg[1][e] = dct * si * (1.f - tj * tj);
-                        dg[2][e] = dct * p.c[ci - (int64_t)B * H + e] * sf * (1.f - sf);
+                        dg[2][e] = dct * a_cp[e] * sf * (1.f - sf);
                         dg[3][e] = dhv * tc * so * (1.f - so);
                         dcs[rr][e] = dct * sf;
                         dhc[rr][e] = 0.f;
