@@ -8,6 +8,7 @@
 //             of the Inception concat buffer (replaces tf.concat, inception_v1.py:96..248).
 //   backward: g = dy*(y>0); dbeta = sum(g); dz = rstd*(g - mean(g) - xhat*mean(g*xhat)).
 // All kernels move 16 B per lane per access and use a fixed (deterministic) reduction order.
+#include <stdlib.h>
 #include "ds_common.h"
 
 namespace {
@@ -109,10 +110,16 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *z, int6
 // Each workgroup owns a contiguous block of rows; a thread owns one float4 column group and strides
 // over the rows, so every wave reads whole contiguous rows (coalesced) and the per-channel sums stay
 // in registers until one LDS combine at the end.
-// rows per workgroup: 512 for the big maps, fewer on the 14x14 / 7x7 maps so the grid still
-// covers the chip (>= ~2000 workgroups where the tensor allows it)
+// rows per workgroup: 512 for the big maps, fewer on the 14x14 / 7x7 maps so that ~512 workgroups (two per CU)
+// remain: with ~2000 the reduce of the small maps was 15-25 % slower (a thread then sums ~10 rows and the LDS
+// combine and the partial stores weigh as much as the loads); DS_BN_BWD_BLOCKS overrides the target
 int bwd_rows_per_block(int64_t M) {
-    int64_t r = (M + 2047) / 2048;
+    static int target = -1;
+    if (target < 0) {
+        const char *e = getenv("DS_BN_BWD_BLOCKS");
+        target = e ? atoi(e) : 512;
+    }
+    int64_t r = (M + target - 1) / target;
     r = (r + 7) / 8 * 8;
     if (r < 16) r = 16;
     if (r > 512) r = 512;
