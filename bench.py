@@ -165,6 +165,8 @@ def main():
                     help="A/B aid: one GEMM + one cell launch per LSTM step instead of the persistent ds_lstm_seq kernels")
     ap.add_argument("--lstm-rows", type=int, default=0,
                     help="row groups per workgroup of the persistent LSTM kernels (1, 2, 4, 8; default: the net's choice)")
+    ap.add_argument("--side-mode", type=int, default=-1,
+                    help="A/B: 0 = Branch_2 and Branch_3 chains on a side stream each, 1 = both on one (default), 2 = only Branch_3")
     ap.add_argument("--no-pool-first", action="store_true",
                     help="Mixed backward: fused 1x1 dgrad writes the block-input gradient and the Branch_3 pool adds (default: the reverse)")
     ap.add_argument("--no-stem-direct", action="store_true",
@@ -228,6 +230,8 @@ def main():
         net.image.winograd = False
     if args.no_branch_streams and net.image is not None:
         net.image.branch_streams = False
+    if args.side_mode >= 0 and net.image is not None:
+        net.image.one_side_stream = args.side_mode
     if args.no_pool_first and net.image is not None:
         net.image.pool_first = False
     if args.no_stem_direct and net.image is not None:

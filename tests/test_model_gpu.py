@@ -382,10 +382,11 @@ def test_branch_streams_and_pool_order_do_not_change_a_bit(B):
     from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
     batch = to_device(synthetic_batch_numpy(B, 10, 50, seed=2))
     outs = []
-    for streams, pool_first in ((False, False), (True, True), (True, True), (True, True), (True, False), (False, True)):
+    for streams, pool_first, side in ((False, False, 1), (True, True, 1), (True, True, 1), (True, True, 1), (True, False, 1),
+                                      (False, True, 1), (True, True, 0), (True, True, 2)):
         net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10)
         net.initialize(seed=3)
-        net.image.branch_streams, net.image.pool_first = streams, pool_first
+        net.image.branch_streams, net.image.pool_first, net.image.one_side_stream = streams, pool_first, side
         for _ in range(2):
             net.train_step(batch, 1e-3)
         torch.cuda.synchronize()

@@ -405,8 +405,8 @@ class MixedStage(Stage):
         self.c3.make_dgrad(cin)
 
     # The three chains behind the block input -- [fused 1x1 -> Branch_1 3x3], [... -> Branch_2 3x3] and
-    # [3x3/1 pool -> Branch_3 1x1] -- are independent: Branch_2 and Branch_3 are issued on two side streams (fork /
-    # join by events, each with its own scratch set), so one chain's single-workgroup finalize kernels and the
+    # [3x3/1 pool -> Branch_3 1x1] -- are independent: Branch_3 and then Branch_2 are issued on a side stream (fork /
+    # join by events, each chain with its own scratch set), so one chain's single-workgroup finalize kernels and the
     # partly filled last round of its conv launches run under another chain's kernels.
     def _events(self):
         if self.ev is None:
@@ -429,12 +429,22 @@ class MixedStage(Stage):
         s1, s2 = eng.side
         e_in, e_f, e_2, e_3 = self._events()
         e_in.record(main)
+        if eng.one_side_stream:
+            s1 = s2
         with torch.cuda.stream(s2):
             s2.wait_event(e_in)
             ops.maxpool_fwd(p.out, self.pooled, self.argmax, self.B, p.H, p.W, p.C, 3, 1, "SAME")
             self.c3.forward(ops._p(self.pooled), p.C, self.seg_3)
-            e_3.record(s2)
+            if not eng.one_side_stream:
+                e_3.record(s2)
         self.fused.forward(x, p.C, self.seg_f)
+        if eng.one_side_stream == 2:        # only the Branch_3 chain on the side stream
+            with torch.cuda.stream(s2):
+                e_2.record(s2)
+            self.c2.forward(ops._p(self.r2), b2a, self.seg_2)
+            self.c1.forward(ops._p(self.r1), b1a, self.seg_1)
+            main.wait_event(e_2)
+            return
         e_f.record(main)
         with torch.cuda.stream(s1):
             s1.wait_event(e_f)
@@ -442,7 +452,8 @@ class MixedStage(Stage):
             e_2.record(s1)
         self.c1.forward(ops._p(self.r1), b1a, self.seg_1)
         main.wait_event(e_2)
-        main.wait_event(e_3)
+        if not eng.one_side_stream:
+            main.wait_event(e_3)
 
     def backward(self, need_dx):
         p = self.prev
@@ -469,17 +480,27 @@ class MixedStage(Stage):
             s1, s2 = eng.side
             e_in, e_f, e_2, e_3 = self._events()
             e_in.record(main)
+            if eng.one_side_stream:
+                s1 = s2
             with torch.cuda.stream(s2):
                 s2.wait_event(e_in)
                 branch3()
-                e_3.record(s2)
-            with torch.cuda.stream(s1):
-                s1.wait_event(e_in)
+                if not eng.one_side_stream:
+                    e_3.record(s2)
+            if eng.one_side_stream == 2:
+                with torch.cuda.stream(s2):
+                    e_2.record(s2)
                 self.c2.backward(self.dseg_2, ops._p(self.r2), b2a, ops._p(self.dr2), True)
-                e_2.record(s1)
+            else:
+                with torch.cuda.stream(s1):
+                    if not eng.one_side_stream:
+                        s1.wait_event(e_in)
+                    self.c2.backward(self.dseg_2, ops._p(self.r2), b2a, ops._p(self.dr2), True)
+                    e_2.record(s1)
             self.c1.backward(self.dseg_1, ops._p(self.r1), b1a, ops._p(self.dr1), True)
             main.wait_event(e_2)
-            main.wait_event(e_3)
+            if not eng.one_side_stream:
+                main.wait_event(e_3)
         self.fused.backward(self.dseg_f, x, p.C, ops._p(p.dout) if need_dx else None, need_dx)
         if need_dx and not pool_first:
             ops.maxpool_bwd(self.dpooled, self.argmax, p.dout, True, self.B, p.H, p.W, p.C, 3, 1, "SAME")
@@ -507,6 +528,9 @@ class InceptionV1Engine:
         self.training = True         # False: BatchNorm uses moving statistics, dropout is the identity
         self.reducer = None          # dp.GradientReducer, set by SentimentNet
         self.seed_dev = None         # device int64 added to the dropout seed (hipGraph replay draws fresh masks)
+        # 1 (default): the Branch_3 chain, then the Branch_2 chain, on ONE side stream -- one cross-queue join per block (a join
+        # costs ~17 us of idle GPU: 17.74 -> 17.58 ms/step against two side streams); 0: a side stream each; 2: Branch_3 only
+        self.one_side_stream = 1
         self.pool_first = True       # Mixed backward: Branch_3's pool gradient written first, fused dgrad accumulates (False: the reverse)
         self.stem_direct = True      # Conv2d_1a_7x7 from the packed RGB batch (ds_conv_stem; False: generic kernel on a 4-channel copy)
         self.branch_streams = True   # Mixed blocks: Branch_2 and Branch_3 on side streams next to Branch_0/1 (False: one stream)
