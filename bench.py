@@ -357,7 +357,7 @@ def main():
                         timing_pass="second pass of the same %d steps with HIP events around every launch and the "
                                     "Mixed-block branches on one stream, so a bracket is the launch's own duration "
                                     "(%.3f ms/step in that pass); the headline pass carries no events and runs the "
-                                    "branches on three streams" % (args.steps, 1e3 * dt_events / args.steps),
+                                    "branches on a side stream" % (args.steps, 1e3 * dt_events / args.steps),
                         whole_step_tflops=round(value * flop_per_sample / 1e3, 2),
                         whole_step_frac=round(value * flop_per_sample / 1e3 / peak, 4))
         out = {
