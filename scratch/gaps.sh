@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && export PYTHONPATH=$GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace -d $R/gpurun_out/_kg -o kg -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-gather --no-conv-timing > /dev/null 2>&1
+rocprofv3 --kernel-trace -d $R/gpurun_out/_kg -o kg -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-gather --no-conv-timing $EXTRA > /dev/null 2>&1
 python - <<PY
 import sqlite3, glob
 db = sqlite3.connect(glob.glob("$R/gpurun_out/_kg/*.db")[0])
