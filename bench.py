@@ -182,6 +182,10 @@ def main():
                          "is host launch cost)")
     ap.add_argument("--serial-towers", action="store_true",
                     help="A/B aid: text tower on the main stream instead of concurrently with the image tower")
+    ap.add_argument("--rccl-world1", action="store_true",
+                    help="--gpus 1 only: initialise the nccl (= RCCL) backend with ONE rank and take the bucketed all-reduce path "
+                         "(early bucket 1 on the side stream, async work handle) exactly as a multi-GPU run does; prints the `dp` "
+                         "block.  What a 1-GPU box can show of the 8-GPU code path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--cpu-warmup", type=int, default=3)
@@ -209,8 +213,14 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    force_dp = bool(args.rccl_world1 and world == 1)
+    if force_dp:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     rccl_ranks = None
-    if world > 1:          # a real collective before anything is timed: how many ranks does the backend connect?
+    if world > 1 or force_dp:          # a real collective before anything is timed: how many ranks does the backend connect?
         probe = torch.ones(1, device="cuda")
         dist.all_reduce(probe)
         torch.cuda.synchronize()
@@ -220,7 +230,7 @@ def main():
     net = SentimentNet(mode=args.mode, nb_emotions=15, im_features_size=256, rnn_size=H, fc_size=512, vocab_size=V,
                        embedding_dim=D, post_size=T, dropout_keep_prob=0.8, train_all=args.train_all,
                        trainable_embedding=args.train_all, concurrent_towers=not args.serial_towers,
-                       dtype=args.dtype)
+                       dtype=args.dtype, force_dp_buckets=force_dp)
     net.initialize(seed=1)
     if args.lstm_rows and net.text is not None:
         net.text.seq_rows = args.lstm_rows
@@ -266,7 +276,7 @@ def main():
         dt = float(tmax.item())
     loss = net.total_loss_value()
     dp_report = None
-    if world > 1:          # two more steps with event pairs around the early bucket-1 reduce (not in the timed region)
+    if world > 1 or force_dp:          # two more steps with event pairs around the early bucket-1 reduce (not in the timed region)
         net.reducer.timing = True
         for _ in range(2):
             net.train_step(batch, lr)
@@ -387,6 +397,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()            # rank 0 is still printing / timing the gather: leave together
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

@@ -78,16 +78,22 @@ typedef struct ds_conv_desc {
     int32_t grid_x;           /* 0: automatic.  >0: persistent workgroups per column tile (each walks  */
                               /* row tiles blockIdx.x, +grid_x, ...); also the stats partial count P   */
     int32_t dtype;            /* DS_DTYPE_F32 (0, default) or DS_DTYPE_BF16                             */
+    int32_t partials;         /* 0: unchecked.  >0 with DS_EPI_STATS: the partial count P the caller sized and  */
+                              /* finalises with (ds_conv_igemm_partials at plan time); a launch that would     */
+                              /* write a different count fails with DS_ERR_ARG instead of corrupting the stats */
 } ds_conv_desc;
 
-/* Tuning aid: pin the workgroup tile to (128*mt) x (32*nt) rows x columns; 0,0 = automatic.  */
-int ds_conv_set_tile(int mt, int nt);
-/* Tuning aid: 0 = automatic, 1 = register-staged LDS kernel (K-tile 16), 2 = register-direct (LDS-free)
+/* DEBUG / A-B AIDS (ds_debug_*): process-global switches for tests and tuning scripts.  They are NOT re-entrant,
+ * are never called by the product path (tests/test_abi_cpu.py checks that) and none is needed for correct results;
+ * per-layer choices go through ds_conv_desc.tile_nt / grid_x instead.
+ * Pin the workgroup tile to (128*mt) x (32*nt) rows x columns; 0,0 = automatic.  */
+int ds_debug_conv_set_tile(int mt, int nt);
+/* 0 = automatic, 1 = register-staged LDS kernel (K-tile 16), 2 = register-direct (LDS-free)
  * kernel, 3 = LDS-DMA kernel (buffer_load ... lds, K-tile 32; falls back to 1 where it does not apply). */
-int ds_conv_set_path(int path);
-/* Tuning aid: the wide-tile register-direct kernel for plain 1x1 / GEMM shapes (flags within DS_EPI_STATS):
+int ds_debug_conv_set_path(int path);
+/* the wide-tile register-direct kernel for plain 1x1 / GEMM shapes (flags within DS_EPI_STATS):
  * 0 = never, 1 = automatic (default), 2 = wherever the shape allows.                                      */
-int ds_conv_set_wide(int mode);
+int ds_debug_conv_set_wide(int mode);
 /* Number of row-tile blocks (P) the launch for `d` will use = number of stats partials.   */
 int ds_conv_igemm_partials(const ds_conv_desc *d);
 /* stats (DS_EPI_STATS): float[2][Cout][P] partial column sums of (z - pivot) and (z - pivot)^2.
@@ -247,24 +253,31 @@ int ds_lstm_cell_bwd(const float *acts, const float *c_t, const float *c_prev, c
  *   gates  [T, B, 4H]   in: x_t Wx + bias for every step (the hoisted input projection); out: activations
  *   h, c   [T+1, B, H]  slot 0 = initial state (zeros in the reference), slot t+1 = state after step t with
  *                       dynamic_rnn's copy-through past seq_len, so h[T] is the last valid output
- *   ws     ds_lstm_seq_workspace(B, H) bytes of device scratch (arrival counters, re-zeroed by every call)
- * Supported: H in {32, 64, 128, 256, 512, 1024} (ds_lstm_seq_supported); other sizes use the step-wise pair
- * above.  All workgroups of a row group must become resident for the launch to finish; every wait is bounded
- * and ds_lstm_seq_status (after the caller synchronised) reports a timeout instead of a hang.            */
+ *   rows   row groups (32 batch rows each) a workgroup walks per time step: 1, 2, 4 or 8.  1 = the shortest
+ *          sequence time (one workgroup per (16 units, 32 rows) pair); R > 1 = 1/R of the CUs for a longer time,
+ *          one row group's hand-off wait covered by work on the others (beside a concurrent kernel that needs
+ *          whole CUs).  Scheduling only: every cell's arithmetic and summation order are the same.
+ *   ws     ds_lstm_seq_workspace(B, H) bytes of device scratch, ZEROED ONCE BY THE CALLER: forward and backward
+ *          arrival counters (each launch re-zeroes its own) and one sticky error word per direction.
+ * Supported: H in {32, 64, 128, 256, 512, 1024} with H / 16 <= the device's compute units (ds_lstm_seq_supported);
+ * other sizes use the step-wise pair above.  All H / 16 workgroups of a row group must become resident for the
+ * launch to finish; every wait is bounded, a timeout sets the direction's error word (results then invalid) and
+ * ds_lstm_seq_status -- called wherever the caller synchronises anyway -- reports it instead of a hang:
+ * 0 = ok, bit 0 = a forward launch timed out, bit 1 = a backward launch.  Re-entrant: no process-global state;
+ * two sequences on two streams need two workspaces.                                                        */
 int ds_lstm_seq_supported(int32_t B, int32_t H);
 size_t ds_lstm_seq_workspace(int32_t B, int32_t H);
 int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float *h, float *c, const int64_t *seq_len, int32_t T,
-                    int32_t B, int32_t H, float forget_bias, void *ws, size_t ws_bytes, void *stream);
+                    int32_t B, int32_t H, float forget_bias, int32_t rows, void *ws, size_t ws_bytes, void *stream);
 /* BPTT: dgates [T, B, 4H] (zero rows past seq_len) from d(loss)/d(h[T]) = dh_last [B, ld_dh]; acts = the
  * activations ds_lstm_seq_fwd left in `gates`.  The two weight gradients are GEMMs over dgates afterwards. */
 int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, const float *c, const float *dh_last,
-                    int32_t ld_dh, const int64_t *seq_len, int32_t T, int32_t B, int32_t H, float *dgates, void *ws,
-                    size_t ws_bytes, void *stream);
+                    int32_t ld_dh, const int64_t *seq_len, int32_t T, int32_t B, int32_t H, float *dgates, int32_t rows,
+                    void *ws, size_t ws_bytes, void *stream);
 int ds_lstm_seq_status(const void *ws, int32_t B);
-/* Tuning aid: device buffer of T*8 uint64; workgroup (0,0) of the following ds_lstm_seq_fwd launches stamps
- * s_memtime at its phase boundaries (scripts/lstm_phase_prof.py).  NULL = off (default).   */
-int ds_lstm_seq_set_rows(int32_t rows);   /* row groups per workgroup: 1 (default), 2, 4, 8 -- fewer, longer-running workgroups */
-int ds_lstm_seq_set_profile(void *buf);
+/* Debug aid (process-global, never called by the product path): device buffer of T*8 uint64; workgroup (0,0) of the
+ * following ds_lstm_seq_fwd launches stamps s_memtime at its phase boundaries (scripts/lstm_phase_prof.py).  NULL = off. */
+int ds_debug_lstm_seq_set_profile(void *buf);
 
 /* slim.losses.softmax_cross_entropy + its gradient (im_text_rnn_model.py:124-125):
  * loss[0] = mean_b(logsumexp(z_b) - z_b[y_b]); dlogits = (softmax - onehot) * grad_scale / B;

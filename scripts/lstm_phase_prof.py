@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where does a step of the persistent LSTM forward kernel spend its time?  Workgroup (0,0) stamps s_memtime at
-its phase boundaries (ds_lstm_seq_set_profile); prints the per-phase mean over the steps in microseconds.
+its phase boundaries (ds_debug_lstm_seq_set_profile); prints the per-phase mean over the steps in microseconds.
     python scripts/lstm_phase_prof.py [B] [H] [T]"""
 import os
 import sys
@@ -22,7 +22,7 @@ prof = torch.zeros(T, 8, dtype=torch.int64, device="cuda")
 g0 = gates.clone()
 for it in range(3):
     gates.copy_(g0)
-    lib.ds_lstm_seq_set_profile(ops._p(prof) if it == 2 else None)
+    lib.ds_debug_lstm_seq_set_profile(ops._p(prof) if it == 2 else None)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     ops.lstm_seq_fwd(gates, ops._p(wh), 4 * H, h, c, seq, T, B, H, 1.0, ws)
@@ -30,7 +30,7 @@ for it in range(3):
     torch.cuda.synchronize()
     launch_us = 1e3 * e0.elapsed_time(e1)
     print("launch %d: %.1f us" % (it, launch_us))
-lib.ds_lstm_seq_set_profile(None)
+lib.ds_debug_lstm_seq_set_profile(None)
 p = prof.cpu().numpy().astype(np.float64)
 tick = None                 # s_memtime counts shader cycles: calibrated against the event-timed launch below
 names = ["wait for h[t]", "A loads + MFMA + LDS write", "barrier", "reduce + cell + stores issued", "drain (vmcnt 0)",

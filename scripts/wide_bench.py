@@ -41,7 +41,7 @@ for (hw, ci, co) in SHAPES:
         z = torch.empty(M, N, device="cuda")
         res = []
         for mode in (0, 2, 1):
-            lib.ds_conv_set_wide(mode)
+            lib.ds_debug_conv_set_wide(mode)
             if dgrad:
                 plan = ops.gemm_plan(M, K, N, K, N, co, transposed_w=True)
             else:
@@ -49,7 +49,7 @@ for (hw, ci, co) in SHAPES:
             stats = torch.zeros(2 * N * max(plan.partials, 1) + 16, device="cuda")
             res.append(timeit(lambda: plan.run(ops._p(x), ops._p(w), ops._p(z), stats=ops._p(stats))))
         fl = 2.0 * M * K * N
-        lib.ds_conv_set_wide(1)
+        lib.ds_debug_conv_set_wide(1)
         auto = ops.ConvPlan(M, 1, 1, K, K, 1, 1, 1, N, N, 0, 1, N, pad_t=0, pad_l=0, OH=1, OW=1) if not dgrad else None
         tot[0] += res[0]
         tot[1] += res[1]
@@ -57,5 +57,5 @@ for (hw, ci, co) in SHAPES:
         tot[3] += res[2]
         print("%4d %5d %5d %6s | %9.1f %7.1f | %9.1f %7.1f | %6.2f" % (hw, K, N, "dgrad" if dgrad else "", res[0], fl / res[0] / 1e6,
                                                                      res[1], fl / res[1] / 1e6, res[0] / res[1]))
-lib.ds_conv_set_wide(1)
+lib.ds_debug_conv_set_wide(1)
 print("sum: lds %.1f us, wide %.1f us, best of both %.1f us, library's own choice %.1f us" % tuple(tot))

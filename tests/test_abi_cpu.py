@@ -39,7 +39,7 @@ def test_errors_are_reported_not_thrown(lib):
     l = lib.load()
     assert l.ds_gather_rows(None, None, None, 1, 1, 1, 1, 1, None) == -1          # DS_ERR_ARG
     assert b"ds_gather_rows" in l.ds_last_error()
-    assert l.ds_conv_set_tile(3, 1) == -1 and l.ds_conv_set_tile(0, 0) == 0
+    assert l.ds_debug_conv_set_tile(3, 1) == -1 and l.ds_debug_conv_set_tile(0, 0) == 0
 
 
 def test_product_path_has_no_cpu_fallback(lib):
@@ -60,3 +60,29 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith(".py") or f.endswith(".hip") or f.endswith(".h") or f.endswith(".cpp"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+def test_product_path_never_calls_the_debug_switches():
+    """the library keeps no mutable process-global state on the product path.  The ds_debug_* entry
+    points (tile / kernel-family pins, LSTM phase stamps) are A-B aids for tests/ and scripts/ only."""
+    pkg = os.path.join(ROOT, "tumblr_emotions_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py") and f != "_lib.py":
+                text = open(os.path.join(dirpath, f)).read()
+                assert "ds_debug_" not in text, os.path.join(dirpath, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert "ds_debug_" not in bench
+
+
+def test_lstm_seq_entry_points_take_rows_and_keep_no_global(lib):
+    """`rows` is an argument of ds_lstm_seq_fwd / _bwd (round 2 kept it in a process global set before each launch)."""
+    assert "ds_lstm_seq_set_rows" not in lib.SIGNATURES
+    dll = ctypes.CDLL(lib.LIB_PATH)
+    assert not hasattr(dll, "ds_lstm_seq_set_rows")
+    l = lib.load()
+    # workspace: forward + backward counters per 32-row group and two error words, 16-byte granules
+    assert l.ds_lstm_seq_workspace(256, 512) == (2 * 8 + 2 + 3) // 4 * 16
+    assert l.ds_lstm_seq_supported(256, 512) == 1 and l.ds_lstm_seq_supported(256, 48) == 0
+    # argument errors are reported before anything is launched (no device needed)
+    assert l.ds_lstm_seq_fwd(None, None, 0, None, None, None, 1, 1, 32, 1.0, 1, None, 0, None) == -1

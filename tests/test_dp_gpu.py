@@ -79,3 +79,57 @@ def test_two_rank_data_parallel_steps_on_one_gpu():
     # everywhere and tightly in the mean
     assert np.abs(single - got[0]["text"]).max() <= 2.5e-3
     assert np.abs(single - got[0]["text"]).mean() <= 2e-5
+
+
+def _rccl_world1_worker(port, out):
+    """One rank, backend nccl (= RCCL on ROCm): the bucketed path with the early bucket-1 launch on the side stream,
+    RCCL's async work handle and the event ordering across the text-tower stream -- the code path of an 8-GPU run."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from tumblr_emotions_amd.net import SentimentNet
+        from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+        probe = torch.ones(1, device="cuda")
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        res = {"rccl_ranks": int(round(float(probe.item()))), "backend": dist.get_backend()}
+        batch = to_device(synthetic_batch_numpy(4, 10, 50, seed=4, with_images=True))
+        for forced in (False, True):
+            net = SentimentNet(mode="joint", force_dp_buckets=forced, **TEXT)
+            assert net.reducer.active == forced and net.reducer.overlap == forced
+            net.initialize(seed=3)
+            if forced:
+                net.reducer.timing = True
+            for _ in range(3):
+                net.train_step(batch, 1e-3, seed=11)
+            torch.cuda.synchronize()
+            res["theta_%d" % forced] = net.store.theta.detach().cpu().numpy()
+            res["grad_%d" % forced] = net.store.grad.detach().cpu().numpy()
+            if forced:
+                res["report"] = net.reducer.overlap_report()
+                assert net.capture_step(batch) is False        # RCCL stays outside a captured graph
+        out.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_single_rank_bucketed_allreduce_is_the_identity():
+    """RCCL itself (backend "nccl"), which gloo tests cannot exercise.  With one rank the sum is the
+    identity and the scale is 1/1, so three training steps through the forced bucket path -- all-reduce of bucket 1
+    launched from inside the backward pass on the side stream with async_op=True, bucket 2 at the end -- must leave
+    bit-identical parameters and gradients to the plain step; the early reduce must really have run (event report)."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), out))
+    p.start()
+    res = out.get(timeout=600)
+    p.join(60)
+    assert p.exitcode == 0
+    assert res["rccl_ranks"] == 1 and res["backend"] == "nccl"
+    print("rccl_ranks == %d (backend %s); bucket-1 report: %s" % (res["rccl_ranks"], res["backend"], res["report"]))
+    assert np.array_equal(res["theta_0"], res["theta_1"])
+    assert np.array_equal(res["grad_0"], res["grad_1"])
+    rep = res["report"]
+    assert rep and rep["bucket1_bytes"] > 0 and rep["bucket1_allreduce_ms"] > 0.0

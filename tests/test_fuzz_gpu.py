@@ -28,7 +28,7 @@ def test_random_conv_shapes_forward_dgrad_wgrad():
             x = rng.normal(size=(N, H, W, Ci)); w = rng.normal(size=(k, k, Ci, Co)) * 0.2
             ref = S.conv2d_same(x, w, stride)
             OH, OW = ref.shape[1], ref.shape[2]
-            lib.ds_conv_set_path(path); lib.ds_conv_set_tile(1 if nt else 0, nt)
+            lib.ds_debug_conv_set_path(path); lib.ds_debug_conv_set_tile(1 if nt else 0, nt)
             flags = int(rng.choice([0, ops.DS_EPI_STATS, ops.DS_EPI_BIAS | ops.DS_EPI_RELU, ops.DS_EPI_ACCUM]))
             bias = rng.normal(size=Co); prev = rng.normal(size=(N * OH * OW, Co))
             plan = ops.ConvPlan(N, H, W, Ci, Ci, k, k, stride, Co, Co, Ci * Co, 1, Co, flags=flags)
@@ -65,8 +65,8 @@ def test_random_conv_shapes_forward_dgrad_wgrad():
                 failures.append("case %d: N=%d H=%d W=%d Ci=%d Co=%d k=%d stride=%d path=%d nt=%d flags=%d"
                                 % (case, N, H, W, Ci, Co, k, stride, path, nt, flags))
     finally:
-        lib.ds_conv_set_path(0)
-        lib.ds_conv_set_tile(0, 0)
+        lib.ds_debug_conv_set_path(0)
+        lib.ds_debug_conv_set_tile(0, 0)
     assert not failures, "conv parity mismatches:\n" + "\n".join(failures)
 
 
@@ -119,7 +119,7 @@ def test_random_shapes_round2_kernels():
                 ok = ok and not bad(dx, S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1).reshape(-1, Ci), 3e-4)
             if not ok:
                 failures.append("winograd case %d: N=%d H=%d W=%d Ci=%d Co=%d pad=%d" % (case, N, H, W, Ci, Co, pad))
-        lib.ds_conv_set_wide(2)
+        lib.ds_debug_conv_set_wide(2)
         for case in range(24):                                   # ---- wide 1x1
             M = int(rng.randint(1, 700)); K = int(rng.choice([32, 40, 64, 72, 104, 192, 296])); Nn = int(rng.choice([8, 24, 32, 40, 64, 96, 104, 160, 200, 224, 256, 300]))
             a = rng.normal(size=(M, K)); w = rng.normal(size=(K, Nn)) * 0.2; prev = rng.normal(size=(M, Nn))
@@ -138,7 +138,7 @@ def test_random_shapes_round2_kernels():
                 ok = ok and not bad(dx, dz @ w.T, 3e-4)
             if not ok:
                 failures.append("wide case %d: M=%d K=%d N=%d" % (case, M, K, Nn))
-        lib.ds_conv_set_wide(1)
+        lib.ds_debug_conv_set_wide(1)
         for case in range(8):                                    # ---- stem
             N = int(rng.randint(1, 4)); H = int(rng.randint(7, 70)); W = int(rng.randint(7, 70)); cs = int(rng.choice([3, 4]))
             x = rng.uniform(-1, 1, size=(N, H, W, 3)); w = rng.normal(size=(7, 7, 3, 64)) * 0.1
@@ -183,7 +183,7 @@ def test_random_shapes_round2_kernels():
             if bad(z, ref.reshape(-1, Co), 3e-4):
                 failures.append("bf16 case %d: N=%d H=%d W=%d Ci=%d Co=%d k=%d stride=%d" % (case, N, H, W, Ci, Co, k, stride))
     finally:
-        lib.ds_conv_set_wide(1)
+        lib.ds_debug_conv_set_wide(1)
     assert not failures, "parity mismatches:\n" + "\n".join(failures)
 
 

@@ -285,7 +285,7 @@ def test_wide_1x1_kernel_forward_and_dgrad_match_oracle(case):
     xd = dev(np.ascontiguousarray(np.pad(x, ((0, 0), (0, 8)), constant_values=np.nan)))   # NaN in the row padding
     xd = torch.nan_to_num(xd, nan=7.0)                            # (finite garbage: the kernel may read it against zero weights)
     wd = dev(w)
-    lib.ds_conv_set_wide(2)
+    lib.ds_debug_conv_set_wide(2)
     try:
         plan = ops.ConvPlan(M, 1, 1, K, K + 8, 1, 1, 1, N, N, 0, 1, N, flags=ops.DS_EPI_STATS, pad_t=0, pad_l=0, OH=1, OW=1)
         z = torch.full((M, N), float("nan"), device="cuda")
@@ -315,7 +315,7 @@ def test_wide_1x1_kernel_forward_and_dgrad_match_oracle(case):
             torch.cuda.synchronize()
             close(dx, prev + dz @ w.T)
     finally:
-        lib.ds_conv_set_wide(1)
+        lib.ds_debug_conv_set_wide(1)
 
 
 def _bf16_round(a):
@@ -525,23 +525,70 @@ def test_lstm_sequence_kernels_match_oracle(case):
     ops.lstm_seq_bwd(gates, ops._p(whd), 4 * H, c, dhd, dhd.stride(0), seqd, T, B, H, dg2, ws)
     torch.cuda.synchronize()
     assert torch.equal(dg, dg2)
-    # ds_lstm_seq_set_rows: R row groups per workgroup (fewer, longer workgroups) changes scheduling only: the forward
+    # `rows`: R row groups per workgroup (fewer, longer workgroups) changes scheduling only: the forward
     # pass gives the same bits, the backward pass the same values to the last bit or two (hipcc contracts the gate
     # derivatives' multiply-adds differently in the R > 1 instantiations of the small hidden sizes); a last workgroup
     # with fewer than R row groups is included
-    try:
-        for rows in (2, 4, 8):
-            ops.lstm_seq_set_rows(rows)
-            g2, h2, c2 = dev(pre), torch.zeros_like(h), torch.zeros_like(c)
-            ops.lstm_seq_fwd(g2, ops._p(whd), 4 * H, h2, c2, seqd, T, B, H, S.FORGET_BIAS, ws)
-            dg3 = torch.empty_like(dg)
-            ops.lstm_seq_bwd(g2, ops._p(whd), 4 * H, c2, dhd, dhd.stride(0), seqd, T, B, H, dg3, ws)
-            torch.cuda.synchronize()
-            ops.lstm_seq_status(ws, B)
-            assert torch.equal(h2, h) and torch.equal(c2, c) and torch.equal(g2, gates), rows
-            assert float((dg3 - dg).abs().max()) <= 4e-7 * float(dg.abs().max()), rows
-    finally:
-        ops.lstm_seq_set_rows(1)
+    for rows in (2, 4, 8):
+        g2, h2, c2 = dev(pre), torch.zeros_like(h), torch.zeros_like(c)
+        ops.lstm_seq_fwd(g2, ops._p(whd), 4 * H, h2, c2, seqd, T, B, H, S.FORGET_BIAS, ws, rows=rows)
+        dg3 = torch.empty_like(dg)
+        ops.lstm_seq_bwd(g2, ops._p(whd), 4 * H, c2, dhd, dhd.stride(0), seqd, T, B, H, dg3, ws, rows=rows)
+        torch.cuda.synchronize()
+        ops.lstm_seq_status(ws, B)
+        assert torch.equal(h2, h) and torch.equal(c2, c) and torch.equal(g2, gates), rows
+        assert float((dg3 - dg).abs().max()) <= 4e-7 * float(dg.abs().max()), rows
+
+
+def test_lstm_sequence_is_reentrant_across_streams_and_row_settings():
+    """no global mutable state.  Two text towers with DIFFERENT `rows` settings run at the same time on
+    two streams (each with its own workspace) and give the bits each gives alone; the forward and the backward
+    launch keep separate, sticky error words (a backward launch no longer wipes the forward's)."""
+    ops = _ops()
+    from tumblr_emotions_amd import _lib
+    lib = _lib.load()
+    B, T, H = 96, 12, 128
+    rng = np.random.RandomState(11)
+    wh = dev(rng.normal(size=(H, 4 * H)) * (0.5 / np.sqrt(H)))
+    seqd = torch.from_numpy(rng.randint(1, T + 1, size=B).astype(np.int64)).cuda()
+    dh_last = dev(rng.normal(size=(B, H)))
+
+    def run(pre, rows, ws):
+        g, h, c = pre.clone(), torch.zeros(T + 1, B, H, device="cuda"), torch.zeros(T + 1, B, H, device="cuda")
+        dg = torch.empty(T, B, 4 * H, device="cuda")
+        ops.lstm_seq_fwd(g, ops._p(wh), 4 * H, h, c, seqd, T, B, H, S.FORGET_BIAS, ws, rows=rows)
+        ops.lstm_seq_bwd(g, ops._p(wh), 4 * H, c, dh_last, H, seqd, T, B, H, dg, ws, rows=rows)
+        return h, dg
+
+    pres = [dev(rng.normal(size=(T, B, 4 * H)) * 0.7) for _ in range(2)]
+    wss = [torch.zeros(max(ops.lstm_seq_workspace(B, H) // 4, 4), dtype=torch.int32, device="cuda") for _ in range(2)]
+    alone = [run(pres[i], (1, 2)[i], wss[i]) for i in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(3):
+        both = []
+        for i in range(2):
+            streams[i].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(streams[i]):
+                both.append(run(pres[i], (1, 2)[i], wss[i]))
+        torch.cuda.synchronize()
+        for i in range(2):
+            ops.lstm_seq_status(wss[i], B)
+            assert torch.equal(both[i][0], alone[i][0]) and torch.equal(both[i][1], alone[i][1]), (rep, i)
+    # sticky, separate error words: poke the forward word, run a backward launch, the status still reports bit 0
+    nrg = (B + 31) // 32
+    wss[0][2 * nrg] = 1
+    run(pres[0], 1, wss[0])
+    torch.cuda.synchronize()
+    assert lib.ds_lstm_seq_status(ops._p(wss[0]), B) == 1
+    with pytest.raises(RuntimeError, match="forward"):
+        ops.lstm_seq_status(wss[0], B)
+    wss[0][2 * nrg + 1] = 1
+    assert lib.ds_lstm_seq_status(ops._p(wss[0]), B) == 3
+    # rows outside {1, 2, 4, 8} is an argument error, not a silent default
+    with pytest.raises(RuntimeError, match="rows"):
+        ops.lstm_seq_fwd(pres[0].clone(), ops._p(wh), 4 * H, torch.zeros(T + 1, B, H, device="cuda"),
+                         torch.zeros(T + 1, B, H, device="cuda"), seqd, T, B, H, S.FORGET_BIAS, wss[1], rows=3)
 
 
 def test_text_tower_persistent_and_stepwise_paths_agree():
@@ -951,7 +998,7 @@ def test_every_conv_instantiation_matches_the_oracle():
         for path, nts in ((1, range(1, 7)), (2, range(1, 5)), (3, range(1, 4))):
             for mt in (1, 2):
                 for nt in nts:
-                    assert lib.ds_conv_set_path(path) == 0 and lib.ds_conv_set_tile(mt, nt) == 0
+                    assert lib.ds_debug_conv_set_path(path) == 0 and lib.ds_debug_conv_set_tile(mt, nt) == 0
                     plan = ops.ConvPlan(N, H, W, Ci, Ci, k, k, 1, Co, Co, Ci * Co, 1, Co, flags=ops.DS_EPI_STATS)
                     z = torch.empty(plan.M, Co, device="cuda")
                     stats = torch.zeros(2, Co, plan.partials, device="cuda")
@@ -965,8 +1012,8 @@ def test_every_conv_instantiation_matches_the_oracle():
                     assert np.abs(stats[0].sum(1).cpu().numpy() - fwd_ref.sum(0)).max() <= 1e-3 * np.abs(fwd_ref.sum(0)).max() + 1e-3, tag
                     assert np.abs(dx.cpu().numpy() - dgr_ref).max() <= 2e-4 * np.abs(dgr_ref).max(), tag
     finally:
-        lib.ds_conv_set_path(0)
-        lib.ds_conv_set_tile(0, 0)
+        lib.ds_debug_conv_set_path(0)
+        lib.ds_debug_conv_set_tile(0, 0)
 
 
 def test_split_k_gemm_slabs_feed_lstm_cell():

@@ -62,9 +62,20 @@ def _check_step(net, ref, batch, lr, mask_np=None, logit_tol=1e-3, first=True, g
     w_before = net.state_dict()
     net.train_step(_dev_batch(batch), lr, dropout_mask=mask_d)
     torch.cuda.synchronize()
+    plain_logits = None
     if net.image is not None:
+        # the un-injected oracle forward from the same state (forward() does not touch the moving statistics): the
+        # decisions read back from the HIP buffers may move the fp64 forward pass by rounding-size amounts only.  A
+        # forward bug that corrupts a ReLU mask or a pool winner CONSISTENTLY would be followed by the injected oracle
+        # below -- it cannot be followed by this one.
+        ref.inject = None
+        with torch.no_grad():
+            plain_logits = ref.forward(batch, mask_t).detach().clone()
         ref.inject = hip_decisions(net)
     out = ref.train_step(batch, lr, mask_t)
+    if plain_logits is not None:
+        moved = float((out["logits"] - plain_logits).abs().max())
+        assert moved <= 1e-4, "following the HIP decisions moved the oracle's logits by %.3e" % moved
     logits = net.logits.detach().cpu().numpy()
     err = np.abs(logits - out["logits"].numpy()).max()
     assert err <= logit_tol, "logits differ by %.3e" % err
@@ -370,6 +381,45 @@ def test_captured_step_matches_eager_step(mode):
     # the replayed steps are the eager steps, bit for bit
     assert l0 == l1
     assert torch.equal(z0, z1) and torch.equal(th0, th1) and torch.equal(fr0, fr1)
+
+
+def test_captured_step_is_dropped_when_buffers_or_weights_change():
+    """A hipGraph bakes in buffer addresses and (for the frozen 3x3 layers) the transformed filters.  After a
+    predict() at another batch size re-allocated the engines' buffers, or after a load changed the weights, a
+    train_step on the captured batch must NOT replay the stale graph: it runs eagerly and gives the eager bits."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    kw = dict(nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10)
+    batch = to_device(synthetic_batch_numpy(4, 10, 50, seed=1))
+    other = to_device(synthetic_batch_numpy(2, 10, 50, seed=2))
+    ref = SentimentNet(mode="joint", **kw)
+    ref.initialize(seed=3)
+    net = SentimentNet(mode="joint", **kw)
+    net.initialize(seed=3)
+    assert net.capture_step(batch) and net._graph is not None
+    for n in (ref, net):
+        n.train_step(batch, 1e-3)
+    assert net._graph is not None                       # replayed
+    # (a) another batch size in between: every buffer the graph points at is re-allocated
+    for n in (ref, net):
+        n.predict(other)
+        n.train_step(batch, 1e-3)
+    torch.cuda.synchronize()
+    assert net._graph is None, "a stale graph survived a re-allocation"
+    assert net.image.seed_dev is None
+    assert torch.equal(net.store.theta, ref.store.theta) and torch.equal(net.logits, ref.logits)
+    # (b) a load after a capture: the frozen layers' Winograd filters in the graph would be stale
+    assert net.capture_step(batch) and net._graph is not None
+    sd = ref.state_dict()
+    k = "InceptionV1/Mixed_3b/Branch_1/Conv2d_0b_3x3/weights"
+    sd[k] = sd[k] * 1.5
+    for n in (ref, net):
+        n.load_state_dict(sd)
+    assert net._graph is None, "load_state_dict must drop the captured step"
+    for n in (ref, net):
+        n.train_step(batch, 1e-3)
+    torch.cuda.synchronize()
+    assert torch.equal(net.logits, ref.logits) and torch.equal(net.store.theta, ref.store.theta)
 
 
 @pytest.mark.parametrize("B", [16, 96])

@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
         ("w_tap_stride", C.c_int64), ("w_n_stride", C.c_int32), ("w_k_stride", C.c_int32),
         ("flip", C.c_int32), ("fold_cin", C.c_int32), ("flags", C.c_int32), ("ldmask", C.c_int32),
         ("splits", C.c_int32), ("z_split_stride", C.c_int64),
-        ("tile_nt", C.c_int32), ("grid_x", C.c_int32), ("dtype", C.c_int32),
+        ("tile_nt", C.c_int32), ("grid_x", C.c_int32), ("dtype", C.c_int32), ("partials", C.c_int32),
     ]
 
 
@@ -39,9 +39,9 @@ _SG = C.POINTER(Segments)
 SIGNATURES = {
     "ds_version": (C.c_int, []),
     "ds_last_error": (C.c_char_p, []),
-    "ds_conv_set_tile": (C.c_int, [C.c_int, C.c_int]),
-    "ds_conv_set_path": (C.c_int, [C.c_int]),
-    "ds_conv_set_wide": (C.c_int, [C.c_int]),
+    "ds_debug_conv_set_tile": (C.c_int, [C.c_int, C.c_int]),
+    "ds_debug_conv_set_path": (C.c_int, [C.c_int]),
+    "ds_debug_conv_set_wide": (C.c_int, [C.c_int]),
     "ds_conv_igemm_partials": (C.c_int, [_CD]),
     "ds_conv_igemm": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ds_weights_bf16_bytes": (C.c_size_t, [_i32, _i32, _i32, _i32]),
@@ -77,11 +77,10 @@ SIGNATURES = {
     "ds_lstm_cell_bwd": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i64, _P, _P, _i32, _i32, _i32, _P, _P, _P, _P]),
     "ds_lstm_seq_supported": (C.c_int, [_i32, _i32]),
     "ds_lstm_seq_workspace": (C.c_size_t, [_i32, _i32]),
-    "ds_lstm_seq_fwd": (C.c_int, [_P, _P, _i32, _P, _P, _P, _i32, _i32, _i32, _f32, _P, C.c_size_t, _P]),
-    "ds_lstm_seq_bwd": (C.c_int, [_P, _P, _i32, _P, _P, _i32, _P, _i32, _i32, _i32, _P, _P, C.c_size_t, _P]),
+    "ds_lstm_seq_fwd": (C.c_int, [_P, _P, _i32, _P, _P, _P, _i32, _i32, _i32, _f32, _i32, _P, C.c_size_t, _P]),
+    "ds_lstm_seq_bwd": (C.c_int, [_P, _P, _i32, _P, _P, _i32, _P, _i32, _i32, _i32, _P, _i32, _P, C.c_size_t, _P]),
     "ds_lstm_seq_status": (C.c_int, [_P, _i32]),
-    "ds_lstm_seq_set_rows": (C.c_int, [_i32]),
-    "ds_lstm_seq_set_profile": (C.c_int, [_P]),
+    "ds_debug_lstm_seq_set_profile": (C.c_int, [_P]),
     "ds_softmax_ce": (C.c_int, [_P, _P, _i32, _i32, _f32, _P, _P, _P, _P]),
     "ds_adam_tf": (C.c_int, [_P, _P, _P, _P, _i64, _i64, _f32, _f32, _f32, _P, _f32, _f32, _f32, _P]),
     "ds_sumsq": (C.c_int, [_P, _i64, _P, _P, _P]),

@@ -1627,7 +1627,7 @@ int resident_per_cu(TileCfg c, Variant v) {
     return slot;
 }
 
-// tuning aids: ds_conv_set_tile() / DS_CONV_CFG="mt,nt" pin the tile; ds_conv_set_path() /
+// tuning aids: ds_debug_conv_set_tile() / DS_CONV_CFG="mt,nt" pin the tile; ds_debug_conv_set_path() /
 // DS_CONV_PATH=lds|direct pins the kernel family
 int force_mt = -1, force_nt = -1, force_path = -1;
 
@@ -1735,21 +1735,21 @@ void grid_for(const ds_conv_desc *d, TileCfg c, Variant v, int *gx, int *gy, int
 
 }  // namespace
 
-extern "C" int ds_conv_set_tile(int mt, int nt) {
-    DS_REQUIRE((mt == 0 && nt == 0) || ((mt == 1 || mt == 2) && nt >= 1 && nt <= 6), "ds_conv_set_tile: mt in {1,2}, nt in 1..6, or 0,0 = automatic");
+extern "C" int ds_debug_conv_set_tile(int mt, int nt) {
+    DS_REQUIRE((mt == 0 && nt == 0) || ((mt == 1 || mt == 2) && nt >= 1 && nt <= 6), "ds_debug_conv_set_tile: mt in {1,2}, nt in 1..6, or 0,0 = automatic");
     force_mt = mt;
     force_nt = nt;
     return DS_OK;
 }
 
-extern "C" int ds_conv_set_wide(int mode) {
-    DS_REQUIRE(mode >= 0 && mode <= 2, "ds_conv_set_wide: 0 = never, 1 = automatic, 2 = wherever the shape allows");
+extern "C" int ds_debug_conv_set_wide(int mode) {
+    DS_REQUIRE(mode >= 0 && mode <= 2, "ds_debug_conv_set_wide: 0 = never, 1 = automatic, 2 = wherever the shape allows");
     force_wide = mode;
     return DS_OK;
 }
 
-extern "C" int ds_conv_set_path(int path) {
-    DS_REQUIRE(path >= 0 && path <= 3, "ds_conv_set_path: 0 = automatic, 1 = register-staged LDS kernel, 2 = register-direct kernel, 3 = LDS-DMA kernel");
+extern "C" int ds_debug_conv_set_path(int path) {
+    DS_REQUIRE(path >= 0 && path <= 3, "ds_debug_conv_set_path: 0 = automatic, 1 = register-staged LDS kernel, 2 = register-direct kernel, 3 = LDS-DMA kernel");
     force_path = path;
     return DS_OK;
 }
@@ -1814,6 +1814,11 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     int gx, gy, rt;
     bool one;
     grid_for(d, c, v, &gx, &gy, &rt, &one);
+    // the statistics partial count the caller planned with (ds_conv_igemm_partials at plan time) must be the one this
+    // launch writes: the tile choice depends on debug switches / environment caches that may have changed since
+    DS_REQUIRE(!(d->flags & DS_EPI_STATS) || d->partials <= 0 || d->partials == (c.direct ? gx * 4 : gx),
+               "ds_conv_igemm: the launch would write %d statistics partials but the plan was made for %d "
+               "(a ds_debug_conv_set_* switch changed after planning?)", c.direct ? gx * 4 : gx, d->partials);
     p.row_tiles = rt;
     static int xcd_remap = -1;
     if (xcd_remap < 0) {

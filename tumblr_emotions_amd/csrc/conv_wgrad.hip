@@ -496,9 +496,12 @@ WgradPlan plan_direct(const ds_conv_desc *d, int64_t M, int wx, int wz) {
     return best;
 }
 
-WgradPlan plan_wgrad(const ds_conv_desc *d, int64_t M, const float *x, const float *dz, int lddz) {
+WgradPlan plan_wgrad(const ds_conv_desc *d, int64_t M, const float *x, const float *dz, int lddz, const float *dw,
+                     const void *ws) {
     if (direct_ok(d, M)) {
-        WgradPlan pl = plan_direct(d, M, max_width(d->Cin, d->ldx, (uintptr_t)x), max_width(d->Cout, lddz, (uintptr_t)dz));
+        // BJ is also the width of the kernel's vector stores into dw (or the split-K workspace): their alignment counts
+        const uintptr_t zalign = (uintptr_t)dz | (uintptr_t)dw | (uintptr_t)ws;
+        WgradPlan pl = plan_direct(d, M, max_width(d->Cin, d->ldx, (uintptr_t)x), max_width(d->Cout, lddz, zalign));
         if (const char *e = getenv("DS_WGRAD_FORCE")) {          // "ai,bj,slabs" (tuning aid; the caller sizes the workspace)
             int a = 0, b = 0, sl = 0;
             if (sscanf(e, "%d,%d,%d", &a, &b, &sl) == 3) {
@@ -539,7 +542,7 @@ extern "C" int ds_conv_wgrad(const ds_conv_desc *d, const float *x, const float 
     DS_REQUIRE(M < (1ll << 31), "ds_conv_wgrad: M too large");
     DS_REQUIRE(d->fold_cin == 0 || (d->KW == 1 && d->ldx == d->fold_cin && d->fold_cin % 4 == 0 && d->Cin % d->fold_cin == 0),
                "ds_conv_wgrad: fold_cin needs KW=1, ldx==fold_cin, fold_cin %% 4 == 0");
-    const WgradPlan pl = plan_wgrad(d, M, x, dz, lddz);
+    const WgradPlan pl = plan_wgrad(d, M, x, dz, lddz, dw, ws);
     if (getenv("DS_WGRAD_DEBUG"))
         fprintf(stderr, "wgrad M=%lld Cin=%d Cout=%d k=%d: direct=%d ai=%d bj=%d slabs=%d\n", (long long)M, d->Cin, d->Cout, d->KH,
                 pl.direct, pl.ai, pl.bj, pl.splits);

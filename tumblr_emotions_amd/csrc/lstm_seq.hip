@@ -44,9 +44,10 @@ struct SeqParams {
     const int64_t *seq_len;
     int T, B, H;
     float forget_bias;
-    unsigned *sync;            // [row groups] arrival counters, then one error word
+    unsigned *sync;            // this direction's [row groups] arrival counters
+    unsigned *err;             // this direction's error word (sticky: launches never clear it)
     int nrg;
-    unsigned long long *prof;  // tuning aid (ds_lstm_seq_set_profile): workgroup (0,0) stamps its phases, [T][8]
+    unsigned long long *prof;  // tuning aid (ds_debug_lstm_seq_set_profile): workgroup (0,0) stamps its phases, [T][8]
 };
 
 #define DS_STAMP(slot)                                                                  \
@@ -88,7 +89,7 @@ __device__ __forceinline__ void store_sc1(float *p, const float *v) {
 // ================================================================================================
 // forward: H = 8 * NCH * NW; workgroup tile 32 rows x 64 gate columns (16 units x i,j,f,o), K = H split over NW waves
 // ================================================================================================
-template <int NCH, int NW, int R>      // R row groups per workgroup (see ds_lstm_seq_set_rows)
+template <int NCH, int NW, int R>      // R row groups per workgroup (the `rows` argument)
 __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const SeqParams p) {
     constexpr int H = 8 * NCH * NW, KQ = 8 * NCH;
     constexpr int UPT = 8 / NW;                    // hidden units per thread in the cell phase (512 cells / threads)
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
     const int u0 = cg * 16;
     const int ncg = gridDim.x;
     const int B = p.B, T = p.T;
-    unsigned *err = p.sync + p.nrg;
+    unsigned *err = p.err;
 
     // ---- this wave's slice of Wh as MFMA B fragments: column c64 = 16 g + u  <->  Wh column g H + u0 + u ------
     float bfr[2][NCH][4];
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
     const int u0 = cg * 16;
     const int ncg = gridDim.x;
     const int B = p.B, T = p.T;
-    unsigned *err = p.sync + p.nrg;
+    unsigned *err = p.err;
 
     // ---- Wh[u0 + n, this wave's K range] as B fragments of the 16x16x4 MFMA (k-contiguous rows) ----------------
     f32x4 bfr[NQ];
@@ -383,12 +384,11 @@ struct SeqCfg {
     int nw;
 };
 
-// Row groups per workgroup (ds_lstm_seq_set_rows).  1: every (unit block, row group) pair is a workgroup -- the
+// Row groups per workgroup (the `rows` argument of ds_lstm_seq_fwd / _bwd).  1: every (unit block, row group) pair is a workgroup -- the
 // shortest sequence time, but at B = 256, H = 512 that is 256 workgroups of 256-register waves which spend ~40 % of a
 // step waiting for their row group: nothing that needs a whole SIMD (the Winograd conv of the image tower) can run
 // beside them.  R > 1: a workgroup walks R row groups per time step with the same register-resident Wh slice; the
 // hand-off wait of one row group is covered by the work on the others and the launch occupies 1/R of the CUs.
-int g_rows = 1;
 
 template <int R>
 bool seq_cfg_r(int H, SeqCfg *c) {
@@ -413,10 +413,27 @@ bool seq_cfg(int H, SeqCfg *c, int rows = 1) {
 }
 
 // the R in use for a batch of nrg row groups: never more than there are row groups
-int rows_for(int nrg) {
-    int r = g_rows;
+int rows_for(int rows, int nrg) {
+    int r = rows;
     while (r > 1 && r > nrg) r >>= 1;
     return r;
+}
+
+// compute units of the current device (init-once property cache; 256 when no device can be queried, e.g. in a
+// build container).  Every workgroup of a row group must be resident at once and the kernels ask for one workgroup
+// per CU (exclusive_lds), so a launch needs H / 16 CUs.
+int device_cus() {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        else
+            cus = 256;
+        (void)hipGetLastError();
+    }
+    return cus;
 }
 
 // One workgroup per CU: two co-resident workgroups would share the CU's four matrix pipes and finish their step
@@ -435,10 +452,12 @@ size_t exclusive_lds(int nw, bool fwd) {
     return stat >= want ? 0 : want - stat;
 }
 
-int common_checks(const char *who, const void *a, const void *b, const void *c, int T, int B, int H, int ldw, void *ws,
-                  size_t ws_bytes) {
+int common_checks(const char *who, const void *a, const void *b, const void *c, int T, int B, int H, int ldw, int rows,
+                  void *ws, size_t ws_bytes) {
     DS_REQUIRE(a && b && c && ws, "%s: null argument", who);
-    DS_REQUIRE(T > 0 && B > 0 && ds_lstm_seq_supported(B, H), "%s: unsupported size (H must be 32 ... 1024, a power of two)", who);
+    DS_REQUIRE(rows == 1 || rows == 2 || rows == 4 || rows == 8, "%s: rows (row groups per workgroup) must be 1, 2, 4 or 8", who);
+    DS_REQUIRE(T > 0 && B > 0 && ds_lstm_seq_supported(B, H),
+               "%s: unsupported size (H must be 32 ... 1024, a power of two, and H / 16 workgroups must fit the device's CUs)", who);
     DS_REQUIRE(ldw >= 4 * H && ldw % 4 == 0 && (((uintptr_t)b) & 15) == 0, "%s: Wh must be 16-byte aligned with ldw %% 4 == 0", who);
     DS_REQUIRE((int64_t)(T + 1) * B * 4 * H * 4 < (1ll << 31), "%s: sequence buffers above 2 GiB (split the batch)", who);
     DS_REQUIRE(ws_bytes >= ds_lstm_seq_workspace(B, H), "%s: workspace too small", who);
@@ -449,31 +468,37 @@ int common_checks(const char *who, const void *a, const void *b, const void *c, 
 
 extern "C" int ds_lstm_seq_supported(int32_t B, int32_t H) {
     SeqCfg c;
-    return B > 0 && seq_cfg(H, &c) ? 1 : 0;
+    // the H / 16 workgroups of a row group spin on each other: all of them must be resident, one per CU
+    return B > 0 && seq_cfg(H, &c) && H / 16 <= device_cus() ? 1 : 0;
 }
 
+// workspace words: [0, nrg) forward arrival counters, [nrg, 2 nrg) backward arrival counters, then the forward and
+// the backward error word.  A launch re-zeroes ITS counters only; the error words are sticky until the caller
+// clears the workspace (it is zero-initialised once by the caller).
 extern "C" size_t ds_lstm_seq_workspace(int32_t B, int32_t H) {
     (void)H;
     const int nrg = (B + 31) / 32;
-    return (size_t)(nrg + 1 + 3) / 4 * 16;       // arrival counter per row group + error word, 16-byte granules
+    return (size_t)(2 * nrg + 2 + 3) / 4 * 16;
 }
 
 extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float *h, float *c, const int64_t *seq_len,
-                               int32_t T, int32_t B, int32_t H, float forget_bias, void *ws, size_t ws_bytes,
-                               void *stream) {
-    if (int e = common_checks("ds_lstm_seq_fwd", gates, wh, h, T, B, H, ldw, ws, ws_bytes)) return e;
+                               int32_t T, int32_t B, int32_t H, float forget_bias, int32_t rows_arg, void *ws,
+                               size_t ws_bytes, void *stream) {
+    if (int e = common_checks("ds_lstm_seq_fwd", gates, wh, h, T, B, H, ldw, rows_arg, ws, ws_bytes)) return e;
     DS_REQUIRE(c && seq_len, "ds_lstm_seq_fwd: null argument");
     SeqCfg cfg;
-    const int rows = rows_for((B + 31) / 32);
+    const int rows = rows_for(rows_arg, (B + 31) / 32);
     seq_cfg(H, &cfg, rows);
     SeqParams p = {};
     p.gates = gates; p.wh = wh; p.ldw = ldw; p.h = h; p.c = c; p.seq_len = seq_len;
     p.T = T; p.B = B; p.H = H; p.forget_bias = forget_bias;
     p.nrg = (B + 31) / 32;
     p.sync = (unsigned *)ws;
+    p.err = (unsigned *)ws + 2 * p.nrg;
     p.prof = g_prof;
-    // every polled word is re-initialised by a memset node in front of the launch (Guideline 16)
-    if (hipMemsetAsync(ws, 0, ds_lstm_seq_workspace(B, H), (hipStream_t)stream) != hipSuccess)
+    // every polled word is re-initialised by a memset node in front of the launch (Guideline 16); the error words
+    // are left alone
+    if (hipMemsetAsync(p.sync, 0, (size_t)p.nrg * sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
         return ds::check_launch("ds_lstm_seq_fwd(memset)");
     hipLaunchKernelGGL(cfg.fwd, dim3(H / 16, (p.nrg + rows - 1) / rows), dim3(64 * cfg.nw), exclusive_lds(cfg.nw, true), (hipStream_t)stream, p);
     return ds::check_launch("ds_lstm_seq_fwd");
@@ -481,45 +506,38 @@ extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float
 
 extern "C" int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, const float *c, const float *dh_last,
                                int32_t ld_dh, const int64_t *seq_len, int32_t T, int32_t B, int32_t H, float *dgates,
-                               void *ws, size_t ws_bytes, void *stream) {
-    if (int e = common_checks("ds_lstm_seq_bwd", acts, wh, c, T, B, H, ldw, ws, ws_bytes)) return e;
+                               int32_t rows_arg, void *ws, size_t ws_bytes, void *stream) {
+    if (int e = common_checks("ds_lstm_seq_bwd", acts, wh, c, T, B, H, ldw, rows_arg, ws, ws_bytes)) return e;
     DS_REQUIRE(dh_last && seq_len && dgates && ld_dh >= H, "ds_lstm_seq_bwd: bad argument");
     SeqCfg cfg;
-    const int rows = rows_for((B + 31) / 32);
+    const int rows = rows_for(rows_arg, (B + 31) / 32);
     seq_cfg(H, &cfg, rows);
     SeqParams p = {};
     p.gates = const_cast<float *>(acts); p.wh = wh; p.ldw = ldw; p.c = const_cast<float *>(c);
     p.dh_last = dh_last; p.ld_dh = ld_dh; p.dgates = dgates; p.seq_len = seq_len;
     p.T = T; p.B = B; p.H = H;
     p.nrg = (B + 31) / 32;
-    p.sync = (unsigned *)ws;
-    if (hipMemsetAsync(ws, 0, ds_lstm_seq_workspace(B, H), (hipStream_t)stream) != hipSuccess)
+    p.sync = (unsigned *)ws + p.nrg;
+    p.err = (unsigned *)ws + 2 * p.nrg + 1;
+    if (hipMemsetAsync(p.sync, 0, (size_t)p.nrg * sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
         return ds::check_launch("ds_lstm_seq_bwd(memset)");
     hipLaunchKernelGGL(cfg.bwd, dim3(H / 16, (p.nrg + rows - 1) / rows), dim3(64 * cfg.nw), exclusive_lds(cfg.nw, false), (hipStream_t)stream, p);
     return ds::check_launch("ds_lstm_seq_bwd");
 }
 
 extern "C" int ds_lstm_seq_status(const void *ws, int32_t B) {
-    // host-side read of the error word of a FINISHED launch (the caller synchronised): 0 = ok, 1 = a hand-off
-    // wait timed out (a workgroup of the row group never became resident) and the results are invalid
-    unsigned v = 0;
+    // host-side read of the two error words of FINISHED launches (the caller synchronised): 0 = ok, bit 0 = a
+    // hand-off wait of a forward launch timed out (a workgroup of the row group never became resident), bit 1 = the
+    // same in a backward launch; the results are invalid.  The words are sticky across launches.
+    unsigned v[2] = {0, 0};
     const int nrg = (B + 31) / 32;
-    if (hipMemcpy(&v, (const unsigned *)ws + nrg, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return DS_ERR_LAUNCH;
-    return (int)v;
+    if (hipMemcpy(v, (const unsigned *)ws + 2 * nrg, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return DS_ERR_LAUNCH;
+    return (int)((v[0] ? 1u : 0u) | (v[1] ? 2u : 0u));
 }
 
-// Tuning aid (not part of the product path): device buffer of T*8 uint64 in which workgroup (0,0) of the NEXT
-// ds_lstm_seq_fwd launches stamps s_memtime at its phase boundaries; NULL switches it off.
-// Row groups per workgroup for the following ds_lstm_seq_fwd / _bwd launches: 1, 2, 4 or 8 (see g_rows).  Scheduling only:
-// every cell's arithmetic and summation order are the same (results agree to the last bit or two -- the compiler
-// contracts a few multiply-adds differently per instantiation).
-extern "C" int ds_lstm_seq_set_rows(int32_t rows) {
-    DS_REQUIRE(rows == 1 || rows == 2 || rows == 4 || rows == 8, "ds_lstm_seq_set_rows: 1, 2, 4 or 8");
-    g_rows = rows;
-    return DS_OK;
-}
-
-extern "C" int ds_lstm_seq_set_profile(void *buf) {
+// Debug aid (never called by the product path; process-global, not re-entrant): device buffer of T*8 uint64 in which
+// workgroup (0,0) of the NEXT ds_lstm_seq_fwd launches stamps s_memtime at its phase boundaries; NULL switches it off.
+extern "C" int ds_debug_lstm_seq_set_profile(void *buf) {
     g_prof = (unsigned long long *)buf;
     return DS_OK;
 }

@@ -37,10 +37,16 @@ class GradientReducer:
     """Sum-all-reduce of the flat gradient in two buckets, the first one optionally launched early on
     a side stream (overlap with the rest of the backward pass)."""
 
-    def __init__(self, flat_grad, n_bucket1, group=None, overlap=True):
+    def __init__(self, flat_grad, n_bucket1, group=None, overlap=True, force_buckets=False):
         self.g, self.n1, self.group = flat_grad, int(n_bucket1), group
         self.rank, self.world = world_info(group)
-        self.overlap = overlap and self.world > 1 and flat_grad.is_cuda
+        # force_buckets: take the bucketed collective path even with ONE rank (an initialised process group is
+        # required).  On a 1-GPU box this runs the real RCCL all-reduce, its async work handle and the side-stream
+        # ordering exactly as a multi-GPU run does (sum over one rank = identity, scale 1/1), which gloo cannot show.
+        if force_buckets and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("force_buckets needs an initialised torch.distributed process group")
+        self.active = self.world > 1 or bool(force_buckets)
+        self.overlap = overlap and self.active and flat_grad.is_cuda
         self.stream = torch.cuda.Stream() if self.overlap else None
         self._pending = None
         self._ready = set()
@@ -63,7 +69,7 @@ class GradientReducer:
 
     def stage_done(self, name):
         """Called by the engines from inside backward(); launches bucket 1 when the last stage reports."""
-        if self.world == 1:
+        if not self.active:
             return
         self._ready.add(name)
         if self.overlap:       # stages may run on different streams (text tower): remember where each finished
@@ -84,7 +90,7 @@ class GradientReducer:
     def finish(self):
         """Reduce whatever has not been reduced yet and make the current stream wait for all of it.
         Returns the scale (1/world) the optimiser must apply to the summed gradient."""
-        if self.world == 1:
+        if not self.active:
             return 1.0
         if self._pending is not None:
             main = torch.cuda.current_stream()

@@ -584,6 +584,7 @@ class InceptionV1Engine:
             return
         dev = self.device
         self.B = B
+        self.alloc_gen = getattr(self, "alloc_gen", 0) + 1      # SentimentNet: a captured step is stale after this
         self.input.alloc(B)
         for s in self.stages:
             s.alloc(B)

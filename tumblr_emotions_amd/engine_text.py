@@ -52,13 +52,14 @@ class TextTowerEngine:
         self.B = None
         self.reducer = None          # dp.GradientReducer, set by SentimentNet
         self.persistent = True       # False: force the step-wise recurrence (A/B and tests)
-        self.seq_rows = 1            # row groups per workgroup of the persistent kernels (ds_lstm_seq_set_rows)
+        self.seq_rows = 1            # row groups per workgroup of the persistent kernels (`rows` of ds_lstm_seq_fwd/_bwd)
 
     def alloc(self, B):
         if self.B == B:
             return
         dev, T, D, H = self.device, self.T, self.D, self.H
         self.B = B
+        self.alloc_gen = getattr(self, "alloc_gen", 0) + 1
         self.use_seq = self.persistent and ops.lstm_seq_supported(B, H)
         self.seq_ws = torch.zeros(max(ops.lstm_seq_workspace(B, H) // 4, 4), dtype=torch.int32, device=dev)
         self.x = torch.empty(T * B, D, device=dev)                 # time-major embeddings
@@ -108,8 +109,8 @@ class TextTowerEngine:
         ops.gather_rows(self.table, texts, self.x, B, T, self.D, time_major=True)
         self.xproj.run(ops._p(self.x), self.wx, ops._p(self.gates), bias=self.bias)
         if self.use_seq:
-            ops.lstm_seq_set_rows(self.seq_rows)
-            ops.lstm_seq_fwd(self.gates, self.wh, 4 * H, self.h, self.c, seq_lens, T, B, H, FORGET_BIAS, self.seq_ws)
+            ops.lstm_seq_fwd(self.gates, self.wh, 4 * H, self.h, self.c, seq_lens, T, B, H, FORGET_BIAS, self.seq_ws,
+                             rows=self.seq_rows)
             return self.h[T]
         slab = B * 4 * H
         for t in range(T):
@@ -121,12 +122,17 @@ class TextTowerEngine:
                               self.h[t + 1], self.rec_slabs, ns, slab)
         return self.h[T]
 
+    def check_status(self):
+        """Raise if a persistent-LSTM launch since the last check timed out on a hand-off (its h / dgates are then
+        invalid).  Reads two device words: call it where the caller synchronises anyway (loss read-out, logging)."""
+        if self.B is not None and self.use_seq:
+            ops.lstm_seq_status(self.seq_ws, self.B)
+
     def backward(self, dh_last):
         B, T, H = self.B, self.T, self.H
         if self.use_seq:
-            ops.lstm_seq_set_rows(self.seq_rows)
             ops.lstm_seq_bwd(self.gates, self.wh, 4 * H, self.c, dh_last, dh_last.stride(0), self.seq_lens, T, B, H,
-                             self.dgates, self.seq_ws)
+                             self.dgates, self.seq_ws, rows=self.seq_rows)
             return self._weight_grads()
         dh, dh2 = self.dh
         ops.copy2d(dh_last, dh_last.stride(0), dh, H, B, H)
@@ -173,6 +179,7 @@ class JointHeadEngine:
             return
         dev, im, tx, fc, nc = self.device, self.im, self.tx, self.fc, self.nc
         self.B = B
+        self.alloc_gen = getattr(self, "alloc_gen", 0) + 1
         self.dense = torch.empty(B, fc, device=dev)
         self.ddense = torch.empty(B, fc, device=dev)
         self.logits = torch.empty(B, nc, device=dev)
@@ -250,6 +257,7 @@ class TextHeadEngine:
             return
         dev, H, nc = self.device, self.H, self.nc
         self.B = B
+        self.alloc_gen = getattr(self, "alloc_gen", 0) + 1
         self.logits = torch.empty(B, nc, device=dev)
         self.d_tx = torch.empty(B, H, device=dev)
         st = self.store

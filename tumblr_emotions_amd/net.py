@@ -29,7 +29,8 @@ class SentimentNet:
     def __init__(self, mode="joint", nb_emotions=15, im_features_size=256, rnn_size=512, fc_size=512,
                  vocab_size=10000, embedding_dim=300, post_size=32, image_size=224, dropout_keep_prob=0.8,
                  trainable_bn_beta=True, device="cuda", process_group=None, overlap_comm=True,
-                 concurrent_towers=True, train_all=False, trainable_embedding=False, dtype="f32"):
+                 concurrent_towers=True, train_all=False, trainable_embedding=False, dtype="f32",
+                 force_dp_buckets=False):
         assert mode in ("joint", "image", "text")
         self.dtype = dtype
         if not torch.cuda.is_available():
@@ -70,7 +71,8 @@ class SentimentNet:
             # longer time instead of a 256-register wave on every SIMD that mostly waits -- the Winograd conv needs
             # whole SIMDs and could not run beside it (joint step 18.5 -> 17.9 ms; text-only keeps 1: shortest sequence)
             self.text.seq_rows = 4
-        self.reducer = GradientReducer(st.grad, st.n_bucket1, process_group, overlap_comm)
+        self.reducer = GradientReducer(st.grad, st.n_bucket1, process_group, overlap_comm,
+                                       force_buckets=force_dp_buckets)
         self.world = self.reducer.world
         # bucket 1 of the flat gradient is complete once these backward stages have run
         self.reducer.expect(*[n for n, e in (("Mixed_5c", self.image), ("text", self.text), ("head", self.head))
@@ -222,11 +224,21 @@ class SentimentNet:
         return SoftmaxCrossEntropyFunction.apply(logits, labels, self.loss_buf, self.dlogits)
 
     def total_loss_value(self):
-        """Host value of slim.losses.get_total_loss(): CE + sum_conv wd*||W||^2/2 (syncs)."""
+        """Host value of slim.losses.get_total_loss(): CE + sum_conv wd*||W||^2/2 (syncs).  Since this read
+        synchronises anyway it also checks the persistent LSTM's error words (ds_lstm_seq_status) and raises if a
+        launch since the last read timed out on a workgroup hand-off -- its results, and this loss, are invalid."""
         reg = 0.0
         if self.store.n_l2 > 0 or self.frozen_l2_sumsq:
             reg = 0.5 * WEIGHT_DECAY * (self.frozen_l2_sumsq + float(self.l2_buf.item()))
-        return float(self.loss_buf.item()) + reg
+        loss = float(self.loss_buf.item()) + reg
+        self.check_status()
+        return loss
+
+    def check_status(self):
+        """Device-side failure words of the step kernels (today: the persistent LSTM's hand-off timeouts)."""
+        if self.text is not None:
+            torch.cuda.synchronize(self.device)
+            self.text.check_status()
 
     def _rank_seed(self, seed):
         return int(seed) * 4096 + self.reducer.rank
@@ -239,12 +251,15 @@ class SentimentNet:
         lr_t = lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
         # dropout stream: one seed per (step, rank) -- ranks must not share a mask pattern across their shards
         seed = self._rank_seed(self.step) if seed is None else seed
-        if self._graph is not None and self._graph_key == self._batch_key(batch, dropout_mask):
-            # replay of the captured step: only the two per-step scalars change, and they live on the device
-            self.seed_dev.fill_(seed)
-            self.lr_t_dev.fill_(lr_t)
-            self._graph.replay()
-            return self.loss_buf.view(())
+        if self._graph is not None:
+            if self._graph_key == self._batch_key(batch, dropout_mask):
+                # replay of the captured step: only the two per-step scalars change, and they live on the device
+                self.seed_dev.fill_(seed)
+                self.lr_t_dev.fill_(lr_t)
+                self._graph.replay()
+                return self.loss_buf.view(())
+            if self._graph_key[-2:] != self._batch_key(batch, dropout_mask)[-2:]:
+                self.release_graph()     # buffers re-allocated or weights reloaded since the capture: the graph is stale
         for p in self.leaves.values():
             p.grad = None
         logits = self.forward(batch, dropout_mask, seed)
@@ -259,10 +274,13 @@ class SentimentNet:
         return ce
 
     # ---- the same step as one hipGraph ---------------------------------------------------------------
-    @staticmethod
-    def _batch_key(batch, dropout_mask):
+    def _batch_key(self, batch, dropout_mask):
+        # the engines' allocation generation is part of the key: alloc() for another batch size (a predict() in
+        # between) frees every buffer the captured kernels point at, so the old graph must never be replayed
+        gen = tuple(getattr(e, "alloc_gen", 0) for e in (self.image, self.text, self.head) if e is not None)
+        wv = self.image.weights_version if self.image is not None else 0
         return tuple(sorted((k, v.data_ptr(), tuple(v.shape)) for k, v in batch.items())) + (
-            None if dropout_mask is None else dropout_mask.data_ptr(),)
+            None if dropout_mask is None else dropout_mask.data_ptr(), gen, wv)
 
     def _step_kernels(self, batch, dropout_mask):
         """Everything train_step enqueues between the batch and Adam -- forward, CE, L2 term, backward -- with the
@@ -320,7 +338,7 @@ class SentimentNet:
         of ~900 kernel launches, which is what bounds the step below ~64 samples per GPU.  Per-step scalars (Adam's
         lr_t, the dropout seed) are read from device memory.  Single rank only: with data parallelism the RCCL
         all-reduce stays outside a graph and the eager step is used."""
-        if self.world != 1:
+        if self.reducer.active:
             return False
         st = self.store
         # eager warm-up (allocates every buffer, builds every plan) on a snapshot of the optimiser state, so that
@@ -350,6 +368,7 @@ class SentimentNet:
         return True
 
     def release_graph(self):
+        """Drop the captured step (also called by after_load(): a load changes weights the capture baked in)."""
         self._graph = self._graph_key = None
         if self.image is not None:
-            self.image.seed_dev = None
+            self.image.seed_dev = None       # eager steps and predict() take the host seed again

@@ -73,6 +73,7 @@ class ConvPlan:
         self.d = d
         self.M = N * OH * OW
         self.partials = _lib.load().ds_conv_igemm_partials(C.byref(d)) if flags & DS_EPI_STATS else 0
+        d.partials = self.partials      # a launch that would write another count fails instead of corrupting the stats
         # algorithmic FLOPs of one launch (2*M*N*K over the real, unpadded reduction; the folded
         # stem carries a zero 4th input channel that is not counted)
         k_alg = KH * KW * Cin if not fold_cin else KH * (Cin // fold_cin) * 3
@@ -375,31 +376,31 @@ def lstm_seq_supported(B, H):
     return bool(_lib.load().ds_lstm_seq_supported(B, H))
 
 
-def lstm_seq_set_rows(rows):
-    """Row groups per workgroup of the following persistent-LSTM launches (1, 2, 4, 8): scheduling only."""
-    _lib.check(_lib.load().ds_lstm_seq_set_rows(int(rows)), "ds_lstm_seq_set_rows")
-
-
 def lstm_seq_workspace(B, H):
     return int(_lib.load().ds_lstm_seq_workspace(B, H))
 
 
-def lstm_seq_fwd(gates, wh_ptr, ldw, h, c, seq_len, T, B, H, forget_bias, ws):
+def lstm_seq_fwd(gates, wh_ptr, ldw, h, c, seq_len, T, B, H, forget_bias, ws, rows=1):
+    """rows: row groups per workgroup (1, 2, 4, 8) -- scheduling only.  `ws` is zeroed once by its owner."""
     _lib.check(_lib.load().ds_lstm_seq_fwd(_p(gates), wh_ptr, ldw, _p(h), _p(c), _p(seq_len), T, B, H, forget_bias,
-                                           _p(ws), ws.numel() * ws.element_size(), _stream()), "ds_lstm_seq_fwd")
+                                           int(rows), _p(ws), ws.numel() * ws.element_size(), _stream()),
+               "ds_lstm_seq_fwd")
 
 
-def lstm_seq_bwd(acts, wh_ptr, ldw, c, dh_last, ld_dh, seq_len, T, B, H, dgates, ws):
+def lstm_seq_bwd(acts, wh_ptr, ldw, c, dh_last, ld_dh, seq_len, T, B, H, dgates, ws, rows=1):
     _lib.check(_lib.load().ds_lstm_seq_bwd(_p(acts), wh_ptr, ldw, _p(c), _p(dh_last), ld_dh, _p(seq_len), T, B, H,
-                                           _p(dgates), _p(ws), ws.numel() * ws.element_size(), _stream()),
+                                           _p(dgates), int(rows), _p(ws), ws.numel() * ws.element_size(), _stream()),
                "ds_lstm_seq_bwd")
 
 
 def lstm_seq_status(ws, B):
-    """0 = ok; call after a synchronise.  Raises on a hand-off timeout."""
+    """0 = ok; call after a synchronise (it copies two words to the host).  Raises on a hand-off timeout of any
+    forward (bit 0) or backward (bit 1) launch since the workspace was zeroed: the error words are sticky."""
     rc = _lib.load().ds_lstm_seq_status(_p(ws), B)
     if rc != 0:
-        raise RuntimeError("ds_lstm_seq: a workgroup hand-off timed out (status %d): results are invalid" % rc)
+        which = " and ".join(n for b, n in ((1, "forward"), (2, "backward")) if rc > 0 and rc & b) or "status read"
+        raise RuntimeError("ds_lstm_seq: a workgroup hand-off of the %s launch timed out (status %d): the LSTM results "
+                           "of this step are invalid (a workgroup of a row group never became resident)" % (which, rc))
     return rc
 
 

@@ -158,7 +158,7 @@ class SyntheticInput:
                 from .image_model.im_model import load_batch_with_text
                 self._records = load_batch_with_text(self.dataset, self.config["batch_size"], height=224, width=224,
                                                      device=device, rank=rank, world=world, max_token_id=vocab,
-                                                     num_classes=nb)
+                                                     num_classes=getattr(self.dataset, "num_classes", nb))
             b = next(self._records)
             if not with_images:
                 b.pop("images")
