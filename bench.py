@@ -171,6 +171,9 @@ def main():
                     help="Mixed backward: fused 1x1 dgrad writes the block-input gradient and the Branch_3 pool adds (default: the reverse)")
     ap.add_argument("--no-stem-direct", action="store_true",
                     help="Conv2d_1a_7x7 through the generic kernel on a 4-channel copy (default: ds_conv_stem on the packed RGB batch)")
+    ap.add_argument("--no-bwd-sums", action="store_true",
+                    help="A/B aid: BatchNorm backward sums by the separate ds_bn_bwd_reduce pass everywhere (default: from the "
+                         "epilogue of the producing dgrad where the kernel can, DS_EPI_BNSUMS)")
     ap.add_argument("--no-branch-streams", action="store_true",
                     help="Mixed blocks on one stream (default: Branch_2 / Branch_3 on side streams)")
     ap.add_argument("--bf16-staged", action="store_true",
@@ -242,6 +245,8 @@ def main():
         net.image.branch_streams = False
     if args.side_mode >= 0 and net.image is not None:
         net.image.one_side_stream = args.side_mode
+    if args.no_bwd_sums and net.image is not None:
+        net.image.bwd_sums = False
     if args.no_pool_first and net.image is not None:
         net.image.pool_first = False
     if args.no_stem_direct and net.image is not None:
@@ -394,11 +399,19 @@ def main():
             out["cpu_baseline"] = cpu_baseline(T, V, D, H, args.cpu_warmup, args.cpu_steps)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
     if world > 1:
-        barrier()            # rank 0 is still printing / timing the gather: leave together
+        barrier()            # rank 0 is still timing the gather / the CPU baseline: leave together
     if world > 1 or force_dp:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which sits in a
+        # buffer until it is flushed -- flush it first
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -41,6 +41,11 @@ extern "C" {
 #define DS_EPI_ACCUM 4     /* z += previous contents of z          (AddN of two gradient paths)     */
 #define DS_EPI_STATS 8     /* emit per-column sum / sum-of-squares partials for BatchNorm           */
 #define DS_EPI_MASK 16     /* z *= (mask[row*ldmask+col] > 0)      (ReluGrad)                       */
+#define DS_EPI_BNSUMS 32   /* Conv2DBackpropInput whose result dy feeds a BatchNorm+ReLU backward: emit the  */
+                           /* per-column partials of sum(g) and sum(g*y), g = dy*(y > 0), y = mask[row*ldmask */
+                           /* + col] = the forward activation relu(bn(z)) of the layer that consumes dy.  They */
+                           /* replace that layer's ds_bn_bwd_reduce pass over z and dy (ds_bn_bwd_finalize_segs,*/
+                           /* kind 1).  Layout float[2][Cout][P] like DS_EPI_STATS; excludes STATS and MASK.     */
 
 int ds_version(void);
 const char *ds_last_error(void);
@@ -96,6 +101,8 @@ int ds_debug_conv_set_path(int path);
 int ds_debug_conv_set_wide(int mode);
 /* Number of row-tile blocks (P) the launch for `d` will use = number of stats partials.   */
 int ds_conv_igemm_partials(const ds_conv_desc *d);
+/* 1 if a launch for `d` can carry DS_EPI_BNSUMS (plain 1x1 stride-1 shapes that run on the wide kernel).  */
+int ds_conv_igemm_bnsums_supported(const ds_conv_desc *d);
 /* stats (DS_EPI_STATS): float[2][Cout][P] partial column sums of (z - pivot) and (z - pivot)^2.
  * pivot (nullable = 0): float[Cout], any value near the column mean -- the build passes the previous step's
  * batch mean (the moving mean after a restore) -- so that the fp32 partial sums carry the spread of z rather
@@ -132,13 +139,15 @@ int ds_conv_stem(const float *x, const float *w, float *z, float *stats, const f
  *            tensor w [3][3][Cin_w][Cout_w] whenever w changes.  dgrad = 0: forward (Cin = Cin_w, Cout = Cout_w);
  *            dgrad = 1: input gradient -- flipped taps, channel roles swapped (the conv then runs over dz with
  *            Cin = Cout_w, Cout = Cin_w).  ds_wino_transform_weights takes (Cin_w, Cout_w) either way.
- *   x, z   NHWC with pixel strides ldx / ldz; Cin % 8 == 0; flags: 0 or DS_EPI_STATS (partials float[2][Cout][P],
- *          P = ds_conv_wino_partials, about `pivot` like ds_conv_igemm).
+ *   x, z   NHWC with pixel strides ldx / ldz; Cin % 8 == 0; flags: 0, DS_EPI_STATS (partials float[2][Cout][P],
+ *          P = ds_conv_wino_partials, about `pivot` like ds_conv_igemm) or DS_EPI_BNSUMS (dgrad: partials of sum g,
+ *          sum g*y with y = ymask[pixel*ldz + channel], the consumer layer's forward activation; same layout).
  * Results equal the direct kernels' to ~1e-6 relative (the transforms round differently), deterministically.   */
 int ds_wino_transform_weights(const float *w, float *u, int32_t Cin, int32_t Cout, int32_t dgrad, void *stream);
 int ds_conv_wino_partials(int32_t N, int32_t H, int32_t W);
-int ds_conv_wino(const float *x, const float *u, float *z, float *stats, const float *pivot, int32_t N, int32_t H,
-                 int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz, int32_t flags, void *stream);
+int ds_conv_wino(const float *x, const float *u, float *z, float *stats, const float *pivot, const float *ymask,
+                 int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz, int32_t flags,
+                 void *stream);
 
 /* Conv2DBackpropFilter / MatMul-transposed (wgrad), split over pixels.
  *   dw[tap, ci, co] = sum_m x[pixel(m)+tap, ci] * dz[m, co]
@@ -174,10 +183,26 @@ int ds_bn_infer_prepare(const float *beta, const float *moving_mean, const float
 /* BatchNorm(train)+ReLU backward: g = dy*(y>0); dbeta = sum g; dz = rstd*(g - mean(g) - xhat*mean(g*xhat)).
  * dy is gathered from the same segments the forward scattered to.                          */
 int ds_bn_bwd_partials(int64_t M, int32_t C);
-int ds_bn_bwd_reduce(const float *z, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
+/* z: [M, ldz] (ldz >= C: a column sub-range of a layer is reduced by passing z, mean, rstd, shift offset to its
+ * first channel and dy segments numbered from 0); partials float[2][C][P].                                     */
+int ds_bn_bwd_reduce(const float *z, int32_t ldz, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
                      const float *rstd, const float *shift, float *partials, void *stream);
 int ds_bn_bwd_finalize(const float *partials, int32_t P, int64_t M, int32_t C, float *dbeta, float *coef,
                        void *stream);
+/* The same finalize when the sums of a layer's column segments come from different producers: kind 0 = partials of
+ * ds_bn_bwd_reduce over that column range (sum g, sum g*xhat); kind 1 = partials a dgrad launch emitted with
+ * DS_EPI_BNSUMS (sum g, sum g*y: for y > 0, y = xhat + beta, so sum g*xhat = sum g*y - beta*sum g).  s[i] / q[i] point
+ * at the P[i] partials of the segment's first channel; channel c of the segment is P[i]*(c - c_begin[i]) further. */
+typedef struct ds_bn_sum_segments {
+    int32_t nseg;
+    int32_t c_begin[4], c_end[4];
+    int32_t P[4];
+    int32_t kind[4];
+    const float *s[4];
+    const float *q[4];
+} ds_bn_sum_segments;
+int ds_bn_bwd_finalize_segs(const ds_bn_sum_segments *sg, int64_t M, int32_t C, const float *beta, float *dbeta,
+                            float *coef, void *stream);
 int ds_bn_bwd_apply(const float *z, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
                     const float *rstd, const float *shift, const float *coef, float *dz, void *stream);
 

@@ -86,3 +86,22 @@ def test_lstm_seq_entry_points_take_rows_and_keep_no_global(lib):
     assert l.ds_lstm_seq_supported(256, 512) == 1 and l.ds_lstm_seq_supported(256, 48) == 0
     # argument errors are reported before anything is launched (no device needed)
     assert l.ds_lstm_seq_fwd(None, None, 0, None, None, None, 1, 1, 32, 1.0, 1, None, 0, None) == -1
+
+
+def test_no_undefined_names_in_python_sources():
+    """scripts/lint_names.py over the package, the tests and bench.py (a NameError that only shows on the GPU box costs
+    minutes of its budget: no pyflakes is installed here)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lint_names", os.path.join(ROOT, "scripts", "lint_names.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    paths = [os.path.join(ROOT, p) for p in ("tumblr_emotions_amd", "tests", "bench.py", "__graft_entry__.py")]
+    files = []
+    for a in paths:
+        if os.path.isdir(a):
+            for d, _, fs in os.walk(a):
+                files += [os.path.join(d, f) for f in fs if f.endswith(".py")]
+        else:
+            files.append(a)
+    bad = [b for f in sorted(files) for b in m.check(f)]
+    assert not bad, bad

@@ -16,6 +16,22 @@ pytestmark = pytest.mark.gpu
 TEXT = dict(nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10)
 
 
+def _collect(out, procs, n, timeout=600):
+    """n results from the queue; a worker that died (exception on the GPU box) fails the test at once instead of
+    after the queue timeout."""
+    import queue
+    import time
+    got, t0 = [], time.time()
+    while len(got) < n:
+        try:
+            got.append(out.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, "a worker exited with %s" % dead
+            assert time.time() - t0 < timeout, "timeout waiting for the workers"
+    return got
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -56,7 +72,7 @@ def test_two_rank_data_parallel_steps_on_one_gpu():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict(out.get(timeout=300) for _ in range(2))
+    got = dict(_collect(out, procs, 2))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -124,7 +140,7 @@ def test_rccl_single_rank_bucketed_allreduce_is_the_identity():
     out = ctx.Queue()
     p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), out))
     p.start()
-    res = out.get(timeout=600)
+    res = _collect(out, [p], 1)[0]
     p.join(60)
     assert p.exitcode == 0
     assert res["rccl_ranks"] == 1 and res["backend"] == "nccl"

@@ -264,8 +264,22 @@ def test_winograd_conv_forward_and_dgrad_match_oracle(case):
     if Co % 8 == 0:
         g.run(ops._p(dyd), ops._p(ud), ops._p(dx))
         torch.cuda.synchronize()
-        close(dx[:, :Ci], S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1).reshape(-1, Ci), 2e-4)
+        dx_ref = S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1).reshape(-1, Ci)
+        close(dx[:, :Ci], dx_ref, 2e-4)
         assert float(dx[:, Ci:].abs().max()) == 0.0
+        # DS_EPI_BNSUMS: the dgrad also emits, per column, sum(g) and sum(g*y) with g = dx (y > 0), y the forward
+        # activation of the layer whose BatchNorm backward consumes dx (same pixel stride as dx)
+        yv = np.maximum(rng.normal(size=(M, Ci)), 0.0) * (rng.uniform(size=(M, Ci)) < 0.7)
+        yd = dev(np.pad(yv, ((0, 0), (0, 4)), constant_values=5.0))          # positive garbage in the row padding
+        P = g.enable_bnsums()
+        sums = torch.full((2, Ci, P), float("nan"), device="cuda")
+        dx2 = torch.zeros(M, Ci + 4, device="cuda")
+        g.run(ops._p(dyd), ops._p(ud), ops._p(dx2), stats=ops._p(sums), ymask=ops._p(yd))
+        torch.cuda.synchronize()
+        assert torch.equal(dx2, dx)
+        gm = dx_ref * (yv > 0)
+        close(sums[0].sum(1), gm.sum(0), 2e-3)
+        close(sums[1].sum(1), (gm * yv).sum(0), 2e-3)
 
 
 @pytest.mark.parametrize("case", [(300, 64, 64), (1000, 192, 176), (777, 480, 304), (513, 296, 512), (260, 40, 96),
@@ -314,8 +328,88 @@ def test_wide_1x1_kernel_forward_and_dgrad_match_oracle(case):
             g.run(ops._p(dzd), ops._p(wd), ops._p(dx))
             torch.cuda.synchronize()
             close(dx, prev + dz @ w.T)
+            # DS_EPI_BNSUMS (+ ACCUM): column sums of g = dx_final (y > 0) and g * y next to the stores
+            yv = np.maximum(rng.normal(size=(M, K)), 0.0) * (rng.uniform(size=(M, K)) < 0.7)
+            yd = dev(np.pad(yv, ((0, 0), (0, 4)), constant_values=3.0))
+            assert lib.ds_conv_igemm_bnsums_supported(C.byref(g.d)) == 1
+            P = g.enable_bnsums(K + 4)
+            g.d.flags |= ops.DS_EPI_ACCUM
+            sums = torch.full((2, K, P), float("nan"), device="cuda")
+            dx.copy_(dev(prev))
+            g.run(ops._p(dzd), ops._p(wd), ops._p(dx), mask=ops._p(yd), stats=ops._p(sums))
+            torch.cuda.synchronize()
+            full = prev + dz @ w.T
+            close(dx, full)
+            gm = full * (yv > 0)
+            close(sums[0].sum(1), gm.sum(0), 2e-3)
+            close(sums[1].sum(1), (gm * yv).sum(0), 2e-3)
     finally:
         lib.ds_debug_conv_set_wide(1)
+
+
+def test_bn_backward_sums_from_mixed_sources_match_the_single_pass():
+    """ds_bn_bwd_finalize_segs: a layer whose output gradient comes in three parts -- the sums of part 0 and part 2
+    emitted by the producing dgrads (DS_EPI_BNSUMS form: sum g, sum g*y over y > 0, with different partial counts),
+    part 1 reduced over its column range by ds_bn_bwd_reduce (ldz > C) -- gives the dbeta / mean(g) / mean(g*xhat) of
+    the single-pass reduce over the whole layer, and of the oracle."""
+    ops = _ops()
+    rng = np.random.RandomState(77)
+    M, Cc = 1500, 96
+    parts = [(0, 40), (40, 72), (72, 96)]
+    z = rng.normal(size=(M, Cc)) * 1.3 + rng.normal(size=Cc)
+    beta = rng.normal(size=Cc) * 0.3
+    mean, var = z.mean(0), z.var(0)
+    rstd = 1.0 / np.sqrt(var + 1e-3)
+    shift = beta - mean * rstd
+    y = np.maximum(z * rstd + shift, 0.0)
+    dy = rng.normal(size=(M, Cc))
+    g = dy * (y > 0)
+    xhat = (z - mean) * rstd
+    zd, dyd = dev(z), dev(dy)
+    mean_d, rstd_d, shift_d, beta_d = dev(mean), dev(rstd), dev(shift), dev(beta)
+    # reference: the single-pass kernels
+    P0 = ops.bn_bwd_partials(M, Cc)
+    part = torch.empty(2 * Cc * P0, device="cuda")
+    dbeta0, coef0 = torch.empty(Cc, device="cuda"), torch.empty(2, Cc, device="cuda")
+    ops.bn_bwd_reduce(zd, ops.make_segments([(0, Cc, dyd.data_ptr(), Cc)]), M, Cc, mean_d, rstd_d, shift_d, part)
+    ops.bn_bwd_finalize(part, P0, M, Cc, dbeta0, coef0)
+    # mixed sources
+    sg = ops.SumSegments()
+    sg.nseg = 3
+    keep = []
+    for i, (c0, c1) in enumerate(parts):
+        sg.c_begin[i], sg.c_end[i] = c0, c1
+        n = c1 - c0
+        if i == 1:
+            scratch = torch.empty(2 * n * P0, device="cuda")
+            ops.bn_bwd_reduce(C.c_void_p(zd.data_ptr() + 4 * c0), ops.make_segments([(0, n, dyd.data_ptr() + 4 * c0, Cc)]),
+                              M, n, C.c_void_p(mean_d.data_ptr() + 4 * c0), C.c_void_p(rstd_d.data_ptr() + 4 * c0),
+                              C.c_void_p(shift_d.data_ptr() + 4 * c0), C.c_void_p(scratch.data_ptr()), ldz=Cc)
+            sg.P[i], sg.kind[i] = P0, 0
+            sg.s[i], sg.q[i] = scratch.data_ptr(), scratch.data_ptr() + 4 * n * P0
+            keep.append(scratch)
+        else:
+            # what a dgrad with DS_EPI_BNSUMS leaves behind: P row-block partials of sum g and sum g*y inside a wider
+            # [2][Ctot][P] buffer (this part starts at column `off` of the producer's Ctot columns)
+            P, off, ctot = (7, 8, 64) if i == 0 else (13, 0, n)
+            rows = np.array_split(np.arange(M), P)
+            buf = np.full((2, ctot, P), np.nan)
+            for pi, r in enumerate(rows):
+                buf[0, off:off + n, pi] = g[r][:, c0:c1].sum(0)
+                buf[1, off:off + n, pi] = (g[r][:, c0:c1] * y[r][:, c0:c1]).sum(0)
+            bd = dev(buf)
+            sg.P[i], sg.kind[i] = P, 1
+            sg.s[i] = bd.data_ptr() + 4 * off * P
+            sg.q[i] = bd.data_ptr() + 4 * (ctot + off) * P
+            keep.append(bd)
+    dbeta, coef = torch.empty(Cc, device="cuda"), torch.empty(2, Cc, device="cuda")
+    ops.bn_bwd_finalize_segs(sg, M, Cc, beta_d, dbeta, coef)
+    torch.cuda.synchronize()
+    close(dbeta, g.sum(0), 2e-5)
+    close(coef[0], g.mean(0), 2e-5)
+    close(coef[1], (g * xhat).mean(0), 1e-4)
+    close(dbeta, dbeta0.cpu().numpy().astype(np.float64), 2e-6)
+    close(coef[1], coef0[1].cpu().numpy().astype(np.float64), 1e-4)
 
 
 def _bf16_round(a):

@@ -383,6 +383,34 @@ def test_captured_step_matches_eager_step(mode):
     assert torch.equal(z0, z1) and torch.equal(th0, th1) and torch.equal(fr0, fr1)
 
 
+def test_bn_sums_from_dgrad_epilogues_equal_the_separate_reduce_pass():
+    """InceptionV1Engine.bwd_sums: the BatchNorm backward sums of most layers come out of the epilogue of the dgrad
+    that produces their output gradient (DS_EPI_BNSUMS: wide 1x1 and Winograd kernels) instead of a ds_bn_bwd_reduce
+    pass.  Same mathematics, different summation order: every gradient of a training step agrees with the
+    separate-pass step to 1e-5 of its norm, and the switch really changes which kernels run."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    batch = to_device(synthetic_batch_numpy(16, 10, 50, seed=2))
+    grads, used = [], []
+    for on in (True, False):
+        net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10)
+        net.image.bwd_sums = on
+        net.initialize(seed=3)
+        net.train_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        grads.append(net.store.grad.clone())
+        used.append(sum(1 for l in net.image.layers if l.dy_parts is not None and any(ps is not None for ps in l.part_sums)))
+    assert used[0] >= 15 and used[1] == 0, used
+    st = net.store
+    worst = 0.0
+    for e in st.entries.values():
+        if e.trainable:
+            a, b = (g[e.offset:e.offset + e.numel].double() for g in grads)
+            worst = max(worst, float((a - b).norm() / max(float(b.norm()), 1e-30)))
+    print("%d layers take their BatchNorm sums from a dgrad epilogue; worst gradient difference %.2e" % (used[0], worst))
+    assert worst <= 1e-5
+
+
 def test_captured_step_is_dropped_when_buffers_or_weights_change():
     """A hipGraph bakes in buffer addresses and (for the frozen 3x3 layers) the transformed filters.  After a
     predict() at another batch size re-allocated the engines' buffers, or after a load changed the weights, a

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libds_kernels.so")
 
-DS_EPI_BIAS, DS_EPI_RELU, DS_EPI_ACCUM, DS_EPI_STATS, DS_EPI_MASK = 1, 2, 4, 8, 16
+DS_EPI_BIAS, DS_EPI_RELU, DS_EPI_ACCUM, DS_EPI_STATS, DS_EPI_MASK, DS_EPI_BNSUMS = 1, 2, 4, 8, 16, 32
 DS_DTYPE_F32, DS_DTYPE_BF16 = 0, 1
 
 
@@ -30,10 +30,16 @@ class Segments(C.Structure):
                 ("ld", C.c_int32 * 4), ("ptr", C.c_void_p * 4)]
 
 
+class SumSegments(C.Structure):
+    _fields_ = [("nseg", C.c_int32), ("c_begin", C.c_int32 * 4), ("c_end", C.c_int32 * 4), ("P", C.c_int32 * 4),
+                ("kind", C.c_int32 * 4), ("s", C.c_void_p * 4), ("q", C.c_void_p * 4)]
+
+
 _P = C.c_void_p
 _i32, _i64, _f32, _u64 = C.c_int32, C.c_int64, C.c_float, C.c_uint64
 _CD = C.POINTER(ConvDesc)
 _SG = C.POINTER(Segments)
+_SS = C.POINTER(SumSegments)
 
 # name -> (restype, argtypes); mirrors include/ds_kernels.h one to one
 SIGNATURES = {
@@ -43,6 +49,7 @@ SIGNATURES = {
     "ds_debug_conv_set_path": (C.c_int, [C.c_int]),
     "ds_debug_conv_set_wide": (C.c_int, [C.c_int]),
     "ds_conv_igemm_partials": (C.c_int, [_CD]),
+    "ds_conv_igemm_bnsums_supported": (C.c_int, [_CD]),
     "ds_conv_igemm": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ds_weights_bf16_bytes": (C.c_size_t, [_i32, _i32, _i32, _i32]),
     "ds_weights_to_bf16": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _P]),
@@ -53,14 +60,15 @@ SIGNATURES = {
     "ds_conv_stem": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "ds_wino_transform_weights": (C.c_int, [_P, _P, _i32, _i32, _i32, _P]),
     "ds_conv_wino_partials": (C.c_int, [_i32, _i32, _i32]),
-    "ds_conv_wino": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
+    "ds_conv_wino": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "ds_conv_wgrad_workspace": (C.c_size_t, [_CD]),
     "ds_conv_wgrad": (C.c_int, [_CD, _P, _P, _i32, _P, _P, C.c_size_t, _P]),
     "ds_bn_finalize": (C.c_int, [_P, _i32, _i64, _i32, _P, _P, _f32, _f32, _P, _P, _P, _P, _P, _P]),
     "ds_bn_apply_relu": (C.c_int, [_P, _i64, _i32, _P, _P, _SG, _P]),
     "ds_bn_infer_prepare": (C.c_int, [_P, _P, _P, _f32, _i32, _P, _P, _P]),
     "ds_bn_bwd_partials": (C.c_int, [_i64, _i32]),
-    "ds_bn_bwd_reduce": (C.c_int, [_P, _SG, _i64, _i32, _P, _P, _P, _P, _P]),
+    "ds_bn_bwd_reduce": (C.c_int, [_P, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _P]),
+    "ds_bn_bwd_finalize_segs": (C.c_int, [_SS, _i64, _i32, _P, _P, _P, _P]),
     "ds_bn_bwd_finalize": (C.c_int, [_P, _i32, _i64, _i32, _P, _P, _P]),
     "ds_bn_bwd_apply": (C.c_int, [_P, _SG, _i64, _i32, _P, _P, _P, _P, _P, _P]),
     "ds_maxpool_fwd": (C.c_int, [_P, _P, _P] + [_i32] * 10 + [_P]),

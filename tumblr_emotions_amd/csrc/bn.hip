@@ -126,7 +126,7 @@ int bwd_rows_per_block(int64_t M) {
     return (int)r;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *z, SegDev dy, int64_t M, int C,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *z, int ldz, SegDev dy, int64_t M, int C,
                                                             const float *mean, const float *rstd,
                                                             const float *shift, float *partials, int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) float sh[];   // [RG][C4][8]
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *z, SegD
             float4 zv[4], dv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                zv[u] = *reinterpret_cast<const float4 *>(z + (row + u * RG) * C + c);
+                zv[u] = *reinterpret_cast<const float4 *>(z + (row + u * RG) * ldz + c);
                 dv[u] = *reinterpret_cast<const float4 *>(seg_addr(dy, row + u * RG, c));
             }
 #pragma unroll
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *z, SegD
             }
         }
         for (; row < r1; row += RG) {
-            const float4 zv = *reinterpret_cast<const float4 *>(z + row * C + c);
+            const float4 zv = *reinterpret_cast<const float4 *>(z + row * ldz + c);
             const float4 dv = *reinterpret_cast<const float4 *>(seg_addr(dy, row, c));
             const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
@@ -225,6 +225,53 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *parti
             coef[c] = (float)(s * inv_count);          // mean(g)
             coef[C + c] = (float)(q * inv_count);      // mean(g*xhat)
         }
+    }
+}
+
+// Finalize from up to four column segments whose sums come from different producers:
+//   kind 0: partials of ds_bn_bwd_reduce over that column range          (sum g, sum g*xhat)
+//   kind 1: partials a dgrad kernel emitted with DS_EPI_BNSUMS            (sum g, sum g*y over y > 0)
+// For y > 0, y = xhat + beta (y = z*rstd + beta - mean*rstd), so sum g*xhat = sum g*y - beta * sum g.
+struct SumSegDev {
+    int nseg;
+    int c_begin[4], c_end[4], P[4], kind[4];
+    const float *s[4], *q[4];
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_segs_kernel(SumSegDev sg, double inv_count, int C, const float *beta,
+                                                                   float *dbeta, float *coef) {
+    __shared__ double red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x;
+    int P = 0, kind = 0;
+    const float *sp = nullptr, *qp = nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < sg.nseg && c >= sg.c_begin[i] && c < sg.c_end[i]) {
+            P = sg.P[i];
+            kind = sg.kind[i];
+            sp = sg.s[i] + (int64_t)(c - sg.c_begin[i]) * P;
+            qp = sg.q[i] + (int64_t)(c - sg.c_begin[i]) * P;
+        }
+    double s = 0.0, q = 0.0;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        s += (double)sp[p];
+        q += (double)qp[p];
+    }
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    if (lane == 0) {
+        red[0][wave] = s;
+        red[1][wave] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        q = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        if (kind == 1) q -= (double)beta[c] * s;
+        if (dbeta) dbeta[c] = (float)s;
+        coef[c] = (float)(s * inv_count);
+        coef[C + c] = (float)(q * inv_count);
     }
 }
 
@@ -314,16 +361,18 @@ extern "C" int ds_bn_bwd_partials(int64_t M, int32_t C) {
     return (int)((M + rpb - 1) / rpb);
 }
 
-extern "C" int ds_bn_bwd_reduce(const float *z, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
-                                const float *rstd, const float *shift, float *partials, void *stream) {
-    DS_REQUIRE(z && mean && rstd && shift && partials && M > 0 && C > 0 && C % 4 == 0 && C <= 1024,
-               "ds_bn_bwd_reduce: bad argument (need C %% 4 == 0, C <= 1024)");
+extern "C" int ds_bn_bwd_reduce(const float *z, int32_t ldz, const ds_segments *dy, int64_t M, int32_t C,
+                                const float *mean, const float *rstd, const float *shift, float *partials,
+                                void *stream) {
+    DS_REQUIRE(z && mean && rstd && shift && partials && M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldz >= C &&
+                   ldz % 4 == 0 && (((uintptr_t)z | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)shift) & 15) == 0,
+               "ds_bn_bwd_reduce: bad argument (need C %% 4 == 0, C <= 1024, ldz %% 4 == 0, 16-byte aligned pointers)");
     if (int e = check_segments(dy, C, "ds_bn_bwd_reduce")) return e;
     const int C4 = C / 4;
     const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
     const size_t shmem = (size_t)RG * C4 * 8 * sizeof(float);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ds_bn_bwd_partials(M, C)), dim3(256), shmem, (hipStream_t)stream,
-                       z, to_dev(dy), M, C, mean, rstd, shift, partials, bwd_rows_per_block(M));
+                       z, ldz, to_dev(dy), M, C, mean, rstd, shift, partials, bwd_rows_per_block(M));
     return ds::check_launch("ds_bn_bwd_reduce");
 }
 
@@ -333,6 +382,28 @@ extern "C" int ds_bn_bwd_finalize(const float *partials, int32_t P, int64_t M, i
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, P,
                        1.0 / (double)M, C, dbeta, coef);
     return ds::check_launch("ds_bn_bwd_finalize");
+}
+
+extern "C" int ds_bn_bwd_finalize_segs(const ds_bn_sum_segments *sg, int64_t M, int32_t C, const float *beta,
+                                       float *dbeta, float *coef, void *stream) {
+    DS_REQUIRE(sg && coef && M > 0 && C > 0 && sg->nseg >= 1 && sg->nseg <= 4, "ds_bn_bwd_finalize_segs: bad argument");
+    SumSegDev d;
+    d.nseg = sg->nseg;
+    int covered = 0;
+    for (int i = 0; i < 4; ++i) {
+        d.c_begin[i] = sg->c_begin[i]; d.c_end[i] = sg->c_end[i]; d.P[i] = sg->P[i]; d.kind[i] = sg->kind[i];
+        d.s[i] = sg->s[i]; d.q[i] = sg->q[i];
+        if (i < sg->nseg) {
+            DS_REQUIRE(sg->s[i] && sg->q[i] && sg->P[i] > 0 && sg->c_end[i] > sg->c_begin[i] && (sg->kind[i] == 0 || sg->kind[i] == 1),
+                       "ds_bn_bwd_finalize_segs: segment %d is malformed", i);
+            DS_REQUIRE(sg->kind[i] == 0 || beta, "ds_bn_bwd_finalize_segs: DS_EPI_BNSUMS partials need beta");
+            covered += sg->c_end[i] - sg->c_begin[i];
+        }
+    }
+    DS_REQUIRE(covered == C, "ds_bn_bwd_finalize_segs: segments cover %d of %d channels", covered, C);
+    hipLaunchKernelGGL(bn_bwd_finalize_segs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, d, 1.0 / (double)M, C,
+                       beta, dbeta, coef);
+    return ds::check_launch("ds_bn_bwd_finalize_segs");
 }
 
 extern "C" int ds_bn_bwd_apply(const float *z, const ds_segments *dy, int64_t M, int32_t C, const float *mean,

@@ -1222,19 +1222,43 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
         const bool colok = item && col < d.Cout;
         const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
         float s = 0.f, q = 0.f;
+        if (flags & DS_EPI_BNSUMS) {
+            // dgrad whose result dy feeds a BatchNorm + ReLU backward: column sums of g = dy (y > 0) and g * y, y = the
+            // consumer layer's forward activation (same rows / columns as dy).  The y values are requested up front so
+            // they arrive under the accumulate reads and the stores.
+            float yv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row < p.M && colok) {
-                float v = acc[b][r];
-                if (flags & DS_EPI_ACCUM) v += p.z[(int64_t)row * d.ldz + col];
-                p.z[(int64_t)row * d.ldz + col] = v;
-                const float u = v - pv;
-                s += u;
-                q += u * u;
+            for (int r = 0; r < 16; ++r) {
+                const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                yv[r] = (row < p.M && colok) ? p.mask[(int64_t)row * d.ldmask + col] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < p.M && colok) {
+                    float v = acc[b][r];
+                    if (flags & DS_EPI_ACCUM) v += p.z[(int64_t)row * d.ldz + col];
+                    p.z[(int64_t)row * d.ldz + col] = v;
+                    const float u = yv[r] > 0.f ? v : 0.f;
+                    s += u;
+                    q += u * yv[r];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < p.M && colok) {
+                    float v = acc[b][r];
+                    if (flags & DS_EPI_ACCUM) v += p.z[(int64_t)row * d.ldz + col];
+                    p.z[(int64_t)row * d.ldz + col] = v;
+                    const float u = v - pv;
+                    s += u;
+                    q += u * u;
+                }
             }
         }
-        if (flags & DS_EPI_STATS) {
+        if (flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) {
             s += __shfl_xor(s, 32);
             q += __shfl_xor(q, 32);
             __syncthreads();
@@ -1572,7 +1596,7 @@ int wide_nb(const ds_conv_desc *d, bool vec) {
     }
     if (!force_wide || !vec || d->dtype != DS_DTYPE_F32) return 0;
     if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->fold_cin || d->splits > 1) return 0;
-    if (d->flags & ~(DS_EPI_STATS | DS_EPI_ACCUM)) return 0;
+    if (d->flags & ~(DS_EPI_STATS | DS_EPI_ACCUM | DS_EPI_BNSUMS)) return 0;
     if (d->Cin % 8 != 0 || d->Cin < 32) return 0;
     const int64_t M = conv_M(d);
     const int N = d->Cout;
@@ -1767,6 +1791,15 @@ extern "C" int ds_conv_igemm_partials(const ds_conv_desc *d) {
     return c.direct ? gx * 4 : gx;
 }
 
+extern "C" int ds_conv_igemm_bnsums_supported(const ds_conv_desc *d) {
+    // DS_EPI_BNSUMS lives in the wide 1x1 kernel's epilogue: supported where that kernel is the one chosen (16-byte
+    // aligned operands assumed, as for ds_conv_igemm_partials)
+    if (!d) return 0;
+    ds_conv_desc t = *d;
+    t.flags = (t.flags & DS_EPI_ACCUM) | DS_EPI_BNSUMS;
+    return wide_nb(&t, dims_vec(&t)) > 0 ? 1 : 0;
+}
+
 extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float *w, float *z, const float *bias,
                              const float *mask, float *stats, const float *pivot, void *stream) {
     DS_REQUIRE(d && x && w && z, "ds_conv_igemm: null argument");
@@ -1775,6 +1808,8 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     DS_REQUIRE(!(d->flags & DS_EPI_BIAS) || bias, "ds_conv_igemm: DS_EPI_BIAS without bias");
     DS_REQUIRE(!(d->flags & DS_EPI_MASK) || mask, "ds_conv_igemm: DS_EPI_MASK without mask");
     DS_REQUIRE(!(d->flags & DS_EPI_STATS) || stats, "ds_conv_igemm: DS_EPI_STATS without stats buffer");
+    DS_REQUIRE(!(d->flags & DS_EPI_BNSUMS) || (stats && mask && !(d->flags & (DS_EPI_STATS | DS_EPI_MASK)) && d->ldmask >= d->Cout),
+               "ds_conv_igemm: DS_EPI_BNSUMS needs the partials buffer (stats), y (mask, ldmask) and excludes STATS / MASK");
     DS_REQUIRE(conv_M(d) < (1ll << 31), "ds_conv_igemm: M too large");
     DS_REQUIRE(d->dtype == DS_DTYPE_F32 || d->dtype == DS_DTYPE_BF16, "ds_conv_igemm: dtype must be DS_DTYPE_F32 or DS_DTYPE_BF16");
     const Variant v = variant_of(d, x, w);
@@ -1816,7 +1851,9 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     grid_for(d, c, v, &gx, &gy, &rt, &one);
     // the statistics partial count the caller planned with (ds_conv_igemm_partials at plan time) must be the one this
     // launch writes: the tile choice depends on debug switches / environment caches that may have changed since
-    DS_REQUIRE(!(d->flags & DS_EPI_STATS) || d->partials <= 0 || d->partials == (c.direct ? gx * 4 : gx),
+    DS_REQUIRE(!(d->flags & DS_EPI_BNSUMS) || c.wide,
+               "ds_conv_igemm: DS_EPI_BNSUMS is implemented by the wide 1x1 kernel only (ds_conv_igemm_bnsums_supported)");
+    DS_REQUIRE(!(d->flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) || d->partials <= 0 || d->partials == (c.direct ? gx * 4 : gx),
                "ds_conv_igemm: the launch would write %d statistics partials but the plan was made for %d "
                "(a ds_debug_conv_set_* switch changed after planning?)", c.direct ? gx * 4 : gx, d->partials);
     p.row_tiles = rt;

@@ -45,6 +45,7 @@ struct WinoParams {
     float *z;               // [N, H, W, ldz]
     float *stats;           // [2][Cout][P], P = groups
     const float *pivot;
+    const float *y;         // DS_EPI_BNSUMS: forward activation of the layer that consumes z (= dy), same pixel stride ldz
     int N, H, W, Cin, ldx, Cout, ldz;
     int TH, TW, Mt;         // output tiles per column / row / in total
     int groups, ncol;       // 128-tile groups, 32-channel blocks
@@ -71,6 +72,7 @@ __device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
     return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
+template <bool BNS>      // BNS: DS_EPI_BNSUMS epilogue (its own instantiation: the plain kernel's code is untouched)
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     // B tile of one K step: [16 positions][32 channels][8 ci] floats = 16 KB, two buffers
     __shared__ __attribute__((aligned(128))) float smem[2 * 16 * 32 * 8];
@@ -214,39 +216,113 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     const unsigned right = (unsigned)p.ldz * 4u, below = (unsigned)(p.W * p.ldz) * 4u;
     const unsigned cbyte = colok ? (unsigned)col * 4u : kOOB;
     float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int row0 = (e & 3) + 8 * (e >> 2);
-        const unsigned ob0 = __builtin_amdgcn_readlane(obase, row0), ob1 = __builtin_amdgcn_readlane(obase, row0 + 4);
-        const int of0 = __builtin_amdgcn_readlane(oflags, row0), of1 = __builtin_amdgcn_readlane(oflags, row0 + 4);
-        const unsigned ob = kh ? ob1 : ob0;
-        const int of = kh ? of1 : of0;
-        float mm[16];
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) mm[xi] = acc[xi][e];
-        // rows of A^T M: a0 = m0 + m1 + m2, a1 = m1 - m2 - m3 (over the first index), then the same over the second
-        float a0[4], a1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a0[j] = mm[j] + mm[4 + j] + mm[8 + j];
-            a1[j] = mm[4 + j] - mm[8 + j] - mm[12 + j];
+    if constexpr (!BNS) {
+    #pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row0 = (e & 3) + 8 * (e >> 2);
+            const unsigned ob0 = __builtin_amdgcn_readlane(obase, row0), ob1 = __builtin_amdgcn_readlane(obase, row0 + 4);
+            const int of0 = __builtin_amdgcn_readlane(oflags, row0), of1 = __builtin_amdgcn_readlane(oflags, row0 + 4);
+            const unsigned ob = kh ? ob1 : ob0;
+            const int of = kh ? of1 : of0;
+            float mm[16];
+    #pragma unroll
+            for (int xi = 0; xi < 16; ++xi) mm[xi] = acc[xi][e];
+            // rows of A^T M: a0 = m0 + m1 + m2, a1 = m1 - m2 - m3 (over the first index), then the same over the second
+            float a0[4], a1[4];
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0[j] = mm[j] + mm[4 + j] + mm[8 + j];
+                a1[j] = mm[4 + j] - mm[8 + j] - mm[12 + j];
+            }
+            const float y[4] = {a0[0] + a0[1] + a0[2], a0[1] - a0[2] - a0[3], a1[0] + a1[1] + a1[2], a1[1] - a1[2] - a1[3]};
+            // branch-free stores: a pixel outside the image or a column past Cout gets an out-of-range offset, which the
+            // buffer store drops
+            const bool live = ob != kOOB && colok;
+            const bool ok[4] = {live, live && (of & 1), live && (of & 2), live && (of & 3) == 3};
+            const unsigned off[4] = {ob, ob + right, ob + below, ob + below + right};
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(p.flags & 1024))
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[k]), srd_z, ok[k] ? off[k] + cbyte : kOOB, 0, 0);
+                const float u = ok[k] ? y[k] - pv : 0.f;
+                s += u;
+                q += u * u;
+            }
         }
-        const float y[4] = {a0[0] + a0[1] + a0[2], a0[1] - a0[2] - a0[3], a1[0] + a1[1] + a1[2], a1[1] - a1[2] - a1[3]};
-        // branch-free stores: a pixel outside the image or a column past Cout gets an out-of-range offset, which the
-        // buffer store drops
-        const bool live = ob != kOOB && colok;
-        const bool ok[4] = {live, live && (of & 1), live && (of & 2), live && (of & 3) == 3};
-        const unsigned off[4] = {ob, ob + right, ob + below, ob + below + right};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (!(p.flags & 1024))
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[k]), srd_z, ok[k] ? off[k] + cbyte : kOOB, 0, 0);
-            const float u = ok[k] ? y[k] - pv : 0.f;
-            s += u;
-            q += u * u;
+
+    } else {
+        constexpr bool bns = true;
+        const __amdgpu_buffer_rsrc_t srd_y = wsrd(bns ? p.y : p.z, p.z_bytes);
+        // DS_EPI_BNSUMS (this launch is a dgrad whose result dy feeds a BatchNorm + ReLU backward): per column, the sums
+        // of g = dy (y > 0) and g * y.  y sits at the offsets of the stores; element e + 1's four values are requested
+        // while element e is transformed (out-of-range offsets read zeros: y = 0 drops the element from both sums).
+        float ycur[4] = {0.f, 0.f, 0.f, 0.f}, ynxt[4] = {0.f, 0.f, 0.f, 0.f};
+        auto offsets_of = [&](int e, unsigned *off, bool *ok) {
+            const int row0 = (e & 3) + 8 * (e >> 2);
+            const unsigned ob0 = __builtin_amdgcn_readlane(obase, row0), ob1 = __builtin_amdgcn_readlane(obase, row0 + 4);
+            const int of0 = __builtin_amdgcn_readlane(oflags, row0), of1 = __builtin_amdgcn_readlane(oflags, row0 + 4);
+            const unsigned ob = kh ? ob1 : ob0;
+            const int of = kh ? of1 : of0;
+            // branch-free stores: a pixel outside the image or a column past Cout gets an out-of-range offset, which the
+            // buffer store drops
+            const bool live = ob != kOOB && colok;
+            ok[0] = live; ok[1] = live && (of & 1); ok[2] = live && (of & 2); ok[3] = live && (of & 3) == 3;
+            off[0] = ob; off[1] = ob + right; off[2] = ob + below; off[3] = ob + below + right;
+        };
+        if (bns) {
+            unsigned off[4];
+            bool ok[4];
+            offsets_of(0, off, ok);
+    #pragma unroll
+            for (int k = 0; k < 4; ++k)
+                ynxt[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_y, ok[k] ? off[k] + cbyte : kOOB, 0, 0));
         }
+    #pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            unsigned off[4];
+            bool ok[4];
+            offsets_of(e, off, ok);
+            if (bns) {
+    #pragma unroll
+                for (int k = 0; k < 4; ++k) ycur[k] = ynxt[k];
+                if (e < 15) {
+                    unsigned offn[4];
+                    bool okn[4];
+                    offsets_of(e + 1, offn, okn);
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        ynxt[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_y, okn[k] ? offn[k] + cbyte : kOOB, 0, 0));
+                }
+            }
+            float mm[16];
+    #pragma unroll
+            for (int xi = 0; xi < 16; ++xi) mm[xi] = acc[xi][e];
+            // rows of A^T M: a0 = m0 + m1 + m2, a1 = m1 - m2 - m3 (over the first index), then the same over the second
+            float a0[4], a1[4];
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0[j] = mm[j] + mm[4 + j] + mm[8 + j];
+                a1[j] = mm[4 + j] - mm[8 + j] - mm[12 + j];
+            }
+            const float y[4] = {a0[0] + a0[1] + a0[2], a0[1] - a0[2] - a0[3], a1[0] + a1[1] + a1[2], a1[1] - a1[2] - a1[3]};
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(p.flags & 1024))
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[k]), srd_z, ok[k] ? off[k] + cbyte : kOOB, 0, 0);
+                if (bns) {
+                    const float u = (ok[k] && ycur[k] > 0.f) ? y[k] : 0.f;
+                    s += u;
+                    q += u * ycur[k];
+                } else {
+                    const float u = ok[k] ? y[k] - pv : 0.f;
+                    s += u;
+                    q += u * u;
+                }
+            }
+        }
+
     }
-    if (p.flags & DS_EPI_STATS) {
+    if (BNS || (p.flags & DS_EPI_STATS)) {
         float *red = smem;        // [4 waves][32][2]; every wave passed the last K-loop barrier, no DMA in flight
         s += __shfl_xor(s, 32);
         q += __shfl_xor(q, 32);
@@ -318,16 +394,20 @@ extern "C" int ds_conv_wino_partials(int32_t N, int32_t H, int32_t W) {
     return (int)((mt + 127) / 128);
 }
 
-extern "C" int ds_conv_wino(const float *x, const float *u, float *z, float *stats, const float *pivot, int32_t N,
-                            int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz, int32_t flags,
-                            void *stream) {
+extern "C" int ds_conv_wino(const float *x, const float *u, float *z, float *stats, const float *pivot, const float *ymask,
+                            int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz,
+                            int32_t flags, void *stream) {
     DS_REQUIRE(x && u && z && N > 0 && H > 0 && W > 0, "ds_conv_wino: bad argument");
     DS_REQUIRE(Cin > 0 && Cin % 8 == 0 && ldx % 4 == 0 && ldx >= Cin && Cout > 0 && ldz >= Cout &&
                    ((((uintptr_t)x | (uintptr_t)u) & 15) == 0),
                "ds_conv_wino: needs Cin %% 8 == 0, ldx %% 4 == 0 and 16-byte aligned operands");
-    DS_REQUIRE((flags & ~(DS_EPI_STATS | 256 | 512 | 1024 | 2048)) == 0 && (!(flags & DS_EPI_STATS) || stats), "ds_conv_wino: only DS_EPI_STATS is supported");
+    DS_REQUIRE((flags & ~(DS_EPI_STATS | DS_EPI_BNSUMS | 256 | 512 | 1024 | 2048)) == 0 && (!(flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) || stats),
+               "ds_conv_wino: only DS_EPI_STATS / DS_EPI_BNSUMS are supported (with a partials buffer)");
+    DS_REQUIRE(!(flags & DS_EPI_BNSUMS) || (ymask && !(flags & DS_EPI_STATS)),
+               "ds_conv_wino: DS_EPI_BNSUMS needs y (pixel stride ldz) and excludes DS_EPI_STATS");
     WinoParams p;
     p.x = x; p.u = u; p.z = z; p.stats = stats; p.pivot = (flags & DS_EPI_STATS) ? pivot : nullptr;
+    p.y = (flags & DS_EPI_BNSUMS) ? ymask : nullptr;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.ldz = ldz;
     p.TH = (H + 1) / 2; p.TW = (W + 1) / 2;
     const int64_t mt = (int64_t)N * p.TH * p.TW;
@@ -343,6 +423,7 @@ extern "C" int ds_conv_wino(const float *x, const float *u, float *z, float *sta
     p.groups = (int)((mt + 127) / 128);
     p.ncol = (Cout + 31) / 32;
     const dim3 grid((unsigned)(((int64_t)p.groups * p.ncol + 7) / 8 * 8));
-    hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (flags & DS_EPI_BNSUMS) hipLaunchKernelGGL(conv_wino_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv_wino_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
     return ds::check_launch("ds_conv_wino");
 }

@@ -126,6 +126,10 @@ class ConvBN:
         eng.need_bwd_partials(self.pool_P * 2 * cout)
         self.dgrad = None
         self.wgrad = None
+        self.dy_parts = None          # set_dy_parts(): where the gradient of this layer's output lives
+        self.dx_sums = None           # this layer's dgrad emits the consumer's BatchNorm sums (emit_dx_sums)
+        self.dx_y = None
+        self._sum_segs = None
         if self.trainable:
             if self.fold:      # stem (train_all only): KW folded into the channel axis like the forward conv
                 self.wgrad = WgradPlan(B, self.H, self.W, 7 * 4, 4, 7, 1, self.stride, cout, cout, fold_cin=4)
@@ -144,6 +148,67 @@ class ConvBN:
         self.stats_buf, self.bwdp_buf, self.ws_buf = eng.stats_set[self.slot], eng.bwdp_set[self.slot], eng.ws_set[self.slot]
         self.gw_ptr = _vp(st.grad_ptr(self.key + "/weights")) if self.trainable else None
         self.gbeta = st.grad_view(self.key + "/BatchNorm/beta") if self.eng.trainable_bn_beta else None
+
+    def set_dy_parts(self, parts):
+        """parts: [(c0, c1, address, ld)] -- the channel ranges of this layer's output gradient and where each lives
+        (slices of the block's concat gradient, the reduce buffers' gradients).  part_sums[i] is filled in by the
+        stage whose dgrad WRITES that part when it can also emit the part's BatchNorm sums (DS_EPI_BNSUMS):
+        (partials tensor, P, first column of the part in the producer's output, producer's column count)."""
+        self.dy_parts = parts
+        self.dy_segs = make_segments(parts)
+        self.part_segs = [make_segments([(0, c1 - c0, ptr, ld)]) for (c0, c1, ptr, ld) in parts]
+        self.part_sums = [None] * len(parts)
+        self._sum_segs = None
+
+    def emit_dx_sums(self, y):
+        """This layer's dgrad writes the gradient of `y` (an activation relu(bn(.)) with the dgrad output's pixel
+        stride): have its epilogue emit the column sums that layer's BatchNorm backward needs.  Returns
+        (partials tensor, P) or None when the dgrad kernel of this shape cannot (implicit-GEMM fallbacks, bf16)."""
+        eng = self.eng
+        if not eng.bwd_sums or self.dgrad is None:
+            return None
+        if isinstance(self.wino_dgrad, WinoPlan):
+            P = self.wino_dgrad.enable_bnsums()
+        elif self.wino_dgrad is None and self.k == 1:
+            P = self.dgrad.enable_bnsums(self.dgrad.d.ldz)
+        else:
+            P = 0
+        if not P:
+            return None
+        self.dx_sums = torch.empty(2 * self.cin * P, device=eng.device)
+        self.dx_y = y
+        return self.dx_sums, P
+
+    def _bn_bwd_sums(self):
+        """Sum g and sum g*xhat of this layer: parts whose producer emitted them are taken as they are, the others
+        are reduced over their column range; one finalize launch."""
+        eng = self.eng
+        M, Cc = self.M, self.cout
+        if self._sum_segs is None:
+            sg = ops.SumSegments()
+            sg.nseg = len(self.dy_parts)
+            self._reduce_jobs = []
+            scratch, P0 = self.bwdp_buf.data_ptr(), self.bwd_P
+            for i, (c0, c1, _, _) in enumerate(self.dy_parts):
+                sg.c_begin[i], sg.c_end[i] = c0, c1
+                src = self.part_sums[i]
+                if src is not None:
+                    buf, P, off, ctot = src
+                    sg.P[i], sg.kind[i] = P, 1
+                    sg.s[i] = buf.data_ptr() + 4 * off * P
+                    sg.q[i] = buf.data_ptr() + 4 * (ctot + off) * P
+                else:
+                    n = c1 - c0
+                    sg.P[i], sg.kind[i] = P0, 0
+                    sg.s[i], sg.q[i] = scratch, scratch + 4 * n * P0
+                    self._reduce_jobs.append((i, c0, n, _vp(scratch)))
+                    scratch += 4 * 2 * n * P0
+            self._sum_segs = sg
+        for i, c0, n, dst in self._reduce_jobs:
+            off = 4 * c0
+            ops.bn_bwd_reduce(_vp(self.z.data_ptr() + off), self.part_segs[i], M, n, _vp(self.mean.data_ptr() + off),
+                              _vp(self.rstd.data_ptr() + off), _vp(self.shift.data_ptr() + off), dst, ldz=Cc)
+        ops.bn_bwd_finalize_segs(self._sum_segs, M, Cc, self.beta, self.gbeta, self.coef)
 
     def make_dgrad(self, lddx):
         """Conv2DBackpropInput as a forward conv over dz with flipped taps (stride-1 SAME convs only)."""
@@ -237,19 +302,28 @@ class ConvBN:
             self._run_dgrad(dx_ptr)
 
     def _run_dgrad(self, dx_ptr):
+        sums = ops._p(self.dx_sums) if self.dx_sums is not None else None
+        y = ops._p(self.dx_y) if self.dx_sums is not None else None
         if self.wino_dgrad is not None:
-            self.wino_dgrad.run(ops._p(self.z), ops._p(self.u_dgrad), dx_ptr)
+            if sums is not None:
+                self.wino_dgrad.run(ops._p(self.z), ops._p(self.u_dgrad), dx_ptr, stats=sums, ymask=y)
+            else:
+                self.wino_dgrad.run(ops._p(self.z), ops._p(self.u_dgrad), dx_ptr)
         else:
-            self.dgrad.run(ops._p(self.z), self.w_ptr, dx_ptr)
+            self.dgrad.run(ops._p(self.z), self.w_ptr, dx_ptr, mask=y, stats=sums)
 
-    def backward(self, dy_segs, x_ptr=None, ldx=0, dx_ptr=None, need_dx=True):
+    def backward(self, x_ptr=None, ldx=0, dx_ptr=None, need_dx=True):
         eng = self.eng
         M, Cc = self.M, self.cout
+        dy_segs = self.dy_segs
         if self.gbeta is None and not need_dx and not self.trainable:
             return
-        ops.bn_bwd_reduce(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.bwdp_buf)
-        ops.bn_bwd_finalize(self.bwdp_buf, self.bwd_P, M, Cc, self.gbeta if self.gbeta is not None else eng.dummy,
-                            self.coef)
+        if any(ps is not None for ps in self.part_sums):
+            self._bn_bwd_sums()
+        else:
+            ops.bn_bwd_reduce(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.bwdp_buf)
+            ops.bn_bwd_finalize(self.bwdp_buf, self.bwd_P, M, Cc, self.gbeta if self.gbeta is not None else eng.dummy,
+                                self.coef)
         if not (need_dx or self.trainable):
             return
         ops.bn_bwd_apply(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.coef, self.z)   # dz over z
@@ -294,9 +368,14 @@ class ConvStage(Stage):
         self.out = torch.empty(B, self.H, self.W, self.C, device=dev)
         self.dout = torch.empty_like(self.out)
         self.segs = make_segments([(0, self.C, self.out.data_ptr(), self.C)])
-        self.dsegs = make_segments([(0, self.C, self.dout.data_ptr(), self.C)])
+        self.layer.set_dy_parts([(0, self.C, self.dout.data_ptr(), self.C)])
         if not self.layer.fold:
             self.layer.make_dgrad(self.prev.C)
+            # Conv2d_2c's dgrad writes the gradient of Conv2d_2b's activation: it can emit 2b's BatchNorm sums
+            if isinstance(self.prev, ConvStage) and not self.prev.layer.fold:
+                src = self.layer.emit_dx_sums(self.prev.out)
+                if src is not None:
+                    self.prev.layer.part_sums[0] = (src[0], src[1], 0, self.prev.C)
 
     def forward(self):
         # fused_into_pool: this conv feeds nothing but the next max pool, which then reads z and applies BN + ReLU
@@ -309,7 +388,7 @@ class ConvStage(Stage):
         if self.fused_into_pool and self.pool.stride == 2:
             self.layer.backward_pooled(self.pool, ops._p(self.prev.out), self.prev.C, dx, need_dx)
         else:
-            self.layer.backward(self.dsegs, ops._p(self.prev.out), self.prev.C, dx, need_dx)
+            self.layer.backward(ops._p(self.prev.out), self.prev.C, dx, need_dx)
 
 
 class PoolStage(Stage):
@@ -370,7 +449,7 @@ class MixedStage(Stage):
         self.ev = None
 
     def alloc(self, B):
-        dev = self.eng.device
+        eng, dev = self.eng, self.eng.device
         b0, b1a, b1b, b2a, b2b, b3 = self.b
         cin, Ct = self.prev.C, self.C
         self.B = B
@@ -394,15 +473,33 @@ class MixedStage(Stage):
         self.seg_1 = make_segments([(0, b1b, o + 4 * off1, Ct)])
         self.seg_2 = make_segments([(0, b2b, o + 4 * off2, Ct)])
         self.seg_3 = make_segments([(0, b3, o + 4 * off3, Ct)])
-        self.dseg_f = make_segments([(0, b0, do, Ct), (b0, b0 + b1a, self.dr1.data_ptr(), b1a),
-                                     (b0 + b1a, nf, self.dr2.data_ptr(), b2a)])
-        self.dseg_1 = make_segments([(0, b1b, do + 4 * off1, Ct)])
-        self.dseg_2 = make_segments([(0, b2b, do + 4 * off2, Ct)])
-        self.dseg_3 = make_segments([(0, b3, do + 4 * off3, Ct)])
+        self.fused.set_dy_parts([(0, b0, do, Ct), (b0, b0 + b1a, self.dr1.data_ptr(), b1a),
+                                 (b0 + b1a, nf, self.dr2.data_ptr(), b2a)])
+        self.c1.set_dy_parts([(0, b1b, do + 4 * off1, Ct)])
+        self.c2.set_dy_parts([(0, b2b, do + 4 * off2, Ct)])
+        self.c3.set_dy_parts([(0, b3, do + 4 * off3, Ct)])
         self.fused.make_dgrad(cin)
         self.c1.make_dgrad(b1a)
         self.c2.make_dgrad(b2a)
         self.c3.make_dgrad(cin)
+        # BatchNorm backward sums from the epilogue of the dgrad that produces the gradient (DS_EPI_BNSUMS) instead of
+        # a separate pass over z and dy:
+        #  * the Branch_1 / Branch_2 3x3 dgrads write dr1 / dr2, the gradients of the fused 1x1 layer's reduce outputs;
+        for part, (layer, r) in enumerate(((self.c1, self.r1), (self.c2, self.r2)), start=1):
+            src = layer.emit_dx_sums(r)
+            if src is not None:
+                self.fused.part_sums[part] = (src[0], src[1], 0, layer.cin)
+        #  * the fused 1x1 dgrad writes (last, accumulating onto the pool path: pool_first) the gradient of the block
+        #    input = the previous block's concat output, i.e. one part of each of ITS four layers.
+        p = self.prev
+        self.pool_first = bool(eng.pool_first and self.fused.wino_dgrad is None)
+        if isinstance(p, MixedStage) and self.pool_first:
+            src = self.fused.emit_dx_sums(p.out)
+            if src is not None:
+                pb0, _, pb1b, _, pb2b, pb3 = p.b
+                for layer, off in ((p.fused, 0), (p.c1, pb0), (p.c2, pb0 + pb1b), (p.c3, pb0 + pb1b + pb2b)):
+                    layer.part_sums[0] = (src[0], src[1], off, cin)
+                    layer._sum_segs = None
 
     # The three chains behind the block input -- [fused 1x1 -> Branch_1 3x3], [... -> Branch_2 3x3] and
     # [3x3/1 pool -> Branch_3 1x1] -- are independent: Branch_3 and then Branch_2 are issued on a side stream (fork /
@@ -463,18 +560,19 @@ class MixedStage(Stage):
         # AddN of the two paths into the block input.  pool_first: the pool path WRITES p.dout inside the Branch_3 chain
         # (9 B/element, under the other chains' convs) and the fused 1x1 dgrad accumulates onto it in its epilogue;
         # otherwise (dgrad kernels without an accumulate epilogue) the dgrad writes and the pool path adds afterwards.
-        pool_first = need_dx and self.fused.wino_dgrad is None and eng.pool_first
-        self.fused.dgrad.d.flags = ops.DS_EPI_ACCUM if pool_first else 0
+        pool_first = need_dx and self.pool_first
+        keep = self.fused.dgrad.d.flags & ops.DS_EPI_BNSUMS
+        self.fused.dgrad.d.flags = (ops.DS_EPI_ACCUM if pool_first else 0) | keep
 
         def branch3():
-            self.c3.backward(self.dseg_3, ops._p(self.pooled), p.C, ops._p(self.dpooled), need_dx)
+            self.c3.backward(ops._p(self.pooled), p.C, ops._p(self.dpooled), need_dx)
             if pool_first:
                 ops.maxpool_bwd(self.dpooled, self.argmax, p.dout, False, self.B, p.H, p.W, p.C, 3, 1, "SAME")
 
         if not (eng.branch_streams and eng.side):
             branch3()
-            self.c1.backward(self.dseg_1, ops._p(self.r1), b1a, ops._p(self.dr1), True)
-            self.c2.backward(self.dseg_2, ops._p(self.r2), b2a, ops._p(self.dr2), True)
+            self.c1.backward(ops._p(self.r1), b1a, ops._p(self.dr1), True)
+            self.c2.backward(ops._p(self.r2), b2a, ops._p(self.dr2), True)
         else:
             main = torch.cuda.current_stream()
             s1, s2 = eng.side
@@ -490,18 +588,18 @@ class MixedStage(Stage):
             if eng.one_side_stream == 2:
                 with torch.cuda.stream(s2):
                     e_2.record(s2)
-                self.c2.backward(self.dseg_2, ops._p(self.r2), b2a, ops._p(self.dr2), True)
+                self.c2.backward(ops._p(self.r2), b2a, ops._p(self.dr2), True)
             else:
                 with torch.cuda.stream(s1):
                     if not eng.one_side_stream:
                         s1.wait_event(e_in)
-                    self.c2.backward(self.dseg_2, ops._p(self.r2), b2a, ops._p(self.dr2), True)
+                    self.c2.backward(ops._p(self.r2), b2a, ops._p(self.dr2), True)
                     e_2.record(s1)
-            self.c1.backward(self.dseg_1, ops._p(self.r1), b1a, ops._p(self.dr1), True)
+            self.c1.backward(ops._p(self.r1), b1a, ops._p(self.dr1), True)
             main.wait_event(e_2)
             if not eng.one_side_stream:
                 main.wait_event(e_3)
-        self.fused.backward(self.dseg_f, x, p.C, ops._p(p.dout) if need_dx else None, need_dx)
+        self.fused.backward(x, p.C, ops._p(p.dout) if need_dx else None, need_dx)
         if need_dx and not pool_first:
             ops.maxpool_bwd(self.dpooled, self.argmax, p.dout, True, self.B, p.H, p.W, p.C, 3, 1, "SAME")
 
@@ -532,6 +630,7 @@ class InceptionV1Engine:
         # costs ~17 us of idle GPU: 17.74 -> 17.58 ms/step against two side streams); 0: a side stream each; 2: Branch_3 only
         self.one_side_stream = 1
         self.pool_first = True       # Mixed backward: Branch_3's pool gradient written first, fused dgrad accumulates (False: the reverse)
+        self.bwd_sums = True         # BatchNorm backward sums from the producing dgrad's epilogue (DS_EPI_BNSUMS) where it can
         self.stem_direct = True      # Conv2d_1a_7x7 from the packed RGB batch (ds_conv_stem; False: generic kernel on a 4-channel copy)
         self.branch_streams = True   # Mixed blocks: Branch_2 and Branch_3 on side streams next to Branch_0/1 (False: one stream)
         self.side = None

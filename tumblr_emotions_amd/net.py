@@ -163,6 +163,9 @@ class SentimentNet:
         self.frozen_l2_sumsq = tot
         if self.image is not None:
             self.image.weights_version += 1      # Winograd-transformed copies of the frozen filters are stale
+        # ... and so is a captured step: the frozen layers' weight transforms are not part of the capture
+        if getattr(self, "_graph", None) is not None:
+            self.release_graph()
 
     # ---- forward / loss ---------------------------------------------------------------------------
     def forward(self, batch, dropout_mask=None, seed=0):

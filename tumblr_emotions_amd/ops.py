@@ -9,7 +9,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ConvDesc, Segments, DS_EPI_ACCUM, DS_EPI_BIAS, DS_EPI_MASK, DS_EPI_RELU, DS_EPI_STATS,  # noqa: F401
+from ._lib import (ConvDesc, Segments, SumSegments, DS_EPI_ACCUM, DS_EPI_BIAS, DS_EPI_BNSUMS, DS_EPI_MASK, DS_EPI_RELU,  # noqa: F401
+                   DS_EPI_STATS,
                    DS_DTYPE_BF16, DS_DTYPE_F32)
 
 
@@ -72,12 +73,25 @@ class ConvPlan:
         d.splits, d.z_split_stride = splits, z_split_stride
         self.d = d
         self.M = N * OH * OW
-        self.partials = _lib.load().ds_conv_igemm_partials(C.byref(d)) if flags & DS_EPI_STATS else 0
+        self.partials = _lib.load().ds_conv_igemm_partials(C.byref(d)) if flags & (DS_EPI_STATS | DS_EPI_BNSUMS) else 0
         d.partials = self.partials      # a launch that would write another count fails instead of corrupting the stats
         # algorithmic FLOPs of one launch (2*M*N*K over the real, unpadded reduction; the folded
         # stem carries a zero 4th input channel that is not counted)
         k_alg = KH * KW * Cin if not fold_cin else KH * (Cin // fold_cin) * 3
         self.alg_flops = 2.0 * self.M * Cout * k_alg
+
+    def enable_bnsums(self, ldy):
+        """Conv2DBackpropInput whose result feeds a BatchNorm + ReLU backward: emit that layer's column sums from the
+        epilogue (DS_EPI_BNSUMS; y of pixel stride `ldy` goes in as `mask`, the partials come out of `stats`).
+        Returns the partial count, or 0 when the launch for this shape cannot carry the flag."""
+        if not _lib.load().ds_conv_igemm_bnsums_supported(C.byref(self.d)):
+            return 0
+        self.d.partials = 0
+        self.d.flags |= DS_EPI_BNSUMS
+        self.d.ldmask = ldy
+        self.partials = _lib.load().ds_conv_igemm_partials(C.byref(self.d))
+        self.d.partials = self.partials
+        return self.partials
 
     def run(self, x, w, z, bias=None, mask=None, stats=None, pivot=None):
         t = CONV_TIMER
@@ -133,19 +147,26 @@ class WinoPlan:
         self.args = (N, H, W, Cin, ldx, Cout, ldz)
         self.flags = flags
         self.M = N * H * W
-        self.partials = _lib.load().ds_conv_wino_partials(N, H, W) if flags & DS_EPI_STATS else 0
+        self.partials = _lib.load().ds_conv_wino_partials(N, H, W) if flags & (DS_EPI_STATS | DS_EPI_BNSUMS) else 0
         self.alg_flops = 2.0 * self.M * Cout * 9 * Cin          # the convolution's FLOPs, not Winograd's
+
+    def enable_bnsums(self):
+        """As ConvPlan.enable_bnsums (y has the output's pixel stride)."""
+        N, H, W = self.args[:3]
+        self.flags = DS_EPI_BNSUMS
+        self.partials = _lib.load().ds_conv_wino_partials(N, H, W)
+        return self.partials
 
     def set_ldx(self, ldx):
         self.args = self.args[:4] + (ldx,) + self.args[5:]
 
-    def run(self, x, u, z, stats=None, pivot=None):
+    def run(self, x, u, z, stats=None, pivot=None, ymask=None):
         t = CONV_TIMER
         if t is not None:
             t.begin()
         N, H, W, Cin, ldx, Cout, ldz = self.args
-        _lib.check(_lib.load().ds_conv_wino(x, u, z, stats, pivot, N, H, W, Cin, ldx, Cout, ldz, self.flags, _stream()),
-                   "ds_conv_wino")
+        _lib.check(_lib.load().ds_conv_wino(x, u, z, stats, pivot, ymask, N, H, W, Cin, ldx, Cout, ldz, self.flags,
+                                            _stream()), "ds_conv_wino")
         if t is not None:
             t.end(self)
 
@@ -272,9 +293,16 @@ def bn_bwd_partials(M, C_):
     return _lib.load().ds_bn_bwd_partials(M, C_)
 
 
-def bn_bwd_reduce(z, segs, M, C_, mean, rstd, shift, partials):
-    _lib.check(_lib.load().ds_bn_bwd_reduce(_p(z), C.byref(segs), M, C_, _p(mean), _p(rstd), _p(shift),
-                                            _p(partials), _stream()), "ds_bn_bwd_reduce")
+def bn_bwd_reduce(z, segs, M, C_, mean, rstd, shift, partials, ldz=None):
+    """z .. partials: tensors, or raw device addresses (c_void_p) when a column sub-range of a layer is reduced."""
+    ptr = lambda t: t if isinstance(t, C.c_void_p) else _p(t)
+    _lib.check(_lib.load().ds_bn_bwd_reduce(ptr(z), C_ if ldz is None else ldz, C.byref(segs), M, C_, ptr(mean), ptr(rstd),
+                                            ptr(shift), ptr(partials), _stream()), "ds_bn_bwd_reduce")
+
+
+def bn_bwd_finalize_segs(sum_segs, M, C_, beta, dbeta, coef):
+    _lib.check(_lib.load().ds_bn_bwd_finalize_segs(C.byref(sum_segs), M, C_, _p(beta), _p(dbeta), _p(coef), _stream()),
+               "ds_bn_bwd_finalize_segs")
 
 
 def bn_bwd_finalize(partials, P, M, C_, dbeta, coef):
