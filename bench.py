@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_SAMPLE = 6.169          # fwd+bwd, reference-faithful freeze (BASELINE.md section 2 / SURVEY 8d)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA, same guide (never the 2:1-sparsity figure)
+PEAK_FP8_MFMA_TFLOPS = 5000.0     # dense fp8 MFMA
 
 
 def _physical_cores():
@@ -158,7 +159,7 @@ def main():
     ap.add_argument("--train-all", action="store_true",
                     help="optional full fine-tuning (not the BASELINE workload): every conv weight and the "
                          "embedding trainable; 9.032 GFLOP/sample joint (SURVEY 8d)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "fp8"],
                     help="f32: the headline (exact fp32 MFMA, 1e-3 parity path).  bf16: SEPARATE, labelled line -- conv "
                          "forward/dgrad multiplies on the bf16 matrix pipe, fp32 storage/accumulate/statistics/masters")
     ap.add_argument("--stepwise-lstm", action="store_true",
@@ -355,10 +356,13 @@ def main():
             n, ms, flops = timer.summary()
             ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic, traffic_src = pmc_traffic(args)
-            peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
+            peak = {"bf16": PEAK_BF16_MFMA_TFLOPS, "fp8": PEAK_FP8_MFMA_TFLOPS}.get(args.dtype, PEAK_FP32_MFMA_TFLOPS)
             kname = ("conv_bf16_kernel (ds_conv_igemm, DS_DTYPE_BF16: v_mfma_f32_32x32x16_bf16 implicit GEMM, fp32 accumulate; conv "
                      "fwd + dgrad) together with the fp32 GEMMs of the LSTM / heads launched through the same entry point"
                      if args.dtype == "bf16" else
+                     "conv_fp8d_kernel (ds_conv_fp8: v_mfma_f32_32x32x16_fp8_fp8 forward, _bf8_fp8 dgrad, per-tensor power-of-two "
+                     "scales, fp32 accumulate) for the 1x1 / 3x3 convs, bf16 stem, together with the fp32 GEMMs of the LSTM / heads"
+                     if args.dtype == "fp8" else
                      "conv_igemm_kernel + conv_glds_kernel + conv_wino_kernel (fp32 v_mfma_f32_32x32x2_f32: implicit GEMM for conv fwd / "
                      "dgrad / GEMMs through ds_conv_igemm, fused Winograd F(2x2,3x3) for the 3x3 layers through ds_conv_wino; FLOPs "
                      "counted are the convolution's 2*M*N*K, so the Winograd launches can exceed the matrix peak)")
@@ -387,7 +391,10 @@ def main():
                                       "BASELINE workload)" if args.train_all else
                                       "reference freeze (<=Mixed_5b conv weights frozen, all BN betas trainable)")
                                    + (", conv fwd/dgrad multiplies in bf16 (fp32 storage, accumulation, statistics, master "
-                                      "weights; NOT the fp32 parity configuration)" if args.dtype == "bf16" else ""),
+                                      "weights; NOT the fp32 parity configuration)" if args.dtype == "bf16" else
+                                      ", 1x1 / 3x3 conv fwd (e4m3 x e4m3) and dgrad (e5m2 x e4m3) multiplies on the fp8 matrix pipe with "
+                                      "per-tensor power-of-two scales, bf16 stem (fp32 storage, accumulation, statistics, master weights; "
+                                      "BASELINE configs[4]'s conv path, NOT the fp32 parity configuration)" if args.dtype == "fp8" else ""),
                        "global_batch": gb, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
                        "gflop_per_sample": flop_per_sample, "final_loss": round(loss, 5),
                        "launch": "hipGraph replay" if graphed else "eager"},

@@ -124,6 +124,28 @@ int ds_conv_bf16_partials(const ds_conv_desc *d);
 int ds_conv_bf16(const ds_conv_desc *d, const float *x, const void *wb, float *z, float *stats, const float *pivot,
                  void *stream);
 
+/* fp8 convolution path (BASELINE configs[4]: fp8 MFMA conv path on CDNA4), 1x1 and 3x3 convs, forward and
+ * Conv2DBackpropInput (slim.conv2d, image_model/inception_v1.py:71-250): v_mfma_f32_32x32x16_fp8_fp8 / _bf8_fp8, OCP
+ * formats (gfx950), fp32 accumulation, fp32 z.  Per-tensor POWER-OF-TWO scales s = 2^floor(log2(FMAX / amax)):
+ *   weights      e4m3 (FMAX 448): ds_weights_to_fp8 takes amax, fixes s_w and converts the TF HWIO filter into the
+ *                kernel's order [16-channel chunk x tap][column][16 k] (ds_weights_fp8_bytes; dgrad = 1: flipped taps,
+ *                channel roles swapped); wscale = device float[4] {amax, s_w, 1 / s_w, -} written by the call;
+ *   activations  a_format DS_FP8_E4M3 (forward x) or DS_FP8_E5M2 (FMAX 57344: dgrad's dz); the scale is derived in the
+ *                kernel from the device word x_amax[0] = max |x| (ds_absmax, or a producer that tracks it): nothing
+ *                crosses to the host.  Values are scaled, saturated to +-FMAX and rounded to nearest even.
+ * z = acc / (s_a s_w); `d` as for ds_conv_bf16 (flags 0 or DS_EPI_STATS, partials float[2][Cout][ds_conv_fp8_partials]).
+ * Not the fp32 parity path: separately labelled, tolerance documented in tests/test_kernels_gpu.py / DESIGN.md.     */
+#define DS_FP8_E4M3 0
+#define DS_FP8_E5M2 1
+int ds_absmax(const float *x, int64_t n, float *amax, void *stream);
+size_t ds_weights_fp8_bytes(int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad);
+int ds_weights_to_fp8(const float *w, void *wq, float *wscale, int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad,
+                      void *stream);
+int ds_conv_fp8_supported(const ds_conv_desc *d);
+int ds_conv_fp8_partials(const ds_conv_desc *d);
+int ds_conv_fp8(const ds_conv_desc *d, const float *x, const float *x_amax, int32_t a_format, const void *wq,
+                const float *wscale, float *z, float *stats, const float *pivot, void *stream);
+
 /* Conv2d_1a_7x7 (inception_v1.py:63): 7x7 stride-2 SAME conv 3 -> 64 read from the PACKED RGB images
  * x [N, H, W, 3] (no 4-channel copy), w = HWIO [7][7][cin_store][64] (cin_store 3 or 4: the store keeps the stem
  * filter zero-padded to 4 input channels), z [N*OH*OW, ldz].  stats != NULL: BatchNorm column sums about `pivot`

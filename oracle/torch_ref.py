@@ -57,6 +57,65 @@ class _ConvBf16Multiply(torch.autograd.Function):
         return dx, dw, None
 
 
+# ---- fp8 emulation (the build's dtype='fp8' switch, BASELINE configs[4]; no reference counterpart) -----------------------
+FP8_E4M3 = dict(fmax=448.0, mant=3, emin=-6)        # OCP e4m3fn (gfx950): weights, forward activations
+FP8_E5M2 = dict(fmax=57344.0, mant=2, emin=-14)     # OCP e5m2: gradients
+
+
+def fp8_pow2_scale(amax, fmax):
+    """2^floor(log2(fmax / amax)) with the quotient taken in fp32, as ds_conv_fp8 / ds_weights_to_fp8 do."""
+    amax = float(amax)
+    if not amax > 0.0:
+        return 1.0
+    import numpy as np
+    r = np.float32(fmax) / np.float32(amax)
+    e = int(np.frexp(r)[1]) - 1
+    return float(2.0 ** max(-60, min(60, e)))
+
+
+def fp8_round(t, fmt):
+    """saturate to +-fmax and round to the nearest representable value (ties to even), subnormals included; result in
+    t's dtype"""
+    a = t.abs().clamp(max=fmt["fmax"])
+    _, e = torch.frexp(a)
+    E = (e - 1).clamp(min=fmt["emin"])
+    step = torch.ldexp(torch.ones_like(a), E - fmt["mant"])
+    return torch.sign(t) * torch.round(a / step) * step
+
+
+def fp8_quantize(t, fmt):
+    """(values seen by the matrix pipe, scale): per-tensor power-of-two scale from max|t|, then fp8_round."""
+    s = fp8_pow2_scale(t.abs().max(), fmt["fmax"])
+    return fp8_round(t * s, fmt), s
+
+
+class _ConvFp8Multiply(torch.autograd.Function):
+    """VALID cross-correlation as ds_conv_fp8 computes it: forward on e4m3(x s_x) and e4m3(w s_w), input gradient on
+    e5m2(dy s_dy) and e4m3(w s_w), each unscaled afterwards; the weight gradient on the unrounded operands."""
+
+    @staticmethod
+    def forward(ctx, xp, w_oihw, stride):
+        ctx.save_for_backward(xp, w_oihw)
+        ctx.stride = stride
+        xq, sx = fp8_quantize(xp, FP8_E4M3)
+        wq, sw = fp8_quantize(w_oihw, FP8_E4M3)
+        return F.conv2d(xq, wq, stride=stride) / (sx * sw)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, w = ctx.saved_tensors
+        wq, sw = fp8_quantize(w, FP8_E4M3)
+        dq, sd = fp8_quantize(dy, FP8_E5M2)
+        dx = torch.nn.grad.conv2d_input(xp.shape, wq, dq, stride=ctx.stride) / (sd * sw)
+        dw = torch.nn.grad.conv2d_weight(xp, w.shape, dy, stride=ctx.stride)
+        return dx, dw, None
+
+
+def conv2d_same_fp8_multiply(x, w_hwio, stride):
+    k = w_hwio.shape[0]
+    return _ConvFp8Multiply.apply(_same_pad_nchw(x, k, stride, 0.0), w_hwio.permute(3, 2, 0, 1), stride)
+
+
 def conv2d_same_bf16_multiply(x, w_hwio, stride):
     k = w_hwio.shape[0]
     return _ConvBf16Multiply.apply(_same_pad_nchw(x, k, stride, 0.0), w_hwio.permute(3, 2, 0, 1), stride)
@@ -147,7 +206,11 @@ class DeepSentimentRef:
 
     # -- towers -------------------------------------------------------------------------------
     def _cbr(self, x, scope, stride=1):
-        if self.conv_multiply == "bf16":
+        if self.conv_multiply == "fp8" and self.p[scope + "/weights"].shape[0] in (1, 3) and stride == 1 \
+                and x.shape[1] % 8 == 0:
+            # the layers ds_conv_fp8 takes (1x1 / 3x3, stride 1, Cin % 8 == 0); the rest -- the stem -- multiplies in bf16
+            z = conv2d_same_fp8_multiply(x, self.p[scope + "/weights"], stride)
+        elif self.conv_multiply in ("bf16", "fp8"):
             z = conv2d_same_bf16_multiply(x, self.p[scope + "/weights"], stride)
         else:
             z = conv2d_same(x, self.p[scope + "/weights"], stride)

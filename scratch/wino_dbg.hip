@@ -1,0 +1,421 @@
+// 3x3 stride-1 SAME convolution (forward and dgrad) as fused Winograd F(2x2, 3x3) on the fp32 matrix cores.
+//
+// The 3x3 layers are 2/3 of Inception-v1's multiplies (image_model/inception_v1.py: Conv2d_2c_3x3 :74-75 and the
+// Branch_1 / Branch_2 Conv2d_0b_3x3 of all nine Mixed blocks :86-247) and fp32 MFMA runs at the fp32 vector rate, so
+// the direct implicit GEMM is bound by the matrix pipe even when everything else is hidden.  Winograd's minimal
+// filtering trades 36 multiplies per 2x2 output tile and channel pair for 16:
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A            (Lavin & Gray, F(2x2, 3x3); cross-correlation form)
+// i.e. sixteen independent GEMMs  M_xi[tile, co] = sum_ci V_xi[tile, ci] U_xi[ci, co]  over the sixteen positions
+// xi of the transformed 4x4 patch -- 2.25x fewer MFMA passes for the same convolution.
+//
+// Fused form (nothing but x, the pre-transformed weights U and z touches memory):
+//   * a wave owns 32 output tiles x 32 output channels and ALL sixteen positions: sixteen 32x32 fp32 accumulators
+//     = 256 accumulator registers (gfx950's unified 512-register file at one wave per SIMD);
+//   * lane (i, kh) of the 32x32x2 MFMA's A operand is tile i and channels 4 kh .. 4 kh + 3 of the 8-channel K step:
+//     the lane loads the 16 pixels of its own 4x4 input patch as float4 (SRD loads, padding pixels and tiles past
+//     the end read zeros from an out-of-range offset), runs B^T d B on them in registers (32 adds per channel) and
+//     the sixteen results ARE its A fragments -- no LDS round trip, no im2col, no transformed-input tensor;
+//   * the transformed weights U [16][Cout][Cin] (ci contiguous; made once per weight update by
+//     ds_wino_transform_weights) are the B operand: the workgroup's [16][32][8] slice of a K step goes global -> LDS
+//     by LDS-DMA (lane-linear = exactly this layout), double buffered, shared by the four waves (four different
+//     32-tile groups, same 32 channels);
+//   * the matrix pipe needs 64 cycles per MFMA, so between two MFMAs the wave has issue slots for the next
+//     position's ds_read_b128 and for the loads of the next K step: per K step 64 MFMAs (4096 cycles) against
+//     ~128 transform adds, 16 + 4 loads, 16 LDS reads and one barrier;
+//   * epilogue: A^T M A per lane across the sixteen accumulators (the C layout is position independent), 2x2
+//     outputs stored as 128-byte channel runs, BatchNorm column statistics about the pivot as in conv_igemm.hip.
+// dgrad of a 3x3 stride-1 SAME conv is the same correlation over dz with the taps flipped and the channel roles
+// swapped, so it is this kernel with U built from the flipped, transposed filter.
+// Numerics: fp32 throughout; the transforms add ~1e-7-level rounding of their own (inputs are combined before the
+// multiply), so results match the direct kernels to ~1e-6 relative, not bit for bit; reductions are ordered and
+// deterministic.
+#include <stdlib.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#define DS_EPI_STATS 8
+#define DS_EPI_BNSUMS 32
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr unsigned kOOB = 0x80000000u;
+
+struct WinoParams {
+    const float *x;         // [N, H, W, ldx]
+    const float *u;         // [16][Cout][Cin]
+    float *z;               // [N, H, W, ldz]
+    float *stats;           // [2][Cout][P], P = groups
+    const float *pivot;
+    const float *y;         // DS_EPI_BNSUMS: forward activation of the layer that consumes z (= dy), same pixel stride ldz
+    int N, H, W, Cin, ldx, Cout, ldz;
+    int TH, TW, Mt;         // output tiles per column / row / in total
+    int groups, ncol;       // 128-tile groups, 32-channel blocks
+    unsigned x_bytes, u_bytes, z_bytes;
+    int flags;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wsrd(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+typedef __attribute__((address_space(3))) void *lds_ptr;
+
+// a - b on four floats as two v_pk_add_f32 with the second operand negated.  hipcc packs fp32 adds into
+// v_pk_add_f32 by itself but leaves subtractions as four v_sub_f32, and with one wave per SIMD every VALU issue
+// slot of the transform is a slot the matrix pipe idles (scratch/mfma_mix.hip: 64 MFMAs alone 1.73 us, with the K
+// step's 128 VALU ops, 16 LDS reads and barrier 2.15 us): 112 -> 64 VALU instructions per K step, -4 % kernel time.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
+    f32x2 lo, hi;
+    const f32x2 alo = {a[0], a[1]}, ahi = {a[2], a[3]}, blo = {b[0], b[1]}, bhi = {b[2], b[3]};
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(alo), "v"(blo));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(ahi), "v"(bhi));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
+// DBG bits: 1 no transform VALU, 2 no LDS fragment reads, 4 no barrier, 8 no A loads, 16 no B DMA, 32 no epilogue
+template <bool BNS, int DBG>
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
+    // B tile of one K step: [16 positions][32 channels][8 ci] floats = 16 KB, two buffers
+    __shared__ __attribute__((aligned(128))) float smem[2 * 16 * 32 * 8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kh = lane >> 5;
+    // 1-D XCD-aware launch (as conv_igemm.hip's TileId): the row-major list of (tile group, channel block) pairs is
+    // cut into 8 contiguous ranges, one per XCD (workgroup id % 8, observed placement; a different one only costs
+    // speed), so the channel blocks of a tile group -- which read the same input patches -- run back to back on one
+    // XCD and the patches cross the fabric once per tile group instead of once per channel block.
+    const int id = blockIdx.x;
+    const int lin = (id & 7) * (int)(gridDim.x >> 3) + (id >> 3);
+    const int group = lin / p.ncol, cblk = lin - group * p.ncol;
+    const int co0 = cblk * 32;
+    const int tile0 = group < p.groups ? (group * 4 + wave) * 32 : p.Mt;      // surplus workgroups own no tile
+    const __amdgpu_buffer_rsrc_t srd_x = wsrd(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t srd_u = wsrd(p.u, p.u_bytes);
+
+    // ---- this lane's tile: byte offsets of the 16 pixels of its 4x4 input patch (channel 4 kh) -------------
+    const int m = tile0 + li;
+    const bool tv = m < p.Mt;
+    const int tpi = p.TH * p.TW;
+    const int n = (tv ? m : 0) / tpi;
+    const int r = (tv ? m : 0) - n * tpi;
+    const int th = r / p.TW, tw = r - th * p.TW;
+    unsigned voff[16];
+#pragma unroll
+    for (int py = 0; py < 4; ++py)
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const int ih = 2 * th - 1 + py, iw = 2 * tw - 1 + px;
+            const bool ok = tv && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            voff[py * 4 + px] = ok ? (unsigned)(((n * p.H + ih) * p.W + iw) * p.ldx + 4 * kh) * 4u : kOOB;
+        }
+    // ---- B tile DMA slots: instruction i of wave w fills floats [(i*256 + w*64 + lane) * 4, +4) of the buffer ---
+    unsigned uoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 256 + tid;                  // (xi, co, half) = (idx / 64, (idx / 2) % 32, idx % 2)
+        const int xi = idx >> 6, co = (idx >> 1) & 31, half = idx & 1;
+        uoff[i] = (co0 + co < p.Cout) ? (unsigned)(((xi * p.Cout + co0 + co) * p.Cin) + 4 * half) * 4u : kOOB;
+    }
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[xi][e] = 0.f;
+
+    f32x4 raw[16];
+    auto load_raw = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            raw[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff[q], c0 * 4, 0));
+    };
+    auto dma_u = [&](int buf, int c0) {
+        float *dst = smem + buf * 4096 + wave * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_u, (lds_ptr)(dst + i * 1024), 16, uoff[i], c0 * 4, 0, 0);
+    };
+
+    const int ksteps = p.Cin >> 3;
+    load_raw(0);
+    dma_u(0, 0);
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        // ---- V = B^T d B on the 16 pixels, per channel component: the results are the A fragments.  The row pass
+        // (B^T d) needs all 16 pixels and runs first; the column pass of patch row py+1 is issued behind the MFMAs of
+        // row py, in the shadow of the last of them ----------------------------------------------------------------------
+        f32x4 t[16];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const f32x4 d0 = raw[px], d1 = raw[4 + px], d2 = raw[8 + px], d3 = raw[12 + px];
+            if constexpr (DBG & 1) { t[px] = d0; t[4 + px] = d1; t[8 + px] = d2; t[12 + px] = d3; } else {
+            t[px] = sub4(d0, d2);
+            t[4 + px] = d1 + d2;
+            t[8 + px] = sub4(d2, d1);
+            t[12 + px] = sub4(d1, d3); }
+        }
+        // Operands of the next K step are requested BETWEEN the MFMA groups, four patch pixels and one weight DMA per
+        // patch row: each pixel-scattered load occupies the texture-address path for a while, and issued in one burst at
+        // the top of the step they stall the wave's in-order issue with the matrix pipe idle (measured +0.8 us per
+        // step); spread out, they sit in the shadow of the MFMAs in front of them.
+        const bool more = ks + 1 < ksteps;
+        const int cn = (ks + 1) * 8;
+        float *dma_dst = smem + ((ks + 1) & 1) * 4096 + wave * 256;
+        const float *b_s = smem + (ks & 1) * 4096 + li * 8 + kh * 4;
+        f32x4 v[4], vn[4], b[4], bn[4];
+        if constexpr (DBG & 1) { vn[0] = t[0]; vn[1] = t[1]; vn[2] = t[2]; vn[3] = t[3]; } else {
+        vn[0] = sub4(t[0], t[2]); vn[1] = t[1] + t[2]; vn[2] = sub4(t[2], t[1]); vn[3] = sub4(t[1], t[3]); }
+        if constexpr (!(DBG & 2)) {
+#pragma unroll
+        for (int px = 0; px < 4; ++px) bn[px] = *reinterpret_cast<const f32x4 *>(b_s + px * 256);
+        } else if (ks == 0) {
+#pragma unroll
+        for (int px = 0; px < 4; ++px) bn[px] = *reinterpret_cast<const f32x4 *>(b_s + px * 256);
+        }
+#pragma unroll
+        for (int py = 0; py < 4; ++py) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = vn[j]; b[j] = bn[j]; }
+            if constexpr (!(DBG & 2)) {
+            if (py < 3) {       // the next row's weights are read while this row's sixteen MFMAs run
+#pragma unroll
+                for (int px = 0; px < 4; ++px) bn[px] = *reinterpret_cast<const f32x4 *>(b_s + (py * 4 + 4 + px) * 256);
+            } }
+            if (more) {
+                // (flags 256 / 512 / 1024 switch the pixel loads / weight DMAs / stores off for timing experiments.  The
+                // uniform branches also keep hipcc from regrouping the requests: with them removed the same kernel
+                // measured 5.7 % slower, with the loads made unconditional 2 % slower -- scratch A/B on one box.)
+                if (!(DBG & 8)) {
+#pragma unroll
+                    for (int px = 0; px < 4; ++px)
+                        raw[py * 4 + px] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff[py * 4 + px], cn * 4, 0));
+                }
+                if (!(DBG & 16))
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_u, (lds_ptr)(dma_dst + py * 1024), 16, uoff[py], cn * 4, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // positions of this patch row, two at a time: consecutive MFMAs alternate between two accumulators
+#pragma unroll
+            for (int pp = 0; pp < 4; pp += 2)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[py * 4 + pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[pp][j], b[pp][j], acc[py * 4 + pp], 0, 0, 0);
+                    acc[py * 4 + pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[pp + 1][j], b[pp + 1][j], acc[py * 4 + pp + 1], 0, 0, 0);
+                }
+            if (py < 3) {       // column pass of the next patch row, behind this row's MFMAs
+                const f32x4 t0 = t[py * 4 + 4], t1 = t[py * 4 + 5], t2 = t[py * 4 + 6], t3 = t[py * 4 + 7];
+                if constexpr (DBG & 1) { vn[0] = t0; vn[1] = t1; vn[2] = t2; vn[3] = t3; } else {
+                vn[0] = sub4(t0, t2); vn[1] = t1 + t2; vn[2] = sub4(t2, t1); vn[3] = sub4(t1, t3); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!(DBG & 4)) __syncthreads();
+    }
+    if constexpr (DBG & 32) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) sacc += acc[xi][0] + acc[xi][7];
+        if (sacc == 12345.678f) p.z[tid] = sacc;
+        return;
+    }
+
+    // ---- output transform Y = A^T M A, per lane across the sixteen accumulators; store; statistics ---------------
+    // accumulator element e of every position is the same (tile row, channel column): row = (e&3) + 8 (e>>2) + 4 kh
+    const int col = co0 + li;
+    const bool colok = col < p.Cout;
+    const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
+    const __amdgpu_buffer_rsrc_t srd_z = wsrd(p.z, p.z_bytes);
+    // byte offset of the tile's top-left output pixel (channel 0), or out of range; bit 0 / 1 = the tile has a
+    // right column / a bottom row inside the image (odd H, W).  Read from the lane that owns the tile with
+    // v_readlane (the row of an accumulator element is a compile-time constant plus 4 kh).
+    const unsigned obase = tv ? (unsigned)(((n * p.H + 2 * th) * p.W + 2 * tw) * p.ldz) * 4u : kOOB;
+    const int oflags = tv ? ((2 * tw + 1 < p.W ? 1 : 0) | (2 * th + 1 < p.H ? 2 : 0)) : 0;
+    const unsigned right = (unsigned)p.ldz * 4u, below = (unsigned)(p.W * p.ldz) * 4u;
+    const unsigned cbyte = colok ? (unsigned)col * 4u : kOOB;
+    float s = 0.f, q = 0.f;
+    if constexpr (!BNS) {
+    #pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row0 = (e & 3) + 8 * (e >> 2);
+            const unsigned ob0 = __builtin_amdgcn_readlane(obase, row0), ob1 = __builtin_amdgcn_readlane(obase, row0 + 4);
+            const int of0 = __builtin_amdgcn_readlane(oflags, row0), of1 = __builtin_amdgcn_readlane(oflags, row0 + 4);
+            const unsigned ob = kh ? ob1 : ob0;
+            const int of = kh ? of1 : of0;
+            float mm[16];
+    #pragma unroll
+            for (int xi = 0; xi < 16; ++xi) mm[xi] = acc[xi][e];
+            // rows of A^T M: a0 = m0 + m1 + m2, a1 = m1 - m2 - m3 (over the first index), then the same over the second
+            float a0[4], a1[4];
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0[j] = mm[j] + mm[4 + j] + mm[8 + j];
+                a1[j] = mm[4 + j] - mm[8 + j] - mm[12 + j];
+            }
+            const float y[4] = {a0[0] + a0[1] + a0[2], a0[1] - a0[2] - a0[3], a1[0] + a1[1] + a1[2], a1[1] - a1[2] - a1[3]};
+            // branch-free stores: a pixel outside the image or a column past Cout gets an out-of-range offset, which the
+            // buffer store drops
+            const bool live = ob != kOOB && colok;
+            const bool ok[4] = {live, live && (of & 1), live && (of & 2), live && (of & 3) == 3};
+            const unsigned off[4] = {ob, ob + right, ob + below, ob + below + right};
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(p.flags & 1024))
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[k]), srd_z, ok[k] ? off[k] + cbyte : kOOB, 0, 0);
+                const float u = ok[k] ? y[k] - pv : 0.f;
+                s += u;
+                q += u * u;
+            }
+        }
+
+    } else {
+        constexpr bool bns = true;
+        const __amdgpu_buffer_rsrc_t srd_y = wsrd(bns ? p.y : p.z, p.z_bytes);
+        // DS_EPI_BNSUMS (this launch is a dgrad whose result dy feeds a BatchNorm + ReLU backward): per column, the sums
+        // of g = dy (y > 0) and g * y.  y sits at the offsets of the stores; element e + 1's four values are requested
+        // while element e is transformed (out-of-range offsets read zeros: y = 0 drops the element from both sums).
+        float ycur[4] = {0.f, 0.f, 0.f, 0.f}, ynxt[4] = {0.f, 0.f, 0.f, 0.f};
+        auto offsets_of = [&](int e, unsigned *off, bool *ok) {
+            const int row0 = (e & 3) + 8 * (e >> 2);
+            const unsigned ob0 = __builtin_amdgcn_readlane(obase, row0), ob1 = __builtin_amdgcn_readlane(obase, row0 + 4);
+            const int of0 = __builtin_amdgcn_readlane(oflags, row0), of1 = __builtin_amdgcn_readlane(oflags, row0 + 4);
+            const unsigned ob = kh ? ob1 : ob0;
+            const int of = kh ? of1 : of0;
+            // branch-free stores: a pixel outside the image or a column past Cout gets an out-of-range offset, which the
+            // buffer store drops
+            const bool live = ob != kOOB && colok;
+            ok[0] = live; ok[1] = live && (of & 1); ok[2] = live && (of & 2); ok[3] = live && (of & 3) == 3;
+            off[0] = ob; off[1] = ob + right; off[2] = ob + below; off[3] = ob + below + right;
+        };
+        if (bns) {
+            unsigned off[4];
+            bool ok[4];
+            offsets_of(0, off, ok);
+    #pragma unroll
+            for (int k = 0; k < 4; ++k)
+                ynxt[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_y, ok[k] ? off[k] + cbyte : kOOB, 0, 0));
+        }
+    #pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            unsigned off[4];
+            bool ok[4];
+            offsets_of(e, off, ok);
+            if (bns) {
+    #pragma unroll
+                for (int k = 0; k < 4; ++k) ycur[k] = ynxt[k];
+                if (e < 15) {
+                    unsigned offn[4];
+                    bool okn[4];
+                    offsets_of(e + 1, offn, okn);
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        ynxt[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_y, okn[k] ? offn[k] + cbyte : kOOB, 0, 0));
+                }
+            }
+            float mm[16];
+    #pragma unroll
+            for (int xi = 0; xi < 16; ++xi) mm[xi] = acc[xi][e];
+            // rows of A^T M: a0 = m0 + m1 + m2, a1 = m1 - m2 - m3 (over the first index), then the same over the second
+            float a0[4], a1[4];
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0[j] = mm[j] + mm[4 + j] + mm[8 + j];
+                a1[j] = mm[4 + j] - mm[8 + j] - mm[12 + j];
+            }
+            const float y[4] = {a0[0] + a0[1] + a0[2], a0[1] - a0[2] - a0[3], a1[0] + a1[1] + a1[2], a1[1] - a1[2] - a1[3]};
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(p.flags & 1024))
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[k]), srd_z, ok[k] ? off[k] + cbyte : kOOB, 0, 0);
+                if (bns) {
+                    const float u = (ok[k] && ycur[k] > 0.f) ? y[k] : 0.f;
+                    s += u;
+                    q += u * ycur[k];
+                } else {
+                    const float u = ok[k] ? y[k] - pv : 0.f;
+                    s += u;
+                    q += u * u;
+                }
+            }
+        }
+
+    }
+    if (BNS || (p.flags & DS_EPI_STATS)) {
+        float *red = smem;        // [4 waves][32][2]; every wave passed the last K-loop barrier, no DMA in flight
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+        if (kh == 0) {
+            red[(wave * 32 + li) * 2 + 0] = s;
+            red[(wave * 32 + li) * 2 + 1] = q;
+        }
+        __syncthreads();
+        if (tid < 32 && co0 + tid < p.Cout) {
+            float ss = 0.f, qq = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                ss += red[(w * 32 + tid) * 2 + 0];
+                qq += red[(w * 32 + tid) * 2 + 1];
+            }
+            if (group < p.groups) {
+                p.stats[(int64_t)(co0 + tid) * p.groups + group] = ss;
+                p.stats[((int64_t)p.Cout + co0 + tid) * p.groups + group] = qq;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+template <int DBG>
+float run(const WinoParams &p0, int Cin, int reps) {
+    WinoParams p = p0;
+    p.Cin = Cin;
+    const dim3 grid((unsigned)(((int64_t)p.groups * p.ncol + 7) / 8 * 8));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((conv_wino_kernel<false, DBG>), grid, dim3(256), 0, 0, p);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((conv_wino_kernel<false, DBG>), grid, dim3(256), 0, 0, p);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e3f / reps;
+}
+template <int DBG>
+void both(const char *name, const WinoParams &p) {
+    const float t8 = run<DBG>(p, 64, 10), t32 = run<DBG>(p, 256, 10);
+    const double rounds = (double)p.groups * p.ncol / 256.0;
+    printf("%-52s Cin 64: %7.1f us  Cin 256: %7.1f us | per workgroup: %5.2f us per K step, %5.2f us fixed\n", name, t8, t32,
+           (t32 - t8) / 24.0 / rounds, (t8 - 8.0 * (t32 - t8) / 24.0) / rounds);
+}
+int main() {
+    // 28x28 maps, batch 256 -> 50176 tiles = 392 groups; Cout 128 = 4 column blocks: 1568 workgroups = 6.125 rounds;
+    // use batch 256*... exact rounds: N = 64 -> 12544 tiles = 98 groups x 4... pick N so that groups*ncol % 256 == 0
+    const int N = 256, H = 16, W = 16, Cmax = 256, Cout = 128;     // tiles = 256*8*8 = 16384 = 128 groups x 4 = 512 workgroups = 2 rounds
+    WinoParams p = {};
+    float *x, *u, *z;
+    const size_t xb = (size_t)N * H * W * Cmax * 4, ub = (size_t)16 * Cout * Cmax * 4, zb = (size_t)N * H * W * Cout * 4;
+    hipMalloc(&x, xb); hipMalloc(&u, ub); hipMalloc(&z, zb);
+    hipMemset(x, 0, xb); hipMemset(u, 0, ub);
+    p.x = x; p.u = u; p.z = z; p.stats = nullptr; p.pivot = nullptr; p.y = nullptr;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cmax; p.ldx = Cmax; p.Cout = Cout; p.ldz = Cout;
+    p.TH = H / 2; p.TW = W / 2; p.Mt = N * p.TH * p.TW;
+    p.groups = (p.Mt + 127) / 128; p.ncol = (Cout + 31) / 32;
+    p.x_bytes = (unsigned)xb; p.u_bytes = (unsigned)ub; p.z_bytes = (unsigned)zb; p.flags = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        both<0>("full kernel", p);
+        both<1>("no transform VALU", p);
+        both<2>("no LDS fragment reads", p);
+        both<4>("no barrier", p);
+        both<8>("no A loads", p);
+        both<16>("no B DMA", p);
+        both<24>("no A loads, no B DMA", p);
+        both<24 + 4>("no loads, no barrier", p);
+        both<24 + 4 + 2>("no loads, no barrier, no LDS reads", p);
+        both<24 + 4 + 2 + 1>("MFMA + loop control only", p);
+        both<32>("full loop, no epilogue", p);
+    }
+    return 0;
+}

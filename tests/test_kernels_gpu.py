@@ -412,6 +412,133 @@ def test_bn_backward_sums_from_mixed_sources_match_the_single_pass():
     close(coef[1], coef0[1].cpu().numpy().astype(np.float64), 1e-4)
 
 
+def _fp8_round(a, fmax, mant, emin):
+    """saturating round-to-nearest-even to an OCP fp8 format (e4m3fn: 448, 3, -6; e5m2: 57344, 2, -14), as float64"""
+    a = np.asarray(a, np.float64)
+    m = np.minimum(np.abs(a), fmax)
+    e = np.maximum(np.frexp(m)[1] - 1, emin)
+    step = np.ldexp(1.0, e - mant)
+    return np.sign(a) * np.rint(m / step) * step
+
+
+def _pow2_scale(amax, fmax):
+    if not amax > 0:
+        return 1.0
+    r = np.float32(fmax) / np.float32(amax)
+    return float(2.0 ** (int(np.frexp(r)[1]) - 1))
+
+
+def test_absmax_and_fp8_formats_on_this_device():
+    """ds_absmax is exact; and what v_cvt_pk_fp8_f32 / v_cvt_pk_bf8_f32 + the fp8 MFMA do on THIS device is the OCP
+    e4m3fn / e5m2 arithmetic the oracle emulates (gfx942 would be FNUZ: a factor 2 here): a 32 x 16 x 32 product of
+    values that are exactly representable comes out exact, values between two codes round to nearest even (ties
+    included), subnormals keep their absolute step."""
+    ops = _ops()
+    rng = np.random.RandomState(3)
+    x = rng.normal(size=100003).astype(np.float32) * 3
+    x[777] = -41.5
+    out = torch.zeros(1, device="cuda")
+    xd = dev(x)
+    ops.absmax(xd, x.size, out)
+    torch.cuda.synchronize()
+    assert float(out.item()) == 41.5
+    # one tile: M = 32, K = 16, N = 32, identity-like weights pick single products
+    for a_format, fmax, mant, emin in ((ops.DS_FP8_E4M3, 448.0, 3, -6), (ops.DS_FP8_E5M2, 57344.0, 2, -14)):
+        M, K, N = 32, 16, 32
+        # column 0 pins amax = fmax (s_a = 1); 1.0625 / 1.1875 are ties in e4m3, 1.125 is one in e5m2; subnormals
+        vals = [fmax, 1.0, 1.125, 1.0625, 1.1875, 0.3, -2.7, 300.0, 2.0 ** emin, 2.0 ** (emin - 2), 1e-4, 17.0, -0.5, 3.3,
+                100.0, 0.0]
+        xs = np.tile(np.array(vals, np.float32)[None, :], (M, 1))
+        w = np.zeros((1, 1, K, N), np.float32)
+        for k in range(K):
+            w[0, 0, k, k] = 1.0                            # column k = operand k
+        w[0, 0, 0, 16] = 448.0                             # pins the weight amax -> s_w = 1
+        plan = ops.Fp8Plan(M, 1, 1, K, K, 1, 1, N, N, a_format=a_format, pad_t=0, pad_l=0, OH=1, OW=1)
+        wq = torch.empty(ops.weights_fp8_bytes(K, N, 1, False), dtype=torch.uint8, device="cuda")
+        ws = torch.zeros(4, device="cuda")
+        ops.weights_to_fp8(ops._p(dev(w)), wq, ws, K, N, 1, False)
+        xd = dev(xs)
+        amax = torch.zeros(1, device="cuda")
+        ops.absmax(xd, xs.size, amax)
+        z = torch.empty(M, N, device="cuda")
+        plan.run(ops._p(xd), ops._p(wq), ops._p(z), x_amax=ops._p(amax), wscale=ops._p(ws))
+        torch.cuda.synchronize()
+        assert float(ws[1].item()) == 1.0 and float(amax.item()) == fmax
+        want = _fp8_round(xs, fmax, mant, emin)
+        got = z.cpu().numpy().astype(np.float64)[:, :K]
+        np.testing.assert_array_equal(got, want, err_msg="format %d" % a_format)
+
+
+FP8_CASES = [
+    # (N, H, W, Cin, Cout, k)
+    (2, 9, 9, 16, 32, 1),
+    (3, 14, 14, 24, 64, 3),
+    (2, 28, 28, 96, 128, 3),
+    (4, 7, 7, 832, 624, 1),
+    (2, 13, 11, 48, 176, 3),
+    (1, 8, 8, 8, 200, 1),
+]
+
+
+@pytest.mark.parametrize("case", FP8_CASES)
+def test_fp8_conv_forward_and_dgrad_match_quantising_oracle(case):
+    """ds_conv_fp8 against the fp64 convolution of the SAME quantised operands (per-tensor power-of-two scale from
+    max|.|, saturating round-to-nearest-even to e4m3 / e5m2): products of fp8 values are exact in fp32, so only the
+    accumulation separates the two -- measured 3.5e-5 of the largest output on MI355X (the fp8 MFMA sums its 16 products
+    with ~15 bits of alignment before the fp32 accumulate), gate 1e-4; forward with BatchNorm statistics, the
+    input gradient through the flipped / transposed filter with e5m2 gradients.  Against the UNQUANTISED convolution
+    the error is the formats' own: ~4 % (e4m3 x e4m3) and ~8 % (e5m2 x e4m3) relative L2, printed."""
+    ops = _ops()
+    N, H, W, Ci, Co, k = case
+    rng = np.random.RandomState(9)
+    x = (np.maximum(rng.normal(size=(N, H, W, Ci)), 0) * 1.7).astype(np.float32)         # post-ReLU like
+    w = (rng.normal(size=(k, k, Ci, Co)) * 0.05).astype(np.float32)
+    sx, sw = _pow2_scale(np.abs(x).max(), 448.0), _pow2_scale(np.abs(w).max(), 448.0)
+    xq, wq_ = _fp8_round(x.astype(np.float64) * sx, 448.0, 3, -6), _fp8_round(w.astype(np.float64) * sw, 448.0, 3, -6)
+    ref = S.conv2d_same(xq, wq_, 1) / (sx * sw)
+    exact = S.conv2d_same(x.astype(np.float64), w.astype(np.float64), 1)
+    xd, wd = dev(x), dev(w)
+    M = N * H * W
+    plan = ops.Fp8Plan(N, H, W, Ci, Ci, k, 1, Co, Co, flags=ops.DS_EPI_STATS, a_format=ops.DS_FP8_E4M3)
+    wq = torch.empty(ops.weights_fp8_bytes(Ci, Co, k * k, False), dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(4, device="cuda")
+    ops.weights_to_fp8(ops._p(wd), wq, ws, Ci, Co, k * k, False)
+    amax = torch.zeros(1, device="cuda")
+    ops.absmax(xd, x.size, amax)
+    z = torch.full((M, Co), float("nan"), device="cuda")
+    stats = torch.zeros(2, Co, plan.partials, device="cuda")
+    pivot = dev(rng.normal(size=Co) * 0.1)
+    plan.run(ops._p(xd), ops._p(wq), ops._p(z), stats=ops._p(stats), pivot=ops._p(pivot), x_amax=ops._p(amax), wscale=ops._p(ws))
+    torch.cuda.synchronize()
+    assert float(ws[1].item()) == sw
+    zz = ref.reshape(M, Co)
+    close(z, zz, 1e-4)
+    pv = pivot.cpu().numpy().astype(np.float64)
+    close(stats[0].sum(1), (zz - pv).sum(0), 2e-3)
+    close(stats[1].sum(1), ((zz - pv) ** 2).sum(0), 2e-3)
+    e_fwd = np.linalg.norm(z.cpu().numpy().reshape(exact.shape) - exact) / np.linalg.norm(exact)
+    # dgrad: e5m2 gradients x e4m3 flipped / transposed filter
+    if Co % 8 == 0:
+        dy = (rng.normal(size=ref.shape) * 3e-4).astype(np.float32)
+        sd = _pow2_scale(np.abs(dy).max(), 57344.0)
+        dq = _fp8_round(dy.astype(np.float64) * sd, 57344.0, 2, -14)
+        dref = S.conv2d_same_bwd_input(dq, wq_, (N, H, W, Ci), 1) / (sd * sw)
+        dexact = S.conv2d_same_bwd_input(dy.astype(np.float64), w.astype(np.float64), (N, H, W, Ci), 1)
+        g = ops.Fp8Plan(N, H, W, Co, Co, k, 1, Ci, Ci, a_format=ops.DS_FP8_E5M2)
+        wqd = torch.empty(ops.weights_fp8_bytes(Ci, Co, k * k, True), dtype=torch.uint8, device="cuda")
+        wsd = torch.zeros(4, device="cuda")
+        ops.weights_to_fp8(ops._p(wd), wqd, wsd, Ci, Co, k * k, True)
+        dyd = dev(dy)
+        ops.absmax(dyd, dy.size, amax)
+        dx = torch.full((M, Ci), float("nan"), device="cuda")
+        g.run(ops._p(dyd), ops._p(wqd), ops._p(dx), x_amax=ops._p(amax), wscale=ops._p(wsd))
+        torch.cuda.synchronize()
+        close(dx, dref.reshape(M, Ci), 1e-4)
+        e_bwd = np.linalg.norm(dx.cpu().numpy().reshape(dexact.shape) - dexact) / np.linalg.norm(dexact)
+        print("fp8 conv %s: relative L2 against the unquantised convolution: forward %.3f, dgrad %.3f" % (case, e_fwd, e_bwd))
+        assert e_fwd <= 0.08 and e_bwd <= 0.15
+
+
 def _bf16_round(a):
     """round-to-nearest-even to bfloat16, returned as float64 (what v_cvt_pk_bf16_f32 does to the operands)"""
     u = np.asarray(a, np.float32).view(np.uint32).astype(np.uint64)

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libds_kernels.so")
 
 DS_EPI_BIAS, DS_EPI_RELU, DS_EPI_ACCUM, DS_EPI_STATS, DS_EPI_MASK, DS_EPI_BNSUMS = 1, 2, 4, 8, 16, 32
 DS_DTYPE_F32, DS_DTYPE_BF16 = 0, 1
+DS_FP8_E4M3, DS_FP8_E5M2 = 0, 1
 
 
 class ConvDesc(C.Structure):
@@ -56,6 +57,12 @@ SIGNATURES = {
     "ds_conv_bf16_supported": (C.c_int, [_CD]),
     "ds_conv_bf16_partials": (C.c_int, [_CD]),
     "ds_conv_bf16": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P]),
+    "ds_absmax": (C.c_int, [_P, _i64, _P, _P]),
+    "ds_weights_fp8_bytes": (C.c_size_t, [_i32, _i32, _i32, _i32]),
+    "ds_weights_to_fp8": (C.c_int, [_P, _P, _P, _i32, _i32, _i32, _i32, _P]),
+    "ds_conv_fp8_supported": (C.c_int, [_CD]),
+    "ds_conv_fp8_partials": (C.c_int, [_CD]),
+    "ds_conv_fp8": (C.c_int, [_CD, _P, _P, _i32, _P, _P, _P, _P, _P, _P]),
     "ds_conv_stem_partials": (C.c_int, [_i32, _i32, _i32]),
     "ds_conv_stem": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "ds_wino_transform_weights": (C.c_int, [_P, _P, _i32, _i32, _i32, _P]),

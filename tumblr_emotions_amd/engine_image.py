@@ -112,11 +112,23 @@ class ConvBN:
         # bf16: the register-direct kernel (ds_conv_bf16, pre-converted weights) where it beats the LDS-staged one
         # (profiles/r02_bf16_layers.txt): forward from 48 output columns up, dgrad for the 1x1 layers and from 160
         # columns up; it rides the same alternative-plan slots as the Winograd kernel (u_* = its converted weights)
-        bf16 = eng.conv_dtype == ops.DS_DTYPE_BF16 and not self.fold and k in (1, 3) and eng.bf16_direct
+        bf16 = eng.dtype == "bf16" and not self.fold and k in (1, 3) and eng.bf16_direct
         self._bf16_dgrad_ok = bf16 and cout % 8 == 0 and (k == 1 or cin >= 160)
         if bf16 and cin % 8 == 0 and cout >= 48:
             self.wino_fwd = ops.Bf16Plan(B, self.H, self.W, cin, cin, k, self.stride, cout, cout, flags=DS_EPI_STATS)
             self.u_fwd = torch.empty(ops.weights_bf16_bytes(cin, cout, k * k, False), dtype=torch.uint8, device=dev)
+            eng.need_stats(self.wino_fwd.partials * 2 * cout)
+        # fp8: ds_conv_fp8 wherever it applies (same alternative-plan slots; u_* = the e4m3 filter, ws_* its scale
+        # record, amax = device words with max|x| of the forward input / of dz, taken by ds_absmax right before the conv)
+        fp8 = eng.dtype == "fp8" and not self.fold and k in (1, 3) and self.stride == 1
+        self._fp8_dgrad_ok = fp8 and cout % 8 == 0
+        if fp8:
+            self.amax = torch.zeros(2, device=dev)
+        if fp8 and cin % 8 == 0:
+            self.wino_fwd = ops.Fp8Plan(B, self.H, self.W, cin, cin, k, self.stride, cout, cout, flags=DS_EPI_STATS,
+                                        a_format=ops.DS_FP8_E4M3)
+            self.u_fwd = torch.empty(ops.weights_fp8_bytes(cin, cout, k * k, False), dtype=torch.uint8, device=dev)
+            self.ws_fwd = torch.zeros(4, device=dev)
             eng.need_stats(self.wino_fwd.partials * 2 * cout)
         self.u_version = -1
         eng.need_stats(self.fwd.partials * 2 * cout)
@@ -223,6 +235,11 @@ class ConvBN:
             self.wino_dgrad = ops.Bf16Plan(self.B, self.H, self.W, cout, cout, k, 1, cin, lddx)
             self.u_dgrad = torch.empty(ops.weights_bf16_bytes(cin, cout, k * k, True), dtype=torch.uint8,
                                        device=self.eng.device)
+        elif self._fp8_dgrad_ok:
+            self.wino_dgrad = ops.Fp8Plan(self.B, self.H, self.W, cout, cout, k, 1, cin, lddx, a_format=ops.DS_FP8_E5M2)
+            self.u_dgrad = torch.empty(ops.weights_fp8_bytes(cin, cout, k * k, True), dtype=torch.uint8,
+                                       device=self.eng.device)
+            self.ws_dgrad = torch.zeros(4, device=self.eng.device)
 
     def _refresh_wino(self):
         """G g G^T of the filter for the Winograd kernels: redone when the weights changed -- every step for a
@@ -235,7 +252,9 @@ class ConvBN:
         taps = self.k * self.k
         for plan, u, dgrad in ((self.wino_fwd, getattr(self, "u_fwd", None), False),
                                (self.wino_dgrad, getattr(self, "u_dgrad", None), True)):
-            if isinstance(plan, ops.Bf16Plan):
+            if isinstance(plan, ops.Fp8Plan):
+                ops.weights_to_fp8(self.w_ptr, u, self.ws_dgrad if dgrad else self.ws_fwd, self.cin, self.cout, taps, dgrad)
+            elif isinstance(plan, ops.Bf16Plan):
                 ops.weights_to_bf16(self.w_ptr, u, self.cin, self.cout, taps, dgrad)
             elif plan is not None:
                 ops.wino_transform_weights(self.w_ptr, u, self.cin, self.cout, dgrad)
@@ -254,12 +273,16 @@ class ConvBN:
         elif wino is not None:
             wino.set_ldx(ldx)
             u_ptr = ops._p(self.u_fwd)
+        fp8_kw = {}
+        if isinstance(wino, ops.Fp8Plan):      # per-tensor scale of the input: max|x| into a device word
+            ops.absmax(x_ptr, self.B * self.H * self.W * ldx, self.amax[0:1])
+            fp8_kw = dict(x_amax=ops._p(self.amax[0:1]), wscale=ops._p(self.ws_fwd))
         if eng.training:       # batch statistics (slim.batch_norm is_training=True)
             # the column sums are taken about a pivot near the mean -- the previous step's batch mean, the
             # moving mean before the first step (bind) -- so channels with |mean| >> std keep their variance
             if wino is not None:
                 wino.flags = DS_EPI_STATS
-                wino.run(x_ptr, u_ptr, ops._p(self.z), stats=ops._p(self.stats_buf), pivot=ops._p(self.mean))
+                wino.run(x_ptr, u_ptr, ops._p(self.z), stats=ops._p(self.stats_buf), pivot=ops._p(self.mean), **fp8_kw)
                 P = wino.partials
             else:
                 self.fwd.d.flags = DS_EPI_STATS
@@ -271,7 +294,7 @@ class ConvBN:
         else:                  # moving statistics (is_training=False: evaluate_* on the validation split)
             if wino is not None:
                 wino.flags = 0
-                wino.run(x_ptr, u_ptr, ops._p(self.z))
+                wino.run(x_ptr, u_ptr, ops._p(self.z), **fp8_kw)
             else:
                 self.fwd.d.flags = 0
                 self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z))
@@ -304,7 +327,11 @@ class ConvBN:
     def _run_dgrad(self, dx_ptr):
         sums = ops._p(self.dx_sums) if self.dx_sums is not None else None
         y = ops._p(self.dx_y) if self.dx_sums is not None else None
-        if self.wino_dgrad is not None:
+        if isinstance(self.wino_dgrad, ops.Fp8Plan):
+            ops.absmax(self.z, self.M * self.cout, self.amax[1:2])
+            self.wino_dgrad.run(ops._p(self.z), ops._p(self.u_dgrad), dx_ptr, x_amax=ops._p(self.amax[1:2]),
+                                wscale=ops._p(self.ws_dgrad))
+        elif self.wino_dgrad is not None:
             if sums is not None:
                 self.wino_dgrad.run(ops._p(self.z), ops._p(self.u_dgrad), dx_ptr, stats=sums, ymask=y)
             else:
@@ -613,9 +640,12 @@ class InceptionV1Engine:
         self.store, self.num_classes, self.keep = store, num_classes, dropout_keep_prob
         # arithmetic type of the 57 convs' forward and dgrad multiplies: "f32" = exact fp32 MFMA (the parity path),
         # "bf16" = bf16 MFMA with fp32 accumulation; storage, BatchNorm, wgrad, Logits and master weights stay fp32
-        assert dtype in ("f32", "bf16")
+        # "fp8" (BASELINE configs[4]): the 1x1 / 3x3 convs' forward (e4m3 x e4m3) and dgrad (e5m2 x e4m3) multiplies on
+        # the fp8 matrix pipe with per-tensor power-of-two scales (ds_conv_fp8); what that kernel does not take (the
+        # stem, odd channel counts) falls back to the bf16 kernels
+        assert dtype in ("f32", "bf16", "fp8")
         self.dtype = dtype
-        self.conv_dtype = ops.DS_DTYPE_BF16 if dtype == "bf16" else ops.DS_DTYPE_F32
+        self.conv_dtype = ops.DS_DTYPE_F32 if dtype == "f32" else ops.DS_DTYPE_BF16
         self.trainable_bn_beta = trainable_bn_beta
         # train_all: full-tower fine-tuning -- every conv weight trainable, i.e. the
         # reference graph with the `trainable=False` of inception_v1.py:57-59 dropped; wgrad then runs for

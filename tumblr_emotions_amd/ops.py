@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import (ConvDesc, Segments, SumSegments, DS_EPI_ACCUM, DS_EPI_BIAS, DS_EPI_BNSUMS, DS_EPI_MASK, DS_EPI_RELU,  # noqa: F401
                    DS_EPI_STATS,
-                   DS_DTYPE_BF16, DS_DTYPE_F32)
+                   DS_DTYPE_BF16, DS_DTYPE_F32, DS_FP8_E4M3, DS_FP8_E5M2)
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -239,6 +239,44 @@ class Bf16Plan:
         _lib.check(_lib.load().ds_conv_bf16(C.byref(self.d), x, wb, z, stats, pivot, _stream()), "ds_conv_bf16")
         if t is not None:
             t.end(self)
+
+
+class Fp8Plan(Bf16Plan):
+    """1x1 / 3x3 conv (or its dgrad) through ds_conv_fp8: register-direct fp8 MFMA with per-tensor power-of-two scales.
+    `wq`, `wscale`: the filter converted by `weights_to_fp8`; `x_amax`: device word holding max|x| (`absmax`);
+    a_format: DS_FP8_E4M3 for forward activations, DS_FP8_E5M2 for gradients.  Geometry arguments as ConvPlan's."""
+
+    def __init__(self, N, H, W, Cin, ldx, k, stride, Cout, ldz, flags=0, a_format=DS_FP8_E4M3, **kw):
+        super().__init__(N, H, W, Cin, ldx, k, stride, Cout, ldz, flags=flags, **kw)
+        lib = _lib.load()
+        if not lib.ds_conv_fp8_supported(C.byref(self.d)):
+            raise ValueError("ds_conv_fp8 does not take this geometry")
+        self.a_format = a_format
+        self.partials = lib.ds_conv_fp8_partials(C.byref(self.d)) if flags & DS_EPI_STATS else 0
+
+    def run(self, x, wq, z, stats=None, pivot=None, x_amax=None, wscale=None):
+        t = CONV_TIMER
+        if t is not None:
+            t.begin()
+        _lib.check(_lib.load().ds_conv_fp8(C.byref(self.d), x, x_amax, self.a_format, wq, wscale, z, stats, pivot,
+                                           _stream()), "ds_conv_fp8")
+        if t is not None:
+            t.end(self)
+
+
+def absmax(x, n, out):
+    """out[0] = max |x[:n]| on the device (no host sync)."""
+    _lib.check(_lib.load().ds_absmax(_p(x) if not isinstance(x, C.c_void_p) else x, n, _p(out), _stream()), "ds_absmax")
+
+
+def weights_fp8_bytes(Cin, Cout, taps, dgrad):
+    return int(_lib.load().ds_weights_fp8_bytes(Cin, Cout, taps, int(dgrad)))
+
+
+def weights_to_fp8(w_ptr, wq, wscale, Cin, Cout, taps, dgrad):
+    """HWIO fp32 filter -> ds_conv_fp8's e4m3 weight tensor `wq` + its scale record `wscale` (4 device floats)."""
+    _lib.check(_lib.load().ds_weights_to_fp8(w_ptr, _p(wq), _p(wscale), Cin, Cout, taps, int(dgrad), _stream()),
+               "ds_weights_to_fp8")
 
 
 def weights_bf16_bytes(Cin, Cout, taps, dgrad):
