@@ -179,6 +179,8 @@ def main():
                     help="Mixed blocks on one stream (default: Branch_2 / Branch_3 on side streams)")
     ap.add_argument("--bf16-staged", action="store_true",
                     help="--dtype bf16: the LDS-staged bf16 kernel for every conv (default: ds_conv_bf16 where it wins)")
+    ap.add_argument("--no-act16", action="store_true",
+                    help="--dtype bf16 / fp8: keep the activations in fp32 storage (default there: 16-bit activation storage)")
     ap.add_argument("--no-winograd", action="store_true",
                     help="A/B aid: implicit GEMM for every 3x3 layer instead of the fused Winograd F(2x2,3x3) kernel")
     ap.add_argument("--graph", action="store_true",
@@ -254,6 +256,9 @@ def main():
         net.image.stem_direct = False
     if args.bf16_staged and net.image is not None:
         net.image.bf16_direct = False
+        net.image.act16 = False
+    if args.no_act16 and net.image is not None:
+        net.image.act16 = False
     strong = args.global_batch > 0
     if strong:
         assert args.global_batch % world == 0, "--global-batch must divide by the number of ranks"

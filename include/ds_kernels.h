@@ -83,6 +83,8 @@ typedef struct ds_conv_desc {
     int32_t grid_x;           /* 0: automatic.  >0: persistent workgroups per column tile (each walks  */
                               /* row tiles blockIdx.x, +grid_x, ...); also the stats partial count P   */
     int32_t dtype;            /* DS_DTYPE_F32 (0, default) or DS_DTYPE_BF16                             */
+    int32_t x_dtype;          /* storage type of x for ds_conv_bf16 / ds_conv_fp8: DS_DTYPE_F32 (0) or            */
+                              /* DS_DTYPE_BF16 (16-bit activation storage: ldx counts bf16 elements)              */
     int32_t partials;         /* 0: unchecked.  >0 with DS_EPI_STATS: the partial count P the caller sized and  */
                               /* finalises with (ds_conv_igemm_partials at plan time); a launch that would     */
                               /* write a different count fails with DS_ERR_ARG instead of corrupting the stats */
@@ -121,7 +123,7 @@ size_t ds_weights_bf16_bytes(int32_t Cin, int32_t Cout, int32_t taps, int32_t dg
 int ds_weights_to_bf16(const float *w, void *wb, int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad, void *stream);
 int ds_conv_bf16_supported(const ds_conv_desc *d);
 int ds_conv_bf16_partials(const ds_conv_desc *d);
-int ds_conv_bf16(const ds_conv_desc *d, const float *x, const void *wb, float *z, float *stats, const float *pivot,
+int ds_conv_bf16(const ds_conv_desc *d, const void *x, const void *wb, float *z, float *stats, const float *pivot,
                  void *stream);
 
 /* fp8 convolution path (BASELINE configs[4]: fp8 MFMA conv path on CDNA4), 1x1 and 3x3 convs, forward and
@@ -137,13 +139,13 @@ int ds_conv_bf16(const ds_conv_desc *d, const float *x, const void *wb, float *z
  * Not the fp32 parity path: separately labelled, tolerance documented in tests/test_kernels_gpu.py / DESIGN.md.     */
 #define DS_FP8_E4M3 0
 #define DS_FP8_E5M2 1
-int ds_absmax(const float *x, int64_t n, float *amax, void *stream);
+int ds_absmax(const void *x, int64_t n, int32_t x_dtype, float *amax, void *stream);
 size_t ds_weights_fp8_bytes(int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad);
 int ds_weights_to_fp8(const float *w, void *wq, float *wscale, int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad,
                       void *stream);
 int ds_conv_fp8_supported(const ds_conv_desc *d);
 int ds_conv_fp8_partials(const ds_conv_desc *d);
-int ds_conv_fp8(const ds_conv_desc *d, const float *x, const float *x_amax, int32_t a_format, const void *wq,
+int ds_conv_fp8(const ds_conv_desc *d, const void *x, const float *x_amax, int32_t a_format, const void *wq,
                 const float *wscale, float *z, float *stats, const float *pivot, void *stream);
 
 /* Conv2d_1a_7x7 (inception_v1.py:63): 7x7 stride-2 SAME conv 3 -> 64 read from the PACKED RGB images
@@ -192,8 +194,11 @@ typedef struct ds_segments {
     int32_t nseg;
     int32_t c_begin[4];       /* first channel of the segment in the [M,C] source/gradient           */
     int32_t c_end[4];
-    int32_t ld[4];            /* pixel stride of the destination                                     */
-    float *ptr[4];            /* destination (already offset to its first channel)                   */
+    int32_t ld[4];            /* pixel stride of the destination, in elements                        */
+    void *ptr[4];             /* destination (already offset to its first channel)                   */
+    int32_t dtype[4];         /* ds_bn_apply_relu only: DS_DTYPE_F32 (0) or DS_DTYPE_BF16 -- the activation is  */
+                              /* stored rounded to bf16 (16-bit activation storage of the bf16 / fp8          */
+                              /* configurations); gradient segments are always fp32                           */
 } ds_segments;
 int ds_bn_apply_relu(const float *z, int64_t M, int32_t C, const float *rstd, const float *shift,
                      const ds_segments *dst, void *stream);
@@ -229,15 +234,16 @@ int ds_bn_bwd_apply(const float *z, const ds_segments *dy, int64_t M, int32_t C,
                     const float *rstd, const float *shift, const float *coef, float *dz, void *stream);
 
 /* slim.max_pool2d SAME/VALID (inception_v1.py:67,79,94,118,208) with arg-max record, and MaxPoolGrad. */
-int ds_maxpool_fwd(const float *x, float *y, uint8_t *argmax, int32_t N, int32_t H, int32_t W, int32_t C,
+/* act_dtype: storage type of x AND y (DS_DTYPE_F32 / DS_DTYPE_BF16; max and arg-max are exact in either).   */
+int ds_maxpool_fwd(const void *x, void *y, uint8_t *argmax, int32_t N, int32_t H, int32_t W, int32_t C,
                    int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW,
-                   void *stream);
+                   int32_t act_dtype, void *stream);
 /* BatchNorm + ReLU + 3x3 max pool of a conv that feeds nothing else (Conv2d_1a_7x7 -> MaxPool_2a_3x3,
  * Conv2d_2c_3x3 -> MaxPool_3a_3x3, inception_v1.py:63-79): y = relu(rstd*maxpool(z) + shift), identical to
  * maxpool(relu(bn(z))) because rstd > 0; the full-resolution activation is never materialised.           */
-int ds_maxpool_bn_relu_fwd(const float *z, const float *rstd, const float *shift, float *y, uint8_t *argmax,
+int ds_maxpool_bn_relu_fwd(const float *z, const float *rstd, const float *shift, void *y, uint8_t *argmax,
                            int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad_t,
-                           int32_t pad_l, int32_t OH, int32_t OW, void *stream);
+                           int32_t pad_l, int32_t OH, int32_t OW, int32_t y_dtype, void *stream);
 /* ... and its backward: BatchNorm(+ReLU) backward of that conv straight from the POOLED gradient (3x3 stride-2
  * SAME pools).  MaxPoolGrad's full-resolution result is rebuilt per 2x2 input patch on the fly instead of being
  * written and re-read twice.  reduce -> partials float[2][C][P] (P = ds_bn_pool_bwd_partials), then

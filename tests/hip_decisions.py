@@ -6,6 +6,11 @@ import numpy as np
 from oracle import tf_semantics as S
 
 
+def _np(t):
+    """activation buffer -> numpy (bf16 under 16-bit activation storage: widened exactly)"""
+    return t.float().cpu().numpy()
+
+
 def hip_decisions(net):
     from tumblr_emotions_amd.engine_image import ConvStage, MixedStage, PoolStage
     eng = net.image
@@ -22,20 +27,20 @@ def hip_decisions(net):
                 inj["pool/" + st.name] = st.argmax.cpu().numpy()
                 inj["poolrelu/" + st.name] = (st.out > 0).cpu().numpy()
             else:
-                inj["pool/" + st.name] = S.max_pool_argmax(st.prev.out.cpu().numpy(), st.k, st.stride, "SAME")
+                inj["pool/" + st.name] = S.max_pool_argmax(_np(st.prev.out), st.k, st.stride, "SAME")
         elif isinstance(st, MixedStage):
             b0, b1a, b1b, b2a, b2b, b3 = st.b
             B, H, W = st.B, st.H, st.W
-            out = st.out.cpu().numpy()
+            out = _np(st.out)
             pre = "InceptionV1/%s/" % st.name
             nm = [n for (n, _, _, _) in S.mixed_conv_names(st.name)]
             o1, o2, o3 = b0, b0 + b1b, b0 + b1b + b2b
             inj["relu/" + pre + nm[0]] = out[..., :o1] > 0
-            inj["relu/" + pre + nm[1]] = st.r1.view(B, H, W, b1a).cpu().numpy() > 0
+            inj["relu/" + pre + nm[1]] = _np(st.r1.view(B, H, W, b1a)) > 0
             inj["relu/" + pre + nm[2]] = out[..., o1:o2] > 0
-            inj["relu/" + pre + nm[3]] = st.r2.view(B, H, W, b2a).cpu().numpy() > 0
+            inj["relu/" + pre + nm[3]] = _np(st.r2.view(B, H, W, b2a)) > 0
             inj["relu/" + pre + nm[4]] = out[..., o2:o3] > 0
             inj["relu/" + pre + nm[5]] = out[..., o3:] > 0
-            inj["pool/%s/Branch_3" % st.name] = S.max_pool_argmax(st.prev.out.cpu().numpy(), 3, 1, "SAME")
+            inj["pool/%s/Branch_3" % st.name] = S.max_pool_argmax(_np(st.prev.out), 3, 1, "SAME")
     assert sum(k.startswith(("relu/", "norelu/")) for k in inj) == 57
     return inj

@@ -22,13 +22,14 @@ class ConvDesc(C.Structure):
         ("w_tap_stride", C.c_int64), ("w_n_stride", C.c_int32), ("w_k_stride", C.c_int32),
         ("flip", C.c_int32), ("fold_cin", C.c_int32), ("flags", C.c_int32), ("ldmask", C.c_int32),
         ("splits", C.c_int32), ("z_split_stride", C.c_int64),
-        ("tile_nt", C.c_int32), ("grid_x", C.c_int32), ("dtype", C.c_int32), ("partials", C.c_int32),
+        ("tile_nt", C.c_int32), ("grid_x", C.c_int32), ("dtype", C.c_int32), ("x_dtype", C.c_int32),
+        ("partials", C.c_int32),
     ]
 
 
 class Segments(C.Structure):
     _fields_ = [("nseg", C.c_int32), ("c_begin", C.c_int32 * 4), ("c_end", C.c_int32 * 4),
-                ("ld", C.c_int32 * 4), ("ptr", C.c_void_p * 4)]
+                ("ld", C.c_int32 * 4), ("ptr", C.c_void_p * 4), ("dtype", C.c_int32 * 4)]
 
 
 class SumSegments(C.Structure):
@@ -57,7 +58,7 @@ SIGNATURES = {
     "ds_conv_bf16_supported": (C.c_int, [_CD]),
     "ds_conv_bf16_partials": (C.c_int, [_CD]),
     "ds_conv_bf16": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P]),
-    "ds_absmax": (C.c_int, [_P, _i64, _P, _P]),
+    "ds_absmax": (C.c_int, [_P, _i64, _i32, _P, _P]),
     "ds_weights_fp8_bytes": (C.c_size_t, [_i32, _i32, _i32, _i32]),
     "ds_weights_to_fp8": (C.c_int, [_P, _P, _P, _i32, _i32, _i32, _i32, _P]),
     "ds_conv_fp8_supported": (C.c_int, [_CD]),
@@ -78,8 +79,8 @@ SIGNATURES = {
     "ds_bn_bwd_finalize_segs": (C.c_int, [_SS, _i64, _i32, _P, _P, _P, _P]),
     "ds_bn_bwd_finalize": (C.c_int, [_P, _i32, _i64, _i32, _P, _P, _P]),
     "ds_bn_bwd_apply": (C.c_int, [_P, _SG, _i64, _i32, _P, _P, _P, _P, _P, _P]),
-    "ds_maxpool_fwd": (C.c_int, [_P, _P, _P] + [_i32] * 10 + [_P]),
-    "ds_maxpool_bn_relu_fwd": (C.c_int, [_P, _P, _P, _P, _P] + [_i32] * 10 + [_P]),
+    "ds_maxpool_fwd": (C.c_int, [_P, _P, _P] + [_i32] * 11 + [_P]),
+    "ds_maxpool_bn_relu_fwd": (C.c_int, [_P, _P, _P, _P, _P] + [_i32] * 11 + [_P]),
     "ds_bn_pool_bwd_partials": (C.c_int, [_i32, _i32, _i32, _i32]),
     "ds_bn_pool_bwd_reduce": (C.c_int, [_P, _P, _P] + [_i32] * 8 + [_P, _P, _P, _P, _P]),
     "ds_bn_pool_bwd_apply": (C.c_int, [_P, _P, _P] + [_i32] * 8 + [_P, _P, _P, _P, _P, _P]),

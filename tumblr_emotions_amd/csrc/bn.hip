@@ -17,6 +17,7 @@ struct SegDev {
     int nseg;
     int c_begin[4], c_end[4], ld[4];
     float *ptr[4];
+    int dtype[4];
 };
 
 SegDev to_dev(const ds_segments *s) {
@@ -26,7 +27,8 @@ SegDev to_dev(const ds_segments *s) {
         o.c_begin[i] = s->c_begin[i];
         o.c_end[i] = s->c_end[i];
         o.ld[i] = s->ld[i];
-        o.ptr[i] = s->ptr[i];
+        o.ptr[i] = (float *)s->ptr[i];
+        o.dtype[i] = s->dtype[i];
     }
     return o;
 }
@@ -101,8 +103,20 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *z, int6
         y.y = fmaxf(v.y * r.y + s.y, 0.f);
         y.z = fmaxf(v.z * r.z + s.z, 0.f);
         y.w = fmaxf(v.w * r.w + s.w, 0.f);
-        float *o = seg_addr(dst, row, c);
-        if (o) *reinterpret_cast<float4 *>(o) = y;
+        // destination segment: fp32, or bf16 (16-bit activation storage; round to nearest even)
+#pragma unroll
+        for (int sgi = 0; sgi < 4; ++sgi)
+            if (sgi < dst.nseg && c >= dst.c_begin[sgi] && c < dst.c_end[sgi]) {
+                const int64_t e = row * dst.ld[sgi] + (c - dst.c_begin[sgi]);
+                if (dst.dtype[sgi] == DS_DTYPE_BF16) {
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    typedef float f32x4v __attribute__((ext_vector_type(4)));
+                    const f32x4v yv = {y.x, y.y, y.z, y.w};
+                    *reinterpret_cast<bf16x4 *>(reinterpret_cast<__bf16 *>(dst.ptr[sgi]) + e) = __builtin_convertvector(yv, bf16x4);
+                } else {
+                    *reinterpret_cast<float4 *>(dst.ptr[sgi] + e) = y;
+                }
+            }
     }
 }
 
@@ -304,13 +318,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, SegDe
     }
 }
 
-int check_segments(const ds_segments *s, int C, const char *who) {
+int check_segments(const ds_segments *s, int C, const char *who, bool allow_bf16 = false) {
     DS_REQUIRE(s && s->nseg >= 1 && s->nseg <= 4, "%s: 1..4 segments required", who);
     int covered = 0;
     for (int i = 0; i < s->nseg; ++i) {
+        DS_REQUIRE(s->dtype[i] == DS_DTYPE_F32 || (allow_bf16 && s->dtype[i] == DS_DTYPE_BF16),
+                   "%s: segment %d has an unsupported storage type", who, i);
         DS_REQUIRE(s->c_begin[i] % 4 == 0 && s->c_end[i] % 4 == 0 && s->ld[i] % 4 == 0 && s->ptr[i] &&
-                       (((uintptr_t)s->ptr[i]) & 15) == 0,
-                   "%s: segment %d not 4-channel / 16-byte aligned", who, i);
+                       (((uintptr_t)s->ptr[i]) & (s->dtype[i] == DS_DTYPE_BF16 ? 7 : 15)) == 0,
+                   "%s: segment %d not 4-channel aligned", who, i);
         covered += s->c_end[i] - s->c_begin[i];
     }
     DS_REQUIRE(covered == C, "%s: segments cover %d of %d channels", who, covered, C);
@@ -349,7 +365,7 @@ extern "C" int ds_bn_infer_prepare(const float *beta, const float *moving_mean, 
 extern "C" int ds_bn_apply_relu(const float *z, int64_t M, int32_t C, const float *rstd, const float *shift,
                                 const ds_segments *dst, void *stream) {
     DS_REQUIRE(z && rstd && shift && M > 0 && C > 0 && C % 4 == 0, "ds_bn_apply_relu: bad argument (C %% 4 != 0?)");
-    if (int e = check_segments(dst, C, "ds_bn_apply_relu")) return e;
+    if (int e = check_segments(dst, C, "ds_bn_apply_relu", true)) return e;
     hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(ds::stream_grid(M * (C / 4), 256 * 4)), dim3(256), 0,
                        (hipStream_t)stream, z, M, C, rstd, shift, to_dev(dst));
     return ds::check_launch("ds_bn_apply_relu");

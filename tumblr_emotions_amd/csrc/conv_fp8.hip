@@ -19,6 +19,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void *lds_ptr;
 
 namespace {
@@ -65,7 +66,7 @@ __device__ __forceinline__ int cvt_pk(float a, float b, int old, bool hi) {
     return hi ? __builtin_amdgcn_cvt_pk_fp8_f32(a, b, old, true) : __builtin_amdgcn_cvt_pk_fp8_f32(a, b, old, false);
 }
 
-template <int NB, int KS, bool E5M2>      // KS x KS taps (1 or 3); E5M2: the A operand is a gradient (e5m2)
+template <int NB, int KS, bool E5M2, bool XB>      // KS x KS taps (1 or 3); E5M2: the A operand is a gradient (e5m2); XB: x stored as bf16
 __global__ __launch_bounds__(256, 2) void conv_fp8d_kernel(const Fp8Params p) {
     constexpr int BN = NB * 32, SI = 4, TAPS = KS * KS;
     constexpr int BSZ = SI * BN * 16;                          // bytes per B buffer
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8d_kernel(const Fp8Params p) {
         for (int b = 0; b < KS; ++b) {
             const int ih = oh * d.stride - d.pad_t + a, iw = ow * d.stride - d.pad_l + b;
             const bool ok = rv && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
-            voff[a * KS + b] = ok ? ((unsigned)((n * d.H + ih) * d.W + iw) * (unsigned)d.ldx + 8u * kh) * 4u : kOOB;
+            voff[a * KS + b] = ok ? ((unsigned)((n * d.H + ih) * d.W + iw) * (unsigned)d.ldx + 8u * kh) * (XB ? 2u : 4u) : kOOB;
         }
     // B DMA slots: 16-byte slot sl of a step = (local iteration sl / BN, column sl % BN); the source is linear in w
     unsigned uoff[DJ];
@@ -125,8 +126,12 @@ __global__ __launch_bounds__(256, 2) void conv_fp8d_kernel(const Fp8Params p) {
         unsigned vo = voff[0];
 #pragma unroll
         for (int k = 1; k < TAPS; ++k) vo = tap == k ? voff[k] : vo;
-        lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vo, chunk * 64, 0));
-        hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vo, chunk * 64 + 16, 0));
+        if (XB) {           // eight bf16 channels in one 16-byte load; widened below
+            lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vo, chunk * 32, 0));
+        } else {
+            lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vo, chunk * 64, 0));
+            hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vo, chunk * 64 + 16, 0));
+        }
     };
 
     f32x16 acc[NB];
@@ -148,10 +153,22 @@ __global__ __launch_bounds__(256, 2) void conv_fp8d_kernel(const Fp8Params p) {
 #pragma unroll
         for (int j = 0; j < SI; ++j) {
             // A fragment: 8 consecutive channels, scaled by the power of two, saturated, rounded to fp8 (RNE)
-            int w0 = cvt_pk<E5M2>(alo[j][0] * sa, alo[j][1] * sa, 0, false);
-            w0 = cvt_pk<E5M2>(alo[j][2] * sa, alo[j][3] * sa, w0, true);
-            int w1 = cvt_pk<E5M2>(ahi[j][0] * sa, ahi[j][1] * sa, 0, false);
-            w1 = cvt_pk<E5M2>(ahi[j][2] * sa, ahi[j][3] * sa, w1, true);
+            float a8[8];
+            if (XB) {       // bf16 -> fp32 is a 16-bit shift
+                const u32x4 raw = __builtin_bit_cast(u32x4, alo[j]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a8[2 * q] = __builtin_bit_cast(float, raw[q] << 16);
+                    a8[2 * q + 1] = __builtin_bit_cast(float, raw[q] & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a8[q] = alo[j][q]; a8[4 + q] = ahi[j][q]; }
+            }
+            int w0 = cvt_pk<E5M2>(a8[0] * sa, a8[1] * sa, 0, false);
+            w0 = cvt_pk<E5M2>(a8[2] * sa, a8[3] * sa, w0, true);
+            int w1 = cvt_pk<E5M2>(a8[4] * sa, a8[5] * sa, 0, false);
+            w1 = cvt_pk<E5M2>(a8[6] * sa, a8[7] * sa, w1, true);
             const long af = (long)(((unsigned long long)(unsigned)w1 << 32) | (unsigned)w0);
             if (more) {
                 load_a((st + 1) * SI + j, nlo[j], nhi[j]);
@@ -220,6 +237,20 @@ __global__ __launch_bounds__(256, 2) void conv_fp8d_kernel(const Fp8Params p) {
 
 // max |x| into out[0] (as float bits; non-negative floats order like unsigned integers, so atomicMax is exact and
 // order independent).  out[0] must be zero on entry (the entry point clears it).
+__global__ __launch_bounds__(256) void absmax_bf16_kernel(const unsigned *x, int64_t n2, unsigned *out) {
+    // n2 pairs of bf16: |v| of a bf16 is its 15 low bits; as fp32 bits that is (bits << 16), and non-negative floats
+    // order like unsigned integers
+    unsigned m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+        const unsigned v = x[i];
+        const unsigned a = (v & 0x7fffu) << 16, b = v & 0x7fff0000u;
+        m = max(m, max(a, b));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+
 __global__ __launch_bounds__(256) void absmax_kernel(const float *x, int64_t n, unsigned *out) {
     float m = 0.f;
     const int64_t n4 = n >> 2;
@@ -284,22 +315,31 @@ int64_t fp8_M(const ds_conv_desc *d) { return (int64_t)d->N * d->OH * d->OW; }
 
 template <int NB>
 void launch_fp8(const ds_conv_desc *d, int a_format, dim3 grid, hipStream_t st, const Fp8Params &p) {
+    const bool xb = d->x_dtype == DS_DTYPE_BF16;      // forward activations only (checked by the caller)
     if (d->KH == 1) {
-        if (a_format == DS_FP8_E5M2) hipLaunchKernelGGL((conv_fp8d_kernel<NB, 1, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_fp8d_kernel<NB, 1, false>), grid, dim3(256), 0, st, p);
+        if (a_format == DS_FP8_E5M2) hipLaunchKernelGGL((conv_fp8d_kernel<NB, 1, true, false>), grid, dim3(256), 0, st, p);
+        else if (xb) hipLaunchKernelGGL((conv_fp8d_kernel<NB, 1, false, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_fp8d_kernel<NB, 1, false, false>), grid, dim3(256), 0, st, p);
     } else {
-        if (a_format == DS_FP8_E5M2) hipLaunchKernelGGL((conv_fp8d_kernel<NB, 3, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_fp8d_kernel<NB, 3, false>), grid, dim3(256), 0, st, p);
+        if (a_format == DS_FP8_E5M2) hipLaunchKernelGGL((conv_fp8d_kernel<NB, 3, true, false>), grid, dim3(256), 0, st, p);
+        else if (xb) hipLaunchKernelGGL((conv_fp8d_kernel<NB, 3, false, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_fp8d_kernel<NB, 3, false, false>), grid, dim3(256), 0, st, p);
     }
 }
 
 }  // namespace
 
-extern "C" int ds_absmax(const float *x, int64_t n, float *amax, void *stream) {
+extern "C" int ds_absmax(const void *x, int64_t n, int32_t x_dtype, float *amax, void *stream) {
     DS_REQUIRE(x && amax && n > 0 && (((uintptr_t)x) & 15) == 0, "ds_absmax: bad argument (x must be 16-byte aligned)");
+    DS_REQUIRE(x_dtype == DS_DTYPE_F32 || (x_dtype == DS_DTYPE_BF16 && n % 2 == 0),
+               "ds_absmax: x_dtype must be DS_DTYPE_F32 or DS_DTYPE_BF16 (an even count)");
     if (hipMemsetAsync(amax, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return ds::check_launch("ds_absmax(memset)");
-    hipLaunchKernelGGL(absmax_kernel, dim3(ds::stream_grid(n / 4 + 1, 256 * 4)), dim3(256), 0, (hipStream_t)stream, x, n,
-                       (unsigned *)amax);
+    if (x_dtype == DS_DTYPE_BF16)
+        hipLaunchKernelGGL(absmax_bf16_kernel, dim3(ds::stream_grid(n / 2, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned *)x, n / 2, (unsigned *)amax);
+    else
+        hipLaunchKernelGGL(absmax_kernel, dim3(ds::stream_grid(n / 4 + 1, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)x, n, (unsigned *)amax);
     return ds::check_launch("ds_absmax");
 }
 
@@ -312,7 +352,7 @@ extern "C" int ds_weights_to_fp8(const float *w, void *wq, float *wscale, int32_
                                  int32_t dgrad, void *stream) {
     DS_REQUIRE(w && wq && wscale && Cin > 0 && Cout > 0 && taps > 0, "ds_weights_to_fp8: bad argument");
     const int64_t n = (int64_t)taps * Cin * Cout;
-    if (int e = ds_absmax(w, n, wscale, stream)) return e;
+    if (int e = ds_absmax(w, n, DS_DTYPE_F32, wscale, stream)) return e;
     const int64_t pairs = (int64_t)ds_weights_fp8_bytes(Cin, Cout, taps, dgrad) / 2;
     hipLaunchKernelGGL(weights_to_fp8_kernel, dim3(ds::stream_grid(pairs, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        (unsigned char *)wq, wscale, Cin, Cout, taps, dgrad);
@@ -323,16 +363,18 @@ extern "C" int ds_conv_fp8_supported(const ds_conv_desc *d) { return d && fp8_ok
 
 extern "C" int ds_conv_fp8_partials(const ds_conv_desc *d) { return (int)((fp8_M(d) + 127) / 128); }
 
-extern "C" int ds_conv_fp8(const ds_conv_desc *d, const float *x, const float *x_amax, int32_t a_format, const void *wq,
+extern "C" int ds_conv_fp8(const ds_conv_desc *d, const void *x, const float *x_amax, int32_t a_format, const void *wq,
                            const float *wscale, float *z, float *stats, const float *pivot, void *stream) {
     DS_REQUIRE(d && x && x_amax && wq && wscale && z, "ds_conv_fp8: null argument");
+    DS_REQUIRE(d->x_dtype == DS_DTYPE_F32 || (d->x_dtype == DS_DTYPE_BF16 && a_format == DS_FP8_E4M3 && d->ldx % 8 == 0),
+               "ds_conv_fp8: x_dtype DS_DTYPE_BF16 is for forward activations (e4m3) with ldx %% 8 == 0");
     DS_REQUIRE(fp8_ok(d), "ds_conv_fp8: needs a 1x1 or 3x3 conv, Cin %% 8 == 0, ldx %% 4 == 0, flags within DS_EPI_STATS");
     DS_REQUIRE(a_format == DS_FP8_E4M3 || a_format == DS_FP8_E5M2, "ds_conv_fp8: a_format must be DS_FP8_E4M3 or DS_FP8_E5M2");
     DS_REQUIRE(((((uintptr_t)x | (uintptr_t)wq) & 15) == 0) && fp8_M(d) < (1ll << 31), "ds_conv_fp8: operands must be 16-byte aligned");
     DS_REQUIRE(!(d->flags & DS_EPI_STATS) || stats, "ds_conv_fp8: DS_EPI_STATS without stats buffer");
     Fp8Params p = {};
     p.d = *d;
-    p.x = x; p.w = (const unsigned char *)wq; p.x_amax = x_amax; p.wscale = wscale; p.z = z; p.stats = stats;
+    p.x = (const float *)x; p.w = (const unsigned char *)wq; p.x_amax = x_amax; p.wscale = wscale; p.z = z; p.stats = stats;
     p.pivot = (d->flags & DS_EPI_STATS) ? pivot : nullptr;
     p.M = (int)fp8_M(d);
     const int taps = d->KH * d->KW;
@@ -340,7 +382,7 @@ extern "C" int ds_conv_fp8(const ds_conv_desc *d, const float *x, const float *x
     p.ncols = (d->Cout + 31) / 32 * 32;
     const int64_t wq_bytes = (int64_t)((d->Cin + 15) / 16) * taps * p.ncols * 16;
     DS_REQUIRE(x_elems * 4 < (1ll << 31) && wq_bytes < (1ll << 31), "ds_conv_fp8: operand larger than 2 GiB");
-    p.x_bytes = (unsigned)(x_elems * 4);
+    p.x_bytes = (unsigned)(x_elems * (d->x_dtype == DS_DTYPE_BF16 ? 2 : 4));
     p.w_bytes = (unsigned)wq_bytes;
     const int nb = fp8_nb(d->Cout);
     p.row_tiles = (int)((fp8_M(d) + 127) / 128);

@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
 //     fragment feeds NB MFMAs; the next step's eight A loads and NB weight DMAs are issued between the MFMA groups.
 // Epilogue: fp32 stores + BatchNorm column statistics about the pivot (flags 0 or DS_EPI_STATS).
 // ================================================================================================
-template <int NB, int KS>      // KS x KS taps (1 or 3)
+template <int NB, int KS, bool XB>      // KS x KS taps (1 or 3); XB: x is stored as bf16 (16-bit activation storage)
 __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) {
     constexpr int BN = NB * 32, SI = 4, TAPS = KS * KS;
     constexpr int BSZ = SI * BN * 16;                          // bf16 elements per B buffer
@@ -1330,7 +1330,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
         for (int b = 0; b < KS; ++b) {
             const int ih = oh * d.stride - d.pad_t + a, iw = ow * d.stride - d.pad_l + b;
             const bool ok = rv && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
-            voff[a * KS + b] = ok ? ((unsigned)((n * d.H + ih) * d.W + iw) * (unsigned)d.ldx + 8u * kh) * 4u : kOOB;
+            voff[a * KS + b] = ok ? ((unsigned)((n * d.H + ih) * d.W + iw) * (unsigned)d.ldx + 8u * kh) * (XB ? 2u : 4u) : kOOB;
         }
     // ---- B DMA slots of a step: slot -> (local iteration, column, 8-k half); source is linear in wb ---------------
     const int ncols = p.col_total;                              // columns of wb (Cout rounded up to 32)
@@ -1355,8 +1355,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
         unsigned vo = voff[0];
 #pragma unroll
         for (int k = 1; k < TAPS; ++k) vo = tap == k ? voff[k] : vo;
-        lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vo, chunk * 64, 0));
-        hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vo, chunk * 64 + 16, 0));
+        if (XB) {           // eight bf16 channels = one 16-byte load, already the fragment
+            lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vo, chunk * 32, 0));
+        } else {
+            lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vo, chunk * 64, 0));
+            hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vo, chunk * 64 + 16, 0));
+        }
     };
 
     f32x16 acc[NB];
@@ -1379,7 +1383,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
         for (int j = 0; j < SI; ++j) {
             // A fragment: 8 consecutive channels rounded to bf16
             bf16x8 af;
-            {
+            if (XB) {
+                af = __builtin_bit_cast(bf16x8, alo[j]);
+            } else {
                 const bf16x4 l4 = __builtin_convertvector(alo[j], bf16x4), h4 = __builtin_convertvector(ahi[j], bf16x4);
                 af = __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
             }
@@ -1909,22 +1915,25 @@ extern "C" int ds_conv_bf16_supported(const ds_conv_desc *d) { return d && bf16d
 
 extern "C" int ds_conv_bf16_partials(const ds_conv_desc *d) { return (int)((conv_M(d) + 127) / 128); }
 
-extern "C" int ds_conv_bf16(const ds_conv_desc *d, const float *x, const void *wb, float *z, float *stats,
+extern "C" int ds_conv_bf16(const ds_conv_desc *d, const void *x, const void *wb, float *z, float *stats,
                             const float *pivot, void *stream) {
     DS_REQUIRE(d && x && wb && z, "ds_conv_bf16: null argument");
+    DS_REQUIRE(d->x_dtype == DS_DTYPE_F32 || (d->x_dtype == DS_DTYPE_BF16 && d->ldx % 8 == 0),
+               "ds_conv_bf16: x_dtype must be DS_DTYPE_F32 or DS_DTYPE_BF16 (then ldx %% 8 == 0)");
+    const bool xb = d->x_dtype == DS_DTYPE_BF16;
     DS_REQUIRE(bf16d_ok(d), "ds_conv_bf16: needs a 1x1 or 3x3 conv, Cin %% 8 == 0, ldx %% 4 == 0, flags within DS_EPI_STATS");
     DS_REQUIRE(((((uintptr_t)x | (uintptr_t)wb) & 15) == 0) && conv_M(d) < (1ll << 31), "ds_conv_bf16: operands must be 16-byte aligned");
     DS_REQUIRE(!(d->flags & DS_EPI_STATS) || stats, "ds_conv_bf16: DS_EPI_STATS without stats buffer");
     ConvParams p = {};
     p.d = *d;
-    p.x = x; p.w = (const float *)wb; p.z = z; p.stats = stats;
+    p.x = (const float *)x; p.w = (const float *)wb; p.z = z; p.stats = stats;
     p.pivot = (d->flags & DS_EPI_STATS) ? pivot : nullptr;
     p.M = (int)conv_M(d);
     p.taps = d->KH * d->KW;
     const int64_t x_elems = ((int64_t)d->N * d->H * d->W - 1) * d->ldx + d->Cin;
     const int64_t wb_bytes = (int64_t)((d->Cin + 15) / 16) * p.taps * ((d->Cout + 31) / 32 * 32) * 32;
     DS_REQUIRE(x_elems * 4 < (1ll << 31) && wb_bytes < (1ll << 31), "ds_conv_bf16: operand larger than 2 GiB");
-    p.x_bytes = (unsigned)(x_elems * 4);
+    p.x_bytes = (unsigned)(x_elems * (xb ? 2 : 4));
     p.w_bytes = (unsigned)wb_bytes;
     p.col_total = (d->Cout + 31) / 32 * 32;
     const int nb = bf16d_nb(d->Cout);
@@ -1934,8 +1943,13 @@ extern "C" int ds_conv_bf16(const ds_conv_desc *d, const float *x, const void *w
     hipStream_t st = (hipStream_t)stream;
 #define DS_B16(NBV)                                                                                        \
     case NBV:                                                                                              \
-        if (d->KH == 1) hipLaunchKernelGGL((conv_bf16d_kernel<NBV, 1>), grid, dim3(256), 0, st, p);        \
-        else hipLaunchKernelGGL((conv_bf16d_kernel<NBV, 3>), grid, dim3(256), 0, st, p);                   \
+        if (xb) {                                                                                          \
+            if (d->KH == 1) hipLaunchKernelGGL((conv_bf16d_kernel<NBV, 1, true>), grid, dim3(256), 0, st, p);  \
+            else hipLaunchKernelGGL((conv_bf16d_kernel<NBV, 3, true>), grid, dim3(256), 0, st, p);             \
+        } else {                                                                                           \
+            if (d->KH == 1) hipLaunchKernelGGL((conv_bf16d_kernel<NBV, 1, false>), grid, dim3(256), 0, st, p); \
+            else hipLaunchKernelGGL((conv_bf16d_kernel<NBV, 3, false>), grid, dim3(256), 0, st, p);            \
+        }                                                                                                  \
         break;
     switch (nb) {
         DS_B16(1)

@@ -7,7 +7,28 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float *x, float *y, uint8_t *am, int N, int H, int W,
+// activation storage: fp32 or bf16 (16-bit activation storage of the bf16 / fp8 configurations); four channels at a time
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ float4 ld4(const T *p);
+template <>
+__device__ __forceinline__ float4 ld4<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+template <>
+__device__ __forceinline__ float4 ld4<__bf16>(const __bf16 *p) {
+    const f32x4v v = __builtin_convertvector(*reinterpret_cast<const bf16x4 *>(p), f32x4v);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st4(float *p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void st4(__bf16 *p, float a, float b, float c, float d) {
+    const f32x4v v = {a, b, c, d};
+    *reinterpret_cast<bf16x4 *>(p) = __builtin_convertvector(v, bf16x4);
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const TI *x, TO *y, uint8_t *am, int N, int H, int W,
                                                           int C, int k, int stride, int pad_t, int pad_l, int OH,
                                                           int OW) {
     const int C4 = C >> 2;
@@ -28,7 +49,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float *x, float 
             for (int kw = 0; kw < k; ++kw) {
                 const int iw = ow * stride - pad_l + kw;
                 if ((unsigned)iw >= (unsigned)W) continue;
-                const float4 v = *reinterpret_cast<const float4 *>(x + (((int64_t)n * H + ih) * W + iw) * C + c);
+                const float4 v = ld4<TI>(x + (((int64_t)n * H + ih) * W + iw) * C + c);
                 const float vv[4] = {v.x, v.y, v.z, v.w};
                 const int t = kh * k + kw;
 #pragma unroll
@@ -41,7 +62,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float *x, float 
             }
         }
         const int64_t o = (((int64_t)n * OH + oh) * OW + ow) * C + c;
-        *reinterpret_cast<float4 *>(y + o) = make_float4(best[0], best[1], best[2], best[3]);
+        st4(y + o, best[0], best[1], best[2], best[3]);
         if (am) *reinterpret_cast<uchar4 *>(am + o) = make_uchar4(arg[0], arg[1], arg[2], arg[3]);
     }
 }
@@ -104,7 +125,8 @@ struct RowMax {
     int k[4];
 };
 
-__device__ __forceinline__ RowMax row_max3(const float *x, int64_t row_base, int iw0, int W, int C, int c, bool row_ok) {
+template <typename TI>
+__device__ __forceinline__ RowMax row_max3(const TI *x, int64_t row_base, int iw0, int W, int C, int c, bool row_ok) {
     RowMax r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -117,7 +139,7 @@ __device__ __forceinline__ RowMax row_max3(const float *x, int64_t row_base, int
     for (int kw = 0; kw < 3; ++kw) {
         const int iw = iw0 + kw;
         if ((unsigned)iw >= (unsigned)W) continue;
-        const float4 v = *reinterpret_cast<const float4 *>(x + (row_base + iw) * C + c);
+        const float4 v = ld4<TI>(x + (row_base + iw) * C + c);
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -134,8 +156,8 @@ __device__ __forceinline__ RowMax row_max3(const float *x, int64_t row_base, int
 // relu(rstd*max(z) + shift).  With rstd > 0 the affine map and the ReLU are monotone, so this equals the max of
 // relu(bn(z)) over the window (and ties only appear among positions whose ReLU gradient is zero anyway): the
 // full-resolution activation of a conv that only feeds a pool is never written or re-read.
-template <int STRIDE>
-__global__ __launch_bounds__(256) void maxpool3_fwd_rolling(const float *x, float *y, uint8_t *am, int N, int H, int W,
+template <int STRIDE, typename TI, typename TO>
+__global__ __launch_bounds__(256) void maxpool3_fwd_rolling(const TI *x, TO *y, uint8_t *am, int N, int H, int W,
                                                             int C, int pad_t, int pad_l, int OH, int OW,
                                                             const float *rstd, const float *shift) {
     const int C4 = C >> 2;
@@ -170,7 +192,7 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_rolling(const float *x, floa
                 best[2] = fmaxf(best[2] * r.z + s.z, 0.f);
                 best[3] = fmaxf(best[3] * r.w + s.w, 0.f);
             }
-            *reinterpret_cast<float4 *>(y + o) = make_float4(best[0], best[1], best[2], best[3]);
+            st4(y + o, best[0], best[1], best[2], best[3]);
             if (am) *reinterpret_cast<uchar4 *>(am + o) = make_uchar4(arg[0], arg[1], arg[2], arg[3]);
             if (STRIDE == 1) {
                 r0 = r1;
@@ -534,38 +556,50 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float *z, 
 
 }  // namespace
 
-extern "C" int ds_maxpool_fwd(const float *x, float *y, uint8_t *argmax, int32_t N, int32_t H, int32_t W, int32_t C,
+namespace {
+template <typename TI, typename TO>
+void launch_pool3(int stride, hipStream_t st, const TI *x, TO *y, uint8_t *argmax, int N, int H, int W, int C, int pad_t,
+                  int pad_l, int OH, int OW, const float *rstd, const float *shift) {
+    const int64_t cols = (int64_t)N * OW * (C / 4);
+    if (stride == 1)
+        hipLaunchKernelGGL((maxpool3_fwd_rolling<1, TI, TO>), dim3(ds::stream_grid(cols, 256)), dim3(256), 0, st, x, y, argmax,
+                           N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift);
+    else
+        hipLaunchKernelGGL((maxpool3_fwd_rolling<2, TI, TO>), dim3(ds::stream_grid(cols, 256)), dim3(256), 0, st, x, y, argmax,
+                           N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift);
+}
+}  // namespace
+
+extern "C" int ds_maxpool_fwd(const void *x, void *y, uint8_t *argmax, int32_t N, int32_t H, int32_t W, int32_t C,
                               int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW,
-                              void *stream) {
+                              int32_t act_dtype, void *stream) {
     DS_REQUIRE(x && y && C % 4 == 0 && k >= 1 && k <= 15 && stride >= 1, "ds_maxpool_fwd: bad argument (C %% 4?)");
+    DS_REQUIRE(act_dtype == DS_DTYPE_F32 || act_dtype == DS_DTYPE_BF16, "ds_maxpool_fwd: act_dtype must be DS_DTYPE_F32 or DS_DTYPE_BF16");
+    const bool b16 = act_dtype == DS_DTYPE_BF16;
+    hipStream_t st = (hipStream_t)stream;
     if (k == 3 && (stride == 1 || stride == 2)) {      // every 3x3 pool of Inception-v1: rolling window
-        const int64_t cols = (int64_t)N * OW * (C / 4);
-        if (stride == 1)
-            hipLaunchKernelGGL(maxpool3_fwd_rolling<1>, dim3(ds::stream_grid(cols, 256)), dim3(256), 0,
-                               (hipStream_t)stream, x, y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, nullptr, nullptr);
-        else
-            hipLaunchKernelGGL(maxpool3_fwd_rolling<2>, dim3(ds::stream_grid(cols, 256)), dim3(256), 0,
-                               (hipStream_t)stream, x, y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, nullptr, nullptr);
+        if (b16) launch_pool3(stride, st, (const __bf16 *)x, (__bf16 *)y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, nullptr, nullptr);
+        else launch_pool3(stride, st, (const float *)x, (float *)y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, nullptr, nullptr);
         return ds::check_launch("ds_maxpool_fwd");
     }
     const int64_t total = (int64_t)N * OH * OW * (C / 4);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ds::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
-                       argmax, N, H, W, C, k, stride, pad_t, pad_l, OH, OW);
+    if (b16)
+        hipLaunchKernelGGL((maxpool_fwd_kernel<__bf16, __bf16>), dim3(ds::stream_grid(total, 256)), dim3(256), 0, st,
+                           (const __bf16 *)x, (__bf16 *)y, argmax, N, H, W, C, k, stride, pad_t, pad_l, OH, OW);
+    else
+        hipLaunchKernelGGL((maxpool_fwd_kernel<float, float>), dim3(ds::stream_grid(total, 256)), dim3(256), 0, st,
+                           (const float *)x, (float *)y, argmax, N, H, W, C, k, stride, pad_t, pad_l, OH, OW);
     return ds::check_launch("ds_maxpool_fwd");
 }
 
-extern "C" int ds_maxpool_bn_relu_fwd(const float *z, const float *rstd, const float *shift, float *y, uint8_t *argmax,
+extern "C" int ds_maxpool_bn_relu_fwd(const float *z, const float *rstd, const float *shift, void *y, uint8_t *argmax,
                                       int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride,
-                                      int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW, void *stream) {
+                                      int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW, int32_t y_dtype, void *stream) {
     DS_REQUIRE(z && rstd && shift && y && C % 4 == 0 && k == 3 && (stride == 1 || stride == 2),
                "ds_maxpool_bn_relu_fwd: bad argument (3x3 pools, stride 1 or 2, C %% 4 == 0)");
-    const int64_t cols = (int64_t)N * OW * (C / 4);
-    if (stride == 1)
-        hipLaunchKernelGGL(maxpool3_fwd_rolling<1>, dim3(ds::stream_grid(cols, 256)), dim3(256), 0, (hipStream_t)stream,
-                           z, y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift);
-    else
-        hipLaunchKernelGGL(maxpool3_fwd_rolling<2>, dim3(ds::stream_grid(cols, 256)), dim3(256), 0, (hipStream_t)stream,
-                           z, y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift);
+    DS_REQUIRE(y_dtype == DS_DTYPE_F32 || y_dtype == DS_DTYPE_BF16, "ds_maxpool_bn_relu_fwd: y_dtype must be DS_DTYPE_F32 or DS_DTYPE_BF16");
+    if (y_dtype == DS_DTYPE_BF16) launch_pool3(stride, (hipStream_t)stream, z, (__bf16 *)y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift);
+    else launch_pool3(stride, (hipStream_t)stream, z, (float *)y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift);
     return ds::check_launch("ds_maxpool_bn_relu_fwd");
 }
 

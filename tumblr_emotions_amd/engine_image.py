@@ -114,7 +114,7 @@ class ConvBN:
         # columns up; it rides the same alternative-plan slots as the Winograd kernel (u_* = its converted weights)
         bf16 = eng.dtype == "bf16" and not self.fold and k in (1, 3) and eng.bf16_direct
         self._bf16_dgrad_ok = bf16 and cout % 8 == 0 and (k == 1 or cin >= 160)
-        if bf16 and cin % 8 == 0 and cout >= 48:
+        if bf16 and cin % 8 == 0 and (cout >= 48 or eng.act16):
             self.wino_fwd = ops.Bf16Plan(B, self.H, self.W, cin, cin, k, self.stride, cout, cout, flags=DS_EPI_STATS)
             self.u_fwd = torch.empty(ops.weights_bf16_bytes(cin, cout, k * k, False), dtype=torch.uint8, device=dev)
             eng.need_stats(self.wino_fwd.partials * 2 * cout)
@@ -262,10 +262,14 @@ class ConvBN:
 
     # x_ptr: input activations [B,H,W,ldx]; segs: where relu(bn(conv)) is scattered (None: the consumer, a max
     # pool, applies BatchNorm + ReLU to its own output instead -- PoolStage.forward)
-    def forward(self, x_ptr, ldx, segs):
+    def forward(self, x_ptr, ldx, segs, x_dtype=ops.DS_DTYPE_F32):
         eng = self.eng
         if not self.fold:
             self.fwd.d.ldx = ldx
+        if x_dtype != ops.DS_DTYPE_F32 and not isinstance(self.wino_fwd, ops.Bf16Plan):
+            raise RuntimeError("16-bit activation storage needs ds_conv_bf16 / ds_conv_fp8 for %s" % self.key)
+        if isinstance(self.wino_fwd, ops.Bf16Plan):
+            self.wino_fwd.d.x_dtype = x_dtype
         self._refresh_wino()
         wino = self.wino_fwd
         if self.stem_direct:
@@ -275,7 +279,7 @@ class ConvBN:
             u_ptr = ops._p(self.u_fwd)
         fp8_kw = {}
         if isinstance(wino, ops.Fp8Plan):      # per-tensor scale of the input: max|x| into a device word
-            ops.absmax(x_ptr, self.B * self.H * self.W * ldx, self.amax[0:1])
+            ops.absmax(x_ptr, self.B * self.H * self.W * ldx, self.amax[0:1], x_dtype)
             fp8_kw = dict(x_amax=ops._p(self.amax[0:1]), wscale=ops._p(self.ws_fwd))
         if eng.training:       # batch statistics (slim.batch_norm is_training=True)
             # the column sums are taken about a pivot near the mean -- the previous step's batch mean, the
@@ -392,9 +396,10 @@ class ConvStage(Stage):
     def alloc(self, B):
         dev = self.eng.device
         self.layer.alloc(B)
-        self.out = torch.empty(B, self.H, self.W, self.C, device=dev)
-        self.dout = torch.empty_like(self.out)
-        self.segs = make_segments([(0, self.C, self.out.data_ptr(), self.C)])
+        self.out16 = self.eng.act16 and not self.layer.fold       # Conv2d_2b / 2c (the stem's output is read by hip tests only)
+        self.out = torch.empty(B, self.H, self.W, self.C, device=dev, dtype=torch.bfloat16 if self.out16 else torch.float32)
+        self.dout = torch.empty(B, self.H, self.W, self.C, device=dev)
+        self.segs = make_segments([(0, self.C, self.out.data_ptr(), self.C, ops.act_dtype(self.out))])
         self.layer.set_dy_parts([(0, self.C, self.dout.data_ptr(), self.C)])
         if not self.layer.fold:
             self.layer.make_dgrad(self.prev.C)
@@ -407,7 +412,8 @@ class ConvStage(Stage):
     def forward(self):
         # fused_into_pool: this conv feeds nothing but the next max pool, which then reads z and applies BN + ReLU
         # after pooling (a quarter of the elements); `out` is not produced
-        self.layer.forward(ops._p(self.prev.out), self.prev.C, None if self.fused_into_pool else self.segs)
+        self.layer.forward(ops._p(self.prev.out), self.prev.C, None if self.fused_into_pool else self.segs,
+                           ops.act_dtype(self.prev.out))
 
     def backward(self, need_dx):
         need_dx = need_dx and not self.layer.fold
@@ -429,8 +435,11 @@ class PoolStage(Stage):
     def alloc(self, B):
         dev = self.eng.device
         self.B = B
-        self.out = torch.empty(B, self.H, self.W, self.C, device=dev)
-        self.dout = torch.empty_like(self.out)
+        # storage follows the input's (a pool copies values); behind a conv fused into it (reads z) the engine's choice
+        p = self.prev
+        o16 = p.out.dtype == torch.bfloat16 or (self.eng.act16 and isinstance(p, ConvStage) and self.k == 3)
+        self.out = torch.empty(B, self.H, self.W, self.C, device=dev, dtype=torch.bfloat16 if o16 else torch.float32)
+        self.dout = torch.empty(B, self.H, self.W, self.C, device=dev)
         self.argmax = torch.empty(B, self.H, self.W, self.C, dtype=torch.uint8, device=dev)
 
     def forward(self):
@@ -439,6 +448,8 @@ class PoolStage(Stage):
             ops.maxpool_bn_relu_fwd(p.layer.z, p.layer.rstd, p.layer.shift, self.out, self.argmax, self.B, p.H, p.W, p.C,
                                     self.k, self.stride)
         else:
+            if p.out.dtype != self.out.dtype:
+                raise RuntimeError("%s: input and output storage differ (fuse_bn_pool switched after alloc?)" % self.name)
             ops.maxpool_fwd(p.out, self.out, self.argmax, self.B, p.H, p.W, p.C, self.k, self.stride, "SAME")
 
     def backward(self, need_dx):
@@ -483,23 +494,29 @@ class MixedStage(Stage):
         M = B * self.H * self.W
         for l in self.layers:
             l.alloc(B)
-        self.out = torch.empty(B, self.H, self.W, Ct, device=dev)
-        self.dout = torch.empty_like(self.out)
-        self.r1 = torch.empty(M, b1a, device=dev)
-        self.r2 = torch.empty(M, b2a, device=dev)
-        self.dr1 = torch.empty_like(self.r1)
-        self.dr2 = torch.empty_like(self.r2)
-        self.pooled = torch.empty(M, cin, device=dev)
-        self.dpooled = torch.empty_like(self.pooled)
+        # 16-bit activation storage (eng.act16): not for what an fp32 wgrad or the average pool reads -- Mixed_5b's
+        # output, Mixed_5c's reduce outputs and output
+        out16 = eng.act16 and self.name not in ("Mixed_5b", "Mixed_5c")
+        r16 = eng.act16 and self.name != "Mixed_5c"
+        a16 = lambda f: torch.bfloat16 if f else torch.float32
+        self.out = torch.empty(B, self.H, self.W, Ct, device=dev, dtype=a16(out16))
+        self.dout = torch.empty(B, self.H, self.W, Ct, device=dev)
+        self.r1 = torch.empty(M, b1a, device=dev, dtype=a16(r16))
+        self.r2 = torch.empty(M, b2a, device=dev, dtype=a16(r16))
+        self.dr1 = torch.empty(M, b1a, device=dev)
+        self.dr2 = torch.empty(M, b2a, device=dev)
+        self.pooled = torch.empty(M, cin, device=dev, dtype=self.prev.out.dtype)       # a pool copies values
+        self.dpooled = torch.empty(M, cin, device=dev)
         self.argmax = torch.empty(M, cin, dtype=torch.uint8, device=dev)
         o, do = self.out.data_ptr(), self.dout.data_ptr()
         off1, off2, off3 = b0, b0 + b1b, b0 + b1b + b2b
         nf = b0 + b1a + b2a
-        self.seg_f = make_segments([(0, b0, o, Ct), (b0, b0 + b1a, self.r1.data_ptr(), b1a),
-                                    (b0 + b1a, nf, self.r2.data_ptr(), b2a)])
-        self.seg_1 = make_segments([(0, b1b, o + 4 * off1, Ct)])
-        self.seg_2 = make_segments([(0, b2b, o + 4 * off2, Ct)])
-        self.seg_3 = make_segments([(0, b3, o + 4 * off3, Ct)])
+        es, dt_o, dt_r = self.out.element_size(), ops.act_dtype(self.out), ops.act_dtype(self.r1)
+        self.seg_f = make_segments([(0, b0, o, Ct, dt_o), (b0, b0 + b1a, self.r1.data_ptr(), b1a, dt_r),
+                                    (b0 + b1a, nf, self.r2.data_ptr(), b2a, dt_r)])
+        self.seg_1 = make_segments([(0, b1b, o + es * off1, Ct, dt_o)])
+        self.seg_2 = make_segments([(0, b2b, o + es * off2, Ct, dt_o)])
+        self.seg_3 = make_segments([(0, b3, o + es * off3, Ct, dt_o)])
         self.fused.set_dy_parts([(0, b0, do, Ct), (b0, b0 + b1a, self.dr1.data_ptr(), b1a),
                                  (b0 + b1a, nf, self.dr2.data_ptr(), b2a)])
         self.c1.set_dy_parts([(0, b1b, do + 4 * off1, Ct)])
@@ -542,12 +559,13 @@ class MixedStage(Stage):
         b0, b1a, b1b, b2a, b2b, b3 = self.b
         x = ops._p(p.out)
         eng = self.eng
+        dx_, dr_ = ops.act_dtype(p.out), ops.act_dtype(self.r1)
         if not (eng.branch_streams and eng.side):
-            self.fused.forward(x, p.C, self.seg_f)
-            self.c1.forward(ops._p(self.r1), b1a, self.seg_1)
-            self.c2.forward(ops._p(self.r2), b2a, self.seg_2)
+            self.fused.forward(x, p.C, self.seg_f, dx_)
+            self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_)
+            self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_)
             ops.maxpool_fwd(p.out, self.pooled, self.argmax, self.B, p.H, p.W, p.C, 3, 1, "SAME")
-            self.c3.forward(ops._p(self.pooled), p.C, self.seg_3)
+            self.c3.forward(ops._p(self.pooled), p.C, self.seg_3, dx_)
             return
         main = torch.cuda.current_stream()
         s1, s2 = eng.side
@@ -558,23 +576,23 @@ class MixedStage(Stage):
         with torch.cuda.stream(s2):
             s2.wait_event(e_in)
             ops.maxpool_fwd(p.out, self.pooled, self.argmax, self.B, p.H, p.W, p.C, 3, 1, "SAME")
-            self.c3.forward(ops._p(self.pooled), p.C, self.seg_3)
+            self.c3.forward(ops._p(self.pooled), p.C, self.seg_3, dx_)
             if not eng.one_side_stream:
                 e_3.record(s2)
-        self.fused.forward(x, p.C, self.seg_f)
+        self.fused.forward(x, p.C, self.seg_f, dx_)
         if eng.one_side_stream == 2:        # only the Branch_3 chain on the side stream
             with torch.cuda.stream(s2):
                 e_2.record(s2)
-            self.c2.forward(ops._p(self.r2), b2a, self.seg_2)
-            self.c1.forward(ops._p(self.r1), b1a, self.seg_1)
+            self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_)
+            self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_)
             main.wait_event(e_2)
             return
         e_f.record(main)
         with torch.cuda.stream(s1):
             s1.wait_event(e_f)
-            self.c2.forward(ops._p(self.r2), b2a, self.seg_2)
+            self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_)
             e_2.record(s1)
-        self.c1.forward(ops._p(self.r1), b1a, self.seg_1)
+        self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_)
         main.wait_event(e_2)
         if not eng.one_side_stream:
             main.wait_event(e_3)
@@ -660,6 +678,12 @@ class InceptionV1Engine:
         # costs ~17 us of idle GPU: 17.74 -> 17.58 ms/step against two side streams); 0: a side stream each; 2: Branch_3 only
         self.one_side_stream = 1
         self.pool_first = True       # Mixed backward: Branch_3's pool gradient written first, fused dgrad accumulates (False: the reverse)
+        # 16-bit activation storage (bf16 / fp8 configurations only): the post-ReLU activations that only feed convs and
+        # pools are written as bf16 by ds_bn_apply_relu / the pools and read as bf16 by ds_conv_bf16 / ds_conv_fp8 --
+        # half the bytes of every forward HBM-bound pass and of the convs' A fetch.  z, gradients, statistics, master
+        # weights stay fp32; so do Mixed_5b's output and Mixed_5c's intermediates (inputs of the fp32 wgrads) and
+        # Mixed_5c's output (average pool).  Not with train_all (every conv's wgrad reads its input in fp32).
+        self.act16 = dtype in ("bf16", "fp8") and not train_all
         self.bwd_sums = True         # BatchNorm backward sums from the producing dgrad's epilogue (DS_EPI_BNSUMS) where it can
         self.stem_direct = True      # Conv2d_1a_7x7 from the packed RGB batch (ds_conv_stem; False: generic kernel on a 4-channel copy)
         self.branch_streams = True   # Mixed blocks: Branch_2 and Branch_3 on side streams next to Branch_0/1 (False: one stream)

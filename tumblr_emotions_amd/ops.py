@@ -42,13 +42,21 @@ def same_pad(n, k, s):
 
 
 def make_segments(entries):
-    """entries: list of (c_begin, c_end, tensor_view, ld) -> Segments struct."""
+    """entries: list of (c_begin, c_end, address, ld[, dtype]) -> Segments struct (dtype: DS_DTYPE_F32 default, or
+    DS_DTYPE_BF16 for an activation destination kept in 16-bit storage; ld in elements)."""
     sg = Segments()
     sg.nseg = len(entries)
-    for i, (c0, c1, ptr, ld) in enumerate(entries):
+    for i, e in enumerate(entries):
+        c0, c1, ptr, ld = e[:4]
         sg.c_begin[i], sg.c_end[i], sg.ld[i] = c0, c1, ld
         sg.ptr[i] = ptr
+        sg.dtype[i] = e[4] if len(e) > 4 else DS_DTYPE_F32
     return sg
+
+
+def act_dtype(t):
+    """DS_DTYPE_* of an activation tensor (fp32, or bf16 under 16-bit activation storage)."""
+    return DS_DTYPE_BF16 if t.dtype == torch.bfloat16 else DS_DTYPE_F32
 
 
 class ConvPlan:
@@ -264,9 +272,12 @@ class Fp8Plan(Bf16Plan):
             t.end(self)
 
 
-def absmax(x, n, out):
-    """out[0] = max |x[:n]| on the device (no host sync)."""
-    _lib.check(_lib.load().ds_absmax(_p(x) if not isinstance(x, C.c_void_p) else x, n, _p(out), _stream()), "ds_absmax")
+def absmax(x, n, out, x_dtype=DS_DTYPE_F32):
+    """out[0] = max |x[:n]| on the device (no host sync).  x: tensor (its dtype counts) or raw address + x_dtype."""
+    if not isinstance(x, C.c_void_p):
+        x_dtype = act_dtype(x)
+        x = _p(x)
+    _lib.check(_lib.load().ds_absmax(x, n, x_dtype, _p(out), _stream()), "ds_absmax")
 
 
 def weights_fp8_bytes(Cin, Cout, taps, dgrad):
@@ -359,8 +370,9 @@ def maxpool_fwd(x, y, argmax, N, H, W, C_, k, stride, mode="SAME"):
         OW, pl = same_pad(W, k, stride)
     else:
         OH, OW, pt, pl = (H - k) // stride + 1, (W - k) // stride + 1, 0, 0
+    assert x.dtype == y.dtype
     _lib.check(_lib.load().ds_maxpool_fwd(_p(x), _p(y), _p(argmax), N, H, W, C_, k, stride, pt, pl, OH, OW,
-                                          _stream()), "ds_maxpool_fwd")
+                                          act_dtype(x), _stream()), "ds_maxpool_fwd")
     return OH, OW
 
 
@@ -369,7 +381,7 @@ def maxpool_bn_relu_fwd(z, rstd, shift, y, argmax, N, H, W, C_, k, stride):
     OH, pt = same_pad(H, k, stride)
     OW, pl = same_pad(W, k, stride)
     _lib.check(_lib.load().ds_maxpool_bn_relu_fwd(_p(z), _p(rstd), _p(shift), _p(y), _p(argmax), N, H, W, C_, k, stride,
-                                                  pt, pl, OH, OW, _stream()), "ds_maxpool_bn_relu_fwd")
+                                                  pt, pl, OH, OW, act_dtype(y), _stream()), "ds_maxpool_bn_relu_fwd")
     return OH, OW
 
 
