@@ -131,14 +131,20 @@ int ds_conv_bf16(const ds_conv_desc *d, const void *x, const void *wb, float *z,
  * formats (gfx950), fp32 accumulation, fp32 z.  Per-tensor POWER-OF-TWO scales s = 2^floor(log2(FMAX / amax)):
  *   weights      e4m3 (FMAX 448): ds_weights_to_fp8 takes amax, fixes s_w and converts the TF HWIO filter into the
  *                kernel's order [16-channel chunk x tap][column][16 k] (ds_weights_fp8_bytes; dgrad = 1: flipped taps,
- *                channel roles swapped); wscale = device float[4] {amax, s_w, 1 / s_w, -} written by the call;
+ *                channel roles swapped); wscale = device float[4 + DS_AMAX_FLOATS]: {amax, s_w, 1 / s_w, -} written by
+ *                the call, followed by scratch for the filter's amax record;
  *   activations  a_format DS_FP8_E4M3 (forward x) or DS_FP8_E5M2 (FMAX 57344: dgrad's dz); the scale is derived in the
- *                kernel from the device word x_amax[0] = max |x| (ds_absmax, or a producer that tracks it): nothing
+ *                kernel from the device record x_amax (max |x|: ds_absmax, or a producer that tracks it): nothing
  *                crosses to the host.  Values are scaled, saturated to +-FMAX and rounded to nearest even.
  * z = acc / (s_a s_w); `d` as for ds_conv_bf16 (flags 0 or DS_EPI_STATS, partials float[2][Cout][ds_conv_fp8_partials]).
  * Not the fp32 parity path: separately labelled, tolerance documented in tests/test_kernels_gpu.py / DESIGN.md.     */
 #define DS_FP8_E4M3 0
 #define DS_FP8_E5M2 1
+/* A max|.| record ("amax", "x_amax" below and in ds_segments / ds_bn_bwd_apply / ds_maxpool_bn_relu_fwd) is
+ * DS_AMAX_FLOATS device floats: 16 slots, one per 128-byte line (float 0, 32, 64, ...), that the producing kernels
+ * raise by atomic max -- spread so that thousands of waves do not queue on one word; its value is the maximum of the 16
+ * slots.  The owner zeroes a record before its first producer of a step (ds_absmax zeroes its own).            */
+#define DS_AMAX_FLOATS 512
 int ds_absmax(const void *x, int64_t n, int32_t x_dtype, float *amax, void *stream);
 size_t ds_weights_fp8_bytes(int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad);
 int ds_weights_to_fp8(const float *w, void *wq, float *wscale, int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad,
@@ -199,6 +205,9 @@ typedef struct ds_segments {
     int32_t dtype[4];         /* ds_bn_apply_relu only: DS_DTYPE_F32 (0) or DS_DTYPE_BF16 -- the activation is  */
                               /* stored rounded to bf16 (16-bit activation storage of the bf16 / fp8          */
                               /* configurations); gradient segments are always fp32                           */
+    float *amax[4];           /* ds_bn_apply_relu only, nullable: device word that receives max(y) of the segment by  */
+                              /* atomic max (the caller zeroes it once per step): the per-tensor scale of the fp8     */
+                              /* conv that reads the segment, without a separate ds_absmax pass                     */
 } ds_segments;
 int ds_bn_apply_relu(const float *z, int64_t M, int32_t C, const float *rstd, const float *shift,
                      const ds_segments *dst, void *stream);
@@ -230,8 +239,9 @@ typedef struct ds_bn_sum_segments {
 } ds_bn_sum_segments;
 int ds_bn_bwd_finalize_segs(const ds_bn_sum_segments *sg, int64_t M, int32_t C, const float *beta, float *dbeta,
                             float *coef, void *stream);
+/* amax (nullable): device word that receives max|dz| by atomic max (zeroed by the caller): the scale of an fp8 dgrad */
 int ds_bn_bwd_apply(const float *z, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
-                    const float *rstd, const float *shift, const float *coef, float *dz, void *stream);
+                    const float *rstd, const float *shift, const float *coef, float *dz, float *amax, void *stream);
 
 /* slim.max_pool2d SAME/VALID (inception_v1.py:67,79,94,118,208) with arg-max record, and MaxPoolGrad. */
 /* act_dtype: storage type of x AND y (DS_DTYPE_F32 / DS_DTYPE_BF16; max and arg-max are exact in either).   */
@@ -243,7 +253,7 @@ int ds_maxpool_fwd(const void *x, void *y, uint8_t *argmax, int32_t N, int32_t H
  * maxpool(relu(bn(z))) because rstd > 0; the full-resolution activation is never materialised.           */
 int ds_maxpool_bn_relu_fwd(const float *z, const float *rstd, const float *shift, void *y, uint8_t *argmax,
                            int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad_t,
-                           int32_t pad_l, int32_t OH, int32_t OW, int32_t y_dtype, void *stream);
+                           int32_t pad_l, int32_t OH, int32_t OW, int32_t y_dtype, float *amax, void *stream);
 /* ... and its backward: BatchNorm(+ReLU) backward of that conv straight from the POOLED gradient (3x3 stride-2
  * SAME pools).  MaxPoolGrad's full-resolution result is rebuilt per 2x2 input patch on the fly instead of being
  * written and re-read twice.  reduce -> partials float[2][C][P] (P = ds_bn_pool_bwd_partials), then

@@ -437,11 +437,14 @@ def test_absmax_and_fp8_formats_on_this_device():
     rng = np.random.RandomState(3)
     x = rng.normal(size=100003).astype(np.float32) * 3
     x[777] = -41.5
-    out = torch.zeros(1, device="cuda")
+    out = torch.zeros(ops.AMAX_FLOATS, device="cuda")
     xd = dev(x)
     ops.absmax(xd, x.size, out)
     torch.cuda.synchronize()
-    assert float(out.item()) == 41.5
+    assert ops.amax_value(out) == 41.5
+    ops.absmax(xd.to(torch.bfloat16), x.size - 1, out)             # bf16 storage (an even count)
+    torch.cuda.synchronize()
+    assert ops.amax_value(out) == 41.5
     # one tile: M = 32, K = 16, N = 32, identity-like weights pick single products
     for a_format, fmax, mant, emin in ((ops.DS_FP8_E4M3, 448.0, 3, -6), (ops.DS_FP8_E5M2, 57344.0, 2, -14)):
         M, K, N = 32, 16, 32
@@ -455,15 +458,15 @@ def test_absmax_and_fp8_formats_on_this_device():
         w[0, 0, 0, 16] = 448.0                             # pins the weight amax -> s_w = 1
         plan = ops.Fp8Plan(M, 1, 1, K, K, 1, 1, N, N, a_format=a_format, pad_t=0, pad_l=0, OH=1, OW=1)
         wq = torch.empty(ops.weights_fp8_bytes(K, N, 1, False), dtype=torch.uint8, device="cuda")
-        ws = torch.zeros(4, device="cuda")
+        ws = torch.zeros(ops.WSCALE_FLOATS, device="cuda")
         ops.weights_to_fp8(ops._p(dev(w)), wq, ws, K, N, 1, False)
         xd = dev(xs)
-        amax = torch.zeros(1, device="cuda")
+        amax = torch.zeros(ops.AMAX_FLOATS, device="cuda")
         ops.absmax(xd, xs.size, amax)
         z = torch.empty(M, N, device="cuda")
         plan.run(ops._p(xd), ops._p(wq), ops._p(z), x_amax=ops._p(amax), wscale=ops._p(ws))
         torch.cuda.synchronize()
-        assert float(ws[1].item()) == 1.0 and float(amax.item()) == fmax
+        assert float(ws[1].item()) == 1.0 and ops.amax_value(amax) == fmax and float(ws[0].item()) == 448.0
         want = _fp8_round(xs, fmax, mant, emin)
         got = z.cpu().numpy().astype(np.float64)[:, :K]
         np.testing.assert_array_equal(got, want, err_msg="format %d" % a_format)
@@ -501,9 +504,9 @@ def test_fp8_conv_forward_and_dgrad_match_quantising_oracle(case):
     M = N * H * W
     plan = ops.Fp8Plan(N, H, W, Ci, Ci, k, 1, Co, Co, flags=ops.DS_EPI_STATS, a_format=ops.DS_FP8_E4M3)
     wq = torch.empty(ops.weights_fp8_bytes(Ci, Co, k * k, False), dtype=torch.uint8, device="cuda")
-    ws = torch.zeros(4, device="cuda")
+    ws = torch.zeros(ops.WSCALE_FLOATS, device="cuda")
     ops.weights_to_fp8(ops._p(wd), wq, ws, Ci, Co, k * k, False)
-    amax = torch.zeros(1, device="cuda")
+    amax = torch.zeros(ops.AMAX_FLOATS, device="cuda")
     ops.absmax(xd, x.size, amax)
     z = torch.full((M, Co), float("nan"), device="cuda")
     stats = torch.zeros(2, Co, plan.partials, device="cuda")
@@ -526,7 +529,7 @@ def test_fp8_conv_forward_and_dgrad_match_quantising_oracle(case):
         dexact = S.conv2d_same_bwd_input(dy.astype(np.float64), w.astype(np.float64), (N, H, W, Ci), 1)
         g = ops.Fp8Plan(N, H, W, Co, Co, k, 1, Ci, Ci, a_format=ops.DS_FP8_E5M2)
         wqd = torch.empty(ops.weights_fp8_bytes(Ci, Co, k * k, True), dtype=torch.uint8, device="cuda")
-        wsd = torch.zeros(4, device="cuda")
+        wsd = torch.zeros(ops.WSCALE_FLOATS, device="cuda")
         ops.weights_to_fp8(ops._p(wd), wqd, wsd, Ci, Co, k * k, True)
         dyd = dev(dy)
         ops.absmax(dyd, dy.size, amax)

@@ -29,7 +29,8 @@ class ConvDesc(C.Structure):
 
 class Segments(C.Structure):
     _fields_ = [("nseg", C.c_int32), ("c_begin", C.c_int32 * 4), ("c_end", C.c_int32 * 4),
-                ("ld", C.c_int32 * 4), ("ptr", C.c_void_p * 4), ("dtype", C.c_int32 * 4)]
+                ("ld", C.c_int32 * 4), ("ptr", C.c_void_p * 4), ("dtype", C.c_int32 * 4),
+                ("amax", C.c_void_p * 4)]
 
 
 class SumSegments(C.Structure):
@@ -78,9 +79,9 @@ SIGNATURES = {
     "ds_bn_bwd_reduce": (C.c_int, [_P, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _P]),
     "ds_bn_bwd_finalize_segs": (C.c_int, [_SS, _i64, _i32, _P, _P, _P, _P]),
     "ds_bn_bwd_finalize": (C.c_int, [_P, _i32, _i64, _i32, _P, _P, _P]),
-    "ds_bn_bwd_apply": (C.c_int, [_P, _SG, _i64, _i32, _P, _P, _P, _P, _P, _P]),
+    "ds_bn_bwd_apply": (C.c_int, [_P, _SG, _i64, _i32, _P, _P, _P, _P, _P, _P, _P]),
     "ds_maxpool_fwd": (C.c_int, [_P, _P, _P] + [_i32] * 11 + [_P]),
-    "ds_maxpool_bn_relu_fwd": (C.c_int, [_P, _P, _P, _P, _P] + [_i32] * 11 + [_P]),
+    "ds_maxpool_bn_relu_fwd": (C.c_int, [_P, _P, _P, _P, _P] + [_i32] * 11 + [_P, _P]),
     "ds_bn_pool_bwd_partials": (C.c_int, [_i32, _i32, _i32, _i32]),
     "ds_bn_pool_bwd_reduce": (C.c_int, [_P, _P, _P] + [_i32] * 8 + [_P, _P, _P, _P, _P]),
     "ds_bn_pool_bwd_apply": (C.c_int, [_P, _P, _P] + [_i32] * 8 + [_P, _P, _P, _P, _P, _P]),

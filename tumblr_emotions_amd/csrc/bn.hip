@@ -18,6 +18,7 @@ struct SegDev {
     int c_begin[4], c_end[4], ld[4];
     float *ptr[4];
     int dtype[4];
+    float *amax[4];
 };
 
 SegDev to_dev(const ds_segments *s) {
@@ -29,6 +30,7 @@ SegDev to_dev(const ds_segments *s) {
         o.ld[i] = s->ld[i];
         o.ptr[i] = (float *)s->ptr[i];
         o.dtype[i] = s->dtype[i];
+        o.amax[i] = s->amax[i];
     }
     return o;
 }
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *z, int6
                                                             const float *shift, SegDev dst) {
     const int C4 = C >> 2;
     const int64_t total = M * C4;
+    float smax[4] = {0.f, 0.f, 0.f, 0.f};      // max(y) per destination segment (y >= 0), for the segments that ask
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t row = i / C4;
         const int c = (int)(i - row * C4) * 4;
@@ -107,6 +110,7 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *z, int6
 #pragma unroll
         for (int sgi = 0; sgi < 4; ++sgi)
             if (sgi < dst.nseg && c >= dst.c_begin[sgi] && c < dst.c_end[sgi]) {
+                smax[sgi] = fmaxf(smax[sgi], fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w)));
                 const int64_t e = row * dst.ld[sgi] + (c - dst.c_begin[sgi]);
                 if (dst.dtype[sgi] == DS_DTYPE_BF16) {
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -118,6 +122,14 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *z, int6
                 }
             }
     }
+#pragma unroll
+    for (int sgi = 0; sgi < 4; ++sgi)
+        if (sgi < dst.nseg && dst.amax[sgi]) {      // (uniform) non-negative floats order like unsigned integers
+            float m = smax[sgi];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if ((threadIdx.x & 63) == 0) ds::atomic_max_nonneg(dst.amax[sgi], m);
+        }
 }
 
 // ---- backward -----------------------------------------------------------------------------------
@@ -291,9 +303,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_segs_kernel(SumSegDev sg,
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, SegDev dy, int64_t M, int C,
                                                            const float *mean, const float *rstd, const float *shift,
-                                                           const float *coef, float *dz) {
+                                                           const float *coef, float *dz, float *amax) {
     const int C4 = C >> 2;
     const int64_t total = M * C4;
+    float am = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t row = i / C4;
         const int c = (int)(i - row * C4) * 4;
@@ -315,6 +328,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, SegDe
             o[j] = rr[j] * (g - a1[j] - xh * a2[j]);
         }
         *reinterpret_cast<float4 *>(dz + row * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+    }
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+        if ((threadIdx.x & 63) == 0) ds::atomic_max_nonneg(amax, am);
     }
 }
 
@@ -423,10 +442,11 @@ extern "C" int ds_bn_bwd_finalize_segs(const ds_bn_sum_segments *sg, int64_t M, 
 }
 
 extern "C" int ds_bn_bwd_apply(const float *z, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
-                               const float *rstd, const float *shift, const float *coef, float *dz, void *stream) {
+                               const float *rstd, const float *shift, const float *coef, float *dz, float *amax,
+                               void *stream) {
     DS_REQUIRE(z && mean && rstd && shift && coef && dz && M > 0 && C > 0 && C % 4 == 0, "ds_bn_bwd_apply: bad argument");
     if (int e = check_segments(dy, C, "ds_bn_bwd_apply")) return e;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ds::stream_grid(M * (C / 4), 256 * 4)), dim3(256), 0,
-                       (hipStream_t)stream, z, to_dev(dy), M, C, mean, rstd, shift, coef, dz);
+                       (hipStream_t)stream, z, to_dev(dy), M, C, mean, rstd, shift, coef, dz, amax);
     return ds::check_launch("ds_bn_bwd_apply");
 }

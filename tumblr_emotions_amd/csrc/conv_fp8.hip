@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8d_kernel(const Fp8Params p) {
     const int chunks = (d.Cin + 15) >> 4;
     const int iters = chunks * TAPS;
     const int nsteps = (iters + SI - 1) / SI;
-    const float sa = pow2_scale(p.x_amax[0], E5M2 ? kMaxE5M2 : kMaxE4M3);
+    const float sa = pow2_scale(ds::amax_read(p.x_amax), E5M2 ? kMaxE5M2 : kMaxE4M3);
     const float inv = p.wscale[2] / sa;                        // 1 / (s_a s_w): exact, both are powers of two
 
     const int m = trow * 128 + wave * 32 + li;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void absmax_bf16_kernel(const unsigned *x, int
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) ds::atomic_max_nonneg(reinterpret_cast<float *>(out), __uint_as_float(m));
 }
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float *x, int64_t n, unsigned *out) {
@@ -261,16 +261,17 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *x, int64_t n, 
     for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) ds::atomic_max_nonneg(reinterpret_cast<float *>(out), m);
 }
 
 // wq[it][column][16] e4m3, it = chunk * taps + tap, from the TF HWIO filter w [taps][Cin][Cout] scaled by
 // s_w = pow2_scale(amax): layout rules as weights_to_bf16_kernel (conv_igemm.hip).  wscale[0] = amax on entry.
-__global__ __launch_bounds__(256) void weights_to_fp8_kernel(const float *w, unsigned char *wq, float *wscale, int Cin,
-                                                            int Cout, int taps, int dgrad) {
+__global__ __launch_bounds__(256) void weights_to_fp8_kernel(const float *w, unsigned char *wq, const float *wamax,
+                                                            float *wscale, int Cin, int Cout, int taps, int dgrad) {
     const int K = dgrad ? Cout : Cin, Ncol = dgrad ? Cin : Cout;
     const int chunks = (K + 15) >> 4, ncols = (Ncol + 31) / 32 * 32;
-    const float sw = pow2_scale(wscale[0], kMaxE4M3);
+    const float wmax = ds::amax_read(wamax);       // every lane (wave shuffles inside)
+    const float sw = pow2_scale(wmax, kMaxE4M3);
     const int64_t total = (int64_t)chunks * taps * ncols * 8;            // pairs of consecutive k
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int j = (int)(i & 7) * 2;
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(256) void weights_to_fp8_kernel(const float *w, uns
         reinterpret_cast<unsigned short *>(wq)[i] = (unsigned short)(pk & 0xffff);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        wscale[0] = wmax;
         wscale[1] = sw;
         wscale[2] = 1.f / sw;
     }
@@ -333,7 +335,7 @@ extern "C" int ds_absmax(const void *x, int64_t n, int32_t x_dtype, float *amax,
     DS_REQUIRE(x && amax && n > 0 && (((uintptr_t)x) & 15) == 0, "ds_absmax: bad argument (x must be 16-byte aligned)");
     DS_REQUIRE(x_dtype == DS_DTYPE_F32 || (x_dtype == DS_DTYPE_BF16 && n % 2 == 0),
                "ds_absmax: x_dtype must be DS_DTYPE_F32 or DS_DTYPE_BF16 (an even count)");
-    if (hipMemsetAsync(amax, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return ds::check_launch("ds_absmax(memset)");
+    if (hipMemsetAsync(amax, 0, DS_AMAX_FLOATS * sizeof(float), (hipStream_t)stream) != hipSuccess) return ds::check_launch("ds_absmax(memset)");
     if (x_dtype == DS_DTYPE_BF16)
         hipLaunchKernelGGL(absmax_bf16_kernel, dim3(ds::stream_grid(n / 2, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
                            (const unsigned *)x, n / 2, (unsigned *)amax);
@@ -352,10 +354,11 @@ extern "C" int ds_weights_to_fp8(const float *w, void *wq, float *wscale, int32_
                                  int32_t dgrad, void *stream) {
     DS_REQUIRE(w && wq && wscale && Cin > 0 && Cout > 0 && taps > 0, "ds_weights_to_fp8: bad argument");
     const int64_t n = (int64_t)taps * Cin * Cout;
-    if (int e = ds_absmax(w, n, DS_DTYPE_F32, wscale, stream)) return e;
+    float *wamax = wscale + 4;                 // the scale record is followed by the amax record of the filter
+    if (int e = ds_absmax(w, n, DS_DTYPE_F32, wamax, stream)) return e;
     const int64_t pairs = (int64_t)ds_weights_fp8_bytes(Cin, Cout, taps, dgrad) / 2;
     hipLaunchKernelGGL(weights_to_fp8_kernel, dim3(ds::stream_grid(pairs, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       (unsigned char *)wq, wscale, Cin, Cout, taps, dgrad);
+                       (unsigned char *)wq, wamax, wscale, Cin, Cout, taps, dgrad);
     return ds::check_launch("ds_weights_to_fp8");
 }
 

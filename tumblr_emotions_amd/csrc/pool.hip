@@ -159,9 +159,10 @@ __device__ __forceinline__ RowMax row_max3(const TI *x, int64_t row_base, int iw
 template <int STRIDE, typename TI, typename TO>
 __global__ __launch_bounds__(256) void maxpool3_fwd_rolling(const TI *x, TO *y, uint8_t *am, int N, int H, int W,
                                                             int C, int pad_t, int pad_l, int OH, int OW,
-                                                            const float *rstd, const float *shift) {
+                                                            const float *rstd, const float *shift, float *amax) {
     const int C4 = C >> 2;
     const int64_t total = (int64_t)N * OW * C4;
+    float ymax = 0.f;      // max of the (non-negative) outputs of the fused BatchNorm + ReLU + pool, when asked for
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % C4) * 4;
         const int ow = (int)((i / C4) % OW);
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_rolling(const TI *x, TO *y, 
                 best[1] = fmaxf(best[1] * r.y + s.y, 0.f);
                 best[2] = fmaxf(best[2] * r.z + s.z, 0.f);
                 best[3] = fmaxf(best[3] * r.w + s.w, 0.f);
+                ymax = fmaxf(ymax, fmaxf(fmaxf(best[0], best[1]), fmaxf(best[2], best[3])));
             }
             st4(y + o, best[0], best[1], best[2], best[3]);
             if (am) *reinterpret_cast<uchar4 *>(am + o) = make_uchar4(arg[0], arg[1], arg[2], arg[3]);
@@ -203,6 +205,11 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_rolling(const TI *x, TO *y, 
             }
             ih0 += STRIDE;
         }
+    }
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+        if ((threadIdx.x & 63) == 0) ds::atomic_max_nonneg(amax, ymax);
     }
 }
 
@@ -559,14 +566,14 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float *z, 
 namespace {
 template <typename TI, typename TO>
 void launch_pool3(int stride, hipStream_t st, const TI *x, TO *y, uint8_t *argmax, int N, int H, int W, int C, int pad_t,
-                  int pad_l, int OH, int OW, const float *rstd, const float *shift) {
+                  int pad_l, int OH, int OW, const float *rstd, const float *shift, float *amax = nullptr) {
     const int64_t cols = (int64_t)N * OW * (C / 4);
     if (stride == 1)
         hipLaunchKernelGGL((maxpool3_fwd_rolling<1, TI, TO>), dim3(ds::stream_grid(cols, 256)), dim3(256), 0, st, x, y, argmax,
-                           N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift);
+                           N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift, amax);
     else
         hipLaunchKernelGGL((maxpool3_fwd_rolling<2, TI, TO>), dim3(ds::stream_grid(cols, 256)), dim3(256), 0, st, x, y, argmax,
-                           N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift);
+                           N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift, amax);
 }
 }  // namespace
 
@@ -594,12 +601,13 @@ extern "C" int ds_maxpool_fwd(const void *x, void *y, uint8_t *argmax, int32_t N
 
 extern "C" int ds_maxpool_bn_relu_fwd(const float *z, const float *rstd, const float *shift, void *y, uint8_t *argmax,
                                       int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride,
-                                      int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW, int32_t y_dtype, void *stream) {
+                                      int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW, int32_t y_dtype, float *amax,
+                                      void *stream) {
     DS_REQUIRE(z && rstd && shift && y && C % 4 == 0 && k == 3 && (stride == 1 || stride == 2),
                "ds_maxpool_bn_relu_fwd: bad argument (3x3 pools, stride 1 or 2, C %% 4 == 0)");
     DS_REQUIRE(y_dtype == DS_DTYPE_F32 || y_dtype == DS_DTYPE_BF16, "ds_maxpool_bn_relu_fwd: y_dtype must be DS_DTYPE_F32 or DS_DTYPE_BF16");
-    if (y_dtype == DS_DTYPE_BF16) launch_pool3(stride, (hipStream_t)stream, z, (__bf16 *)y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift);
-    else launch_pool3(stride, (hipStream_t)stream, z, (float *)y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift);
+    if (y_dtype == DS_DTYPE_BF16) launch_pool3(stride, (hipStream_t)stream, z, (__bf16 *)y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift, amax);
+    else launch_pool3(stride, (hipStream_t)stream, z, (float *)y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift, amax);
     return ds::check_launch("ds_maxpool_bn_relu_fwd");
 }
 

@@ -123,12 +123,13 @@ class ConvBN:
         fp8 = eng.dtype == "fp8" and not self.fold and k in (1, 3) and self.stride == 1
         self._fp8_dgrad_ok = fp8 and cout % 8 == 0
         if fp8:
-            self.amax = torch.zeros(2, device=dev)
+            self.amax = torch.zeros(2, ops.AMAX_FLOATS, device=dev)      # fallback records for ds_absmax passes
+            self.dz_amax = eng.new_amax()                # max|dz|, collected by ds_bn_bwd_apply
         if fp8 and cin % 8 == 0:
             self.wino_fwd = ops.Fp8Plan(B, self.H, self.W, cin, cin, k, self.stride, cout, cout, flags=DS_EPI_STATS,
                                         a_format=ops.DS_FP8_E4M3)
             self.u_fwd = torch.empty(ops.weights_fp8_bytes(cin, cout, k * k, False), dtype=torch.uint8, device=dev)
-            self.ws_fwd = torch.zeros(4, device=dev)
+            self.ws_fwd = torch.zeros(ops.WSCALE_FLOATS, device=dev)
             eng.need_stats(self.wino_fwd.partials * 2 * cout)
         self.u_version = -1
         eng.need_stats(self.fwd.partials * 2 * cout)
@@ -139,6 +140,7 @@ class ConvBN:
         self.dgrad = None
         self.wgrad = None
         self.dy_parts = None          # set_dy_parts(): where the gradient of this layer's output lives
+        self._dz_amax_live = False
         self.dx_sums = None           # this layer's dgrad emits the consumer's BatchNorm sums (emit_dx_sums)
         self.dx_y = None
         self._sum_segs = None
@@ -239,7 +241,7 @@ class ConvBN:
             self.wino_dgrad = ops.Fp8Plan(self.B, self.H, self.W, cout, cout, k, 1, cin, lddx, a_format=ops.DS_FP8_E5M2)
             self.u_dgrad = torch.empty(ops.weights_fp8_bytes(cin, cout, k * k, True), dtype=torch.uint8,
                                        device=self.eng.device)
-            self.ws_dgrad = torch.zeros(4, device=self.eng.device)
+            self.ws_dgrad = torch.zeros(ops.WSCALE_FLOATS, device=self.eng.device)
 
     def _refresh_wino(self):
         """G g G^T of the filter for the Winograd kernels: redone when the weights changed -- every step for a
@@ -262,7 +264,7 @@ class ConvBN:
 
     # x_ptr: input activations [B,H,W,ldx]; segs: where relu(bn(conv)) is scattered (None: the consumer, a max
     # pool, applies BatchNorm + ReLU to its own output instead -- PoolStage.forward)
-    def forward(self, x_ptr, ldx, segs, x_dtype=ops.DS_DTYPE_F32):
+    def forward(self, x_ptr, ldx, segs, x_dtype=ops.DS_DTYPE_F32, x_amax=None):
         eng = self.eng
         if not self.fold:
             self.fwd.d.ldx = ldx
@@ -278,9 +280,11 @@ class ConvBN:
             wino.set_ldx(ldx)
             u_ptr = ops._p(self.u_fwd)
         fp8_kw = {}
-        if isinstance(wino, ops.Fp8Plan):      # per-tensor scale of the input: max|x| into a device word
-            ops.absmax(x_ptr, self.B * self.H * self.W * ldx, self.amax[0:1], x_dtype)
-            fp8_kw = dict(x_amax=ops._p(self.amax[0:1]), wscale=ops._p(self.ws_fwd))
+        if isinstance(wino, ops.Fp8Plan):      # per-tensor scale of the input from max|x| in a device word
+            if x_amax is None:                  # no producer tracked it: one pass over x
+                x_amax = self.amax[0]
+                ops.absmax(x_ptr, self.B * self.H * self.W * ldx, x_amax, x_dtype)
+            fp8_kw = dict(x_amax=ops._p(x_amax), wscale=ops._p(self.ws_fwd))
         if eng.training:       # batch statistics (slim.batch_norm is_training=True)
             # the column sums are taken about a pivot near the mean -- the previous step's batch mean, the
             # moving mean before the first step (bind) -- so channels with |mean| >> std keep their variance
@@ -322,6 +326,7 @@ class ConvBN:
             return
         ops.bn_pool_bwd_apply(self.z, pool.dout, pool.argmax, B, H, W, Cc, self.mean, self.rstd, self.shift, self.coef,
                               self.z)
+        self._dz_amax_live = False
         if self.trainable:
             self.wgrad.d.ldx = ldx
             self.wgrad.run(x_ptr, ops._p(self.z), self.gw_ptr, ops._p(self.ws_buf), eng.ws_bytes)
@@ -332,9 +337,10 @@ class ConvBN:
         sums = ops._p(self.dx_sums) if self.dx_sums is not None else None
         y = ops._p(self.dx_y) if self.dx_sums is not None else None
         if isinstance(self.wino_dgrad, ops.Fp8Plan):
-            ops.absmax(self.z, self.M * self.cout, self.amax[1:2])
-            self.wino_dgrad.run(ops._p(self.z), ops._p(self.u_dgrad), dx_ptr, x_amax=ops._p(self.amax[1:2]),
-                                wscale=ops._p(self.ws_dgrad))
+            am = self.dz_amax if self._dz_amax_live else self.amax[1]
+            if not self._dz_amax_live:          # dz came from a kernel that does not track max|dz| (pooled BatchNorm backward)
+                ops.absmax(self.z, self.M * self.cout, am)
+            self.wino_dgrad.run(ops._p(self.z), ops._p(self.u_dgrad), dx_ptr, x_amax=ops._p(am), wscale=ops._p(self.ws_dgrad))
         elif self.wino_dgrad is not None:
             if sums is not None:
                 self.wino_dgrad.run(ops._p(self.z), ops._p(self.u_dgrad), dx_ptr, stats=sums, ymask=y)
@@ -357,7 +363,10 @@ class ConvBN:
                                 self.coef)
         if not (need_dx or self.trainable):
             return
-        ops.bn_bwd_apply(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.coef, self.z)   # dz over z
+        track = isinstance(self.wino_dgrad, ops.Fp8Plan)
+        ops.bn_bwd_apply(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.coef, self.z,    # dz over z
+                         amax=self.dz_amax if track else None)
+        self._dz_amax_live = track
         if self.trainable:
             self.wgrad.d.ldx = ldx
             self.wgrad.run(x_ptr, ops._p(self.z), self.gw_ptr, ops._p(self.ws_buf), eng.ws_bytes)
@@ -399,7 +408,9 @@ class ConvStage(Stage):
         self.out16 = self.eng.act16 and not self.layer.fold       # Conv2d_2b / 2c (the stem's output is read by hip tests only)
         self.out = torch.empty(B, self.H, self.W, self.C, device=dev, dtype=torch.bfloat16 if self.out16 else torch.float32)
         self.dout = torch.empty(B, self.H, self.W, self.C, device=dev)
-        self.segs = make_segments([(0, self.C, self.out.data_ptr(), self.C, ops.act_dtype(self.out))])
+        self.out_amax = self.eng.new_amax()
+        self.segs = make_segments([(0, self.C, self.out.data_ptr(), self.C, ops.act_dtype(self.out),
+                                    ops._p(self.out_amax))])
         self.layer.set_dy_parts([(0, self.C, self.dout.data_ptr(), self.C)])
         if not self.layer.fold:
             self.layer.make_dgrad(self.prev.C)
@@ -413,7 +424,7 @@ class ConvStage(Stage):
         # fused_into_pool: this conv feeds nothing but the next max pool, which then reads z and applies BN + ReLU
         # after pooling (a quarter of the elements); `out` is not produced
         self.layer.forward(ops._p(self.prev.out), self.prev.C, None if self.fused_into_pool else self.segs,
-                           ops.act_dtype(self.prev.out))
+                           ops.act_dtype(self.prev.out), getattr(self.prev, "out_amax", None))
 
     def backward(self, need_dx):
         need_dx = need_dx and not self.layer.fold
@@ -441,12 +452,21 @@ class PoolStage(Stage):
         self.out = torch.empty(B, self.H, self.W, self.C, device=dev, dtype=torch.bfloat16 if o16 else torch.float32)
         self.dout = torch.empty(B, self.H, self.W, self.C, device=dev)
         self.argmax = torch.empty(B, self.H, self.W, self.C, dtype=torch.uint8, device=dev)
+        self._own_amax = self.eng.new_amax()
+
+    @property
+    def out_amax(self):
+        # behind a conv fused into the pool the pool kernel produces the activation and tracks its maximum; a plain
+        # pool copies values, so its input's maximum bounds its output's
+        if getattr(self.prev, "fused_into_pool", False):
+            return self._own_amax
+        return getattr(self.prev, "out_amax", None)
 
     def forward(self):
         p = self.prev
         if getattr(p, "fused_into_pool", False):
             ops.maxpool_bn_relu_fwd(p.layer.z, p.layer.rstd, p.layer.shift, self.out, self.argmax, self.B, p.H, p.W, p.C,
-                                    self.k, self.stride)
+                                    self.k, self.stride, amax=self._own_amax)
         else:
             if p.out.dtype != self.out.dtype:
                 raise RuntimeError("%s: input and output storage differ (fuse_bn_pool switched after alloc?)" % self.name)
@@ -512,11 +532,13 @@ class MixedStage(Stage):
         off1, off2, off3 = b0, b0 + b1b, b0 + b1b + b2b
         nf = b0 + b1a + b2a
         es, dt_o, dt_r = self.out.element_size(), ops.act_dtype(self.out), ops.act_dtype(self.r1)
-        self.seg_f = make_segments([(0, b0, o, Ct, dt_o), (b0, b0 + b1a, self.r1.data_ptr(), b1a, dt_r),
-                                    (b0 + b1a, nf, self.r2.data_ptr(), b2a, dt_r)])
-        self.seg_1 = make_segments([(0, b1b, o + es * off1, Ct, dt_o)])
-        self.seg_2 = make_segments([(0, b2b, o + es * off2, Ct, dt_o)])
-        self.seg_3 = make_segments([(0, b3, o + es * off3, Ct, dt_o)])
+        self.out_amax, self.r1_amax, self.r2_amax = eng.new_amax(), eng.new_amax(), eng.new_amax()
+        am_o, am_1, am_2 = ops._p(self.out_amax), ops._p(self.r1_amax), ops._p(self.r2_amax)
+        self.seg_f = make_segments([(0, b0, o, Ct, dt_o, am_o), (b0, b0 + b1a, self.r1.data_ptr(), b1a, dt_r, am_1),
+                                    (b0 + b1a, nf, self.r2.data_ptr(), b2a, dt_r, am_2)])
+        self.seg_1 = make_segments([(0, b1b, o + es * off1, Ct, dt_o, am_o)])
+        self.seg_2 = make_segments([(0, b2b, o + es * off2, Ct, dt_o, am_o)])
+        self.seg_3 = make_segments([(0, b3, o + es * off3, Ct, dt_o, am_o)])
         self.fused.set_dy_parts([(0, b0, do, Ct), (b0, b0 + b1a, self.dr1.data_ptr(), b1a),
                                  (b0 + b1a, nf, self.dr2.data_ptr(), b2a)])
         self.c1.set_dy_parts([(0, b1b, do + 4 * off1, Ct)])
@@ -560,12 +582,13 @@ class MixedStage(Stage):
         x = ops._p(p.out)
         eng = self.eng
         dx_, dr_ = ops.act_dtype(p.out), ops.act_dtype(self.r1)
+        ax_, a1_, a2_ = getattr(p, "out_amax", None), self.r1_amax, self.r2_amax      # fp8: max|.| words of the inputs
         if not (eng.branch_streams and eng.side):
-            self.fused.forward(x, p.C, self.seg_f, dx_)
-            self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_)
-            self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_)
+            self.fused.forward(x, p.C, self.seg_f, dx_, ax_)
+            self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_, a1_)
+            self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_, a2_)
             ops.maxpool_fwd(p.out, self.pooled, self.argmax, self.B, p.H, p.W, p.C, 3, 1, "SAME")
-            self.c3.forward(ops._p(self.pooled), p.C, self.seg_3, dx_)
+            self.c3.forward(ops._p(self.pooled), p.C, self.seg_3, dx_, ax_)
             return
         main = torch.cuda.current_stream()
         s1, s2 = eng.side
@@ -576,23 +599,23 @@ class MixedStage(Stage):
         with torch.cuda.stream(s2):
             s2.wait_event(e_in)
             ops.maxpool_fwd(p.out, self.pooled, self.argmax, self.B, p.H, p.W, p.C, 3, 1, "SAME")
-            self.c3.forward(ops._p(self.pooled), p.C, self.seg_3, dx_)
+            self.c3.forward(ops._p(self.pooled), p.C, self.seg_3, dx_, ax_)
             if not eng.one_side_stream:
                 e_3.record(s2)
-        self.fused.forward(x, p.C, self.seg_f, dx_)
+        self.fused.forward(x, p.C, self.seg_f, dx_, ax_)
         if eng.one_side_stream == 2:        # only the Branch_3 chain on the side stream
             with torch.cuda.stream(s2):
                 e_2.record(s2)
-            self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_)
-            self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_)
+            self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_, a2_)
+            self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_, a1_)
             main.wait_event(e_2)
             return
         e_f.record(main)
         with torch.cuda.stream(s1):
             s1.wait_event(e_f)
-            self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_)
+            self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_, a2_)
             e_2.record(s1)
-        self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_)
+        self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_, a1_)
         main.wait_event(e_2)
         if not eng.one_side_stream:
             main.wait_event(e_3)
@@ -722,6 +745,14 @@ class InceptionV1Engine:
         # first stage (from the top) below which nothing is trainable -> backward can stop there
         self.layers = [l for s in self.stages for l in s.layers]
 
+    def new_amax(self):
+        """One word of the amax pool (None outside the fp8 configuration)."""
+        if self.amax_pool is None:
+            return None
+        i = self._amax_next
+        self._amax_next += ops.AMAX_FLOATS
+        return self.amax_pool[i:i + ops.AMAX_FLOATS]
+
     # scratch sizing (called by layers during alloc)
     def need_stats(self, n):
         self._stats_n = max(self._stats_n, n)
@@ -738,6 +769,10 @@ class InceptionV1Engine:
         dev = self.device
         self.B = B
         self.alloc_gen = getattr(self, "alloc_gen", 0) + 1      # SentimentNet: a captured step is stale after this
+        # fp8: device words that collect max|.| of the tensors the fp8 convs read (atomic max in the producing kernels,
+        # zeroed at the start of every forward pass): the per-tensor scales without separate ds_absmax passes
+        self.amax_pool = torch.zeros(128 * ops.AMAX_FLOATS, device=dev) if self.dtype == "fp8" else None
+        self._amax_next = 0
         self.input.alloc(B)
         for s in self.stages:
             s.alloc(B)
@@ -783,6 +818,8 @@ class InceptionV1Engine:
         if not images.is_contiguous():      # the stem kernel reads the packed batch through a raw pointer
             images = images.contiguous()
         self.images = images
+        if self.amax_pool is not None:
+            ops.fill(self.amax_pool, self._amax_next, 0.0)
         stem = self.stages[0].layer
         if not stem.stem_direct or (stem.trainable and self.training):
             # the generic stem kernel and the stem's wgrad (train_all) read a zero-padded 4-channel copy

@@ -42,8 +42,9 @@ def same_pad(n, k, s):
 
 
 def make_segments(entries):
-    """entries: list of (c_begin, c_end, address, ld[, dtype]) -> Segments struct (dtype: DS_DTYPE_F32 default, or
-    DS_DTYPE_BF16 for an activation destination kept in 16-bit storage; ld in elements)."""
+    """entries: list of (c_begin, c_end, address, ld[, dtype[, amax address]]) -> Segments struct (dtype: DS_DTYPE_F32
+    default, or DS_DTYPE_BF16 for an activation destination kept in 16-bit storage; ld in elements; amax: device word
+    that collects max(y) of the segment for an fp8 consumer)."""
     sg = Segments()
     sg.nseg = len(entries)
     for i, e in enumerate(entries):
@@ -51,6 +52,7 @@ def make_segments(entries):
         sg.c_begin[i], sg.c_end[i], sg.ld[i] = c0, c1, ld
         sg.ptr[i] = ptr
         sg.dtype[i] = e[4] if len(e) > 4 else DS_DTYPE_F32
+        sg.amax[i] = e[5] if len(e) > 5 else None
     return sg
 
 
@@ -272,8 +274,18 @@ class Fp8Plan(Bf16Plan):
             t.end(self)
 
 
+AMAX_FLOATS = 512       # DS_AMAX_FLOATS: a max|.| record = 16 slots, one per 128-byte line; its value = max of the slots
+WSCALE_FLOATS = 4 + AMAX_FLOATS
+
+
+def amax_value(record):
+    """Host value of a max|.| record (tests)."""
+    return float(record.view(-1)[:AMAX_FLOATS:32].max().item())
+
+
 def absmax(x, n, out, x_dtype=DS_DTYPE_F32):
-    """out[0] = max |x[:n]| on the device (no host sync).  x: tensor (its dtype counts) or raw address + x_dtype."""
+    """out (a record of AMAX_FLOATS floats) <- max |x[:n]| on the device (no host sync).  x: tensor (its dtype counts) or
+    raw address + x_dtype."""
     if not isinstance(x, C.c_void_p):
         x_dtype = act_dtype(x)
         x = _p(x)
@@ -359,9 +371,9 @@ def bn_bwd_finalize(partials, P, M, C_, dbeta, coef):
                "ds_bn_bwd_finalize")
 
 
-def bn_bwd_apply(z, segs, M, C_, mean, rstd, shift, coef, dz):
+def bn_bwd_apply(z, segs, M, C_, mean, rstd, shift, coef, dz, amax=None):
     _lib.check(_lib.load().ds_bn_bwd_apply(_p(z), C.byref(segs), M, C_, _p(mean), _p(rstd), _p(shift), _p(coef),
-                                           _p(dz), _stream()), "ds_bn_bwd_apply")
+                                           _p(dz), _p(amax), _stream()), "ds_bn_bwd_apply")
 
 
 def maxpool_fwd(x, y, argmax, N, H, W, C_, k, stride, mode="SAME"):
@@ -376,12 +388,13 @@ def maxpool_fwd(x, y, argmax, N, H, W, C_, k, stride, mode="SAME"):
     return OH, OW
 
 
-def maxpool_bn_relu_fwd(z, rstd, shift, y, argmax, N, H, W, C_, k, stride):
+def maxpool_bn_relu_fwd(z, rstd, shift, y, argmax, N, H, W, C_, k, stride, amax=None):
     """y = maxpool(relu(z*rstd + shift)) computed as relu(rstd*maxpool(z) + shift): SAME padding, 3x3 only."""
     OH, pt = same_pad(H, k, stride)
     OW, pl = same_pad(W, k, stride)
     _lib.check(_lib.load().ds_maxpool_bn_relu_fwd(_p(z), _p(rstd), _p(shift), _p(y), _p(argmax), N, H, W, C_, k, stride,
-                                                  pt, pl, OH, OW, act_dtype(y), _stream()), "ds_maxpool_bn_relu_fwd")
+                                                  pt, pl, OH, OW, act_dtype(y), _p(amax), _stream()),
+               "ds_maxpool_bn_relu_fwd")
     return OH, OW
 
 
