@@ -319,7 +319,9 @@ int ds_lstm_cell_bwd(const float *acts, const float *c_t, const float *c_prev, c
  *   rows   row groups (32 batch rows each) a workgroup walks per time step: 1, 2, 4 or 8.  1 = the shortest
  *          sequence time (one workgroup per (16 units, 32 rows) pair); R > 1 = 1/R of the CUs for a longer time,
  *          one row group's hand-off wait covered by work on the others (beside a concurrent kernel that needs
- *          whole CUs).  Scheduling only: every cell's arithmetic and summation order are the same.
+ *          whole CUs).  Scheduling only: every cell's arithmetic and summation order are the same.  With rows = 1
+ *          and H <= 512 the launch is XCD-local: the H / 16 workgroups of a row group share one XCD, so the per-step
+ *          exchange stays inside its L2 (text-only step at B = 256: 1.67 -> 1.27 ms).
  *   ws     ds_lstm_seq_workspace(B, H) bytes of device scratch, ZEROED ONCE BY THE CALLER: forward and backward
  *          arrival counters (each launch re-zeroes its own) and one sticky error word per direction.
  * Supported: H in {32, 64, 128, 256, 512, 1024} with H / 16 <= the device's compute units (ds_lstm_seq_supported);

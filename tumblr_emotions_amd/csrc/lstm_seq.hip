@@ -47,12 +47,14 @@ struct SeqParams {
     unsigned *sync;            // this direction's [row groups] arrival counters
     unsigned *err;             // this direction's error word (sticky: launches never clear it)
     int nrg;
+    int ncg, nrgw;             // unit blocks (H / 16); workgroup rows (ceil(nrg / R))
+    int xcd_map;               // 1: 1-D XCD-local launch (see wg_coords)
     unsigned long long *prof;  // tuning aid (ds_debug_lstm_seq_set_profile): workgroup (0,0) stamps its phases, [T][8]
 };
 
 #define DS_STAMP(slot)                                                                  \
     do {                                                                                \
-        if (p.prof && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)                   \
+        if (p.prof && tid == 0 && cg == 0 && yb == 0)                                       \
             p.prof[(int64_t)t * 8 + (slot)] = __builtin_amdgcn_s_memtime();             \
     } while (0)
 
@@ -61,6 +63,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t srd_of(const void *p, unsigned
 }
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// Which (unit block cg, workgroup row yb) is this workgroup?  The H / 16 workgroups of a row group exchange h_t / dgates_t
+// every step: 64 KB per workgroup and step at H = 512, 16 MB per step over the whole launch at B = 256.  With the plain
+// 2-D grid a row group's workgroups land on all eight XCDs (workgroup id % 8, observed placement) and that traffic crosses
+// the fabric -- it was the 6.5 us "wait" of a 15.5 us step.  xcd_map: a 1-D grid whose id % 8 picks the XCD and whose
+// id / 8 walks the unit blocks of the row groups assigned to that XCD (yb = xcd, xcd + 8, ...), so one row group's
+// exchange stays inside one XCD's L2.  Only used when a row group fits an XCD's 32 CUs at one workgroup per CU
+// (H <= 512); a different hardware placement only costs speed -- the hand-off protocol is placement independent.
+__device__ __forceinline__ bool wg_coords(const SeqParams &p, int &cg, int &yb) {
+    if (p.xcd_map) {
+        const int lin = blockIdx.x, s = lin >> 3;
+        cg = s % p.ncg;
+        yb = (lin & 7) + 8 * (s / p.ncg);
+        return yb < p.nrgw;
+    }
+    cg = blockIdx.x;
+    yb = blockIdx.y;
+    return true;
+}
 
 // one lane waits until the row group's counter reaches `target`; bounded
 __device__ __forceinline__ void wait_counter(unsigned *cnt, unsigned target, unsigned *err) {
@@ -99,9 +120,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
-    const int cg = blockIdx.x, rg0 = blockIdx.y * R;
+    int cg, yb;
+    if (!wg_coords(p, cg, yb)) return;                  // (uniform) surplus workgroup of the XCD-local launch
+    const int rg0 = yb * R;
     const int u0 = cg * 16;
-    const int ncg = gridDim.x;
+    const int ncg = p.ncg;
     const int B = p.B, T = p.T;
     unsigned *err = p.err;
 
@@ -244,9 +267,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kb = lane >> 4;
-    const int cg = blockIdx.x, rg0 = blockIdx.y * R;
+    int cg, yb;
+    if (!wg_coords(p, cg, yb)) return;
+    const int rg0 = yb * R;
     const int u0 = cg * 16;
-    const int ncg = gridDim.x;
+    const int ncg = p.ncg;
     const int B = p.B, T = p.T;
     unsigned *err = p.err;
 
@@ -452,6 +477,24 @@ size_t exclusive_lds(int nw, bool fwd) {
     return stat >= want ? 0 : want - stat;
 }
 
+// launch geometry: XCD-local 1-D grid when a row group's H / 16 workgroups fit one XCD (32 CUs, one workgroup each);
+// DS_LSTM_XCD=0 switches back to the 2-D grid (A/B aid)
+dim3 seq_grid(SeqParams &p, int H, int rows) {
+    static int use = -1;
+    if (use < 0) {
+        const char *e = getenv("DS_LSTM_XCD");
+        use = e ? atoi(e) : 1;
+    }
+    p.ncg = H / 16;
+    p.nrgw = (p.nrg + rows - 1) / rows;
+    // rows > 1 is the setting for running BESIDE another kernel that needs whole CUs (the image tower's Winograd conv):
+    // there the row groups stay spread over all XCDs -- packed onto one or two XCDs they would leave those XCDs no CU
+    // for the other kernel's workgroups (joint step 17.8 -> 19.0 ms, measured)
+    p.xcd_map = (use && p.ncg <= 32 && rows == 1) ? 1 : 0;
+    if (p.xcd_map) return dim3((unsigned)(8 * p.ncg * ((p.nrgw + 7) / 8)));
+    return dim3((unsigned)p.ncg, (unsigned)p.nrgw);
+}
+
 int common_checks(const char *who, const void *a, const void *b, const void *c, int T, int B, int H, int ldw, int rows,
                   void *ws, size_t ws_bytes) {
     DS_REQUIRE(a && b && c && ws, "%s: null argument", who);
@@ -500,7 +543,8 @@ extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float
     // are left alone
     if (hipMemsetAsync(p.sync, 0, (size_t)p.nrg * sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
         return ds::check_launch("ds_lstm_seq_fwd(memset)");
-    hipLaunchKernelGGL(cfg.fwd, dim3(H / 16, (p.nrg + rows - 1) / rows), dim3(64 * cfg.nw), exclusive_lds(cfg.nw, true), (hipStream_t)stream, p);
+    const dim3 grid = seq_grid(p, H, rows);
+    hipLaunchKernelGGL(cfg.fwd, grid, dim3(64 * cfg.nw), exclusive_lds(cfg.nw, true), (hipStream_t)stream, p);
     return ds::check_launch("ds_lstm_seq_fwd");
 }
 
@@ -521,7 +565,8 @@ extern "C" int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, 
     p.err = (unsigned *)ws + 2 * p.nrg + 1;
     if (hipMemsetAsync(p.sync, 0, (size_t)p.nrg * sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
         return ds::check_launch("ds_lstm_seq_bwd(memset)");
-    hipLaunchKernelGGL(cfg.bwd, dim3(H / 16, (p.nrg + rows - 1) / rows), dim3(64 * cfg.nw), exclusive_lds(cfg.nw, false), (hipStream_t)stream, p);
+    const dim3 grid = seq_grid(p, H, rows);
+    hipLaunchKernelGGL(cfg.bwd, grid, dim3(64 * cfg.nw), exclusive_lds(cfg.nw, false), (hipStream_t)stream, p);
     return ds::check_launch("ds_lstm_seq_bwd");
 }
 
