@@ -192,6 +192,9 @@ def main():
                     help="--gpus 1 only: initialise the nccl (= RCCL) backend with ONE rank and take the bucketed all-reduce path "
                          "(early bucket 1 on the side stream, async work handle) exactly as a multi-GPU run does; prints the `dp` "
                          "block.  What a 1-GPU box can show of the 8-GPU code path")
+    ap.add_argument("--no-overlap-comm", action="store_true",
+                    help="data parallel A/B: both gradient buckets all-reduced after the backward pass on the main stream "
+                         "(default: bucket 1 launched early on a side stream, under the Inception backward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--cpu-warmup", type=int, default=3)
@@ -213,6 +216,9 @@ def main():
     # all-reduce, because RCCL refuses two ranks on one device.  Never set for a real measurement.
     one_device = os.environ.get("DS_BENCH_ONE_DEVICE") == "1"
     torch.cuda.set_device(0 if one_device else local_rank)
+    from tumblr_emotions_amd import streams
+    if os.environ.get("DS_BENCH_NO_RESERVE") != "1":
+        streams.reserve()          # the step's streams take their hardware queues BEFORE RCCL creates its own
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if one_device:
@@ -236,7 +242,8 @@ def main():
     net = SentimentNet(mode=args.mode, nb_emotions=15, im_features_size=256, rnn_size=H, fc_size=512, vocab_size=V,
                        embedding_dim=D, post_size=T, dropout_keep_prob=0.8, train_all=args.train_all,
                        trainable_embedding=args.train_all, concurrent_towers=not args.serial_towers,
-                       dtype=args.dtype, force_dp_buckets=force_dp)
+                       dtype=args.dtype, force_dp_buckets=force_dp and os.environ.get("DS_BENCH_INIT_ONLY") != "1",
+                       overlap_comm=not args.no_overlap_comm)
     net.initialize(seed=1)
     if args.lstm_rows and net.text is not None:
         net.text.seq_rows = args.lstm_rows
@@ -279,6 +286,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         net.train_step(batch, lr)
+    t_enq = time.perf_counter() - t0          # host time to ENQUEUE the K steps (the GPU runs behind it)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -402,7 +410,8 @@ def main():
                                       "BASELINE configs[4]'s conv path, NOT the fp32 parity configuration)" if args.dtype == "fp8" else ""),
                        "global_batch": gb, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
                        "gflop_per_sample": flop_per_sample, "final_loss": round(loss, 5),
-                       "launch": "hipGraph replay" if graphed else "eager"},
+                       "launch": "hipGraph replay" if graphed else "eager",
+                       "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3)},
             "roofline": roof,
             "dp": dp_report,
             "gather": gather_bandwidth() if (args.mode != "image" and not args.no_gather) else None,

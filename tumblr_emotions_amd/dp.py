@@ -47,7 +47,11 @@ class GradientReducer:
             raise RuntimeError("force_buckets needs an initialised torch.distributed process group")
         self.active = self.world > 1 or bool(force_buckets)
         self.overlap = overlap and self.active and flat_grad.is_cuda
-        self.stream = torch.cuda.Stream() if self.overlap else None
+        if self.overlap:
+            from . import streams
+            self.stream = streams.get("comm")
+        else:
+            self.stream = None
         self._pending = None
         self._ready = set()
         self._needed = set()
@@ -83,8 +87,13 @@ class GradientReducer:
                 if self.timing:
                     self._t = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                     self._t[0].record(self.stream)          # bucket-1 reduce enters the side stream
+                if self.timing:
+                    import time
+                    h0 = time.perf_counter()
                 self._pending = dist.all_reduce(self.g[:self.n1], op=dist.ReduceOp.SUM, group=self.group,
                                                 async_op=True)
+                if self.timing:
+                    self._host_ms = 1e3 * (time.perf_counter() - h0)      # does the launch block the host?
 
     # -- end of backward -------------------------------------------------------------------------
     def finish(self):
@@ -117,4 +126,5 @@ class GradientReducer:
         return dict(bucket1_bytes=int(self.n1) * 4, bucket2_bytes=int(self.g.numel() - self.n1) * 4,
                     bucket1_allreduce_ms=round(t0.elapsed_time(t1), 3),
                     backward_after_launch_ms=round(t0.elapsed_time(t2), 3),
-                    bucket1_exposed_ms=round(max(0.0, t2.elapsed_time(t1)), 3))
+                    bucket1_exposed_ms=round(max(0.0, t2.elapsed_time(t1)), 3),
+                    bucket1_launch_host_ms=round(getattr(self, "_host_ms", 0.0), 3))

@@ -792,7 +792,8 @@ class InceptionV1Engine:
         self.ws_set = [torch.empty(max(self._ws_bytes // 4, 4), device=dev) for _ in range(3)]
         self.stats, self.bwd_partials, self.ws = self.stats_set[0], self.bwdp_set[0], self.ws_set[0]
         if self.side is None and self.device.type == "cuda":
-            self.side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            from . import streams
+            self.side = [streams.get("side0"), streams.get("side1")]
         self.ws_bytes = self._ws_bytes
         self.dummy = torch.empty(1024, device=dev)
         for l in self.layers:

@@ -65,7 +65,9 @@ class SentimentNet:
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.dlogits = None
         self.pg = process_group
-        self.text_stream = torch.cuda.Stream() if (mode == "joint" and concurrent_towers) else None
+        from . import streams
+        streams.reserve(self.device)
+        self.text_stream = streams.get("text") if (mode == "joint" and concurrent_towers) else None
         if self.text_stream is not None:
             # beside the image tower the persistent LSTM runs four row groups per workgroup: a quarter of the CUs for a
             # longer time instead of a 256-register wave on every SIMD that mostly waits -- the Winograd conv needs

@@ -1,0 +1,39 @@
+"""The HIP streams of the training step, created and first used in a FIXED order.
+
+ROCm gives a process a small number of hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and binds a hipStream to one of
+them round-robin when the stream first submits work.  Two streams on one hardware queue serialise.  The step keeps four
+streams busy at once (main, the Mixed-block side stream, the text tower's stream, the gradient all-reduce stream);
+measured on MI355X: with the RCCL communicator initialised BEFORE these streams first ran, its internal streams had
+taken queue slots and the text tower's stream landed on the main stream's queue -- the towers serialised and the step
+went 17.7 -> 19.1 ms although the all-reduce itself took 0.03 ms (profiles/r03_notes.md).  Reserving the step's streams
+-- create, submit one tiny kernel each, in this order -- before anything else creates streams keeps them on distinct
+queues whether or not a process group exists.  Call `reserve()` right after `torch.cuda.set_device(...)` and before
+`torch.distributed.init_process_group(...)` (bench.py and the train_* entry points do).
+"""
+import torch
+
+_ORDER = ("side1", "text", "comm", "side0")
+_streams = {}
+
+
+def reserve(device=None):
+    """Create the step's streams and bind each to a hardware queue now (idempotent)."""
+    if _streams or not torch.cuda.is_available():
+        return
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    touch = torch.zeros(64, device=dev)
+    touch.add_(1.0)                                   # the main (current) stream submits first
+    for name in _ORDER:
+        s = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(s):
+            touch.add_(1.0)                           # first submission: the stream takes its hardware queue
+        _streams[name] = s
+    torch.cuda.synchronize(dev)
+
+
+def get(name):
+    """The reserved stream for a role: 'side0' / 'side1' (Mixed-block branch chains), 'text' (text tower), 'comm'
+    (gradient all-reduce)."""
+    if not _streams:
+        reserve()
+    return _streams[name]
