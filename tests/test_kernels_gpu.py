@@ -472,6 +472,71 @@ def test_absmax_and_fp8_formats_on_this_device():
         np.testing.assert_array_equal(got, want, err_msg="format %d" % a_format)
 
 
+def test_storage_and_amax_side_outputs_of_the_streaming_kernels():
+    """What the bf16 / fp8 configurations add to the HBM-bound kernels: ds_bn_apply_relu writes a destination segment
+    as bf16 (round to nearest even) and raises the segment's max|.| record; ds_bn_bwd_apply raises max|dz|; the forward
+    pools read and write bf16 storage with the same winners; the pool fused with BatchNorm + ReLU writes bf16 and raises
+    its record.  Values against NumPy, records exact (a maximum is order independent)."""
+    ops = _ops()
+    rng = np.random.RandomState(123)
+    M, Cc = 777, 48
+    z = rng.normal(size=(M, Cc)) * 2
+    rstd = np.abs(rng.normal(size=Cc)) + 0.5
+    shift = rng.normal(size=Cc) * 0.3
+    y = np.maximum(z * rstd + shift, 0.0)
+    zd, rd, sd = dev(z), dev(rstd), dev(shift)
+    out16 = torch.zeros(M, 32, dtype=torch.bfloat16, device="cuda")
+    out32 = torch.zeros(M, 16, device="cuda")
+    am16, am32 = torch.zeros(ops.AMAX_FLOATS, device="cuda"), torch.zeros(ops.AMAX_FLOATS, device="cuda")
+    segs = ops.make_segments([(0, 32, out16.data_ptr(), 32, ops.DS_DTYPE_BF16, ops._p(am16)),
+                              (32, 48, out32.data_ptr(), 16, ops.DS_DTYPE_F32, ops._p(am32))])
+    ops.bn_apply_relu(zd, M, Cc, rd, sd, segs)
+    torch.cuda.synchronize()
+    close(out32, y[:, 32:], 1e-6)
+    close(out16.float(), y[:, :32], 4e-3)                    # bf16: 8 significant bits
+    # every stored value is the bf16 rounding of an fp32 value within rounding of the oracle's
+    assert float((out16.float() - dev(y[:, :32])).abs().max()) <= 2.0 ** -8 * float(y[:, :32].max())
+    assert ops.amax_value(am32) == float(out32.max())        # the record holds the fp32 maximum, before any rounding
+    assert abs(ops.amax_value(am16) - float(y[:, :32].max())) <= 1e-6 * float(y[:, :32].max())
+    # BatchNorm backward apply with max|dz|
+    dy = rng.normal(size=(M, Cc))
+    mean = z.mean(0)
+    coef = rng.normal(size=(2, Cc)) * 0.01
+    dyd, md, cd = dev(dy), dev(mean), dev(coef)
+    dz = torch.empty(M, Cc, device="cuda")
+    amz = torch.zeros(ops.AMAX_FLOATS, device="cuda")
+    ops.bn_bwd_apply(zd, ops.make_segments([(0, Cc, dyd.data_ptr(), Cc)]), M, Cc, md, rd, sd, cd, dz, amax=amz)
+    torch.cuda.synchronize()
+    g = dy * (y > 0)
+    close(dz, rstd * (g - coef[0] - (z - mean) * rstd * coef[1]), 1e-5)
+    assert ops.amax_value(amz) == float(dz.abs().max())
+    # pools on bf16 storage: same values and winners as on the widened input
+    N, H, W, C_ = 3, 9, 9, 16
+    x16 = dev(np.maximum(rng.normal(size=(N, H, W, C_)), 0)).to(torch.bfloat16)
+    for k, stride in ((3, 1), (3, 2), (2, 2)):
+        OH = -(-H // stride) if k == 3 else H // 2
+        outs = []
+        for x in (x16, x16.float()):
+            yv = torch.zeros(N, OH, OH, C_, dtype=x.dtype, device="cuda")
+            am = torch.zeros(N, OH, OH, C_, dtype=torch.uint8, device="cuda")
+            ops.maxpool_fwd(x, yv, am, N, H, W, C_, k, stride, "SAME" if k == 3 else "VALID")
+            outs.append((yv.float(), am))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (k, stride)
+    zc = dev(rng.normal(size=(N, H, W, C_)))
+    r2, s2 = dev(np.abs(rng.normal(size=C_)) + 0.5), dev(rng.normal(size=C_) * 0.2)
+    res = []
+    for dt in (torch.bfloat16, torch.float32):
+        yv = torch.zeros(N, 5, 5, C_, dtype=dt, device="cuda")
+        am = torch.zeros(N, 5, 5, C_, dtype=torch.uint8, device="cuda")
+        rec = torch.zeros(ops.AMAX_FLOATS, device="cuda")
+        ops.maxpool_bn_relu_fwd(zc, r2, s2, yv, am, N, H, W, C_, 3, 2, amax=rec)
+        torch.cuda.synchronize()
+        res.append((yv, am, ops.amax_value(rec)))
+    assert torch.equal(res[0][0], res[1][0].to(torch.bfloat16)) and torch.equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2] == float(res[1][0].max())
+
+
 FP8_CASES = [
     # (N, H, W, Cin, Cout, k)
     (2, 9, 9, 16, 32, 1),
