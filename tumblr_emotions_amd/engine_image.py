@@ -172,6 +172,7 @@ class ConvBN:
         self.dy_segs = make_segments(parts)
         self.part_segs = [make_segments([(0, c1 - c0, ptr, ld)]) for (c0, c1, ptr, ld) in parts]
         self.part_sums = [None] * len(parts)
+        self.part_pool = [None] * len(parts)     # (pool stage, first column): the part feeds nothing but that max pool
         self._sum_segs = None
 
     def emit_dx_sums(self, y):
@@ -211,14 +212,35 @@ class ConvBN:
                     sg.P[i], sg.kind[i] = P, 1
                     sg.s[i] = buf.data_ptr() + 4 * off * P
                     sg.q[i] = buf.data_ptr() + 4 * (ctot + off) * P
+                elif self.part_pool[i] is not None:
+                    # The part feeds only a max pool.  Every window hands its gradient to ONE input pixel p*, whose
+                    # activation is the pooled value, so   sum_pixels g = sum_windows dpool (ypool > 0)   and
+                    # sum_pixels g*xhat = sum_windows dpool (ypool - beta) (ypool > 0)   -- both sums from the POOLED
+                    # tensors (a quarter of the elements; z is not read at all).  That is ds_bn_bwd_reduce run on
+                    # (z := ypool, mean := beta, rstd := 1, shift := 0).
+                    pool, off = self.part_pool[i]
+                    n = c1 - c0
+                    Mp = pool.B * pool.H * pool.W
+                    Pp = ops.bn_bwd_partials(Mp, n)
+                    sg.P[i], sg.kind[i] = Pp, 0
+                    sg.s[i], sg.q[i] = scratch, scratch + 4 * n * Pp
+                    seg = make_segments([(0, n, pool.dout.data_ptr() + 4 * off, pool.C)])
+                    self._reduce_jobs.append(("pool", seg, Mp, n, _vp(pool.out.data_ptr() + 4 * off), pool.C,
+                                              _vp(self.beta.data_ptr() + 4 * c0), _vp(scratch)))
+                    scratch += 4 * 2 * n * Pp
                 else:
                     n = c1 - c0
                     sg.P[i], sg.kind[i] = P0, 0
                     sg.s[i], sg.q[i] = scratch, scratch + 4 * n * P0
-                    self._reduce_jobs.append((i, c0, n, _vp(scratch)))
+                    self._reduce_jobs.append(("full", i, c0, n, _vp(scratch)))
                     scratch += 4 * 2 * n * P0
             self._sum_segs = sg
-        for i, c0, n, dst in self._reduce_jobs:
+        for job in self._reduce_jobs:
+            if job[0] == "pool":
+                _, seg, Mp, n, yp, ldy, beta_p, dst = job
+                ops.bn_bwd_reduce(yp, seg, Mp, n, beta_p, ops._p(eng.ones), ops._p(eng.zeros), dst, ldz=ldy)
+                continue
+            _, i, c0, n, dst = job
             off = 4 * c0
             ops.bn_bwd_reduce(_vp(self.z.data_ptr() + off), self.part_segs[i], M, n, _vp(self.mean.data_ptr() + off),
                               _vp(self.rstd.data_ptr() + off), _vp(self.shift.data_ptr() + off), dst, ldz=Cc)
@@ -318,10 +340,13 @@ class ConvBN:
         if self.gbeta is None and not need_dx and not self.trainable:
             return
         B, H, W = self.B, self.OH, self.OW
-        ops.bn_pool_bwd_reduce(self.z, pool.dout, pool.argmax, B, H, W, Cc, self.mean, self.rstd, self.shift,
-                               self.bwdp_buf)
-        ops.bn_bwd_finalize(self.bwdp_buf, self.pool_P, M, Cc, self.gbeta if self.gbeta is not None else eng.dummy,
-                            self.coef)
+        if self.part_pool[0] is not None:        # both sums from the pooled tensors: z is not read (see _bn_bwd_sums)
+            self._bn_bwd_sums()
+        else:
+            ops.bn_pool_bwd_reduce(self.z, pool.dout, pool.argmax, B, H, W, Cc, self.mean, self.rstd, self.shift,
+                                   self.bwdp_buf)
+            ops.bn_bwd_finalize(self.bwdp_buf, self.pool_P, M, Cc, self.gbeta if self.gbeta is not None else eng.dummy,
+                                self.coef)
         if not (need_dx or self.trainable):
             return
         ops.bn_pool_bwd_apply(self.z, pool.dout, pool.argmax, B, H, W, Cc, self.mean, self.rstd, self.shift, self.coef,
@@ -355,7 +380,7 @@ class ConvBN:
         dy_segs = self.dy_segs
         if self.gbeta is None and not need_dx and not self.trainable:
             return
-        if any(ps is not None for ps in self.part_sums):
+        if any(ps is not None for ps in self.part_sums) or any(pp is not None for pp in self.part_pool):
             self._bn_bwd_sums()
         else:
             ops.bn_bwd_reduce(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.bwdp_buf)
@@ -453,6 +478,19 @@ class PoolStage(Stage):
         self.dout = torch.empty(B, self.H, self.W, self.C, device=dev)
         self.argmax = torch.empty(B, self.H, self.W, self.C, dtype=torch.uint8, device=dev)
         self._own_amax = self.eng.new_amax()
+        # the layers whose activation feeds nothing but this pool take their BatchNorm backward sums from the pooled
+        # tensors (ConvBN._bn_bwd_sums)
+        if self.eng.bwd_sums and self.out.dtype == torch.float32:
+            if isinstance(p, ConvStage) and self.k == 3 and self.stride == 2:
+                targets = [(p.layer, 0)]
+            elif isinstance(p, MixedStage):
+                pb0, _, pb1b, _, pb2b, _ = p.b
+                targets = [(p.fused, 0), (p.c1, pb0), (p.c2, pb0 + pb1b), (p.c3, pb0 + pb1b + pb2b)]
+            else:
+                targets = []
+            for layer, off in targets:
+                layer.part_pool[0] = (self, off)
+                layer._sum_segs = None
 
     @property
     def out_amax(self):
@@ -796,6 +834,8 @@ class InceptionV1Engine:
             self.side = [streams.get("side0"), streams.get("side1")]
         self.ws_bytes = self._ws_bytes
         self.dummy = torch.empty(1024, device=dev)
+        self.ones = torch.ones(1024, device=dev)
+        self.zeros = torch.zeros(1024, device=dev)
         for l in self.layers:
             l.bind()
         st = self.store
