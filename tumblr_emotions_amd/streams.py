@@ -10,10 +10,14 @@ went 17.7 -> 19.1 ms although the all-reduce itself took 0.03 ms (profiles/r03_n
 queues whether or not a process group exists.  Call `reserve()` right after `torch.cuda.set_device(...)` and before
 `torch.distributed.init_process_group(...)` (bench.py and the train_* entry points do).
 """
+import os
+
 import torch
 
 _ORDER = ("side1", "text", "comm", "side0")
 _streams = {}
+# (A/B aid, measured neutral: DS_TEXT_PRIO=1 gives the text stream high priority)
+_PRIORITY = {"text": -1 if os.environ.get("DS_TEXT_PRIO", "0") == "1" else 0}
 
 
 def reserve(device=None):
@@ -23,11 +27,19 @@ def reserve(device=None):
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     touch = torch.zeros(64, device=dev)
     touch.add_(1.0)                                   # the main (current) stream submits first
-    for name in _ORDER:
-        s = torch.cuda.Stream(device=dev)
+    plan = os.environ.get("DS_STREAM_PLAN")           # experiment aid: creation order, "x" = a dummy stream
+    order = tuple(plan.split(",")) if plan else _ORDER
+    for name in order:
+        s = torch.cuda.Stream(device=dev, priority=_PRIORITY.get(name, 0))
         with torch.cuda.stream(s):
             touch.add_(1.0)                           # first submission: the stream takes its hardware queue
-        _streams[name] = s
+        if name == "x":
+            _streams.setdefault("_dummies", []).append(s)
+        else:
+            _streams[name] = s
+    for name in _ORDER:
+        if name not in _streams:
+            _streams[name] = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize(dev)
 
 
