@@ -220,9 +220,11 @@ int ds_bn_infer_prepare(const float *beta, const float *moving_mean, const float
  * dy is gathered from the same segments the forward scattered to.                          */
 int ds_bn_bwd_partials(int64_t M, int32_t C);
 /* z: [M, ldz] (ldz >= C: a column sub-range of a layer is reduced by passing z, mean, rstd, shift offset to its
- * first channel and dy segments numbered from 0); partials float[2][C][P].                                     */
-int ds_bn_bwd_reduce(const float *z, int32_t ldz, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
-                     const float *rstd, const float *shift, float *partials, void *stream);
+ * first channel and dy segments numbered from 0); partials float[2][C][P].  z_dtype DS_DTYPE_BF16: the kernel is run
+ * on a POOLED activation in 16-bit storage (z := ypool, mean := beta, rstd := 1, shift := 0: the sums of a layer that
+ * feeds nothing but a max pool, from a quarter of the elements).                                                */
+int ds_bn_bwd_reduce(const void *z, int32_t ldz, int32_t z_dtype, const ds_segments *dy, int64_t M, int32_t C,
+                     const float *mean, const float *rstd, const float *shift, float *partials, void *stream);
 int ds_bn_bwd_finalize(const float *partials, int32_t P, int64_t M, int32_t C, float *dbeta, float *coef,
                        void *stream);
 /* The same finalize when the sums of a layer's column segments come from different producers: kind 0 = partials of

@@ -76,7 +76,7 @@ SIGNATURES = {
     "ds_bn_apply_relu": (C.c_int, [_P, _i64, _i32, _P, _P, _SG, _P]),
     "ds_bn_infer_prepare": (C.c_int, [_P, _P, _P, _f32, _i32, _P, _P, _P]),
     "ds_bn_bwd_partials": (C.c_int, [_i64, _i32]),
-    "ds_bn_bwd_reduce": (C.c_int, [_P, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _P]),
+    "ds_bn_bwd_reduce": (C.c_int, [_P, _i32, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _P]),
     "ds_bn_bwd_finalize_segs": (C.c_int, [_SS, _i64, _i32, _P, _P, _P, _P]),
     "ds_bn_bwd_finalize": (C.c_int, [_P, _i32, _i64, _i32, _P, _P, _P]),
     "ds_bn_bwd_apply": (C.c_int, [_P, _SG, _i64, _i32, _P, _P, _P, _P, _P, _P, _P]),

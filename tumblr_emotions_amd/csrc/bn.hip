@@ -43,6 +43,19 @@ __device__ __forceinline__ float *seg_addr(const SegDev &sg, int64_t row, int c)
     return nullptr;
 }
 
+// z in fp32, or -- when ds_bn_bwd_reduce runs on a POOLED activation kept in 16-bit storage -- bf16
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ float4 ldz4(const T *p);
+template <>
+__device__ __forceinline__ float4 ldz4<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+template <>
+__device__ __forceinline__ float4 ldz4<__bf16>(const __bf16 *p) {
+    const f32x4_t v = __builtin_convertvector(*reinterpret_cast<const bf16x4_t *>(p), f32x4_t);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -152,7 +165,8 @@ int bwd_rows_per_block(int64_t M) {
     return (int)r;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *z, int ldz, SegDev dy, int64_t M, int C,
+template <typename TZ>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const TZ *z, int ldz, SegDev dy, int64_t M, int C,
                                                             const float *mean, const float *rstd,
                                                             const float *shift, float *partials, int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) float sh[];   // [RG][C4][8]
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *z, int 
             float4 zv[4], dv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                zv[u] = *reinterpret_cast<const float4 *>(z + (row + u * RG) * ldz + c);
+                zv[u] = ldz4<TZ>(z + (row + u * RG) * ldz + c);
                 dv[u] = *reinterpret_cast<const float4 *>(seg_addr(dy, row + u * RG, c));
             }
 #pragma unroll
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *z, int 
             }
         }
         for (; row < r1; row += RG) {
-            const float4 zv = *reinterpret_cast<const float4 *>(z + row * ldz + c);
+            const float4 zv = ldz4<TZ>(z + row * ldz + c);
             const float4 dv = *reinterpret_cast<const float4 *>(seg_addr(dy, row, c));
             const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
@@ -396,18 +410,24 @@ extern "C" int ds_bn_bwd_partials(int64_t M, int32_t C) {
     return (int)((M + rpb - 1) / rpb);
 }
 
-extern "C" int ds_bn_bwd_reduce(const float *z, int32_t ldz, const ds_segments *dy, int64_t M, int32_t C,
+extern "C" int ds_bn_bwd_reduce(const void *z, int32_t ldz, int32_t z_dtype, const ds_segments *dy, int64_t M, int32_t C,
                                 const float *mean, const float *rstd, const float *shift, float *partials,
                                 void *stream) {
     DS_REQUIRE(z && mean && rstd && shift && partials && M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldz >= C &&
-                   ldz % 4 == 0 && (((uintptr_t)z | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)shift) & 15) == 0,
-               "ds_bn_bwd_reduce: bad argument (need C %% 4 == 0, C <= 1024, ldz %% 4 == 0, 16-byte aligned pointers)");
+                   ldz % 4 == 0 && (((uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)shift) & 15) == 0 &&
+                   (z_dtype == DS_DTYPE_F32 || z_dtype == DS_DTYPE_BF16) &&
+                   (((uintptr_t)z) & (z_dtype == DS_DTYPE_BF16 ? 7 : 15)) == 0,
+               "ds_bn_bwd_reduce: bad argument (need C %% 4 == 0, C <= 1024, ldz %% 4 == 0, aligned pointers, z_dtype f32 / bf16)");
     if (int e = check_segments(dy, C, "ds_bn_bwd_reduce")) return e;
     const int C4 = C / 4;
     const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
     const size_t shmem = (size_t)RG * C4 * 8 * sizeof(float);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ds_bn_bwd_partials(M, C)), dim3(256), shmem, (hipStream_t)stream,
-                       z, ldz, to_dev(dy), M, C, mean, rstd, shift, partials, bwd_rows_per_block(M));
+    if (z_dtype == DS_DTYPE_BF16)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, dim3(ds_bn_bwd_partials(M, C)), dim3(256), shmem, (hipStream_t)stream,
+                           (const __bf16 *)z, ldz, to_dev(dy), M, C, mean, rstd, shift, partials, bwd_rows_per_block(M));
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(ds_bn_bwd_partials(M, C)), dim3(256), shmem, (hipStream_t)stream,
+                           (const float *)z, ldz, to_dev(dy), M, C, mean, rstd, shift, partials, bwd_rows_per_block(M));
     return ds::check_launch("ds_bn_bwd_reduce");
 }
 

@@ -225,8 +225,9 @@ class ConvBN:
                     sg.P[i], sg.kind[i] = Pp, 0
                     sg.s[i], sg.q[i] = scratch, scratch + 4 * n * Pp
                     seg = make_segments([(0, n, pool.dout.data_ptr() + 4 * off, pool.C)])
-                    self._reduce_jobs.append(("pool", seg, Mp, n, _vp(pool.out.data_ptr() + 4 * off), pool.C,
-                                              _vp(self.beta.data_ptr() + 4 * c0), _vp(scratch)))
+                    self._reduce_jobs.append(("pool", seg, Mp, n, _vp(pool.out.data_ptr() + pool.out.element_size() * off),
+                                              pool.C, _vp(self.beta.data_ptr() + 4 * c0), _vp(scratch),
+                                              ops.act_dtype(pool.out)))
                     scratch += 4 * 2 * n * Pp
                 else:
                     n = c1 - c0
@@ -237,8 +238,8 @@ class ConvBN:
             self._sum_segs = sg
         for job in self._reduce_jobs:
             if job[0] == "pool":
-                _, seg, Mp, n, yp, ldy, beta_p, dst = job
-                ops.bn_bwd_reduce(yp, seg, Mp, n, beta_p, ops._p(eng.ones), ops._p(eng.zeros), dst, ldz=ldy)
+                _, seg, Mp, n, yp, ldy, beta_p, dst, ydt = job
+                ops.bn_bwd_reduce(yp, seg, Mp, n, beta_p, ops._p(eng.ones), ops._p(eng.zeros), dst, ldz=ldy, z_dtype=ydt)
                 continue
             _, i, c0, n, dst = job
             off = 4 * c0
@@ -480,7 +481,7 @@ class PoolStage(Stage):
         self._own_amax = self.eng.new_amax()
         # the layers whose activation feeds nothing but this pool take their BatchNorm backward sums from the pooled
         # tensors (ConvBN._bn_bwd_sums)
-        if self.eng.bwd_sums and self.out.dtype == torch.float32:
+        if self.eng.bwd_sums:
             if isinstance(p, ConvStage) and self.k == 3 and self.stride == 2:
                 targets = [(p.layer, 0)]
             elif isinstance(p, MixedStage):

@@ -354,11 +354,14 @@ def bn_bwd_partials(M, C_):
     return _lib.load().ds_bn_bwd_partials(M, C_)
 
 
-def bn_bwd_reduce(z, segs, M, C_, mean, rstd, shift, partials, ldz=None):
-    """z .. partials: tensors, or raw device addresses (c_void_p) when a column sub-range of a layer is reduced."""
+def bn_bwd_reduce(z, segs, M, C_, mean, rstd, shift, partials, ldz=None, z_dtype=DS_DTYPE_F32):
+    """z .. partials: tensors, or raw device addresses (c_void_p) when a column sub-range of a layer is reduced
+    (then z_dtype names z's storage: bf16 for a pooled activation in 16-bit storage)."""
     ptr = lambda t: t if isinstance(t, C.c_void_p) else _p(t)
-    _lib.check(_lib.load().ds_bn_bwd_reduce(ptr(z), C_ if ldz is None else ldz, C.byref(segs), M, C_, ptr(mean), ptr(rstd),
-                                            ptr(shift), ptr(partials), _stream()), "ds_bn_bwd_reduce")
+    if not isinstance(z, C.c_void_p):
+        z_dtype = act_dtype(z)
+    _lib.check(_lib.load().ds_bn_bwd_reduce(ptr(z), C_ if ldz is None else ldz, z_dtype, C.byref(segs), M, C_, ptr(mean),
+                                            ptr(rstd), ptr(shift), ptr(partials), _stream()), "ds_bn_bwd_reduce")
 
 
 def bn_bwd_finalize_segs(sum_segs, M, C_, beta, dbeta, coef):
