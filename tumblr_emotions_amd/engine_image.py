@@ -395,7 +395,17 @@ class ConvBN:
         self._dz_amax_live = track
         if self.trainable:
             self.wgrad.d.ldx = ldx
-            self.wgrad.run(x_ptr, ops._p(self.z), self.gw_ptr, ops._p(self.ws_buf), eng.ws_bytes)
+            if eng.wgrad_stream is not None:
+                # Conv2DBackpropFilter is a leaf of the backward graph (only the optimiser and the all-reduce wait for
+                # it): off the chain that the next layer's dgrad waits on, onto the weight-gradient stream
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())          # dz is complete here
+                eng.wgrad_stream.wait_event(ev)
+                with torch.cuda.stream(eng.wgrad_stream):
+                    self.wgrad.run(x_ptr, ops._p(self.z), self.gw_ptr, ops._p(eng.ws_set[3]), eng.ws_bytes)
+                eng.wgrad_pending = True
+            else:
+                self.wgrad.run(x_ptr, ops._p(self.z), self.gw_ptr, ops._p(self.ws_buf), eng.ws_bytes)
         if need_dx:
             self._run_dgrad(dx_ptr)
 
@@ -746,6 +756,9 @@ class InceptionV1Engine:
         # weights stay fp32; so do Mixed_5b's output and Mixed_5c's intermediates (inputs of the fp32 wgrads) and
         # Mixed_5c's output (average pool).  Not with train_all (every conv's wgrad reads its input in fp32).
         self.act16 = dtype in ("bf16", "fp8") and not train_all
+        self.wgrad_side = True       # Mixed_5c's weight gradients on their own stream, off the dgrad chain
+        self.side_w = None
+        self.wgrad_stream = None
         self.bwd_sums = True         # BatchNorm backward sums from the producing dgrad's epilogue (DS_EPI_BNSUMS) where it can
         self.stem_direct = True      # Conv2d_1a_7x7 from the packed RGB batch (ds_conv_stem; False: generic kernel on a 4-channel copy)
         self.branch_streams = True   # Mixed blocks: Branch_2 and Branch_3 on side streams next to Branch_0/1 (False: one stream)
@@ -828,11 +841,12 @@ class InceptionV1Engine:
         # three scratch sets: the branches of a Mixed block run on three streams (MixedStage.forward)
         self.stats_set = [torch.empty(max(self._stats_n, 4), device=dev) for _ in range(3)]
         self.bwdp_set = [torch.empty(max(self._bwdp_n, 4), device=dev) for _ in range(3)]
-        self.ws_set = [torch.empty(max(self._ws_bytes // 4, 4), device=dev) for _ in range(3)]
+        self.ws_set = [torch.empty(max(self._ws_bytes // 4, 4), device=dev) for _ in range(4)]      # [3]: weight-gradient stream
         self.stats, self.bwd_partials, self.ws = self.stats_set[0], self.bwdp_set[0], self.ws_set[0]
         if self.side is None and self.device.type == "cuda":
             from . import streams
             self.side = [streams.get("side0"), streams.get("side1")]
+            self.side_w = streams.get("side0")       # free while one_side_stream == 1
         self.ws_bytes = self._ws_bytes
         self.dummy = torch.empty(1024, device=dev)
         self.ones = torch.ones(1024, device=dev)
@@ -888,11 +902,19 @@ class InceptionV1Engine:
         stop = 0
         if not self.trainable_bn_beta:
             stop = min(i for i, s in enumerate(self.stages) if any(l.trainable for l in s.layers))
+        self.wgrad_stream = self.side_w if (self.wgrad_side and not self.train_all and self.side_w is not None) else None
+        self.wgrad_pending = False
         for i in range(n - 1, stop - 1, -1):
             self.stages[i].backward(need_dx=(i > stop))
             if self.reducer is not None and not self.train_all and self.stages[i].name in TRAINABLE_ENDPOINTS:
                 # every conv-weight gradient and the Logits gradients now sit in bucket 1 of the flat
                 # gradient: its all-reduce can start while dgrad continues through the frozen blocks
-                self.reducer.stage_done(self.stages[i].name)
+                if self.wgrad_pending:      # ... once the weight-gradient stream is through: report from there
+                    with torch.cuda.stream(self.wgrad_stream):
+                        self.reducer.stage_done(self.stages[i].name)
+                else:
+                    self.reducer.stage_done(self.stages[i].name)
+        if self.wgrad_pending:              # the optimiser (and the next forward pass, which rewrites z) wait for it
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
         if self.reducer is not None and self.train_all:
             self.reducer.stage_done(TRAINABLE_ENDPOINTS[0])      # whole tower trainable: bucket 1 closes with the stem
