@@ -902,7 +902,7 @@ class InceptionV1Engine:
         stop = 0
         if not self.trainable_bn_beta:
             stop = min(i for i, s in enumerate(self.stages) if any(l.trainable for l in s.layers))
-        self.wgrad_stream = self.side_w if (self.wgrad_side and not self.train_all and self.side_w is not None) else None
+        self.wgrad_stream = self.side_w if (self.wgrad_side and self.side_w is not None) else None
         self.wgrad_pending = False
         for i in range(n - 1, stop - 1, -1):
             self.stages[i].backward(need_dx=(i > stop))
