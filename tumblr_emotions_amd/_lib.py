@@ -70,6 +70,10 @@ SIGNATURES = {
     "ds_wino_transform_weights": (C.c_int, [_P, _P, _i32, _i32, _i32, _P]),
     "ds_conv_wino_partials": (C.c_int, [_i32, _i32, _i32]),
     "ds_conv_wino": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
+    "ds_conv_wino4_supported": (C.c_int, [_i32, _i32, _i32, _i32]),
+    "ds_wino4_transform_weights": (C.c_int, [_P, _P, _i32, _i32, _i32, _P]),
+    "ds_conv_wino4_partials": (C.c_int, [_i32, _i32, _i32]),
+    "ds_conv_wino4": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "ds_conv_wgrad_workspace": (C.c_size_t, [_CD]),
     "ds_conv_wgrad": (C.c_int, [_CD, _P, _P, _i32, _P, _P, C.c_size_t, _P]),
     "ds_bn_finalize": (C.c_int, [_P, _i32, _i64, _i32, _P, _P, _f32, _f32, _P, _P, _P, _P, _P, _P]),

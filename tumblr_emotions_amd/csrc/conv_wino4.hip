@@ -1,0 +1,434 @@
+// 3x3 stride-1 SAME convolution (forward and dgrad) as fused Winograd F(4x4, 3x3) on the fp32 matrix cores, for the
+// maps whose height and width are multiples of four (Conv2d_2c_3x3 at 56 x 56 and the Branch_1 / Branch_2 3x3 layers
+// of Mixed_3b / 3c at 28 x 28: image_model/inception_v1.py:74-75, :86-115) -- half of the 3x3 layers' multiplies.
+//
+// F(4x4, 3x3) trades the 144 multiplies of a 4x4 output tile and channel pair for 36 (F(2x2, 3x3), conv_wino.hip: 64):
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A        (Lavin & Gray, interpolation points 0, +-1, +-2, inf)
+// i.e. thirty-six independent GEMMs  M_xi[tile, co] = sum_ci V_xi[tile, ci] U_xi[ci, co]  -- 4x fewer MFMA passes than
+// the direct convolution, 1.78x fewer than F(2x2, 3x3).  fp32 MFMA runs at the fp32 vector rate, so the multiplies
+// saved are the time saved as long as the transforms stay small next to them.
+//
+// 36 accumulators of 32 x 32 do not fit one wave (576 registers), so unlike conv_wino.hip the positions are SPLIT over
+// the four waves of a workgroup (nine each) and the transformed input goes through LDS once:
+//   * workgroup = 32 tiles (4x4 outputs each) x 32 NB output channels (NB = 1, 2), K step = 8 input channels;
+//   * transform role: thread (tile t = tid / 8, channel c = tid % 8) loads the 36 pixels of its 6x6 patch for ONE
+//     channel (dword SRD loads: the eight channel lanes of a pixel are one 32-byte run; pixel offsets are wave-uniform
+//     and ride in the scalar offset, padding pixels read zeros from an out-of-range vector offset), runs B^T d B in
+//     registers (144 fused multiply-adds) and writes the 36 results to V[xi][t][c] in LDS (lane-linear, conflict free);
+//   * matrix role: wave w owns positions 9 w .. 9 w + 8.  Its A fragments are one ds_read_b128 per position
+//     (lane (i, kh): tile i, channels 4 kh .. 4 kh + 3); its B fragments -- U for ITS positions only, nothing another
+//     wave needs -- come straight from global memory into registers, one fully coalesced 1 KB load per position and
+//     channel block (U is stored [36][Cin / 8][Cout][8] by ds_wino4_transform_weights for exactly this), requested
+//     six positions (3072 matrix cycles) ahead into a register ring.  9 NB accumulators of 32 x 32 per wave (288 registers at NB = 2);
+//   * V is double buffered: one barrier per K step;
+//   * epilogue, per channel block: the waves park their accumulators in LDS as M[xi][tile][co] (144 KB -- gfx950's
+//     160 KB LDS, the V buffers are dead by then), then thread (co = tid % 32, tiles 4 (tid / 32) .. + 3) gathers the 36
+//     values of each (tile, co), runs A^T M A (100 adds) and stores the 4x4 outputs as 128-byte channel runs; BatchNorm
+//     column statistics about the pivot (DS_EPI_STATS) or the BatchNorm-backward sums of the consumer (DS_EPI_BNSUMS)
+//     as in conv_wino.hip.
+// dgrad: the same kernel with U built from the flipped, transposed filter.
+// Numerics: fp32 throughout, ordered reductions (deterministic).  The F(4x4) transforms carry constants up to 8 and
+// cost about one decimal digit against F(2x2): relative rms error 2.4e-6 instead of 3.7e-7 on post-ReLU activations
+// with 192 input channels (scratch/wino4_numerics.py), against 2.6e-7 for a direct fp32 sum.
+#include <stdlib.h>
+#include "ds_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr unsigned kOOB = 0x80000000u;
+
+struct Wino4Params {
+    const float *x;         // [N, H, W, ldx]
+    const float *u;         // [36][Cin / 8][Cout][8]
+    float *z;               // [N, H, W, ldz]
+    float *stats;           // [2][Cout][P], P = groups
+    const float *pivot;
+    const float *y;         // DS_EPI_BNSUMS: forward activation of the layer that consumes z (= dy), pixel stride ldz
+    int N, H, W, Cin, ldx, Cout, ldz;
+    int TH, TW, Mt;         // output tiles per column / row / in total
+    int groups, ncol;       // 32-tile groups, (32 NB)-channel blocks
+    unsigned x_bytes, u_bytes, z_bytes;
+    int flags;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t w4srd(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef DS_W4_PXG
+#define DS_W4_PXG 3          // pixel loads of the next K step issued per MFMA group (36 in all)
+#endif
+
+// every operation of the transforms is written as a fused multiply-add on a channel PAIR so that it compiles to one
+// v_pk_fma_f32 (hipcc packs neither subtractions nor mixed add / fma expressions on its own)
+__device__ __forceinline__ f32x2 pfma(float k, f32x2 a, f32x2 b) { return __builtin_elementwise_fma(f32x2{k, k}, a, b); }
+
+// B^T d for one line of six: B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+__device__ __forceinline__ void in1d(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2 d5, f32x2 &t0, f32x2 &t1,
+                                     f32x2 &t2, f32x2 &t3, f32x2 &t4, f32x2 &t5) {
+    const f32x2 a = pfma(-4.f, d2, d4), b = pfma(-4.f, d1, d3);
+    const f32x2 c = pfma(-1.f, d2, d4), e = pfma(-1.f, d1, d3);
+    t0 = pfma(4.f, d0, pfma(-5.f, d2, d4));
+    t1 = pfma(1.f, b, a);
+    t2 = pfma(-1.f, b, a);
+    t3 = pfma(2.f, e, c);
+    t4 = pfma(-2.f, e, c);
+    t5 = pfma(4.f, d1, pfma(-5.f, d3, d5));
+}
+
+// A^T m for one line of six, on four tiles at once: A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+__device__ __forceinline__ f32x4 qfma(float k, f32x4 a, f32x4 b) { return __builtin_elementwise_fma(f32x4{k, k, k, k}, a, b); }
+__device__ __forceinline__ void out1d(f32x4 m0, f32x4 m1, f32x4 m2, f32x4 m3, f32x4 m4, f32x4 m5, f32x4 &y0, f32x4 &y1,
+                                      f32x4 &y2, f32x4 &y3) {
+    const f32x4 s0 = qfma(1.f, m2, m1), s1 = qfma(-1.f, m2, m1), s2 = qfma(1.f, m4, m3), s3 = qfma(-1.f, m4, m3);
+    y0 = qfma(1.f, s2, qfma(1.f, s0, m0));
+    y1 = qfma(2.f, s3, s1);
+    y2 = qfma(4.f, s2, s0);
+    y3 = qfma(1.f, m5, qfma(8.f, s3, s1));
+}
+
+template <int NB, bool BNS>
+__global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p) {
+    // K loop: V[2][36][32 tiles][16 ci] = 144 KB; epilogue: M[36][32 co][32 tiles] = 144 KB
+    __shared__ __attribute__((aligned(128))) float smem[36 * 32 * 32];
+    __shared__ float red[4 * 32 * 2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kh = lane >> 5;
+    // 1-D XCD-aware launch as conv_wino.hip: the channel blocks of a tile group run back to back on one XCD
+    const int id = blockIdx.x;
+    const int lin = (id & 7) * (int)(gridDim.x >> 3) + (id >> 3);
+    const int group = lin / p.ncol, cblk = lin - group * p.ncol;
+    if (group >= p.groups) return;                          // (uniform) surplus workgroup
+    const int co0 = cblk * 32 * NB;
+    const int m0 = group * 32;
+    const int tpi = p.TH * p.TW;
+
+    // ---- transform role: tile lt, channels 2 cp, 2 cp + 1 of the 16-channel K step --------------------------------
+    // The SRD starts (W + 1) pixels in front of x, so the patch origin (4 th - 1, 4 tw - 1) has a non-negative offset
+    // for every tile and the pixel (py, px) of the patch is a wave-uniform, non-negative scalar offset from it.
+    const int lt = tid >> 3, cp = tid & 7;
+    const int64_t shift = (int64_t)(p.W + 1) * p.ldx;
+    const __amdgpu_buffer_rsrc_t srd_x = w4srd(p.x - shift, p.x_bytes + (unsigned)(shift * 4));
+    const __amdgpu_buffer_rsrc_t srd_u = w4srd(p.u, p.u_bytes);
+    unsigned rowoff[6];         // patch row py: the tile's base offset, or out of range (row outside the image / no tile)
+    bool cv[6];                 // patch column px inside the image
+    {
+        const int m = m0 + lt;
+        const bool tv = m < p.Mt;
+        const int n = (tv ? m : 0) / tpi;
+        const int r = (tv ? m : 0) - n * tpi;
+        const int th = r / p.TW, tw = r - th * p.TW;
+        const unsigned vbase = (unsigned)(((n * p.H + 4 * th) * p.W + 4 * tw) * p.ldx + 2 * cp) * 4u;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            rowoff[k] = (tv && (unsigned)(4 * th - 1 + k) < (unsigned)p.H) ? vbase : kOOB;
+            cv[k] = (unsigned)(4 * tw - 1 + k) < (unsigned)p.W;
+        }
+    }
+    const int rowstep = p.W * p.ldx * 4, pixstep = p.ldx * 4;
+
+    // ---- matrix role: B fragment offsets (column li of channel block nb, channels 4 kh .. of an 8-channel half step) ----
+    const int ksteps = p.Cin >> 4, nhalf = 2 * ksteps;
+    unsigned boff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = co0 + 32 * nb + li;
+        boff[nb] = col < p.Cout ? (unsigned)(col * 8 + 4 * kh) * 4u : kOOB;
+    }
+    const int ustep = p.Cout * 32;                                 // bytes between half steps of one position
+    const int upos = nhalf * ustep;                                // bytes between positions
+
+    f32x16 acc[9][NB];
+#pragma unroll
+    for (int pi = 0; pi < 9; ++pi)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[pi][nb][e] = 0.f;
+
+    f32x2 raw[36];
+    f32x4 b[6][NB];             // ring: group g (half step g / 9, position g % 9) uses slot g % 6, six groups of lead
+    auto load_pixel = [&](int q, int c0) {
+        const int py = q / 6, px = q - py * 6;
+        raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(srd_x, cv[px] ? rowoff[py] : kOOB,
+                                                                                 py * rowstep + px * pixstep + c0 * 4, 0));
+    };
+    auto load_b = [&](int slot, int pi, int hs) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            b[slot][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_u, boff[nb], (wave * 9 + pi) * upos + hs * ustep, 0));
+    };
+
+#pragma unroll
+    for (int q = 0; q < 36; ++q) load_pixel(q, 0);
+#pragma unroll
+    for (int g = 0; g < 6; ++g) load_b(g, g, 0);
+
+    for (int ks = 0; ks < ksteps; ++ks) {
+        float *Vw = smem + (ks & 1) * (36 * 512);
+        // ---- V = B^T d B for this thread's (tile, channel pair): columns first, then rows; position-major in LDS ----
+        {
+            f32x2 t[36];
+#pragma unroll
+            for (int px = 0; px < 6; ++px)
+                in1d(raw[px], raw[6 + px], raw[12 + px], raw[18 + px], raw[24 + px], raw[30 + px], t[px], t[6 + px],
+                     t[12 + px], t[18 + px], t[24 + px], t[30 + px]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                f32x2 v[6];
+                in1d(t[i * 6], t[i * 6 + 1], t[i * 6 + 2], t[i * 6 + 3], t[i * 6 + 4], t[i * 6 + 5], v[0], v[1], v[2], v[3], v[4], v[5]);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2 *>(Vw + (i * 6 + j) * 512 + tid * 2) = v[j];
+            }
+        }
+        const bool more = ks + 1 < ksteps;
+        const int cn = (ks + 1) * 16;
+        // (keeps the 36 per-pixel offsets from being hoisted out of the loop into 36 registers the kernel does not have:
+        // they are one v_cndmask on a column mask each)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(rowoff[k]));
+        __syncthreads();
+        // ---- two 8-channel half steps x nine positions: A fragment from LDS, 4 NB MFMAs; the next K step's pixels
+        // (four per group of the first half step) and the weights six groups ahead are requested between the groups ----
+        const float *Va = Vw + (wave * 9) * 512 + li * 16 + kh * 4;
+        f32x4 a = *reinterpret_cast<const f32x4 *>(Va), an = a;
+#pragma unroll
+        for (int g = 0; g < 18; ++g) {
+            const int h = g / 9, pi = g - 9 * h;
+            if (g < 17) an = *reinterpret_cast<const f32x4 *>(Va + ((g + 1) % 9) * 512 + ((g + 1) / 9) * 8);
+            if (more && g * DS_W4_PXG < 36) {        // column-major: the column pass reads column 0 first
+#pragma unroll
+                for (int k = DS_W4_PXG * g; k < DS_W4_PXG * g + DS_W4_PXG && k < 36; ++k) load_pixel((k % 6) * 6 + k / 6, cn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[g % 6][nb][j], acc[pi][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 6 < 18) load_b(g % 6, (g + 6) % 9, 2 * ks + (g + 6) / 9);
+            else if (more) load_b(g % 6, g + 6 - 18, 2 * ks + 2);
+            a = an;
+        }
+    }
+
+    // ---- output transform Y = A^T M A through LDS, one 32-channel block at a time ---------------------------------------
+    // M[xi][co][tile quad ^ (co & 7)][4 tiles]: 16-byte writes (an accumulator's four consecutive rows) and 16-byte
+    // gathers, both conflict free through the quad swizzle
+    const int ec = tid & 31, eg = tid >> 5;
+    const __amdgpu_buffer_rsrc_t srd_z = w4srd(p.z, p.z_bytes);
+    const __amdgpu_buffer_rsrc_t srd_y = w4srd(BNS ? p.y : p.z, p.z_bytes);
+    const int orow = p.W * p.ldz * 4, opix = p.ldz * 4;
+    int tbase[4];               // pixel index of the top-left output of this thread's four tiles, or -1
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + eg * 4 + r;
+        const int n = (m < p.Mt ? m : 0) / tpi;
+        const int rr = (m < p.Mt ? m : 0) - n * tpi;
+        const int th = rr / p.TW, tw = rr - th * p.TW;
+        tbase[r] = m < p.Mt ? (n * p.H + 4 * th) * p.W + 4 * tw : -1;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        __syncthreads();            // the K loop's last fragment reads / the previous block's gathers are done
+        // accumulator elements 4 eq .. 4 eq + 3: tile rows 4 (2 eq + kh) .. + 3 of channel column li
+#pragma unroll
+        for (int pi = 0; pi < 9; ++pi)
+#pragma unroll
+            for (int eq = 0; eq < 4; ++eq) {
+                const f32x4 v = {acc[pi][nb][4 * eq], acc[pi][nb][4 * eq + 1], acc[pi][nb][4 * eq + 2], acc[pi][nb][4 * eq + 3]};
+                *reinterpret_cast<f32x4 *>(smem + (wave * 9 + pi) * 1024 + li * 32 + (((2 * eq + kh) ^ (li & 7)) * 4)) = v;
+            }
+        __syncthreads();
+        const int col = co0 + 32 * nb + ec;
+        const bool colok = col < p.Cout;
+        const float pv = (!BNS && p.pivot && colok) ? p.pivot[col] : 0.f;
+        unsigned vo[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vo[r] = (tbase[r] >= 0 && colok) ? (unsigned)(tbase[r] * p.ldz + col) * 4u : kOOB;
+        const float *Mq = smem + ec * 32 + ((eg ^ (ec & 7)) * 4);
+        f32x4 P[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            out1d(*reinterpret_cast<const f32x4 *>(Mq + (0 * 6 + j) * 1024), *reinterpret_cast<const f32x4 *>(Mq + (1 * 6 + j) * 1024),
+                  *reinterpret_cast<const f32x4 *>(Mq + (2 * 6 + j) * 1024), *reinterpret_cast<const f32x4 *>(Mq + (3 * 6 + j) * 1024),
+                  *reinterpret_cast<const f32x4 *>(Mq + (4 * 6 + j) * 1024), *reinterpret_cast<const f32x4 *>(Mq + (5 * 6 + j) * 1024),
+                  P[0][j], P[1][j], P[2][j], P[3][j]);
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            float yv[4][4];
+            if constexpr (BNS) {        // the consumer's activations at this output row's sixteen store offsets
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        yv[k][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_y, vo[r], rr * orow + k * opix, 0));
+            }
+            f32x4 y[4];
+            out1d(P[rr][0], P[rr][1], P[rr][2], P[rr][3], P[rr][4], P[rr][5], y[0], y[1], y[2], y[3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float yy = y[k][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yy), srd_z, vo[r], rr * orow + k * opix, 0);
+                    if constexpr (BNS) {
+                        const float g = yv[k][r] > 0.f ? yy : 0.f;          // (an out-of-range offset reads y = 0)
+                        s += g;
+                        q += g * yv[k][r];
+                    } else {
+                        const float uu = vo[r] != kOOB ? yy - pv : 0.f;
+                        s += uu;
+                        q += uu * uu;
+                    }
+                }
+            if constexpr (BNS) __builtin_amdgcn_sched_barrier(0);      // one row's loads in flight at a time (registers)
+        }
+        if (BNS || (p.flags & DS_EPI_STATS)) {
+            // the eight threads of a column: lanes ec / ec + 32 of the four waves, combined in a fixed order
+            s += __shfl_xor(s, 32);
+            q += __shfl_xor(q, 32);
+            if (kh == 0) {
+                red[(wave * 32 + li) * 2 + 0] = s;
+                red[(wave * 32 + li) * 2 + 1] = q;
+            }
+            __syncthreads();
+            if (tid < 32 && colok) {
+                float ss = 0.f, qq = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    ss += red[(w * 32 + tid) * 2 + 0];
+                    qq += red[(w * 32 + tid) * 2 + 1];
+                }
+                p.stats[(int64_t)col * p.groups + group] = ss;
+                p.stats[((int64_t)p.Cout + col) * p.groups + group] = qq;
+            }
+        }
+    }
+}
+
+// U = G g G^T (6 x 6) for every (ci, co) pair of the TF HWIO filter w [3][3][Cin][Cout], stored for the kernel's
+// B loads as U[xi][r / 8][o][r % 8] with (r, o) = (reduction channel, output channel):
+//   dgrad == 0: g = w[:, :, ci, co], (r, o) = (ci, co)                               (forward)
+//   dgrad == 1: g = w[2 - kh, 2 - kw, ci, co], (r, o) = (co, ci)                     (Conv2DBackpropInput)
+__global__ __launch_bounds__(256) void wino4_weights_kernel(const float *w, float *u, int Cin, int Cout, int dgrad) {
+    const int64_t total = (int64_t)Cin * Cout;
+    const int R = dgrad ? Cout : Cin, O = dgrad ? Cin : Cout;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ci = (int)(i / Cout), co = (int)(i - (int64_t)ci * Cout);
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                g[a][b] = w[((int64_t)((dgrad ? 2 - a : a) * 3 + (dgrad ? 2 - b : b)) * Cin + ci) * Cout + co];
+        // G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+        auto g1d = [](float g0, float g1, float g2, float *t) {
+            const float e = (g0 + g2) * (-1.f / 6.f), o = g1 * (1.f / 6.f);
+            const float f = fmaf(g0, 1.f / 24.f, g2 * (1.f / 6.f)), h = g1 * (1.f / 12.f);
+            t[0] = g0 * 0.25f;
+            t[1] = e - o;
+            t[2] = e + o;
+            t[3] = f + h;
+            t[4] = f - h;
+            t[5] = g2;
+        };
+        float t[6][3];          // G g
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float c[6];
+            g1d(g[0][b], g[1][b], g[2][b], c);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) t[a][b] = c[a];
+        }
+        const int r = dgrad ? co : ci, o = dgrad ? ci : co;
+        const int64_t base = ((int64_t)(r >> 3) * O + o) * 8 + (r & 7);
+        const int64_t plane = (int64_t)(R >> 3) * O * 8;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            float c[6];
+            g1d(t[a][0], t[a][1], t[a][2], c);
+#pragma unroll
+            for (int bb = 0; bb < 6; ++bb) u[(a * 6 + bb) * plane + base] = c[bb];
+        }
+    }
+}
+
+int pick_nb(int Cout) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = getenv("DS_WINO4_NB");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 1 || forced == 2) return forced;
+    const int rem = Cout % 64;
+    return (Cout >= 64 && (rem == 0 || rem > 32)) ? 2 : 1;
+}
+
+}  // namespace
+
+extern "C" int ds_conv_wino4_supported(int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+    return (H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0) ? 1 : 0;
+}
+
+extern "C" int ds_wino4_transform_weights(const float *w, float *u, int32_t Cin, int32_t Cout, int32_t dgrad, void *stream) {
+    DS_REQUIRE(w && u && Cin > 0 && Cout > 0, "ds_wino4_transform_weights: bad argument");
+    DS_REQUIRE((dgrad ? Cout : Cin) % 8 == 0, "ds_wino4_transform_weights: the reduction channels must be a multiple of 8");
+    hipLaunchKernelGGL(wino4_weights_kernel, dim3(ds::stream_grid((int64_t)Cin * Cout, 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, u, Cin, Cout, dgrad);
+    return ds::check_launch("ds_wino4_transform_weights");
+}
+
+extern "C" int ds_conv_wino4_partials(int32_t N, int32_t H, int32_t W) {
+    const int64_t mt = (int64_t)N * (H / 4) * (W / 4);
+    return (int)((mt + 31) / 32);
+}
+
+extern "C" int ds_conv_wino4(const float *x, const float *u, float *z, float *stats, const float *pivot, const float *ymask,
+                             int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz,
+                             int32_t flags, void *stream) {
+    DS_REQUIRE(x && u && z && N > 0, "ds_conv_wino4: bad argument");
+    DS_REQUIRE(ds_conv_wino4_supported(H, W, Cin, Cout) && ldx >= Cin && ldx % 2 == 0 && ldz >= Cout && (((uintptr_t)u) & 15) == 0 && (((uintptr_t)x) & 7) == 0,
+               "ds_conv_wino4: needs H %% 4 == 0, W %% 4 == 0, Cin %% 16 == 0, even ldx and 16-byte aligned weights");
+    DS_REQUIRE((flags & ~(DS_EPI_STATS | DS_EPI_BNSUMS)) == 0 && (!(flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) || stats),
+               "ds_conv_wino4: only DS_EPI_STATS / DS_EPI_BNSUMS are supported (with a partials buffer)");
+    DS_REQUIRE(!(flags & DS_EPI_BNSUMS) || (ymask && !(flags & DS_EPI_STATS)),
+               "ds_conv_wino4: DS_EPI_BNSUMS needs y (pixel stride ldz) and excludes DS_EPI_STATS");
+    Wino4Params p;
+    p.x = x; p.u = u; p.z = z; p.stats = stats; p.pivot = (flags & DS_EPI_STATS) ? pivot : nullptr;
+    p.y = (flags & DS_EPI_BNSUMS) ? ymask : nullptr;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.ldz = ldz;
+    p.TH = H / 4; p.TW = W / 4;
+    const int64_t mt = (int64_t)N * p.TH * p.TW;
+    const int64_t xb = ((int64_t)N * H * W - 1) * ldx + Cin + (int64_t)(W + 1) * ldx, ub = (int64_t)36 * Cin * Cout;
+    DS_REQUIRE(mt < (1ll << 30) && xb * 4 < (1ll << 31) && ub * 4 < (1ll << 31), "ds_conv_wino4: operand larger than 2 GiB");
+    p.Mt = (int)mt;
+    p.x_bytes = (unsigned)((((int64_t)N * H * W - 1) * ldx + Cin) * 4);
+    p.u_bytes = (unsigned)(ub * 4);
+    const int64_t zb = ((int64_t)N * H * W - 1) * ldz + Cout;
+    DS_REQUIRE(zb * 4 < (1ll << 31), "ds_conv_wino4: output larger than 2 GiB");
+    p.z_bytes = (unsigned)(zb * 4);
+    p.flags = flags;
+    p.groups = (int)((mt + 31) / 32);
+    const int nb = pick_nb(Cout);
+    p.ncol = (Cout + 32 * nb - 1) / (32 * nb);
+    const dim3 grid((unsigned)(((int64_t)p.groups * p.ncol + 7) / 8 * 8));
+    const bool bns = (flags & DS_EPI_BNSUMS) != 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (nb == 2) {
+        if (bns) hipLaunchKernelGGL((conv_wino4_kernel<2, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wino4_kernel<2, false>), grid, dim3(256), 0, st, p);
+    } else {
+        if (bns) hipLaunchKernelGGL((conv_wino4_kernel<1, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wino4_kernel<1, false>), grid, dim3(256), 0, st, p);
+    }
+    return ds::check_launch("ds_conv_wino4");
+}

@@ -14,6 +14,7 @@ slim/nets/inception_utils.py:32-71); how is MI355X-first:
   * all buffers are allocated once per batch size; nothing is allocated or synchronised per step.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -104,11 +105,16 @@ class ConvBN:
         if self.stem_direct:
             self.wino_fwd = ops.StemPlan(B, self.H, self.W, 4, cout, cout)
             eng.need_stats(self.wino_fwd.partials * 2 * cout)
+        # ... and F(4x4,3x3) (ds_conv_wino4) on the maps that are multiples of four (56 x 56, 28 x 28): 1.3-1.6x over
+        # F(2x2) there (profiles/r03_wino4_layers.txt)
+        def wino4_ok(cin_k, cout_k):
+            return eng.winograd4 and ops.wino4_supported(self.H, self.W, cin_k, cout_k)
         if wino_ok(self.H, cin, cout):
-            self.wino_fwd = WinoPlan(B, self.H, self.W, cin, 0, cout, cout, flags=DS_EPI_STATS)
-            self.u_fwd = torch.empty(16, cout, cin, device=dev)
+            self.wino_fwd = WinoPlan(B, self.H, self.W, cin, 0, cout, cout, flags=DS_EPI_STATS, f4=wino4_ok(cin, cout))
+            self.u_fwd = torch.empty(self.wino_fwd.u_elems, device=dev)
             eng.need_stats(self.wino_fwd.partials * 2 * cout)
         self._wino_dgrad_ok = wino_ok(self.H, cout, cin)
+        self._wino4_dgrad = self._wino_dgrad_ok and wino4_ok(cout, cin)
         # bf16: the register-direct kernel (ds_conv_bf16, pre-converted weights) where it beats the LDS-staged one
         # (profiles/r02_bf16_layers.txt): forward from 48 output columns up, dgrad for the 1x1 layers and from 160
         # columns up; it rides the same alternative-plan slots as the Winograd kernel (u_* = its converted weights)
@@ -254,8 +260,8 @@ class ConvBN:
         self.dgrad = ConvPlan(self.B, self.H, self.W, cout, cout, k, k, 1, cin, lddx, cin * cout, cout, 1, flip=1,
                               dtype=self.eng.conv_dtype)
         if self._wino_dgrad_ok:
-            self.wino_dgrad = WinoPlan(self.B, self.H, self.W, cout, cout, cin, lddx)
-            self.u_dgrad = torch.empty(16, cin, cout, device=self.eng.device)
+            self.wino_dgrad = WinoPlan(self.B, self.H, self.W, cout, cout, cin, lddx, f4=self._wino4_dgrad)
+            self.u_dgrad = torch.empty(self.wino_dgrad.u_elems, device=self.eng.device)
         elif self._bf16_dgrad_ok:
             self.wino_dgrad = ops.Bf16Plan(self.B, self.H, self.W, cout, cout, k, 1, cin, lddx)
             self.u_dgrad = torch.empty(ops.weights_bf16_bytes(cin, cout, k * k, True), dtype=torch.uint8,
@@ -282,7 +288,7 @@ class ConvBN:
             elif isinstance(plan, ops.Bf16Plan):
                 ops.weights_to_bf16(self.w_ptr, u, self.cin, self.cout, taps, dgrad)
             elif plan is not None:
-                ops.wino_transform_weights(self.w_ptr, u, self.cin, self.cout, dgrad)
+                ops.wino_transform_weights(self.w_ptr, u, self.cin, self.cout, dgrad, f4=plan.f4)
         self.u_version = eng.weights_version
 
     # x_ptr: input activations [B,H,W,ldx]; segs: where relu(bn(conv)) is scattered (None: the consumer, a max
@@ -765,6 +771,7 @@ class InceptionV1Engine:
         self.side = None
         self.bf16_direct = True      # dtype bf16: ds_conv_bf16 where it wins (False: the LDS-staged bf16 kernel everywhere)
         self.winograd = True         # 3x3 layers through ds_conv_wino where it wins (False: implicit GEMM everywhere)
+        self.winograd4 = os.environ.get("DS_WINO4", "1") != "0"      # ... and ds_conv_wino4 (F(4x4,3x3)) on 56 x 56 / 28 x 28
         self.weights_version = 0     # bumped by SentimentNet.after_load(): frozen layers redo their G g G^T
         self._stats_n = self._bwdp_n = self._ws_bytes = 0
         self.B = None

@@ -151,20 +151,26 @@ def gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=False, flags=0, ldmask=0, sp
 
 
 class WinoPlan:
-    """3x3 stride-1 SAME conv through ds_conv_wino (fused Winograd F(2x2,3x3)); `u` is the transformed filter."""
+    """3x3 stride-1 SAME conv through ds_conv_wino (fused Winograd F(2x2,3x3)) or, with f4, ds_conv_wino4
+    (F(4x4,3x3): H, W multiples of four); `u` is the transformed filter (`u_elems` floats)."""
 
-    def __init__(self, N, H, W, Cin, ldx, Cout, ldz, flags=0):
+    def __init__(self, N, H, W, Cin, ldx, Cout, ldz, flags=0, f4=False):
         self.args = (N, H, W, Cin, ldx, Cout, ldz)
         self.flags = flags
+        self.f4 = bool(f4)
+        lib = _lib.load()
+        self._run, self._name = (lib.ds_conv_wino4, "ds_conv_wino4") if f4 else (lib.ds_conv_wino, "ds_conv_wino")
+        self._partials = lib.ds_conv_wino4_partials if f4 else lib.ds_conv_wino_partials
+        self.u_elems = (36 if f4 else 16) * Cin * Cout
         self.M = N * H * W
-        self.partials = _lib.load().ds_conv_wino_partials(N, H, W) if flags & (DS_EPI_STATS | DS_EPI_BNSUMS) else 0
+        self.partials = self._partials(N, H, W) if flags & (DS_EPI_STATS | DS_EPI_BNSUMS) else 0
         self.alg_flops = 2.0 * self.M * Cout * 9 * Cin          # the convolution's FLOPs, not Winograd's
 
     def enable_bnsums(self):
         """As ConvPlan.enable_bnsums (y has the output's pixel stride)."""
         N, H, W = self.args[:3]
         self.flags = DS_EPI_BNSUMS
-        self.partials = _lib.load().ds_conv_wino_partials(N, H, W)
+        self.partials = self._partials(N, H, W)
         return self.partials
 
     def set_ldx(self, ldx):
@@ -175,15 +181,21 @@ class WinoPlan:
         if t is not None:
             t.begin()
         N, H, W, Cin, ldx, Cout, ldz = self.args
-        _lib.check(_lib.load().ds_conv_wino(x, u, z, stats, pivot, ymask, N, H, W, Cin, ldx, Cout, ldz, self.flags,
-                                            _stream()), "ds_conv_wino")
+        _lib.check(self._run(x, u, z, stats, pivot, ymask, N, H, W, Cin, ldx, Cout, ldz, self.flags, _stream()), self._name)
         if t is not None:
             t.end(self)
 
 
-def wino_transform_weights(w_ptr, u, Cin, Cout, dgrad):
-    _lib.check(_lib.load().ds_wino_transform_weights(w_ptr, _p(u), Cin, Cout, int(dgrad), _stream()),
-               "ds_wino_transform_weights")
+def wino4_supported(H, W, Cin, Cout):
+    return bool(_lib.load().ds_conv_wino4_supported(H, W, Cin, Cout))
+
+
+def wino_transform_weights(w_ptr, u, Cin, Cout, dgrad, f4=False):
+    lib = _lib.load()
+    if f4:
+        _lib.check(lib.ds_wino4_transform_weights(w_ptr, _p(u), Cin, Cout, int(dgrad), _stream()), "ds_wino4_transform_weights")
+    else:
+        _lib.check(lib.ds_wino_transform_weights(w_ptr, _p(u), Cin, Cout, int(dgrad), _stream()), "ds_wino_transform_weights")
 
 
 class StemPlan:
