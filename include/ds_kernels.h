@@ -179,14 +179,18 @@ int ds_conv_wino(const float *x, const float *u, float *z, float *stats, const f
                  int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz, int32_t flags,
                  void *stream);
 
-/* The same convolution as fused Winograd F(4x4, 3x3) for maps with H % 4 == 0 and W % 4 == 0 (Conv2d_2c_3x3 at
- * 56 x 56, the 3x3 layers of Mixed_3b / 3c at 28 x 28: image_model/inception_v1.py:74-75, 86-115): 4x fewer matrix
- * passes than the implicit GEMM, 1.78x fewer than ds_conv_wino.  Same arguments and flags as ds_conv_wino except
+/* The same convolution as fused Winograd F(4x4, 3x3): 4x fewer matrix passes than the implicit GEMM, 1.78x fewer than
+ * ds_conv_wino; 1.3-1.6x faster than ds_conv_wino on the 56 x 56 / 28 x 28 layers (Conv2d_2c_3x3, Mixed_3b / 3c:
+ * image_model/inception_v1.py:74-75, 86-115) and on those 14 x 14 / 7 x 7 layers whose workgroup count fills the chip
+ * better this way.  Same arguments and flags as ds_conv_wino except
  *   u      = G g G^T (6 x 6) as float[36][Cin / 8][Cout][8] from ds_wino4_transform_weights (same dgrad convention);
- *   stats  partials float[2][Cout][P] with P = ds_conv_wino4_partials (one per 32 tiles).
- * ds_conv_wino4_supported says whether a shape can run here.  Results equal the direct kernels' to ~1e-5 relative
- * (F(4x4) costs about one decimal digit against F(2x2): rms 2.4e-6 vs 3.7e-7), deterministically.   */
+ *   stats  partials float[2][Cout][P] with P = ds_conv_wino4_partials (one per 32 tiles of 4 x 4 outputs);
+ *   needs  Cin % 16 == 0, even ldx, 8-byte aligned x (ds_conv_wino4_supported); any H, W (partial border tiles).
+ * ds_conv_wino4_prefer: the launch-time model's advice for a shape -- 0: ds_conv_wino is expected to be faster, else
+ * nonzero.  Results equal the direct kernels' to ~1e-5 relative (F(4x4) costs about one decimal digit against
+ * F(2x2): rms 2.4e-6 vs 3.7e-7), deterministically.   */
 int ds_conv_wino4_supported(int32_t H, int32_t W, int32_t Cin, int32_t Cout);
+int ds_conv_wino4_prefer(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
 int ds_wino4_transform_weights(const float *w, float *u, int32_t Cin, int32_t Cout, int32_t dgrad, void *stream);
 int ds_conv_wino4_partials(int32_t N, int32_t H, int32_t W);
 int ds_conv_wino4(const float *x, const float *u, float *z, float *stats, const float *pivot, const float *ymask,

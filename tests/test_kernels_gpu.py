@@ -227,22 +227,29 @@ def test_gemm_lstm_shape():
     close(dh, dg @ kern[40:].T)
 
 
+@pytest.mark.parametrize("f4", [False, True], ids=["F2x2", "F4x4"])
 @pytest.mark.parametrize("case", [(2, 8, 8, 16, 32), (3, 14, 14, 24, 64), (2, 28, 28, 96, 128), (5, 7, 7, 160, 320),
-                                  (2, 13, 11, 48, 176), (1, 9, 10, 8, 40), (2, 56, 56, 64, 192)])
-def test_winograd_conv_forward_and_dgrad_match_oracle(case):
-    """ds_conv_wino (fused Winograd F(2x2,3x3), fp32 MFMA) against the fp64 direct-convolution oracle: forward with
-    BatchNorm statistics about a pivot, and the input gradient through the flipped / transposed transformed filter;
-    odd map sizes (half-empty border tiles), Cout not a multiple of 32, a ragged last tile group."""
+                                  (2, 13, 11, 48, 176), (1, 9, 10, 8, 40), (2, 56, 56, 64, 192), (3, 14, 14, 32, 64),
+                                  (1, 4, 4, 16, 16), (9, 5, 6, 16, 48)])
+def test_winograd_conv_forward_and_dgrad_match_oracle(case, f4):
+    """ds_conv_wino (fused Winograd F(2x2,3x3), fp32 MFMA) and ds_conv_wino4 (F(4x4,3x3)) against the fp64
+    direct-convolution oracle: forward with BatchNorm statistics about a pivot, and the input gradient through the
+    flipped / transposed transformed filter; map sizes that are not multiples of the tile (half-empty border tiles),
+    Cout not a multiple of 32, a ragged last tile group, one tile per image."""
     ops = _ops()
     N, H, W, Ci, Co = case
+    step = 16 if f4 else 8                      # channels per K step: the reduction axis must be a multiple
+    if Ci % step:
+        assert not (f4 and ops.wino4_supported(H, W, Ci, Co))
+        pytest.skip("Cin %% %d != 0: the engine uses the implicit GEMM there" % step)
     rng = np.random.RandomState(5)
     x = rng.normal(size=(N, H, W, Ci))
     w = rng.normal(size=(3, 3, Ci, Co)) * 0.1
     ref = S.conv2d_same(x, w, 1)
     xd, wd = dev(x), dev(w)
-    u = torch.empty(16, Co, Ci, device="cuda")
-    ops.wino_transform_weights(ops._p(wd), u, Ci, Co, dgrad=False)
-    plan = ops.WinoPlan(N, H, W, Ci, Ci, Co, Co, flags=ops.DS_EPI_STATS)
+    plan = ops.WinoPlan(N, H, W, Ci, Ci, Co, Co, flags=ops.DS_EPI_STATS, f4=f4)
+    u = torch.empty(plan.u_elems, device="cuda")
+    ops.wino_transform_weights(ops._p(wd), u, Ci, Co, dgrad=False, f4=f4)
     M = plan.M
     z = torch.full((M, Co), float("nan"), device="cuda")
     stats = torch.zeros(2, Co, plan.partials, device="cuda")
@@ -256,12 +263,12 @@ def test_winograd_conv_forward_and_dgrad_match_oracle(case):
     close(stats[1].sum(1), ((zz - pv) ** 2).sum(0), 2e-3)
     # dgrad: correlation over dz with the flipped, channel-transposed filter
     dy = rng.normal(size=ref.shape)
-    ud = torch.empty(16, Ci, Co, device="cuda")
-    ops.wino_transform_weights(ops._p(wd), ud, Ci, Co, dgrad=True)
-    g = ops.WinoPlan(N, H, W, Co, Co, Ci, Ci + 4)                 # strided output rows (ldz > Cout)
+    g = ops.WinoPlan(N, H, W, Co, Co, Ci, Ci + 4, f4=f4)          # strided output rows (ldz > Cout)
+    ud = torch.empty(g.u_elems, device="cuda")
     dx = torch.zeros(M, Ci + 4, device="cuda")
     dyd = dev(dy)
-    if Co % 8 == 0:
+    if Co % step == 0:
+        ops.wino_transform_weights(ops._p(wd), ud, Ci, Co, dgrad=True, f4=f4)
         g.run(ops._p(dyd), ops._p(ud), ops._p(dx))
         torch.cuda.synchronize()
         dx_ref = S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1).reshape(-1, Ci)

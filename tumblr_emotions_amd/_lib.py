@@ -71,6 +71,7 @@ SIGNATURES = {
     "ds_conv_wino_partials": (C.c_int, [_i32, _i32, _i32]),
     "ds_conv_wino": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "ds_conv_wino4_supported": (C.c_int, [_i32, _i32, _i32, _i32]),
+    "ds_conv_wino4_prefer": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "ds_wino4_transform_weights": (C.c_int, [_P, _P, _i32, _i32, _i32, _P]),
     "ds_conv_wino4_partials": (C.c_int, [_i32, _i32, _i32]),
     "ds_conv_wino4": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),

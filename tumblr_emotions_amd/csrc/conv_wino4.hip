@@ -30,6 +30,7 @@
 // Numerics: fp32 throughout, ordered reductions (deterministic).  The F(4x4) transforms carry constants up to 8 and
 // cost about one decimal digit against F(2x2): relative rms error 2.4e-6 instead of 3.7e-7 on post-ReLU activations
 // with 192 input channels (scratch/wino4_numerics.py), against 2.6e-7 for a direct fp32 sum.
+#include <math.h>
 #include <stdlib.h>
 #include "ds_common.h"
 
@@ -92,7 +93,7 @@ __device__ __forceinline__ void out1d(f32x4 m0, f32x4 m1, f32x4 m2, f32x4 m3, f3
     y3 = qfma(1.f, m5, qfma(8.f, s3, s1));
 }
 
-template <int NB, bool BNS>
+template <int NB, bool BNS, bool EDGE>      // EDGE: H or W is not a multiple of four (partial last tile row / column)
 __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p) {
     // K loop: V[2][36][32 tiles][16 ci] = 144 KB; epilogue: M[36][32 co][32 tiles] = 144 KB
     __shared__ __attribute__((aligned(128))) float smem[36 * 32 * 32];
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     const __amdgpu_buffer_rsrc_t srd_y = w4srd(BNS ? p.y : p.z, p.z_bytes);
     const int orow = p.W * p.ldz * 4, opix = p.ldz * 4;
     int tbase[4];               // pixel index of the top-left output of this thread's four tiles, or -1
+    int hrem[4], wrem[4];       // EDGE: output rows / columns of the tile inside the image
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int m = m0 + eg * 4 + r;
@@ -234,6 +236,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
         const int rr = (m < p.Mt ? m : 0) - n * tpi;
         const int th = rr / p.TW, tw = rr - th * p.TW;
         tbase[r] = m < p.Mt ? (n * p.H + 4 * th) * p.W + 4 * tw : -1;
+        hrem[r] = p.H - 4 * th;
+        wrem[r] = p.W - 4 * tw;
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -264,13 +268,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
+            unsigned vof[4][4];         // store offsets of this output row: [column k][tile r]
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vof[k][r] = (!EDGE || (rr < hrem[r] && k < wrem[r])) ? vo[r] : kOOB;
             float yv[4][4];
             if constexpr (BNS) {        // the consumer's activations at this output row's sixteen store offsets
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        yv[k][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_y, vo[r], rr * orow + k * opix, 0));
+                        yv[k][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_y, vof[k][r], rr * orow + k * opix, 0));
             }
             f32x4 y[4];
             out1d(P[rr][0], P[rr][1], P[rr][2], P[rr][3], P[rr][4], P[rr][5], y[0], y[1], y[2], y[3]);
@@ -279,13 +288,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float yy = y[k][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yy), srd_z, vo[r], rr * orow + k * opix, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yy), srd_z, vof[k][r], rr * orow + k * opix, 0);
                     if constexpr (BNS) {
                         const float g = yv[k][r] > 0.f ? yy : 0.f;          // (an out-of-range offset reads y = 0)
                         s += g;
                         q += g * yv[k][r];
                     } else {
-                        const float uu = vo[r] != kOOB ? yy - pv : 0.f;
+                        const float uu = vof[k][r] != kOOB ? yy - pv : 0.f;
                         s += uu;
                         q += uu * uu;
                     }
@@ -362,21 +371,46 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float *w, floa
     }
 }
 
-int pick_nb(int Cout) {
+// Which kernel for a shape?  Launch-time model fitted to profiles/r03_wino4_layers.txt (B = 256 and B = 32): a launch
+// takes ceil(workgroups / CUs) rounds of one workgroup's duration,
+//     F(4x4), NB = 2: 13 us + 6.0 us per 16-channel K step      NB = 1: 8.5 us + 3.8 us per K step
+//     F(2x2) (conv_wino.hip): 8.7 us + 2.35 us per 8-channel K step, 128 tiles of 2x2 x 32 channels per workgroup
+// so the 14 x 14 and 7 x 7 maps (128 / 32 tile groups only) go to whichever fills the rounds best.
+struct W4Choice {
+    int nb;             // 1, 2: F(4x4) with that channel-block count
+    double us4, us2;    // expected launch time of F(4x4) with nb / of F(2x2)
+};
+W4Choice w4_choose(int N, int H, int W, int Cin, int Cout) {
     static int forced = -1;
     if (forced < 0) {
         const char *e = getenv("DS_WINO4_NB");
         forced = e ? atoi(e) : 0;
     }
-    if (forced == 1 || forced == 2) return forced;
-    const int rem = Cout % 64;
-    return (Cout >= 64 && (rem == 0 || rem > 32)) ? 2 : 1;
+    const double cus = 256.0;
+    const int64_t mt4 = (int64_t)N * ((H + 3) / 4) * ((W + 3) / 4), g4 = (mt4 + 31) / 32;
+    const int64_t mt2 = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2), g2 = (mt2 + 127) / 128;
+    W4Choice c;
+    double t[3];
+    for (int nb = 1; nb <= 2; ++nb) {
+        const int64_t wgs = g4 * ((Cout + 32 * nb - 1) / (32 * nb));
+        t[nb] = ceil(wgs / cus) * ((Cin / 16) * (nb == 2 ? 6.0 : 3.8) + (nb == 2 ? 13.0 : 8.5));
+    }
+    c.us2 = ceil(g2 * ((Cout + 31) / 32) / cus) * (8.7 + 2.35 * (Cin / 8));
+    c.nb = (forced == 1 || forced == 2) ? forced : (t[2] < t[1] ? 2 : 1);
+    c.us4 = t[c.nb];
+    return c;
 }
 
 }  // namespace
 
 extern "C" int ds_conv_wino4_supported(int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
-    return (H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0) ? 1 : 0;
+    return (H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0) ? 1 : 0;
+}
+
+extern "C" int ds_conv_wino4_prefer(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+    if (!ds_conv_wino4_supported(H, W, Cin, Cout) || N <= 0) return 0;
+    const W4Choice c = w4_choose(N, H, W, Cin, Cout);
+    return c.us4 < c.us2 ? c.nb : 0;
 }
 
 extern "C" int ds_wino4_transform_weights(const float *w, float *u, int32_t Cin, int32_t Cout, int32_t dgrad, void *stream) {
@@ -388,7 +422,7 @@ extern "C" int ds_wino4_transform_weights(const float *w, float *u, int32_t Cin,
 }
 
 extern "C" int ds_conv_wino4_partials(int32_t N, int32_t H, int32_t W) {
-    const int64_t mt = (int64_t)N * (H / 4) * (W / 4);
+    const int64_t mt = (int64_t)N * ((H + 3) / 4) * ((W + 3) / 4);
     return (int)((mt + 31) / 32);
 }
 
@@ -397,7 +431,7 @@ extern "C" int ds_conv_wino4(const float *x, const float *u, float *z, float *st
                              int32_t flags, void *stream) {
     DS_REQUIRE(x && u && z && N > 0, "ds_conv_wino4: bad argument");
     DS_REQUIRE(ds_conv_wino4_supported(H, W, Cin, Cout) && ldx >= Cin && ldx % 2 == 0 && ldz >= Cout && (((uintptr_t)u) & 15) == 0 && (((uintptr_t)x) & 7) == 0,
-               "ds_conv_wino4: needs H %% 4 == 0, W %% 4 == 0, Cin %% 16 == 0, even ldx and 16-byte aligned weights");
+               "ds_conv_wino4: needs Cin %% 16 == 0, even ldx, 8-byte aligned x and 16-byte aligned weights");
     DS_REQUIRE((flags & ~(DS_EPI_STATS | DS_EPI_BNSUMS)) == 0 && (!(flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) || stats),
                "ds_conv_wino4: only DS_EPI_STATS / DS_EPI_BNSUMS are supported (with a partials buffer)");
     DS_REQUIRE(!(flags & DS_EPI_BNSUMS) || (ymask && !(flags & DS_EPI_STATS)),
@@ -406,7 +440,7 @@ extern "C" int ds_conv_wino4(const float *x, const float *u, float *z, float *st
     p.x = x; p.u = u; p.z = z; p.stats = stats; p.pivot = (flags & DS_EPI_STATS) ? pivot : nullptr;
     p.y = (flags & DS_EPI_BNSUMS) ? ymask : nullptr;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.ldz = ldz;
-    p.TH = H / 4; p.TW = W / 4;
+    p.TH = (H + 3) / 4; p.TW = (W + 3) / 4;
     const int64_t mt = (int64_t)N * p.TH * p.TW;
     const int64_t xb = ((int64_t)N * H * W - 1) * ldx + Cin + (int64_t)(W + 1) * ldx, ub = (int64_t)36 * Cin * Cout;
     DS_REQUIRE(mt < (1ll << 30) && xb * 4 < (1ll << 31) && ub * 4 < (1ll << 31), "ds_conv_wino4: operand larger than 2 GiB");
@@ -418,17 +452,20 @@ extern "C" int ds_conv_wino4(const float *x, const float *u, float *z, float *st
     p.z_bytes = (unsigned)(zb * 4);
     p.flags = flags;
     p.groups = (int)((mt + 31) / 32);
-    const int nb = pick_nb(Cout);
+    const int nb = w4_choose(N, H, W, Cin, Cout).nb;
     p.ncol = (Cout + 32 * nb - 1) / (32 * nb);
     const dim3 grid((unsigned)(((int64_t)p.groups * p.ncol + 7) / 8 * 8));
     const bool bns = (flags & DS_EPI_BNSUMS) != 0;
     hipStream_t st = (hipStream_t)stream;
+    const bool edge = (H % 4) != 0 || (W % 4) != 0;
+#define DS_W4_LAUNCH(NBV, BNSV, EDGEV) hipLaunchKernelGGL((conv_wino4_kernel<NBV, BNSV, EDGEV>), grid, dim3(256), 0, st, p)
     if (nb == 2) {
-        if (bns) hipLaunchKernelGGL((conv_wino4_kernel<2, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_wino4_kernel<2, false>), grid, dim3(256), 0, st, p);
+        if (bns) { if (edge) DS_W4_LAUNCH(2, true, true); else DS_W4_LAUNCH(2, true, false); }
+        else { if (edge) DS_W4_LAUNCH(2, false, true); else DS_W4_LAUNCH(2, false, false); }
     } else {
-        if (bns) hipLaunchKernelGGL((conv_wino4_kernel<1, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_wino4_kernel<1, false>), grid, dim3(256), 0, st, p);
+        if (bns) { if (edge) DS_W4_LAUNCH(1, true, true); else DS_W4_LAUNCH(1, true, false); }
+        else { if (edge) DS_W4_LAUNCH(1, false, true); else DS_W4_LAUNCH(1, false, false); }
     }
+#undef DS_W4_LAUNCH
     return ds::check_launch("ds_conv_wino4");
 }

@@ -105,10 +105,11 @@ class ConvBN:
         if self.stem_direct:
             self.wino_fwd = ops.StemPlan(B, self.H, self.W, 4, cout, cout)
             eng.need_stats(self.wino_fwd.partials * 2 * cout)
-        # ... and F(4x4,3x3) (ds_conv_wino4) on the maps that are multiples of four (56 x 56, 28 x 28): 1.3-1.6x over
-        # F(2x2) there (profiles/r03_wino4_layers.txt)
+        # ... and F(4x4,3x3) (ds_conv_wino4) where the library's launch-time model prefers it: 1.3-1.6x over F(2x2) on
+        # the 56 x 56 / 28 x 28 maps, and those 14 x 14 / 7 x 7 layers whose workgroups fill the chip better that way
+        # (profiles/r03_wino4_layers.txt)
         def wino4_ok(cin_k, cout_k):
-            return eng.winograd4 and ops.wino4_supported(self.H, self.W, cin_k, cout_k)
+            return eng.winograd4 and ops.wino4_prefer(B, self.H, self.W, cin_k, cout_k)
         if wino_ok(self.H, cin, cout):
             self.wino_fwd = WinoPlan(B, self.H, self.W, cin, 0, cout, cout, flags=DS_EPI_STATS, f4=wino4_ok(cin, cout))
             self.u_fwd = torch.empty(self.wino_fwd.u_elems, device=dev)
@@ -771,7 +772,7 @@ class InceptionV1Engine:
         self.side = None
         self.bf16_direct = True      # dtype bf16: ds_conv_bf16 where it wins (False: the LDS-staged bf16 kernel everywhere)
         self.winograd = True         # 3x3 layers through ds_conv_wino where it wins (False: implicit GEMM everywhere)
-        self.winograd4 = os.environ.get("DS_WINO4", "1") != "0"      # ... and ds_conv_wino4 (F(4x4,3x3)) on 56 x 56 / 28 x 28
+        self.winograd4 = os.environ.get("DS_WINO4", "1") != "0"      # ... and ds_conv_wino4 (F(4x4,3x3)) where it is faster
         self.weights_version = 0     # bumped by SentimentNet.after_load(): frozen layers redo their G g G^T
         self._stats_n = self._bwdp_n = self._ws_bytes = 0
         self.B = None

@@ -190,6 +190,11 @@ def wino4_supported(H, W, Cin, Cout):
     return bool(_lib.load().ds_conv_wino4_supported(H, W, Cin, Cout))
 
 
+def wino4_prefer(N, H, W, Cin, Cout):
+    """The library's launch-time model: is ds_conv_wino4 expected to beat ds_conv_wino on this shape?"""
+    return bool(_lib.load().ds_conv_wino4_prefer(N, H, W, Cin, Cout))
+
+
 def wino_transform_weights(w_ptr, u, Cin, Cout, dgrad, f4=False):
     lib = _lib.load()
     if f4:
