@@ -41,6 +41,16 @@ namespace {
 
 constexpr unsigned kOOB = 0x80000000u;
 
+#ifdef DS_W4_PROF               // tuning aid (scratch builds only): one mid-grid workgroup stamps its phases, 100 MHz ticks
+__device__ unsigned long long g_w4_prof[8];
+#define W4_STAMP(i)                                                                                         \
+    do {                                                                                                    \
+        if (tid == 0 && blockIdx.x == (gridDim.x / 2 & ~7u)) g_w4_prof[i] = __builtin_amdgcn_s_memrealtime();  \
+    } while (0)
+#else
+#define W4_STAMP(i)
+#endif
+
 struct Wino4Params {
     const float *x;         // [N, H, W, ldx]
     const float *u;         // [36][Cin / 8][Cout][8]
@@ -61,6 +71,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t w4srd(const void *p, unsigned 
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() is a release fence + s_barrier and therefore waits for
+// vmcnt(0) as well: in the epilogue that is the drain of the 64 output stores every thread has just issued (measured:
+// the second channel block's pass cost 9 us instead of ~3), in the K loop the prefetches in flight.  The exchanges here
+// go through LDS alone, so only the LDS counter has to be zero.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #ifndef DS_W4_PXG
 #define DS_W4_PXG 3          // pixel loads of the next K step issued per MFMA group (36 in all)
 #endif
@@ -68,6 +84,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // every operation of the transforms is written as a fused multiply-add on a channel PAIR so that it compiles to one
 // v_pk_fma_f32 (hipcc packs neither subtractions nor mixed add / fma expressions on its own)
 __device__ __forceinline__ f32x2 pfma(float k, f32x2 a, f32x2 b) { return __builtin_elementwise_fma(f32x2{k, k}, a, b); }
+
+// v_mfma_f32_32x32x2_f32 with the accumulator in architectural vector registers
+__device__ __forceinline__ void mfma_v(f32x16 &c, float a, float b) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
 
 // B^T d for one line of six: B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 __device__ __forceinline__ void in1d(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2 d5, f32x2 &t0, f32x2 &t1,
@@ -101,6 +122,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
+    W4_STAMP(0);
     // 1-D XCD-aware launch as conv_wino.hip: the channel blocks of a tile group run back to back on one XCD
     const int id = blockIdx.x;
     const int lin = (id & 7) * (int)(gridDim.x >> 3) + (id >> 3);
@@ -145,13 +167,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     const int ustep = p.Cout * 32;                                 // bytes between half steps of one position
     const int upos = nhalf * ustep;                                // bytes between positions
 
-    f32x16 acc[9][NB];
+    // NB = 2: 18 accumulators but 256 accumulation registers -- left to the compiler, two accumulators share 16 of them
+    // and are swapped through the vector registers around their MFMAs (192 moves and two pipeline drains per K step:
+    // the MFMA-only loop measured 5.5-6.4 us per step against 3.84 of matrix cycles).  Position 8's two accumulators are
+    // therefore pinned to the ARCHITECTURAL vector registers (mfma_v: the gfx90a+ MFMA takes C / D in either file).
+    f32x16 acc[9][NB], accv[NB];
 #pragma unroll
     for (int pi = 0; pi < 9; ++pi)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[pi][nb][e] = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accv[nb][e] = 0.f;
 
     f32x2 raw[36];
     f32x4 b[6][NB];             // ring: group g (half step g / 9, position g % 9) uses slot g % 6, six groups of lead
@@ -171,7 +201,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
 #pragma unroll
     for (int g = 0; g < 6; ++g) load_b(g, g, 0);
 
+    W4_STAMP(1);
+#ifdef DS_W4_NO_LOOP            // timing experiment: prologue + epilogue only
+    for (int ks = 0; ks < (p.flags == 12345 ? ksteps : 0); ++ks) {
+#else
     for (int ks = 0; ks < ksteps; ++ks) {
+#endif
         float *Vw = smem + (ks & 1) * (36 * 512);
         // ---- V = B^T d B for this thread's (tile, channel pair): columns first, then rows; position-major in LDS ----
         {
@@ -184,8 +219,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
             for (int i = 0; i < 6; ++i) {
                 f32x2 v[6];
                 in1d(t[i * 6], t[i * 6 + 1], t[i * 6 + 2], t[i * 6 + 3], t[i * 6 + 4], t[i * 6 + 5], v[0], v[1], v[2], v[3], v[4], v[5]);
+#ifdef DS_W4_X_NOXF
+#pragma unroll
+                for (int j = 0; j < 6; ++j) v[j] = raw[i * 6 + j];
+#endif
+#ifndef DS_W4_X_NOLDSW
 #pragma unroll
                 for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2 *>(Vw + (i * 6 + j) * 512 + tid * 2) = v[j];
+#else
+                if (p.flags == 12345) Vw[tid] = v[0][0] + v[1][0] + v[2][0] + v[3][0] + v[4][0] + v[5][0];
+#endif
             }
         }
         const bool more = ks + 1 < ksteps;
@@ -194,35 +237,62 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
         // they are one v_cndmask on a column mask each)
 #pragma unroll
         for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(rowoff[k]));
-        __syncthreads();
+#ifndef DS_W4_X_NOBAR
+        lds_barrier();
+#endif
         // ---- two 8-channel half steps x nine positions: A fragment from LDS, 4 NB MFMAs; the next K step's pixels
         // (four per group of the first half step) and the weights six groups ahead are requested between the groups ----
         const float *Va = Vw + (wave * 9) * 512 + li * 16 + kh * 4;
-        f32x4 a = *reinterpret_cast<const f32x4 *>(Va), an = a;
+        // NB = 1: two groups at a time, their MFMAs alternating -- four back-to-back MFMAs on ONE accumulator wait for
+        // each other's results (measured: the NB = 1 step took as long as the NB = 2 step)
+        constexpr int GP = NB == 1 ? 2 : 1;
+        f32x4 av[GP], avn[GP];
 #pragma unroll
-        for (int g = 0; g < 18; ++g) {
-            const int h = g / 9, pi = g - 9 * h;
-            if (g < 17) an = *reinterpret_cast<const f32x4 *>(Va + ((g + 1) % 9) * 512 + ((g + 1) / 9) * 8);
-            if (more && g * DS_W4_PXG < 36) {        // column-major: the column pass reads column 0 first
+        for (int u = 0; u < GP; ++u) av[u] = avn[u] = *reinterpret_cast<const f32x4 *>(Va + u * 512);
 #pragma unroll
-                for (int k = DS_W4_PXG * g; k < DS_W4_PXG * g + DS_W4_PXG && k < 36; ++k) load_pixel((k % 6) * 6 + k / 6, cn);
+        for (int g0 = 0; g0 < 18; g0 += GP) {
+#ifndef DS_W4_X_NOAREAD
+#pragma unroll
+            for (int u = 0; u < GP; ++u)
+                if (g0 + GP + u < 18) avn[u] = *reinterpret_cast<const f32x4 *>(Va + ((g0 + GP + u) % 9) * 512 + ((g0 + GP + u) / 9) * 8);
+#endif
+#ifdef DS_W4_X_NOPIX
+            if (false) {
+#else
+            if (more && g0 * DS_W4_PXG < 36) {       // column-major: the column pass reads column 0 first
+#endif
+#pragma unroll
+                for (int k = DS_W4_PXG * g0; k < DS_W4_PXG * (g0 + GP) && k < 36; ++k) load_pixel((k % 6) * 6 + k / 6, cn);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[g % 6][nb][j], acc[pi][nb], 0, 0, 0);
+                for (int u = 0; u < GP; ++u)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int g = g0 + u, pi = g % 9;
+                        if (NB == 2 && pi == 8) mfma_v(accv[nb], av[u][j], b[g % 6][nb][j]);
+                        else acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][j], b[g % 6][nb][j], acc[pi][nb], 0, 0, 0);
+                    }
             __builtin_amdgcn_sched_barrier(0);
-            if (g + 6 < 18) load_b(g % 6, (g + 6) % 9, 2 * ks + (g + 6) / 9);
-            else if (more) load_b(g % 6, g + 6 - 18, 2 * ks + 2);
-            a = an;
+#ifndef DS_W4_X_NOB
+#pragma unroll
+            for (int u = 0; u < GP; ++u) {
+                const int g = g0 + u;
+                if (g + 6 < 18) load_b(g % 6, (g + 6) % 9, 2 * ks + (g + 6) / 9);
+                else if (more) load_b(g % 6, g + 6 - 18, 2 * ks + 2);
+            }
+#endif
+#pragma unroll
+            for (int u = 0; u < GP; ++u) av[u] = avn[u];
         }
     }
-
-    // ---- output transform Y = A^T M A through LDS, one 32-channel block at a time ---------------------------------------
-    // M[xi][co][tile quad ^ (co & 7)][4 tiles]: 16-byte writes (an accumulator's four consecutive rows) and 16-byte
-    // gathers, both conflict free through the quad swizzle
+    W4_STAMP(2);
+#ifdef DS_W4_NO_EPILOGUE        // timing experiment: K loop only (keeps the accumulators alive with one store)
+    if (p.flags == 12345) p.z[tid] = acc[0][0][0] + acc[7][NB - 1][15] + accv[NB - 1][3];
+    return;
+#endif
     const int ec = tid & 31, eg = tid >> 5;
     const __amdgpu_buffer_rsrc_t srd_z = w4srd(p.z, p.z_bytes);
     const __amdgpu_buffer_rsrc_t srd_y = w4srd(BNS ? p.y : p.z, p.z_bytes);
@@ -241,16 +311,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        __syncthreads();            // the K loop's last fragment reads / the previous block's gathers are done
+        lds_barrier();            // the K loop's last fragment reads / the previous block's gathers are done
         // accumulator elements 4 eq .. 4 eq + 3: tile rows 4 (2 eq + kh) .. + 3 of channel column li
 #pragma unroll
         for (int pi = 0; pi < 9; ++pi)
 #pragma unroll
             for (int eq = 0; eq < 4; ++eq) {
-                const f32x4 v = {acc[pi][nb][4 * eq], acc[pi][nb][4 * eq + 1], acc[pi][nb][4 * eq + 2], acc[pi][nb][4 * eq + 3]};
+                const f32x16 &c = (NB == 2 && pi == 8) ? accv[nb] : acc[pi][nb];
+                const f32x4 v = {c[4 * eq], c[4 * eq + 1], c[4 * eq + 2], c[4 * eq + 3]};
                 *reinterpret_cast<f32x4 *>(smem + (wave * 9 + pi) * 1024 + li * 32 + (((2 * eq + kh) ^ (li & 7)) * 4)) = v;
             }
-        __syncthreads();
+        lds_barrier();
+        W4_STAMP(3 + 2 * nb);
         const int col = co0 + 32 * nb + ec;
         const bool colok = col < p.Cout;
         const float pv = (!BNS && p.pivot && colok) ? p.pivot[col] : 0.f;
@@ -301,6 +373,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
                 }
             if constexpr (BNS) __builtin_amdgcn_sched_barrier(0);      // one row's loads in flight at a time (registers)
         }
+        W4_STAMP(4 + 2 * nb);
         if (BNS || (p.flags & DS_EPI_STATS)) {
             // the eight threads of a column: lanes ec / ec + 32 of the four waves, combined in a fixed order
             s += __shfl_xor(s, 32);
@@ -309,7 +382,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
                 red[(wave * 32 + li) * 2 + 0] = s;
                 red[(wave * 32 + li) * 2 + 1] = q;
             }
-            __syncthreads();
+            lds_barrier();
             if (tid < 32 && colok) {
                 float ss = 0.f, qq = 0.f;
 #pragma unroll
@@ -322,6 +395,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
             }
         }
     }
+    W4_STAMP(7);
 }
 
 // U = G g G^T (6 x 6) for every (ci, co) pair of the TF HWIO filter w [3][3][Cin][Cout], stored for the kernel's
@@ -402,6 +476,12 @@ W4Choice w4_choose(int N, int H, int W, int Cin, int Cout) {
 }
 
 }  // namespace
+
+#ifdef DS_W4_PROF
+extern "C" int ds_debug_wino4_prof(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_prof), sizeof(unsigned long long) * 8);
+}
+#endif
 
 extern "C" int ds_conv_wino4_supported(int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
     return (H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0) ? 1 : 0;
