@@ -1,6 +1,6 @@
-// 3x3 stride-1 SAME convolution (forward and dgrad) as fused Winograd F(4x4, 3x3) on the fp32 matrix cores, for the
-// maps whose height and width are multiples of four (Conv2d_2c_3x3 at 56 x 56 and the Branch_1 / Branch_2 3x3 layers
-// of Mixed_3b / 3c at 28 x 28: image_model/inception_v1.py:74-75, :86-115) -- half of the 3x3 layers' multiplies.
+// 3x3 stride-1 SAME convolution (forward and dgrad) as fused Winograd F(4x4, 3x3) on the fp32 matrix cores: Conv2d_2c_3x3
+// at 56 x 56, the Branch_1 / Branch_2 3x3 layers of Mixed_3b / 3c at 28 x 28 (image_model/inception_v1.py:74-75,
+// :86-115) and those 14 x 14 / 7 x 7 layers (:122-247) whose workgroup count suits it (w4_choose below).
 //
 // F(4x4, 3x3) trades the 144 multiplies of a 4x4 output tile and channel pair for 36 (F(2x2, 3x3), conv_wino.hip: 64):
 //     Y = A^T [ (G g G^T) (.) (B^T d B) ] A        (Lavin & Gray, interpolation points 0, +-1, +-2, inf)
@@ -10,28 +10,35 @@
 //
 // 36 accumulators of 32 x 32 do not fit one wave (576 registers), so unlike conv_wino.hip the positions are SPLIT over
 // the four waves of a workgroup (nine each) and the transformed input goes through LDS once:
-//   * workgroup = 32 tiles (4x4 outputs each) x 32 NB output channels (NB = 1, 2), K step = 8 input channels;
-//   * transform role: thread (tile t = tid / 8, channel c = tid % 8) loads the 36 pixels of its 6x6 patch for ONE
-//     channel (dword SRD loads: the eight channel lanes of a pixel are one 32-byte run; pixel offsets are wave-uniform
-//     and ride in the scalar offset, padding pixels read zeros from an out-of-range vector offset), runs B^T d B in
-//     registers (144 fused multiply-adds) and writes the 36 results to V[xi][t][c] in LDS (lane-linear, conflict free);
-//   * matrix role: wave w owns positions 9 w .. 9 w + 8.  Its A fragments are one ds_read_b128 per position
-//     (lane (i, kh): tile i, channels 4 kh .. 4 kh + 3); its B fragments -- U for ITS positions only, nothing another
-//     wave needs -- come straight from global memory into registers, one fully coalesced 1 KB load per position and
-//     channel block (U is stored [36][Cin / 8][Cout][8] by ds_wino4_transform_weights for exactly this), requested
-//     six positions (3072 matrix cycles) ahead into a register ring.  9 NB accumulators of 32 x 32 per wave (288 registers at NB = 2);
-//   * V is double buffered: one barrier per K step;
-//   * epilogue, per channel block: the waves park their accumulators in LDS as M[xi][tile][co] (144 KB -- gfx950's
-//     160 KB LDS, the V buffers are dead by then), then thread (co = tid % 32, tiles 4 (tid / 32) .. + 3) gathers the 36
-//     values of each (tile, co), runs A^T M A (100 adds) and stores the 4x4 outputs as 128-byte channel runs; BatchNorm
-//     column statistics about the pivot (DS_EPI_STATS) or the BatchNorm-backward sums of the consumer (DS_EPI_BNSUMS)
-//     as in conv_wino.hip.
+//   * workgroup = 32 tiles (4x4 outputs each; partial border tiles for any H, W) x 32 NB output channels (NB = 1, 2),
+//     K step = 16 input channels;
+//   * transform role: thread (tile t = tid / 8, channel pair c = tid % 8) loads the 36 pixels of its 6x6 patch for TWO
+//     channels (8-byte SRD loads: the eight lanes of a pixel are one 64-byte run; pixel offsets are wave-uniform and
+//     ride in the scalar offset, padding pixels read zeros from an out-of-range vector offset), runs B^T d B in
+//     registers as 144 v_pk_fma_f32 and writes the 36 results to V[xi][t][2c..] in LDS (lane-linear, conflict free);
+//   * matrix role: wave w owns positions 9 w .. 9 w + 8.  Its A fragments are one ds_read_b128 per position and
+//     8-channel half step (lane (i, kh): tile i, channels 4 kh .. 4 kh + 3); its B fragments -- U for ITS positions
+//     only, nothing another wave needs -- come straight from global memory into registers, one fully coalesced 1 KB
+//     load per position and channel block (U is stored [36][Cin / 8][Cout][8] by ds_wino4_transform_weights for exactly
+//     this), requested six positions (3072 matrix cycles) ahead into a register ring.  9 NB accumulators of 32 x 32
+//     per wave: at NB = 2 that is 288 registers against 256 accumulation registers, so position 8's pair lives in the
+//     architectural file (mfma_v);
+//   * software pipeline: V is double buffered and the transform of K step k + 1 runs in twelve chunks BETWEEN the MFMA
+//     groups of step k, the pixels of step k + 2 are requested behind it into the registers it freed: one barrier per
+//     K step, no load / LDS / dependency latency in front of the matrix pipe (the VALU issue time itself still adds:
+//     measured 5.7 us per step against 4.1 us of MFMAs alone);
+//   * epilogue, per channel block: the waves park their accumulators in LDS as M[xi][co][tile] (144 KB -- gfx950's
+//     160 KB LDS, the V buffers are dead by then; 16-byte writes and gathers, quad-swizzled), then thread
+//     (co = tid % 32, tiles 4 (tid / 32) .. + 3) runs A^T M A on its four tiles at once and stores the 4x4 outputs as
+//     128-byte channel runs; BatchNorm column statistics about the pivot (DS_EPI_STATS) or the BatchNorm-backward
+//     sums of the consumer (DS_EPI_BNSUMS) as in conv_wino.hip.
 // dgrad: the same kernel with U built from the flipped, transposed filter.
 // Numerics: fp32 throughout, ordered reductions (deterministic).  The F(4x4) transforms carry constants up to 8 and
 // cost about one decimal digit against F(2x2): relative rms error 2.4e-6 instead of 3.7e-7 on post-ReLU activations
 // with 192 input channels (scratch/wino4_numerics.py), against 2.6e-7 for a direct fp32 sum.
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "ds_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -40,16 +47,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr unsigned kOOB = 0x80000000u;
-
-#ifdef DS_W4_PROF               // tuning aid (scratch builds only): one mid-grid workgroup stamps its phases, 100 MHz ticks
-__device__ unsigned long long g_w4_prof[8];
-#define W4_STAMP(i)                                                                                         \
-    do {                                                                                                    \
-        if (tid == 0 && blockIdx.x == (gridDim.x / 2 & ~7u)) g_w4_prof[i] = __builtin_amdgcn_s_memrealtime();  \
-    } while (0)
-#else
-#define W4_STAMP(i)
-#endif
 
 struct Wino4Params {
     const float *x;         // [N, H, W, ldx]
@@ -76,10 +73,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // the second channel block's pass cost 9 us instead of ~3), in the K loop the prefetches in flight.  The exchanges here
 // go through LDS alone, so only the LDS counter has to be zero.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-#ifndef DS_W4_PXG
-#define DS_W4_PXG 3          // pixel loads of the next K step issued per MFMA group (36 in all)
-#endif
 
 // every operation of the transforms is written as a fused multiply-add on a channel PAIR so that it compiles to one
 // v_pk_fma_f32 (hipcc packs neither subtractions nor mixed add / fma expressions on its own)
@@ -122,7 +115,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
-    W4_STAMP(0);
     // 1-D XCD-aware launch as conv_wino.hip: the channel blocks of a tile group run back to back on one XCD
     const int id = blockIdx.x;
     const int lin = (id & 7) * (int)(gridDim.x >> 3) + (id >> 3);
@@ -185,9 +177,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
 
     f32x2 raw[36];
     f32x4 b[6][NB];             // ring: group g (half step g / 9, position g % 9) uses slot g % 6, six groups of lead
-    auto load_pixel = [&](int q, int c0) {
+    auto load_pixel = [&](int q, int c0, const unsigned *ro) {
         const int py = q / 6, px = q - py * 6;
-        raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(srd_x, cv[px] ? rowoff[py] : kOOB,
+        raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(srd_x, cv[px] ? ro[py] : kOOB,
                                                                                  py * rowstep + px * pixstep + c0 * 4, 0));
     };
     auto load_b = [&](int slot, int pi, int hs) {
@@ -196,73 +188,82 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
             b[slot][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_u, boff[nb], (wave * 9 + pi) * upos + hs * ustep, 0));
     };
 
+    // ---- the input transform V = B^T d B of this thread's (tile, channel pair), in two halves of six chunks each so it
+    // can be spread over the MFMA groups of the previous K step:
+    //   column chunk px: B^T applied down patch column px (raw[.][px] -> t[.][px]; the pixels of that column are dead)
+    //   row chunk i:     B^T applied along row i of t -> the six positions (i, 0..5), written position-major to LDS
+    f32x2 t[36];
+    auto col_chunk = [&](int px) {
+        in1d(raw[px], raw[6 + px], raw[12 + px], raw[18 + px], raw[24 + px], raw[30 + px], t[px], t[6 + px], t[12 + px],
+             t[18 + px], t[24 + px], t[30 + px]);
+    };
+    auto row_chunk = [&](int i, float *Vw) {
+        f32x2 v[6];
+        in1d(t[i * 6], t[i * 6 + 1], t[i * 6 + 2], t[i * 6 + 3], t[i * 6 + 4], t[i * 6 + 5], v[0], v[1], v[2], v[3], v[4], v[5]);
 #pragma unroll
-    for (int q = 0; q < 36; ++q) load_pixel(q, 0);
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2 *>(Vw + (i * 6 + j) * 512 + tid * 2) = v[j];
+    };
+
+    // prologue: pixels and transform of K step 0, pixels of K step 1, the first six weight fragments
+#pragma unroll
+    for (int q = 0; q < 36; ++q) load_pixel(q, 0, rowoff);
 #pragma unroll
     for (int g = 0; g < 6; ++g) load_b(g, g, 0);
+#pragma unroll
+    for (int px = 0; px < 6; ++px) col_chunk(px);
+    if (ksteps > 1) {
+#pragma unroll
+        for (int q = 0; q < 36; ++q) load_pixel(q, 16, rowoff);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) row_chunk(i, smem);
+    lds_barrier();
 
-    W4_STAMP(1);
-#ifdef DS_W4_NO_LOOP            // timing experiment: prologue + epilogue only
-    for (int ks = 0; ks < (p.flags == 12345 ? ksteps : 0); ++ks) {
-#else
-    for (int ks = 0; ks < ksteps; ++ks) {
-#endif
-        float *Vw = smem + (ks & 1) * (36 * 512);
-        // ---- V = B^T d B for this thread's (tile, channel pair): columns first, then rows; position-major in LDS ----
-        {
-            f32x2 t[36];
+    // One K step.  LAST = false: every step but the last -- the transform of step ks + 1 and the pixel requests of step
+    // ks + 2 are UNCONDITIONAL (past the last step the requests carry out-of-range offsets and return zeros nobody
+    // uses): a condition around them would keep all 72 pixel registers alive across the whole loop next to the 72
+    // registers of the half-transformed patch, which the kernel does not have.  LAST = true: MFMAs only.
+    auto k_step = [&](int ks, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const float *Vr = smem + (ks & 1) * (36 * 512);
+        float *Vw = smem + ((ks + 1) & 1) * (36 * 512);
+        const int c2 = (ks + 2) * 16;
+        // row offsets of the requests for step ks + 2: out of range past the last step (the scalar offset is not part of
+        // the SRD's range check, so a request there could leave the tensor).  The asm keeps the 36 per-pixel offsets
+        // from being hoisted out of the loop into 36 registers the kernel does not have: one v_cndmask each.
+        unsigned ro[6];
 #pragma unroll
-            for (int px = 0; px < 6; ++px)
-                in1d(raw[px], raw[6 + px], raw[12 + px], raw[18 + px], raw[24 + px], raw[30 + px], t[px], t[6 + px],
-                     t[12 + px], t[18 + px], t[24 + px], t[30 + px]);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                f32x2 v[6];
-                in1d(t[i * 6], t[i * 6 + 1], t[i * 6 + 2], t[i * 6 + 3], t[i * 6 + 4], t[i * 6 + 5], v[0], v[1], v[2], v[3], v[4], v[5]);
-#ifdef DS_W4_X_NOXF
-#pragma unroll
-                for (int j = 0; j < 6; ++j) v[j] = raw[i * 6 + j];
-#endif
-#ifndef DS_W4_X_NOLDSW
-#pragma unroll
-                for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2 *>(Vw + (i * 6 + j) * 512 + tid * 2) = v[j];
-#else
-                if (p.flags == 12345) Vw[tid] = v[0][0] + v[1][0] + v[2][0] + v[3][0] + v[4][0] + v[5][0];
-#endif
-            }
+        for (int k = 0; k < 6; ++k) {
+            ro[k] = (ks + 2 < ksteps) ? rowoff[k] : kOOB;
+            asm volatile("" : "+v"(ro[k]));
         }
-        const bool more = ks + 1 < ksteps;
-        const int cn = (ks + 1) * 16;
-        // (keeps the 36 per-pixel offsets from being hoisted out of the loop into 36 registers the kernel does not have:
-        // they are one v_cndmask on a column mask each)
-#pragma unroll
-        for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(rowoff[k]));
-#ifndef DS_W4_X_NOBAR
-        lds_barrier();
-#endif
-        // ---- two 8-channel half steps x nine positions: A fragment from LDS, 4 NB MFMAs; the next K step's pixels
-        // (four per group of the first half step) and the weights six groups ahead are requested between the groups ----
-        const float *Va = Vw + (wave * 9) * 512 + li * 16 + kh * 4;
+        // ---- two 8-channel half steps x nine positions = 18 groups: A fragment from LDS, 4 NB MFMAs.  Between the
+        // groups, in the shadow of the matrix pipe: the transform of K step ks + 1 (column chunks in groups 0-5, row
+        // chunks in groups 6-11: VALU issue still adds to the MFMA time, but load, LDS and dependency latencies no longer
+        // do), behind each row chunk the six pixels of one patch column for K step ks + 2 into the registers the column
+        // chunks freed (used twelve groups later), and the weights six groups ahead -----------------------------------
+        const float *Va = Vr + (wave * 9) * 512 + li * 16 + kh * 4;
         // NB = 1: two groups at a time, their MFMAs alternating -- four back-to-back MFMAs on ONE accumulator wait for
-        // each other's results (measured: the NB = 1 step took as long as the NB = 2 step)
+        // each other's results
         constexpr int GP = NB == 1 ? 2 : 1;
         f32x4 av[GP], avn[GP];
 #pragma unroll
         for (int u = 0; u < GP; ++u) av[u] = avn[u] = *reinterpret_cast<const f32x4 *>(Va + u * 512);
 #pragma unroll
         for (int g0 = 0; g0 < 18; g0 += GP) {
-#ifndef DS_W4_X_NOAREAD
 #pragma unroll
             for (int u = 0; u < GP; ++u)
                 if (g0 + GP + u < 18) avn[u] = *reinterpret_cast<const f32x4 *>(Va + ((g0 + GP + u) % 9) * 512 + ((g0 + GP + u) / 9) * 8);
-#endif
-#ifdef DS_W4_X_NOPIX
-            if (false) {
-#else
-            if (more && g0 * DS_W4_PXG < 36) {       // column-major: the column pass reads column 0 first
-#endif
+            if constexpr (!LAST) {
 #pragma unroll
-                for (int k = DS_W4_PXG * g0; k < DS_W4_PXG * (g0 + GP) && k < 36; ++k) load_pixel((k % 6) * 6 + k / 6, cn);
+                for (int g = g0; g < g0 + GP; ++g) {
+                    if (g < 6) col_chunk(g);
+                    else if (g < 12) {
+                        row_chunk(g - 6, Vw);
+#pragma unroll
+                        for (int py = 0; py < 6; ++py) load_pixel(py * 6 + (g - 6), c2, ro);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -276,23 +277,23 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
                         else acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][j], b[g % 6][nb][j], acc[pi][nb], 0, 0, 0);
                     }
             __builtin_amdgcn_sched_barrier(0);
-#ifndef DS_W4_X_NOB
 #pragma unroll
             for (int u = 0; u < GP; ++u) {
                 const int g = g0 + u;
                 if (g + 6 < 18) load_b(g % 6, (g + 6) % 9, 2 * ks + (g + 6) / 9);
-                else if (more) load_b(g % 6, g + 6 - 18, 2 * ks + 2);
+                else if (!LAST) load_b(g % 6, g + 6 - 18, 2 * ks + 2);
             }
-#endif
 #pragma unroll
             for (int u = 0; u < GP; ++u) av[u] = avn[u];
         }
+    };
+    for (int ks = 0; ks + 1 < ksteps; ++ks) {
+        k_step(ks, std::false_type{});
+        lds_barrier();          // V of step ks + 1 is complete, V of step ks is free
     }
-    W4_STAMP(2);
-#ifdef DS_W4_NO_EPILOGUE        // timing experiment: K loop only (keeps the accumulators alive with one store)
-    if (p.flags == 12345) p.z[tid] = acc[0][0][0] + acc[7][NB - 1][15] + accv[NB - 1][3];
-    return;
-#endif
+    k_step(ksteps - 1, std::true_type{});
+
+    // ---- output transform Y = A^T M A through LDS, one 32-channel block at a time ---------------------------------------
     const int ec = tid & 31, eg = tid >> 5;
     const __amdgpu_buffer_rsrc_t srd_z = w4srd(p.z, p.z_bytes);
     const __amdgpu_buffer_rsrc_t srd_y = w4srd(BNS ? p.y : p.z, p.z_bytes);
@@ -322,7 +323,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
                 *reinterpret_cast<f32x4 *>(smem + (wave * 9 + pi) * 1024 + li * 32 + (((2 * eq + kh) ^ (li & 7)) * 4)) = v;
             }
         lds_barrier();
-        W4_STAMP(3 + 2 * nb);
         const int col = co0 + 32 * nb + ec;
         const bool colok = col < p.Cout;
         const float pv = (!BNS && p.pivot && colok) ? p.pivot[col] : 0.f;
@@ -373,7 +373,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
                 }
             if constexpr (BNS) __builtin_amdgcn_sched_barrier(0);      // one row's loads in flight at a time (registers)
         }
-        W4_STAMP(4 + 2 * nb);
         if (BNS || (p.flags & DS_EPI_STATS)) {
             // the eight threads of a column: lanes ec / ec + 32 of the four waves, combined in a fixed order
             s += __shfl_xor(s, 32);
@@ -395,7 +394,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
             }
         }
     }
-    W4_STAMP(7);
 }
 
 // U = G g G^T (6 x 6) for every (ci, co) pair of the TF HWIO filter w [3][3][Cin][Cout], stored for the kernel's
@@ -447,7 +445,7 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float *w, floa
 
 // Which kernel for a shape?  Launch-time model fitted to profiles/r03_wino4_layers.txt (B = 256 and B = 32): a launch
 // takes ceil(workgroups / CUs) rounds of one workgroup's duration,
-//     F(4x4), NB = 2: 13 us + 6.0 us per 16-channel K step      NB = 1: 8.5 us + 3.8 us per K step
+//     F(4x4), NB = 2: 12.5 us + 5.7 us per 16-channel K step      NB = 1: 8.5 us + 3.2 us per K step
 //     F(2x2) (conv_wino.hip): 8.7 us + 2.35 us per 8-channel K step, 128 tiles of 2x2 x 32 channels per workgroup
 // so the 14 x 14 and 7 x 7 maps (128 / 32 tile groups only) go to whichever fills the rounds best.
 struct W4Choice {
@@ -467,7 +465,7 @@ W4Choice w4_choose(int N, int H, int W, int Cin, int Cout) {
     double t[3];
     for (int nb = 1; nb <= 2; ++nb) {
         const int64_t wgs = g4 * ((Cout + 32 * nb - 1) / (32 * nb));
-        t[nb] = ceil(wgs / cus) * ((Cin / 16) * (nb == 2 ? 6.0 : 3.8) + (nb == 2 ? 13.0 : 8.5));
+        t[nb] = ceil(wgs / cus) * ((Cin / 16) * (nb == 2 ? 5.7 : 3.2) + (nb == 2 ? 12.5 : 8.5));
     }
     c.us2 = ceil(g2 * ((Cout + 31) / 32) / cus) * (8.7 + 2.35 * (Cin / 8));
     c.nb = (forced == 1 || forced == 2) ? forced : (t[2] < t[1] ? 2 : 1);
@@ -476,12 +474,6 @@ W4Choice w4_choose(int N, int H, int W, int Cin, int Cout) {
 }
 
 }  // namespace
-
-#ifdef DS_W4_PROF
-extern "C" int ds_debug_wino4_prof(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_prof), sizeof(unsigned long long) * 8);
-}
-#endif
 
 extern "C" int ds_conv_wino4_supported(int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
     return (H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0) ? 1 : 0;
