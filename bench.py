@@ -382,9 +382,10 @@ def main():
                      "conv_fp8d_kernel (ds_conv_fp8: v_mfma_f32_32x32x16_fp8_fp8 forward, _bf8_fp8 dgrad, per-tensor power-of-two "
                      "scales, fp32 accumulate) for the 1x1 / 3x3 convs, bf16 stem, together with the fp32 GEMMs of the LSTM / heads"
                      if args.dtype == "fp8" else
-                     "conv_igemm_kernel + conv_glds_kernel + conv_wino_kernel (fp32 v_mfma_f32_32x32x2_f32: implicit GEMM for conv fwd / "
-                     "dgrad / GEMMs through ds_conv_igemm, fused Winograd F(2x2,3x3) for the 3x3 layers through ds_conv_wino; FLOPs "
-                     "counted are the convolution's 2*M*N*K, so the Winograd launches can exceed the matrix peak)")
+                     "conv_igemm_kernel + conv_glds_kernel + gemm_wide_kernel + conv_stem_kernel + conv_wino_kernel + conv_wino4_kernel "
+                     "(fp32 v_mfma_f32_32x32x2_f32: implicit GEMM for conv fwd / dgrad / GEMMs through ds_conv_igemm and ds_conv_stem, "
+                     "fused Winograd F(4x4,3x3) / F(2x2,3x3) for the 3x3 layers through ds_conv_wino4 / ds_conv_wino; FLOPs counted "
+                     "are the convolution's 2*M*N*K, so the Winograd launches can exceed the matrix peak)")
             roof = dict(bound="mfma", kernel=kname,
                         achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
                         frac=round(ach / peak, 4), traffic=traffic, traffic_unit="HBM bytes per launch",

@@ -13,6 +13,11 @@ import sqlite3
 import sys
 from collections import defaultdict
 
+# the launches bench.py's roofline pass brackets (ops.ConvTimer: everything that goes through ds_conv_igemm / ds_conv_wino /
+# ds_conv_wino4 / ds_conv_stem / ds_conv_bf16 / ds_conv_fp8)
+CONV_FAMILY = ("conv_igemm_kernel", "conv_glds_kernel", "gemm_wide_kernel", "conv_wino_kernel", "conv_wino4_kernel",
+               "conv_stem_kernel", "conv_bf16_kernel", "conv_bf16d_kernel", "conv_fp8d_kernel")
+
 
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
@@ -48,10 +53,10 @@ def main():
         print("%-60s %8.1f %12.1f %12.1f %12.1f %14.1f" % (n[:60], c, fb / 1e6, 2 * fb / 1e6, wb / 1e6, (2 * fb + wb) / 1e6))
     print("%-60s %8s %12.1f %12.1f %12.1f %14.1f" % ("TOTAL", "", tot[0] / 1e6, 2 * tot[0] / 1e6, tot[1] / 1e6, (2 * tot[0] + tot[1]) / 1e6))
     if len(sys.argv) > 4:
-        conv = [v for k, v in out.items() if k.startswith(("conv_igemm_kernel", "conv_glds_kernel", "conv_wino_kernel", "conv_bf16_kernel"))]
+        conv = [v for k, v in out.items() if k.startswith(CONV_FAMILY)]
         calls = sum(v["calls_per_step"] for v in conv)
         hbm = sum(v["fetch_corrected_bytes"] + v["write_bytes"] for v in conv)
-        json.dump(dict(kernel="conv_igemm_kernel + conv_glds_kernel + conv_wino_kernel (+ conv_bf16_kernel)", launches_per_step=calls, hbm_bytes_per_step=hbm,
+        json.dump(dict(kernel=" + ".join(CONV_FAMILY), launches_per_step=calls, hbm_bytes_per_step=hbm,
                        hbm_bytes_per_launch=hbm / max(calls, 1), per_kernel=out,
                        note="FETCH_SIZE doubled per MI355X_MICROARCH.md; WRITE_SIZE as reported"),
                   open(sys.argv[4], "w"), indent=1)
