@@ -27,11 +27,11 @@
 //     groups of step k, the pixels of step k + 2 are requested behind it into the registers it freed: one barrier per
 //     K step, no load / LDS / dependency latency in front of the matrix pipe (the VALU issue time itself still adds:
 //     measured 5.7 us per step against 4.1 us of MFMAs alone);
-//   * epilogue, per channel block: the waves park their accumulators in LDS as M[xi][co][tile] (144 KB -- gfx950's
-//     160 KB LDS, the V buffers are dead by then; 16-byte writes and gathers, quad-swizzled), then thread
-//     (co = tid % 32, tiles 4 (tid / 32) .. + 3) runs A^T M A on its four tiles at once and stores the 4x4 outputs as
-//     128-byte channel runs; BatchNorm column statistics about the pivot (DS_EPI_STATS) or the BatchNorm-backward
-//     sums of the consumer (DS_EPI_BNSUMS) as in conv_wino.hip.
+//   * epilogue, per channel block: the waves park their accumulators in LDS as M[xi][tile][co] (144 KB -- gfx950's
+//     160 KB LDS, the V buffers are dead by then), then thread (tile = tid / 8, channel quad = tid % 8) gathers its 36
+//     positions with 16-byte reads, runs A^T M A on four channels at once and stores every output pixel as 16 bytes
+//     (eight lanes = one 128-byte run); BatchNorm column statistics about the pivot (DS_EPI_STATS) or the
+//     BatchNorm-backward sums of the consumer (DS_EPI_BNSUMS) as in conv_wino.hip.
 // dgrad: the same kernel with U built from the flipped, transposed filter.
 // Numerics: fp32 throughout, ordered reductions (deterministic).  The F(4x4) transforms carry constants up to 8 and
 // cost about one decimal digit against F(2x2): relative rms error 2.4e-6 instead of 3.7e-7 on post-ReLU activations
@@ -43,6 +43,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -74,9 +75,26 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // go through LDS alone, so only the LDS counter has to be zero.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// every operation of the transforms is written as a fused multiply-add on a channel PAIR so that it compiles to one
-// v_pk_fma_f32 (hipcc packs neither subtractions nor mixed add / fma expressions on its own)
-__device__ __forceinline__ f32x2 pfma(float k, f32x2 a, f32x2 b) { return __builtin_elementwise_fma(f32x2{k, k}, a, b); }
+// The input transform works on channel PAIRS with packed fp32 instructions.  Left to hipcc, the subtractions and the
+// multiply-adds whose constant is not an inline one (-5) came out as two scalar instructions each (72 v_fma_f32 + 40
+// v_add_f32 beside 88 packed ones per K step), and with one wave per SIMD every VALU issue slot is a slot the matrix pipe
+// idles: both forms are pinned here (constant as an SGPR pair, negation as the packed source modifier).
+__device__ __forceinline__ f32x2 pfma(float k, f32x2 a, f32x2 b) {       // k * a + b
+    f32x2 r;
+    const f32x2 kk = {k, k};
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "s"(kk), "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 padd(f32x2 a, f32x2 b) {                // a + b
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 psub(f32x2 a, f32x2 b) {                // a - b
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // v_mfma_f32_32x32x2_f32 with the accumulator in architectural vector registers
 __device__ __forceinline__ void mfma_v(f32x16 &c, float a, float b) {
@@ -87,10 +105,10 @@ __device__ __forceinline__ void mfma_v(f32x16 &c, float a, float b) {
 __device__ __forceinline__ void in1d(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2 d5, f32x2 &t0, f32x2 &t1,
                                      f32x2 &t2, f32x2 &t3, f32x2 &t4, f32x2 &t5) {
     const f32x2 a = pfma(-4.f, d2, d4), b = pfma(-4.f, d1, d3);
-    const f32x2 c = pfma(-1.f, d2, d4), e = pfma(-1.f, d1, d3);
+    const f32x2 c = psub(d4, d2), e = psub(d3, d1);
     t0 = pfma(4.f, d0, pfma(-5.f, d2, d4));
-    t1 = pfma(1.f, b, a);
-    t2 = pfma(-1.f, b, a);
+    t1 = padd(a, b);
+    t2 = psub(a, b);
     t3 = pfma(2.f, e, c);
     t4 = pfma(-2.f, e, c);
     t5 = pfma(4.f, d1, pfma(-5.f, d3, d5));
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
         // ---- two 8-channel half steps x nine positions = 18 groups: A fragment from LDS, 4 NB MFMAs.  Between the
         // groups, in the shadow of the matrix pipe: the transform of K step ks + 1 (column chunks in groups 0-5, row
         // chunks in groups 6-11: VALU issue still adds to the MFMA time, but load, LDS and dependency latencies no longer
-        // do), behind each row chunk the six pixels of one patch column for K step ks + 2 into the registers the column
+        // do), from group 6 on three pixels per group for K step ks + 2, column by column, into the registers the column
         // chunks freed (used twelve groups later), and the weights six groups ahead -----------------------------------
         const float *Va = Vr + (wave * 9) * 512 + li * 16 + kh * 4;
         // NB = 1: two groups at a time, their MFMAs alternating -- four back-to-back MFMAs on ONE accumulator wait for
@@ -258,10 +276,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
 #pragma unroll
                 for (int g = g0; g < g0 + GP; ++g) {
                     if (g < 6) col_chunk(g);
-                    else if (g < 12) {
-                        row_chunk(g - 6, Vw);
+                    else if (g < 12) row_chunk(g - 6, Vw);
+                    if (g >= 6) {               // three pixels per group over groups 6-17, column by column
 #pragma unroll
-                        for (int py = 0; py < 6; ++py) load_pixel(py * 6 + (g - 6), c2, ro);
+                        for (int k = 3 * (g - 6); k < 3 * (g - 6) + 3; ++k) load_pixel((k % 6) * 6 + k / 6, c2, ro);
                     }
                 }
             }
@@ -291,45 +309,46 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
         k_step(ks, std::false_type{});
         lds_barrier();          // V of step ks + 1 is complete, V of step ks is free
     }
-    k_step(ksteps - 1, std::true_type{});
+    k_step(__builtin_amdgcn_readfirstlane(ksteps - 1), std::true_type{});      // (uniform: no waterfall loops around its loads)
 
     // ---- output transform Y = A^T M A through LDS, one 32-channel block at a time ---------------------------------------
-    const int ec = tid & 31, eg = tid >> 5;
+    // The waves park their accumulators as M[xi][tile][co] (dword writes, a wave's 32 channel lanes side by side); then
+    // thread (tile et = tid / 8, channel quad eq = tid % 8) gathers the 36 positions of its tile for FOUR channels with
+    // one ds_read_b128 each (lane-linear), transforms them, and stores every output pixel as 16 bytes: 16 store
+    // instructions per thread and block where a thread-per-channel layout needs 64 (the dword stores were the bulk of the
+    // epilogue's time).
+    const int et = tid >> 3, eq = tid & 7;
     const __amdgpu_buffer_rsrc_t srd_z = w4srd(p.z, p.z_bytes);
     const __amdgpu_buffer_rsrc_t srd_y = w4srd(BNS ? p.y : p.z, p.z_bytes);
     const int orow = p.W * p.ldz * 4, opix = p.ldz * 4;
-    int tbase[4];               // pixel index of the top-left output of this thread's four tiles, or -1
-    int hrem[4], wrem[4];       // EDGE: output rows / columns of the tile inside the image
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = m0 + eg * 4 + r;
+    int tbase, hrem, wrem;      // pixel index of the tile's top-left output (or -1); EDGE: rows / columns inside the image
+    {
+        const int m = m0 + et;
         const int n = (m < p.Mt ? m : 0) / tpi;
         const int rr = (m < p.Mt ? m : 0) - n * tpi;
         const int th = rr / p.TW, tw = rr - th * p.TW;
-        tbase[r] = m < p.Mt ? (n * p.H + 4 * th) * p.W + 4 * tw : -1;
-        hrem[r] = p.H - 4 * th;
-        wrem[r] = p.W - 4 * tw;
+        tbase = m < p.Mt ? (n * p.H + 4 * th) * p.W + 4 * tw : -1;
+        hrem = p.H - 4 * th;
+        wrem = p.W - 4 * tw;
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         lds_barrier();            // the K loop's last fragment reads / the previous block's gathers are done
-        // accumulator elements 4 eq .. 4 eq + 3: tile rows 4 (2 eq + kh) .. + 3 of channel column li
+        // accumulator element e: tile row (e & 3) + 8 (e >> 2) + 4 kh, channel column li
 #pragma unroll
         for (int pi = 0; pi < 9; ++pi)
 #pragma unroll
-            for (int eq = 0; eq < 4; ++eq) {
+            for (int e = 0; e < 16; ++e) {
                 const f32x16 &c = (NB == 2 && pi == 8) ? accv[nb] : acc[pi][nb];
-                const f32x4 v = {c[4 * eq], c[4 * eq + 1], c[4 * eq + 2], c[4 * eq + 3]};
-                *reinterpret_cast<f32x4 *>(smem + (wave * 9 + pi) * 1024 + li * 32 + (((2 * eq + kh) ^ (li & 7)) * 4)) = v;
+                smem[(wave * 9 + pi) * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * kh) * 32 + li] = c[e];
             }
         lds_barrier();
-        const int col = co0 + 32 * nb + ec;
+        const int col = co0 + 32 * nb + 4 * eq;                 // first of this thread's four channels (Cout % 4 == 0)
         const bool colok = col < p.Cout;
-        const float pv = (!BNS && p.pivot && colok) ? p.pivot[col] : 0.f;
-        unsigned vo[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vo[r] = (tbase[r] >= 0 && colok) ? (unsigned)(tbase[r] * p.ldz + col) * 4u : kOOB;
-        const float *Mq = smem + ec * 32 + ((eg ^ (ec & 7)) * 4);
+        f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+        if (!BNS && p.pivot && colok) pv = *reinterpret_cast<const f32x4 *>(p.pivot + col);
+        const unsigned vo = (tbase >= 0 && colok) ? (unsigned)(tbase * p.ldz + col) * 4u : kOOB;
+        const float *Mq = smem + tid * 4;
         f32x4 P[4][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j)
@@ -337,60 +356,64 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
                   *reinterpret_cast<const f32x4 *>(Mq + (2 * 6 + j) * 1024), *reinterpret_cast<const f32x4 *>(Mq + (3 * 6 + j) * 1024),
                   *reinterpret_cast<const f32x4 *>(Mq + (4 * 6 + j) * 1024), *reinterpret_cast<const f32x4 *>(Mq + (5 * 6 + j) * 1024),
                   P[0][j], P[1][j], P[2][j], P[3][j]);
-        float s = 0.f, q = 0.f;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            unsigned vof[4][4];         // store offsets of this output row: [column k][tile r]
+            unsigned vof[4];            // store offsets of this output row's four pixels
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) vof[k][r] = (!EDGE || (rr < hrem[r] && k < wrem[r])) ? vo[r] : kOOB;
-            float yv[4][4];
-            if constexpr (BNS) {        // the consumer's activations at this output row's sixteen store offsets
+            for (int k = 0; k < 4; ++k) vof[k] = (!EDGE || (rr < hrem && k < wrem)) ? vo : kOOB;
+            f32x4 yv[4];
+            if constexpr (BNS) {        // the consumer's activations at this output row's store offsets
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        yv[k][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_y, vof[k][r], rr * orow + k * opix, 0));
+                    yv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_y, vof[k], rr * orow + k * opix, 0));
             }
             f32x4 y[4];
             out1d(P[rr][0], P[rr][1], P[rr][2], P[rr][3], P[rr][4], P[rr][5], y[0], y[1], y[2], y[3]);
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[k]), srd_z, vof[k], rr * orow + k * opix, 0);
+                if constexpr (BNS) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float yy = y[k][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yy), srd_z, vof[k][r], rr * orow + k * opix, 0);
-                    if constexpr (BNS) {
-                        const float g = yv[k][r] > 0.f ? yy : 0.f;          // (an out-of-range offset reads y = 0)
-                        s += g;
-                        q += g * yv[k][r];
-                    } else {
-                        const float uu = vof[k][r] != kOOB ? yy - pv : 0.f;
-                        s += uu;
-                        q += uu * uu;
+                    for (int c = 0; c < 4; ++c) {
+                        const float g = yv[k][c] > 0.f ? y[k][c] : 0.f;          // (an out-of-range offset reads y = 0)
+                        s[c] += g;
+                        q[c] += g * yv[k][c];
                     }
+                } else {
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 uu = vof[k] != kOOB ? y[k] - pv : zero;
+                    s += uu;
+                    q += uu * uu;
                 }
-            if constexpr (BNS) __builtin_amdgcn_sched_barrier(0);      // one row's loads in flight at a time (registers)
+            }
         }
         if (BNS || (p.flags & DS_EPI_STATS)) {
-            // the eight threads of a column: lanes ec / ec + 32 of the four waves, combined in a fixed order
-            s += __shfl_xor(s, 32);
-            q += __shfl_xor(q, 32);
-            if (kh == 0) {
-                red[(wave * 32 + li) * 2 + 0] = s;
-                red[(wave * 32 + li) * 2 + 1] = q;
+            // the 32 tiles of a channel: lanes eq, eq + 8, ... of the four waves, combined in a fixed order
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s[c] += __shfl_xor(s[c], o);
+                    q[c] += __shfl_xor(q[c], o);
+                }
+            if (lane < 8) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    red[(wave * 32 + 4 * lane + c) * 2 + 0] = s[c];
+                    red[(wave * 32 + 4 * lane + c) * 2 + 1] = q[c];
+                }
             }
             lds_barrier();
-            if (tid < 32 && colok) {
+            if (tid < 32 && co0 + 32 * nb + tid < p.Cout) {
                 float ss = 0.f, qq = 0.f;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     ss += red[(w * 32 + tid) * 2 + 0];
                     qq += red[(w * 32 + tid) * 2 + 1];
                 }
-                p.stats[(int64_t)col * p.groups + group] = ss;
-                p.stats[((int64_t)p.Cout + col) * p.groups + group] = qq;
+                p.stats[(int64_t)(co0 + 32 * nb + tid) * p.groups + group] = ss;
+                p.stats[((int64_t)p.Cout + co0 + 32 * nb + tid) * p.groups + group] = qq;
             }
         }
     }
@@ -476,7 +499,7 @@ W4Choice w4_choose(int N, int H, int W, int Cin, int Cout) {
 }  // namespace
 
 extern "C" int ds_conv_wino4_supported(int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
-    return (H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0) ? 1 : 0;
+    return (H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0 && Cout % 4 == 0) ? 1 : 0;
 }
 
 extern "C" int ds_conv_wino4_prefer(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
@@ -502,8 +525,10 @@ extern "C" int ds_conv_wino4(const float *x, const float *u, float *z, float *st
                              int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz,
                              int32_t flags, void *stream) {
     DS_REQUIRE(x && u && z && N > 0, "ds_conv_wino4: bad argument");
-    DS_REQUIRE(ds_conv_wino4_supported(H, W, Cin, Cout) && ldx >= Cin && ldx % 2 == 0 && ldz >= Cout && (((uintptr_t)u) & 15) == 0 && (((uintptr_t)x) & 7) == 0,
-               "ds_conv_wino4: needs Cin %% 16 == 0, even ldx, 8-byte aligned x and 16-byte aligned weights");
+    DS_REQUIRE(ds_conv_wino4_supported(H, W, Cin, Cout) && ldx >= Cin && ldx % 2 == 0 && ldz >= Cout && ldz % 4 == 0 && ((((uintptr_t)u) | ((uintptr_t)z)) & 15) == 0 &&
+                   (((uintptr_t)x) & 7) == 0 && (!(flags & DS_EPI_BNSUMS) || (((uintptr_t)ymask) & 15) == 0) &&
+                   (!(flags & DS_EPI_STATS) || !pivot || (((uintptr_t)pivot) & 15) == 0),
+               "ds_conv_wino4: needs Cin %% 16 == 0, Cout %% 4 == 0, even ldx, ldz %% 4 == 0, 8-byte aligned x, 16-byte aligned u / z / y / pivot");
     DS_REQUIRE((flags & ~(DS_EPI_STATS | DS_EPI_BNSUMS)) == 0 && (!(flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) || stats),
                "ds_conv_wino4: only DS_EPI_STATS / DS_EPI_BNSUMS are supported (with a partials buffer)");
     DS_REQUIRE(!(flags & DS_EPI_BNSUMS) || (ymask && !(flags & DS_EPI_STATS)),
