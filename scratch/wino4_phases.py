@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""Phase stamps of one mid-grid ds_conv_wino4 workgroup (scratch build with -DDS_W4_PROF, DS_LIB=that .so) and the
-launch time; results of ablated builds are wrong by construction -- only the times matter."""
+"""Phase stamps of one mid-grid ds_conv_wino4 workgroup and the launch time.  Needs a build with the s_memrealtime
+stamps and ds_debug_wino4_prof (commit 3b6834c's csrc/conv_wino4.hip compiled with -DDS_W4_PROF, optionally the
+-DDS_W4_X_* ablation switches; DS_LIB=that .so): the product kernel carries neither.  Results of ablated builds are
+wrong by construction -- only the times matter (profiles/r03_notes.md has them)."""
 import ctypes as C
 import os
 import sys
