@@ -99,26 +99,30 @@ def test_random_shapes_round2_kernels():
             xs = x[..., :Ci]
             ref = S.conv2d_same(xs, w, 1).reshape(-1, Co)
             xd, wd = dev(x), dev(w)
-            u = torch.empty(16, Co, Ci, device="cuda")
-            ops.wino_transform_weights(ops._p(wd), u, Ci, Co, False)
-            plan = ops.WinoPlan(N, H, W, Ci, Ci + pad, Co, Co, flags=ops.DS_EPI_STATS)
-            z = torch.full((plan.M, Co), float("nan"), device="cuda")
-            stats = torch.zeros(2, Co, plan.partials, device="cuda"); pv = dev(rng.normal(size=Co))
-            plan.run(ops._p(xd), ops._p(u), ops._p(z), stats=ops._p(stats), pivot=ops._p(pv))
-            torch.cuda.synchronize()
+            pv = dev(rng.normal(size=Co))
+            dy = rng.normal(size=(N, H, W, Co)); dyd = dev(dy)
             um = ref - pv.double().cpu().numpy()
-            ok = not bad(z, ref, 3e-4) and not bad(stats[0].sum(1), um.sum(0), 2e-3) and not bad(stats[1].sum(1), (um ** 2).sum(0), 2e-3)
-            if Co % 8 == 0:
-                dy = rng.normal(size=(N, H, W, Co)); dyd = dev(dy)
-                ug = torch.empty(16, Ci, Co, device="cuda")
-                ops.wino_transform_weights(ops._p(wd), ug, Ci, Co, True)
-                g = ops.WinoPlan(N, H, W, Co, Co, Ci, Ci)
-                dx = torch.full((g.M, Ci), float("nan"), device="cuda")
-                g.run(ops._p(dyd), ops._p(ug), ops._p(dx))
-                torch.cuda.synchronize()
-                ok = ok and not bad(dx, S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1).reshape(-1, Ci), 3e-4)
-            if not ok:
-                failures.append("winograd case %d: N=%d H=%d W=%d Ci=%d Co=%d pad=%d" % (case, N, H, W, Ci, Co, pad))
+            for f4 in (False, True):                             # F(2x2,3x3) and, where the shape allows, F(4x4,3x3)
+                ok = True
+                if not f4 or ops.wino4_supported(H, W, Ci, Co):
+                    plan = ops.WinoPlan(N, H, W, Ci, Ci + pad, Co, Co, flags=ops.DS_EPI_STATS, f4=f4)
+                    u = torch.empty(plan.u_elems, device="cuda")
+                    ops.wino_transform_weights(ops._p(wd), u, Ci, Co, False, f4=f4)
+                    z = torch.full((plan.M, Co), float("nan"), device="cuda")
+                    stats = torch.zeros(2, Co, plan.partials, device="cuda")
+                    plan.run(ops._p(xd), ops._p(u), ops._p(z), stats=ops._p(stats), pivot=ops._p(pv))
+                    torch.cuda.synchronize()
+                    ok = not bad(z, ref, 3e-4) and not bad(stats[0].sum(1), um.sum(0), 2e-3) and not bad(stats[1].sum(1), (um ** 2).sum(0), 2e-3)
+                if Co % 8 == 0 and (not f4 or ops.wino4_supported(H, W, Co, Ci)):
+                    g = ops.WinoPlan(N, H, W, Co, Co, Ci, Ci, f4=f4)
+                    ug = torch.empty(g.u_elems, device="cuda")
+                    ops.wino_transform_weights(ops._p(wd), ug, Ci, Co, True, f4=f4)
+                    dx = torch.full((g.M, Ci), float("nan"), device="cuda")
+                    g.run(ops._p(dyd), ops._p(ug), ops._p(dx))
+                    torch.cuda.synchronize()
+                    ok = ok and not bad(dx, S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1).reshape(-1, Ci), 3e-4)
+                if not ok:
+                    failures.append("winograd %s case %d: N=%d H=%d W=%d Ci=%d Co=%d pad=%d" % ("F4x4" if f4 else "F2x2", case, N, H, W, Ci, Co, pad))
         lib.ds_debug_conv_set_wide(2)
         for case in range(24):                                   # ---- wide 1x1
             M = int(rng.randint(1, 700)); K = int(rng.choice([32, 40, 64, 72, 104, 192, 296])); Nn = int(rng.choice([8, 24, 32, 40, 64, 96, 104, 160, 200, 224, 256, 300]))
