@@ -183,6 +183,9 @@ def main():
                     help="--dtype bf16 / fp8: keep the activations in fp32 storage (default there: 16-bit activation storage)")
     ap.add_argument("--no-winograd", action="store_true",
                     help="A/B aid: implicit GEMM for every 3x3 layer instead of the fused Winograd F(2x2,3x3) kernel")
+    ap.add_argument("--no-zcat", action="store_true",
+                    help="A/B aid: every conv followed by its BatchNorm-apply pass (default: the 3x3 / Branch_3 convs of "
+                         "Mixed_3b..4e write z into the concat and the consumers normalise on load)")
     ap.add_argument("--no-wino4", action="store_true",
                     help="A/B aid: F(2x2,3x3) also on the 56 x 56 / 28 x 28 maps instead of the F(4x4,3x3) kernel")
     ap.add_argument("--graph", action="store_true",
@@ -255,6 +258,8 @@ def main():
         net.image.winograd = False
     if args.no_wino4 and net.image is not None:
         net.image.winograd4 = False
+    if args.no_zcat and net.image is not None:
+        net.image.zcat = False
     if args.no_branch_streams and net.image is not None:
         net.image.branch_streams = False
     if args.side_mode >= 0 and net.image is not None:

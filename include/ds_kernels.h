@@ -88,6 +88,12 @@ typedef struct ds_conv_desc {
     int32_t partials;         /* 0: unchecked.  >0 with DS_EPI_STATS: the partial count P the caller sized and  */
                               /* finalises with (ds_conv_igemm_partials at plan time); a launch that would     */
                               /* write a different count fails with DS_ERR_ARG instead of corrupting the stats */
+    /* BatchNorm + ReLU applied ON LOAD (wide 1x1 kernel only, ds_conv_igemm_norm_supported; all nullable):          */
+    const float *norm_rstd;   /* x holds pre-BatchNorm conv outputs z: the kernel uses relu(x*norm_rstd[k] +          */
+    const float *norm_shift;  /* norm_shift[k]) per reduction channel k (Cin floats each, Cin <= 1024).  Channels      */
+                              /* that are already activations carry (1, 0): relu(y) = y.                               */
+    const float *mask_rstd;   /* DS_EPI_BNSUMS: `mask` holds z of the consumer layer(s) instead of y; y is rebuilt as */
+    const float *mask_shift;  /* relu(mask*mask_rstd[n] + mask_shift[n]) per output column n (Cout floats each)        */
 } ds_conv_desc;
 
 /* DEBUG / A-B AIDS (ds_debug_*): process-global switches for tests and tuning scripts.  They are NOT re-entrant,
@@ -105,6 +111,8 @@ int ds_debug_conv_set_wide(int mode);
 int ds_conv_igemm_partials(const ds_conv_desc *d);
 /* 1 if a launch for `d` can carry DS_EPI_BNSUMS (plain 1x1 stride-1 shapes that run on the wide kernel).  */
 int ds_conv_igemm_bnsums_supported(const ds_conv_desc *d);
+/* ... and whether ds_conv_igemm would apply norm_rstd / norm_shift for this descriptor (same kernel, same rule).   */
+int ds_conv_igemm_norm_supported(const ds_conv_desc *d);
 /* stats (DS_EPI_STATS): float[2][Cout][P] partial column sums of (z - pivot) and (z - pivot)^2.
  * pivot (nullable = 0): float[Cout], any value near the column mean -- the build passes the previous step's
  * batch mean (the moving mean after a restore) -- so that the fp32 partial sums carry the spread of z rather
@@ -260,7 +268,9 @@ typedef struct ds_bn_sum_segments {
 int ds_bn_bwd_finalize_segs(const ds_bn_sum_segments *sg, int64_t M, int32_t C, const float *beta, float *dbeta,
                             float *coef, void *stream);
 /* amax (nullable): device word that receives max|dz| by atomic max (zeroed by the caller): the scale of an fp8 dgrad */
-int ds_bn_bwd_apply(const float *z, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
+/* ldz: row stride of z AND dz in floats (>= C, % 4 == 0): a layer whose conv writes straight into its slice of the   */
+/* Inception concat buffer is differentiated in place there                                                          */
+int ds_bn_bwd_apply(const float *z, int32_t ldz, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
                     const float *rstd, const float *shift, const float *coef, float *dz, float *amax, void *stream);
 
 /* slim.max_pool2d SAME/VALID (inception_v1.py:67,79,94,118,208) with arg-max record, and MaxPoolGrad. */

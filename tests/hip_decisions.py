@@ -11,9 +11,19 @@ def _np(t):
     return t.float().cpu().numpy()
 
 
+def keep_activations(net):
+    """Call BEFORE the step whose decisions are wanted.  By default the 3x3 / Branch_3 convs of Mixed_3b..4e leave
+    pre-BatchNorm values in the concat buffers (zcat) and the backward pass differentiates them in place, so their
+    ReLU masks cannot be read back afterwards; this switches the engine to the materialised form, which
+    test_zcat_step_is_bit_identical proves to give the same bits."""
+    if net.image is not None and net.image.zcat:
+        net.image.zcat, net.image.B = False, None
+
+
 def hip_decisions(net):
     from tumblr_emotions_amd.engine_image import ConvStage, MixedStage, PoolStage
     eng = net.image
+    assert not any(getattr(st, "zcat", False) for st in eng.stages), "call keep_activations(net) before the step"
     inj = {}
     for st in eng.stages:
         if isinstance(st, ConvStage):

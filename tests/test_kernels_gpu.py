@@ -354,6 +354,70 @@ def test_wide_1x1_kernel_forward_and_dgrad_match_oracle(case):
         lib.ds_debug_conv_set_wide(1)
 
 
+def test_batchnorm_relu_applied_on_load_equals_the_materialised_activation():
+    """The three kernel features behind InceptionV1Engine.zcat, each bit-identical to the materialised form:
+    ds_conv_desc.norm_rstd / norm_shift (wide 1x1 kernel: x holds z, the loader applies relu(z*rstd + shift); channels
+    with (1, 0) are activations already), mask_rstd / mask_shift (DS_EPI_BNSUMS epilogue rebuilds y from z), and
+    ds_bn_bwd_apply with a row stride (a layer differentiated in place inside a wider buffer)."""
+    ops = _ops()
+    rng = np.random.RandomState(91)
+    M, K, N = 20000, 192, 176                       # (enough row tiles for the wide kernel to be the one chosen)
+    z_in = rng.normal(size=(M, K)).astype(np.float32)
+    r = (np.abs(rng.normal(size=K)) + 0.5).astype(np.float32)
+    sh = rng.normal(size=K).astype(np.float32) * 0.3
+    r[:64], sh[:64] = 1.0, 0.0
+    z_in[:, :64] = np.maximum(z_in[:, :64], 0)                          # the Branch_0 slice is an activation
+    zt, rt, st = torch.from_numpy(z_in).cuda(), torch.from_numpy(r).cuda(), torch.from_numpy(sh).cuda()
+    y_in = torch.empty(M, K, device="cuda")                               # the materialised form: ds_bn_apply_relu's output
+    ops.bn_apply_relu(zt, M, K, rt, st, ops.make_segments([(0, K, y_in.data_ptr(), K)]))
+    w = torch.from_numpy((rng.normal(size=(K, N)) * 0.1).astype(np.float32)).cuda()
+    pivot = torch.from_numpy(rng.normal(size=N).astype(np.float32) * 0.1).cuda()
+    outs = []
+    for norm in (False, True):
+        plan = ops.ConvPlan(M, 1, 1, K, K, 1, 1, 1, N, N, 0, 1, N, flags=ops.DS_EPI_STATS, pad_t=0, pad_l=0, OH=1, OW=1)
+        if norm:
+            assert ops.conv_norm_supported(plan)
+            plan.d.norm_rstd, plan.d.norm_shift = rt.data_ptr(), st.data_ptr()
+        z = torch.empty(M, N, device="cuda")
+        stats = torch.zeros(2, N, plan.partials, device="cuda")
+        plan.run(ops._p(zt if norm else y_in), ops._p(w), ops._p(z), stats=ops._p(stats), pivot=ops._p(pivot))
+        torch.cuda.synchronize()
+        outs.append((z, stats))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # dgrad with DS_EPI_BNSUMS: mask = z of the consumer (columns = K here) + per-column rstd / shift
+    dz = torch.from_numpy(rng.normal(size=(M, N)).astype(np.float32)).cuda()
+    res = []
+    for norm in (False, True):
+        g = ops.gemm_plan(M, N, K, N, K, N, transposed_w=True)
+        P = g.enable_bnsums(K)
+        assert P > 0
+        if norm:
+            g.d.mask_rstd, g.d.mask_shift = rt.data_ptr(), st.data_ptr()
+        dx = torch.empty(M, K, device="cuda")
+        sums = torch.zeros(2, K, P, device="cuda")
+        g.run(ops._p(dz), ops._p(w), ops._p(dx), mask=ops._p(zt if norm else y_in), stats=ops._p(sums))
+        torch.cuda.synchronize()
+        res.append((dx, sums))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    # BatchNorm backward apply in place inside a wider buffer
+    Cc, ld, off = 64, 160, 32
+    zz = torch.from_numpy(rng.normal(size=(M, Cc)).astype(np.float32)).cuda()
+    dy = torch.from_numpy(rng.normal(size=(M, Cc)).astype(np.float32)).cuda()
+    mean, rstd, shift = (torch.from_numpy(rng.normal(size=Cc).astype(np.float32)).cuda() for _ in range(3))
+    rstd = rstd.abs() + 0.5
+    coef = torch.from_numpy(rng.normal(size=(2, Cc)).astype(np.float32) * 0.1).cuda()
+    segs = ops.make_segments([(0, Cc, dy.data_ptr(), Cc)])
+    dense = torch.empty(M, Cc, device="cuda")
+    ops.bn_bwd_apply(zz, segs, M, Cc, mean, rstd, shift, coef, dense)
+    wide = torch.full((M, ld), 7.0, device="cuda")
+    wide[:, off:off + Cc] = zz
+    view = wide[:, off:off + Cc]
+    ops.bn_bwd_apply(view, segs, M, Cc, mean, rstd, shift, coef, view, ldz=ld)
+    torch.cuda.synchronize()
+    assert torch.equal(wide[:, off:off + Cc], dense)
+    assert float((wide[:, :off] - 7.0).abs().max()) == 0.0 and float((wide[:, off + Cc:] - 7.0).abs().max()) == 0.0
+
+
 def test_bn_backward_sums_from_mixed_sources_match_the_single_pass():
     """ds_bn_bwd_finalize_segs: a layer whose output gradient comes in three parts -- the sums of part 0 and part 2
     emitted by the producing dgrads (DS_EPI_BNSUMS form: sum g, sum g*y over y > 0, with different partial counts),

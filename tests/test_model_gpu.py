@@ -56,10 +56,11 @@ def _check_step(net, ref, batch, lr, mask_np=None, logit_tol=1e-3, first=True, g
     upstream gradient by ~sqrt(f) -- ~1e-2 for this tower at any batch size, also for the oracle run in fp32
     against itself (scripts/oracle_fp32_spread.py) -- which would force a percent-level gate.  Along the same
     decisions the comparison is smooth and every gradient is held to 1e-3 (relative L2 and max-norm)."""
-    from hip_decisions import hip_decisions
+    from hip_decisions import hip_decisions, keep_activations
     mask_t = None if mask_np is None else torch.tensor(mask_np, dtype=ref.dtype)
     mask_d = None if mask_np is None else torch.tensor(mask_np, dtype=torch.float32).cuda()
     w_before = net.state_dict()
+    keep_activations(net)
     net.train_step(_dev_batch(batch), lr, dropout_mask=mask_d)
     torch.cuda.synchronize()
     plain_logits = None
@@ -263,6 +264,8 @@ def test_joint_step_b16_follows_oracle_along_same_decisions():
     net = SentimentNet(mode="joint", nb_emotions=15, im_features_size=256, rnn_size=H, fc_size=512, vocab_size=V,
                        embedding_dim=D, post_size=T)
     net.load_state_dict(dict(params, **{"Text/W_embedding": emb}))
+    from hip_decisions import keep_activations
+    keep_activations(net)
     net.train_step(_dev_batch(batch), 1e-3, dropout_mask=torch.tensor(mask, dtype=torch.float32).cuda())
     torch.cuda.synchronize()
     ref = R.DeepSentimentRef(params, emb, "joint", torch.float64)
@@ -447,6 +450,34 @@ def test_captured_step_matches_eager_step(mode):
     # the replayed steps are the eager steps, bit for bit
     assert l0 == l1
     assert torch.equal(z0, z1) and torch.equal(th0, th1) and torch.equal(fr0, fr1)
+
+
+def test_zcat_step_is_bit_identical():
+    """InceptionV1Engine.zcat (default): the Branch_1 / Branch_2 3x3 and Branch_3 1x1 convs of Mixed_3b .. 4e write z
+    straight into their concat slices, no BatchNorm-apply pass follows, and the consumers -- the next block's fused 1x1
+    conv (ds_conv_desc.norm_rstd / norm_shift), its Branch_3 pool and the stage pool (ds_maxpool_bn_relu_fwd), the
+    BatchNorm-sums epilogue of the next block's fused dgrad (mask_rstd / mask_shift) -- apply relu(z*rstd + shift) on
+    load; the backward pass differentiates the slices in place (ds_bn_bwd_apply with ldz).  Same arithmetic on the same
+    values: logits, loss, every gradient and the updated parameters of two training steps are BIT-identical to the
+    materialised form, in training and in inference mode, and the switch really changes the path."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    batch = to_device(synthetic_batch_numpy(32, 10, 50, seed=5))
+    res, blocks = [], []
+    for on in (True, False):
+        net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10)
+        net.image.zcat = on
+        net.initialize(seed=7)
+        net.train_step(batch, 1e-3)
+        g1 = net.store.grad.clone()
+        net.train_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        blocks.append([st.name for st in net.image.stages if getattr(st, "zcat", False)])
+        res.append((net.logits.clone(), net.total_loss_value(), g1, net.store.grad.clone(), net.store.theta.clone(),
+                    net.store.frozen.clone(), net.predict(batch, is_training=False).clone()))
+    assert blocks[0] == ["Mixed_3b", "Mixed_3c", "Mixed_4b", "Mixed_4c", "Mixed_4d", "Mixed_4e"] and blocks[1] == [], blocks
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b) if torch.is_tensor(a) else a == b
 
 
 def test_bn_sums_from_dgrad_epilogues_equal_the_separate_reduce_pass():

@@ -24,6 +24,7 @@ class ConvDesc(C.Structure):
         ("splits", C.c_int32), ("z_split_stride", C.c_int64),
         ("tile_nt", C.c_int32), ("grid_x", C.c_int32), ("dtype", C.c_int32), ("x_dtype", C.c_int32),
         ("partials", C.c_int32),
+        ("norm_rstd", C.c_void_p), ("norm_shift", C.c_void_p), ("mask_rstd", C.c_void_p), ("mask_shift", C.c_void_p),
     ]
 
 
@@ -53,6 +54,7 @@ SIGNATURES = {
     "ds_debug_conv_set_wide": (C.c_int, [C.c_int]),
     "ds_conv_igemm_partials": (C.c_int, [_CD]),
     "ds_conv_igemm_bnsums_supported": (C.c_int, [_CD]),
+    "ds_conv_igemm_norm_supported": (C.c_int, [_CD]),
     "ds_conv_igemm": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ds_weights_bf16_bytes": (C.c_size_t, [_i32, _i32, _i32, _i32]),
     "ds_weights_to_bf16": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _P]),
@@ -84,7 +86,7 @@ SIGNATURES = {
     "ds_bn_bwd_reduce": (C.c_int, [_P, _i32, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _P]),
     "ds_bn_bwd_finalize_segs": (C.c_int, [_SS, _i64, _i32, _P, _P, _P, _P]),
     "ds_bn_bwd_finalize": (C.c_int, [_P, _i32, _i64, _i32, _P, _P, _P]),
-    "ds_bn_bwd_apply": (C.c_int, [_P, _SG, _i64, _i32, _P, _P, _P, _P, _P, _P, _P]),
+    "ds_bn_bwd_apply": (C.c_int, [_P, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _P, _P, _P]),
     "ds_maxpool_fwd": (C.c_int, [_P, _P, _P] + [_i32] * 11 + [_P]),
     "ds_maxpool_bn_relu_fwd": (C.c_int, [_P, _P, _P, _P, _P] + [_i32] * 11 + [_P, _P]),
     "ds_bn_pool_bwd_partials": (C.c_int, [_i32, _i32, _i32, _i32]),

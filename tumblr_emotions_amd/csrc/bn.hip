@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_segs_kernel(SumSegDev sg,
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, SegDev dy, int64_t M, int C,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, int ldz, SegDev dy, int64_t M, int C,
                                                            const float *mean, const float *rstd, const float *shift,
                                                            const float *coef, float *dz, float *amax) {
     const int C4 = C >> 2;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, SegDe
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t row = i / C4;
         const int c = (int)(i - row * C4) * 4;
-        const float4 zv = *reinterpret_cast<const float4 *>(z + row * C + c);
+        const float4 zv = *reinterpret_cast<const float4 *>(z + row * ldz + c);
         const float4 dv = *reinterpret_cast<const float4 *>(seg_addr(dy, row, c));
         const float4 r = *reinterpret_cast<const float4 *>(rstd + c);
         const float4 s = *reinterpret_cast<const float4 *>(shift + c);
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, SegDe
             const float xh = (zz[j] - mm[j]) * rr[j];
             o[j] = rr[j] * (g - a1[j] - xh * a2[j]);
         }
-        *reinterpret_cast<float4 *>(dz + row * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4 *>(dz + row * ldz + c) = make_float4(o[0], o[1], o[2], o[3]);
         am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
     }
     if (amax) {
@@ -461,12 +461,14 @@ extern "C" int ds_bn_bwd_finalize_segs(const ds_bn_sum_segments *sg, int64_t M, 
     return ds::check_launch("ds_bn_bwd_finalize_segs");
 }
 
-extern "C" int ds_bn_bwd_apply(const float *z, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
+extern "C" int ds_bn_bwd_apply(const float *z, int32_t ldz, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
                                const float *rstd, const float *shift, const float *coef, float *dz, float *amax,
                                void *stream) {
-    DS_REQUIRE(z && mean && rstd && shift && coef && dz && M > 0 && C > 0 && C % 4 == 0, "ds_bn_bwd_apply: bad argument");
+    DS_REQUIRE(z && mean && rstd && shift && coef && dz && M > 0 && C > 0 && C % 4 == 0 && ldz >= C && ldz % 4 == 0 &&
+                   ((((uintptr_t)z) | ((uintptr_t)dz)) & 15) == 0,
+               "ds_bn_bwd_apply: bad argument (need C %% 4 == 0, ldz >= C, ldz %% 4 == 0, 16-byte aligned z / dz)");
     if (int e = check_segments(dy, C, "ds_bn_bwd_apply")) return e;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ds::stream_grid(M * (C / 4), 256 * 4)), dim3(256), 0,
-                       (hipStream_t)stream, z, to_dev(dy), M, C, mean, rstd, shift, coef, dz, amax);
+                       (hipStream_t)stream, z, ldz, to_dev(dy), M, C, mean, rstd, shift, coef, dz, amax);
     return ds::check_launch("ds_bn_bwd_apply");
 }

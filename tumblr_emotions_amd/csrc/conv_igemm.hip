@@ -1115,6 +1115,8 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
     constexpr int DJ = (WK * BN / 4 + 255) / 256;              // 16-byte DMA slots per thread per K step: ceil(NB / 2)
     constexpr int BSZ = DJ * 1024;                             // floats per B buffer (odd NB: the last DMA is half used)
     __shared__ __attribute__((aligned(128))) float smem[2 * BSZ + 256];
+    // BatchNorm + ReLU on load (ds_conv_desc.norm_rstd / norm_shift): rstd and shift of all Cin reduction channels
+    __shared__ __attribute__((aligned(16))) float nrm[2][1024 + WK];
     const ds_conv_desc &d = p.d;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1167,8 +1169,26 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
     f32x4 a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, 32, 0));
 #pragma unroll
     for (int i = 0; i < DJ; ++i) dma_b(0, 0, i);
-    __syncthreads();
     const int ksteps = (K + WK - 1) / WK;
+    // x holds pre-BatchNorm conv outputs: the A fragment becomes relu(x * rstd[k] + shift[k]) as it is loaded (two
+    // packed multiply-adds and two packed max per float4, against 4 NB MFMAs); channels past Cin get (0, 0) -> 0
+    const bool norm = d.norm_rstd != nullptr;          // (uniform)
+    if (norm) {
+        for (int c = tid; c < ksteps * WK; c += 256) {
+            nrm[0][c] = c < K ? d.norm_rstd[c] : 0.f;
+            nrm[1][c] = c < K ? d.norm_shift[c] : 0.f;
+        }
+    }
+    auto apply_norm = [&](f32x4 &a, int c) {           // channels c .. c + 3
+        const f32x4 r = *reinterpret_cast<const f32x4 *>(&nrm[0][c]), sh = *reinterpret_cast<const f32x4 *>(&nrm[1][c]);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        a = __builtin_elementwise_max(__builtin_elementwise_fma(a, r, sh), zero);
+    };
+    __syncthreads();
+    if (norm) {
+        apply_norm(a0, 4 * kh);
+        apply_norm(a1, 8 + 4 * kh);
+    }
     for (int ks = 0; ks < ksteps; ++ks) {
         const bool more = ks + 1 < ksteps;
         const int cn = (ks + 1) * WK;
@@ -1209,6 +1229,10 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
         }
         a0 = n0v;
         a1 = n1v;
+        if (norm && more) {
+            apply_norm(a0, cn + 4 * kh);
+            apply_norm(a1, cn + 8 + 4 * kh);
+        }
         __syncthreads();
     }
 
@@ -1231,6 +1255,11 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
             for (int r = 0; r < 16; ++r) {
                 const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 yv[r] = (row < p.M && colok) ? p.mask[(int64_t)row * d.ldmask + col] : 0.f;
+            }
+            if (d.mask_rstd && colok) {      // `mask` holds z of the consumer layers: y = relu(z * rstd + shift) per column
+                const float mr = d.mask_rstd[col], ms = d.mask_shift[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[r] = fmaxf(fmaf(yv[r], mr, ms), 0.f);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1806,6 +1835,12 @@ extern "C" int ds_conv_igemm_bnsums_supported(const ds_conv_desc *d) {
     return wide_nb(&t, dims_vec(&t)) > 0 ? 1 : 0;
 }
 
+extern "C" int ds_conv_igemm_norm_supported(const ds_conv_desc *d) {
+    // BatchNorm + ReLU on load lives in the wide 1x1 kernel's loader (Cin <= 1024: the per-channel values sit in LDS)
+    if (!d || d->Cin > 1024) return 0;
+    return wide_nb(d, dims_vec(d)) > 0 ? 1 : 0;
+}
+
 extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float *w, float *z, const float *bias,
                              const float *mask, float *stats, const float *pivot, void *stream) {
     DS_REQUIRE(d && x && w && z, "ds_conv_igemm: null argument");
@@ -1857,6 +1892,10 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     grid_for(d, c, v, &gx, &gy, &rt, &one);
     // the statistics partial count the caller planned with (ds_conv_igemm_partials at plan time) must be the one this
     // launch writes: the tile choice depends on debug switches / environment caches that may have changed since
+    DS_REQUIRE((!d->norm_rstd && !d->norm_shift) || (c.wide && d->norm_rstd && d->norm_shift && d->Cin <= 1024),
+               "ds_conv_igemm: norm_rstd / norm_shift are implemented by the wide 1x1 kernel only (ds_conv_igemm_norm_supported)");
+    DS_REQUIRE((!d->mask_rstd && !d->mask_shift) || ((d->flags & DS_EPI_BNSUMS) && d->mask_rstd && d->mask_shift),
+               "ds_conv_igemm: mask_rstd / mask_shift go with DS_EPI_BNSUMS");
     DS_REQUIRE(!(d->flags & DS_EPI_BNSUMS) || c.wide,
                "ds_conv_igemm: DS_EPI_BNSUMS is implemented by the wide 1x1 kernel only (ds_conv_igemm_bnsums_supported)");
     DS_REQUIRE(!(d->flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) || d->partials <= 0 || d->partials == (c.direct ? gx * 4 : gx),

@@ -81,6 +81,8 @@ class ConvBN:
         self.B = B
         self.M = B * self.OH * self.OW
         self.z = torch.empty(self.M, cout, device=dev)
+        self.ldz = cout               # row stride of z (use_concat_slice: the conv writes into the block's concat buffer)
+        self.skip_apply = False       # ... and its consumers apply BatchNorm + ReLU on load
         self.mean = torch.empty(cout, device=dev)
         self.rstd = torch.empty(cout, device=dev)
         self.shift = torch.empty(cout, device=dev)
@@ -157,6 +159,16 @@ class ConvBN:
             else:
                 self.wgrad = WgradPlan(B, self.H, self.W, cin, 0, k, k, self.stride, cout, cout)
             eng.need_ws(self.wgrad.ws_bytes)
+
+    def use_concat_slice(self, zview, ld, rstd, shift):
+        """The conv output goes straight into this layer's channel slice of the block's concat buffer (row stride ld)
+        and stays PRE-BatchNorm there: the consumers of the concat apply relu(z*rstd + shift) as they load it
+        (MixedStage zcat), so the layer's BatchNorm-apply pass and its dense z buffer disappear.  rstd / shift: this
+        layer's slices of the block's per-channel arrays."""
+        self.z, self.ldz, self.rstd, self.shift, self.skip_apply = zview, ld, rstd, shift, True
+        self.fwd.d.ldz = ld
+        if isinstance(self.wino_fwd, WinoPlan):
+            self.wino_fwd.set_ldz(ld)
 
     def bind(self):
         st = self.eng.store
@@ -251,17 +263,17 @@ class ConvBN:
             _, i, c0, n, dst = job
             off = 4 * c0
             ops.bn_bwd_reduce(_vp(self.z.data_ptr() + off), self.part_segs[i], M, n, _vp(self.mean.data_ptr() + off),
-                              _vp(self.rstd.data_ptr() + off), _vp(self.shift.data_ptr() + off), dst, ldz=Cc)
+                              _vp(self.rstd.data_ptr() + off), _vp(self.shift.data_ptr() + off), dst, ldz=self.ldz)
         ops.bn_bwd_finalize_segs(self._sum_segs, M, Cc, self.beta, self.gbeta, self.coef)
 
     def make_dgrad(self, lddx):
         """Conv2DBackpropInput as a forward conv over dz with flipped taps (stride-1 SAME convs only)."""
         assert self.stride == 1
         k, cin, cout = self.k, self.cin, self.cout
-        self.dgrad = ConvPlan(self.B, self.H, self.W, cout, cout, k, k, 1, cin, lddx, cin * cout, cout, 1, flip=1,
+        self.dgrad = ConvPlan(self.B, self.H, self.W, cout, self.ldz, k, k, 1, cin, lddx, cin * cout, cout, 1, flip=1,
                               dtype=self.eng.conv_dtype)
         if self._wino_dgrad_ok:
-            self.wino_dgrad = WinoPlan(self.B, self.H, self.W, cout, cout, cin, lddx, f4=self._wino4_dgrad)
+            self.wino_dgrad = WinoPlan(self.B, self.H, self.W, cout, self.ldz, cin, lddx, f4=self._wino4_dgrad)
             self.u_dgrad = torch.empty(self.wino_dgrad.u_elems, device=self.eng.device)
         elif self._bf16_dgrad_ok:
             self.wino_dgrad = ops.Bf16Plan(self.B, self.H, self.W, cout, cout, k, 1, cin, lddx)
@@ -337,7 +349,7 @@ class ConvBN:
                 self.fwd.d.flags = 0
                 self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z))
             ops.bn_infer_prepare(self.beta, self.mm, self.mv, BN_EPS, self.cout, self.rstd, self.shift)
-        if segs is not None:
+        if segs is not None and not self.skip_apply:
             ops.bn_apply_relu(self.z, self.M, self.cout, self.rstd, self.shift, segs)
 
     def backward_pooled(self, pool, x_ptr=None, ldx=0, dx_ptr=None, need_dx=True):
@@ -391,14 +403,14 @@ class ConvBN:
         if any(ps is not None for ps in self.part_sums) or any(pp is not None for pp in self.part_pool):
             self._bn_bwd_sums()
         else:
-            ops.bn_bwd_reduce(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.bwdp_buf)
+            ops.bn_bwd_reduce(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.bwdp_buf, ldz=self.ldz)
             ops.bn_bwd_finalize(self.bwdp_buf, self.bwd_P, M, Cc, self.gbeta if self.gbeta is not None else eng.dummy,
                                 self.coef)
         if not (need_dx or self.trainable):
             return
         track = isinstance(self.wino_dgrad, ops.Fp8Plan)
         ops.bn_bwd_apply(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.coef, self.z,    # dz over z
-                         amax=self.dz_amax if track else None)
+                         amax=self.dz_amax if track else None, ldz=self.ldz)
         self._dz_amax_live = track
         if self.trainable:
             self.wgrad.d.ldx = ldx
@@ -523,6 +535,9 @@ class PoolStage(Stage):
         if getattr(p, "fused_into_pool", False):
             ops.maxpool_bn_relu_fwd(p.layer.z, p.layer.rstd, p.layer.shift, self.out, self.argmax, self.B, p.H, p.W, p.C,
                                     self.k, self.stride, amax=self._own_amax)
+        elif getattr(p, "zcat", False):      # the block's concat holds pre-BatchNorm values: normalise on load
+            ops.maxpool_bn_relu_fwd(p.out, p.rs_cat[0], p.rs_cat[1], self.out, self.argmax, self.B, p.H, p.W, p.C,
+                                    self.k, self.stride)
         else:
             if p.out.dtype != self.out.dtype:
                 raise RuntimeError("%s: input and output storage differ (fuse_bn_pool switched after alloc?)" % self.name)
@@ -600,6 +615,24 @@ class MixedStage(Stage):
         self.c1.set_dy_parts([(0, b1b, do + 4 * off1, Ct)])
         self.c2.set_dy_parts([(0, b2b, do + 4 * off2, Ct)])
         self.c3.set_dy_parts([(0, b3, do + 4 * off3, Ct)])
+        # zcat: the Branch_1 / Branch_2 3x3 and the Branch_3 1x1 convs write z straight into their slices of the concat
+        # buffer and NO BatchNorm-apply pass follows; whoever reads the concat -- the next block's fused 1x1 conv, its
+        # Branch_3 pool, the stage pool, the BatchNorm-sums epilogue of the next block's fused dgrad -- applies
+        # relu(z*rstd + shift) per channel as it loads (rs_cat; (1, 0) for the Branch_0 slice, which IS an activation:
+        # it comes out of the fused layer's apply pass together with the two reduce outputs).  Bit-identical values.
+        self.zcat = self._zcat_ok(B)
+        self.rs_cat = None
+        if self.zcat:
+            self.rs_cat = torch.empty(2, Ct, device=dev)
+            self.rs_cat[0].fill_(1.0)
+            self.rs_cat[1].zero_()
+            zc = self.out.view(M, Ct)
+            for layer, off in ((self.c1, off1), (self.c2, off2), (self.c3, off3)):
+                n = layer.cout
+                layer.use_concat_slice(zc[:, off:off + n], Ct, self.rs_cat[0, off:off + n], self.rs_cat[1, off:off + n])
+        if getattr(self.prev, "zcat", False):    # this block reads a zcat concat
+            self.fused.fwd.d.norm_rstd = self.prev.rs_cat[0].data_ptr()
+            self.fused.fwd.d.norm_shift = self.prev.rs_cat[1].data_ptr()
         self.fused.make_dgrad(cin)
         self.c1.make_dgrad(b1a)
         self.c2.make_dgrad(b2a)
@@ -617,6 +650,9 @@ class MixedStage(Stage):
         self.pool_first = bool(eng.pool_first and self.fused.wino_dgrad is None)
         if isinstance(p, MixedStage) and self.pool_first:
             src = self.fused.emit_dx_sums(p.out)
+            if src is not None and getattr(p, "zcat", False):      # the epilogue rebuilds y from the concat's z
+                self.fused.dgrad.d.mask_rstd = p.rs_cat[0].data_ptr()
+                self.fused.dgrad.d.mask_shift = p.rs_cat[1].data_ptr()
             if src is not None:
                 pb0, _, pb1b, _, pb2b, pb3 = p.b
                 for layer, off in ((p.fused, 0), (p.c1, pb0), (p.c2, pb0 + pb1b), (p.c3, pb0 + pb1b + pb2b)):
@@ -632,6 +668,32 @@ class MixedStage(Stage):
             self.ev = [torch.cuda.Event() for _ in range(4)]
         return self.ev
 
+    def _zcat_ok(self, B):
+        """Can this block leave z in its concat buffer (see alloc)?  fp32 storage, nothing trainable in this block or in
+        its consumer (a weight gradient reads activations), and a consumer whose loader can normalise: a MixedStage whose
+        fused 1x1 conv runs on the wide kernel (ds_conv_igemm_norm_supported), or a 3x3 max pool."""
+        eng = self.eng
+        nxt = getattr(self, "next", None)
+        if not (eng.zcat and eng.dtype == "f32" and not eng.act16 and not eng.train_all):
+            return False
+        if any(l.trainable for l in self.layers):
+            return False
+        if isinstance(nxt, PoolStage):
+            return nxt.k == 3
+        if isinstance(nxt, MixedStage) and not any(l.trainable for l in nxt.layers):
+            nf = nxt.b[0] + nxt.b[1] + nxt.b[3]
+            probe = ConvPlan(B, self.H, self.W, self.C, self.C, 1, 1, 1, nf, nf, self.C * nf, 1, nf, flags=DS_EPI_STATS)
+            return ops.conv_norm_supported(probe)
+        return False
+
+    def _pool_fwd(self):
+        """Branch_3's 3x3/1 max pool of the block input (normalising on load when that is a zcat concat)."""
+        p = self.prev
+        if getattr(p, "zcat", False):
+            ops.maxpool_bn_relu_fwd(p.out, p.rs_cat[0], p.rs_cat[1], self.pooled, self.argmax, self.B, p.H, p.W, p.C, 3, 1)
+        else:
+            ops.maxpool_fwd(p.out, self.pooled, self.argmax, self.B, p.H, p.W, p.C, 3, 1, "SAME")
+
     def forward(self):
         p = self.prev
         b0, b1a, b1b, b2a, b2b, b3 = self.b
@@ -643,7 +705,7 @@ class MixedStage(Stage):
             self.fused.forward(x, p.C, self.seg_f, dx_, ax_)
             self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_, a1_)
             self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_, a2_)
-            ops.maxpool_fwd(p.out, self.pooled, self.argmax, self.B, p.H, p.W, p.C, 3, 1, "SAME")
+            self._pool_fwd()
             self.c3.forward(ops._p(self.pooled), p.C, self.seg_3, dx_, ax_)
             return
         main = torch.cuda.current_stream()
@@ -654,7 +716,7 @@ class MixedStage(Stage):
             s1 = s2
         with torch.cuda.stream(s2):
             s2.wait_event(e_in)
-            ops.maxpool_fwd(p.out, self.pooled, self.argmax, self.B, p.H, p.W, p.C, 3, 1, "SAME")
+            self._pool_fwd()
             self.c3.forward(ops._p(self.pooled), p.C, self.seg_3, dx_, ax_)
             if not eng.one_side_stream:
                 e_3.record(s2)
@@ -772,6 +834,7 @@ class InceptionV1Engine:
         self.side = None
         self.bf16_direct = True      # dtype bf16: ds_conv_bf16 where it wins (False: the LDS-staged bf16 kernel everywhere)
         self.winograd = True         # 3x3 layers through ds_conv_wino where it wins (False: implicit GEMM everywhere)
+        self.zcat = os.environ.get("DS_ZCAT", "1") != "0"     # 3x3 / Branch_3 convs write z into the concat, consumers normalise on load
         self.winograd4 = os.environ.get("DS_WINO4", "1") != "0"      # ... and ds_conv_wino4 (F(4x4,3x3)) where it is faster
         self.weights_version = 0     # bumped by SentimentNet.after_load(): frozen layers redo their G g G^T
         self._stats_n = self._bwdp_n = self._ws_bytes = 0
@@ -792,6 +855,8 @@ class InceptionV1Engine:
             self.stages.append(st)
             prev = st
         self.last = prev
+        for a, b in zip(self.stages[:-1], self.stages[1:]):
+            a.next = b
         # BatchNorm + ReLU of a conv whose only consumer is a 3x3 max pool (Conv2d_1a_7x7 -> MaxPool_2a,
         # Conv2d_2c_3x3 -> MaxPool_3a) moves behind the pool; set fuse_bn_pool = False before the first forward to
         # get every end point materialised (image_model.inception_v1 does)

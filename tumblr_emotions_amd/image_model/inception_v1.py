@@ -39,6 +39,8 @@ def inception_v1_base(inputs, final_endpoint="Mixed_5c", scope="InceptionV1", ne
     net = net or get_net(scope)
     eng = net.image
     eng.fuse_bn_pool = False             # callers get every end point materialised
+    if eng.zcat:                         # ... as activations, not as the pre-BatchNorm values a zcat concat keeps
+        eng.zcat, eng.B = False, None
     with torch.no_grad():
         eng.forward(inputs, None, 0)
     end_points = {}
@@ -61,6 +63,8 @@ def inception_v1(inputs, final_endpoint="Mixed_5c", num_classes=1000, is_trainin
         raise NotImplementedError("spatial_squeeze=False")
     net = net or get_net(scope, num_classes, dropout_keep_prob, reuse)
     net.image.fuse_bn_pool = False       # callers get every end point materialised
+    if net.image.zcat:
+        net.image.zcat, net.image.B = False, None
     if is_training:
         logits = net.forward({"images": inputs}, dropout_mask)
     else:

@@ -176,6 +176,9 @@ class WinoPlan:
     def set_ldx(self, ldx):
         self.args = self.args[:4] + (ldx,) + self.args[5:]
 
+    def set_ldz(self, ldz):
+        self.args = self.args[:6] + (ldz,)
+
     def run(self, x, u, z, stats=None, pivot=None, ymask=None):
         t = CONV_TIMER
         if t is not None:
@@ -184,6 +187,11 @@ class WinoPlan:
         _lib.check(self._run(x, u, z, stats, pivot, ymask, N, H, W, Cin, ldx, Cout, ldz, self.flags, _stream()), self._name)
         if t is not None:
             t.end(self)
+
+
+def conv_norm_supported(plan):
+    """Would ds_conv_igemm apply ds_conv_desc.norm_rstd / norm_shift (BatchNorm + ReLU on load) for this plan?"""
+    return bool(_lib.load().ds_conv_igemm_norm_supported(C.byref(plan.d)))
 
 
 def wino4_supported(H, W, Cin, Cout):
@@ -391,8 +399,8 @@ def bn_bwd_finalize(partials, P, M, C_, dbeta, coef):
                "ds_bn_bwd_finalize")
 
 
-def bn_bwd_apply(z, segs, M, C_, mean, rstd, shift, coef, dz, amax=None):
-    _lib.check(_lib.load().ds_bn_bwd_apply(_p(z), C.byref(segs), M, C_, _p(mean), _p(rstd), _p(shift), _p(coef),
+def bn_bwd_apply(z, segs, M, C_, mean, rstd, shift, coef, dz, amax=None, ldz=0):
+    _lib.check(_lib.load().ds_bn_bwd_apply(_p(z), ldz or C_, C.byref(segs), M, C_, _p(mean), _p(rstd), _p(shift), _p(coef),
                                            _p(dz), _p(amax), _stream()), "ds_bn_bwd_apply")
 
 
