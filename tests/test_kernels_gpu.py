@@ -1333,6 +1333,9 @@ def test_softmax_ce_and_adam_and_reductions():
     scratch, out = torch.empty(64 * 130, device="cuda"), torch.empty(130, device="cuda")
     ops.colsum(dev(x), 777, 130, 130, scratch, out)
     close(out, x.sum(0), 1e-5)
+    for rows in (256, 3, 512):           # few row splits: the one-launch form (head biases)
+        ops.colsum(dev(x[:rows]), rows, 130, 130, scratch, out)
+        close(out, x[:rows].sum(0), 1e-5)
     ss = torch.empty(1, device="cuda")
     ops.sumsq(dev(x), x.size, scratch, ss)
     torch.cuda.synchronize()

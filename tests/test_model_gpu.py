@@ -453,7 +453,7 @@ def test_captured_step_matches_eager_step(mode):
 
 
 def test_zcat_step_is_bit_identical():
-    """InceptionV1Engine.zcat (default): the Branch_1 / Branch_2 3x3 and Branch_3 1x1 convs of Mixed_3b .. 4e write z
+    """InceptionV1Engine.zcat (default): the Branch_1 / Branch_2 3x3 and Branch_3 1x1 convs of Mixed_3b .. 4f write z
     straight into their concat slices, no BatchNorm-apply pass follows, and the consumers -- the next block's fused 1x1
     conv (ds_conv_desc.norm_rstd / norm_shift), its Branch_3 pool and the stage pool (ds_maxpool_bn_relu_fwd), the
     BatchNorm-sums epilogue of the next block's fused dgrad (mask_rstd / mask_shift) -- apply relu(z*rstd + shift) on
@@ -475,7 +475,7 @@ def test_zcat_step_is_bit_identical():
         blocks.append([st.name for st in net.image.stages if getattr(st, "zcat", False)])
         res.append((net.logits.clone(), net.total_loss_value(), g1, net.store.grad.clone(), net.store.theta.clone(),
                     net.store.frozen.clone(), net.predict(batch, is_training=False).clone()))
-    assert blocks[0] == ["Mixed_3b", "Mixed_3c", "Mixed_4b", "Mixed_4c", "Mixed_4d", "Mixed_4e"] and blocks[1] == [], blocks
+    assert blocks[0] == ["Mixed_3b", "Mixed_3c", "Mixed_4b", "Mixed_4c", "Mixed_4d", "Mixed_4e", "Mixed_4f"] and blocks[1] == [], blocks
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b) if torch.is_tensor(a) else a == b
 

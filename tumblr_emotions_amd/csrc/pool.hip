@@ -30,7 +30,8 @@ __device__ __forceinline__ void st4(__bf16 *p, float a, float b, float c, float 
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const TI *x, TO *y, uint8_t *am, int N, int H, int W,
                                                           int C, int k, int stride, int pad_t, int pad_l, int OH,
-                                                          int OW) {
+                                                          int OW, const float *rstd = nullptr, const float *shift = nullptr) {
+    // rstd / shift (nullable): x holds pre-BatchNorm values, y = relu(rstd * max(x) + shift) = max(relu(bn(x))) (rstd > 0)
     const int C4 = C >> 2;
     const int64_t total = (int64_t)N * OH * OW * C4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -62,6 +63,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const TI *x, TO *y, ui
             }
         }
         const int64_t o = (((int64_t)n * OH + oh) * OW + ow) * C + c;
+        if (rstd) {
+            const float4 r = *reinterpret_cast<const float4 *>(rstd + c), s = *reinterpret_cast<const float4 *>(shift + c);
+            best[0] = fmaxf(best[0] * r.x + s.x, 0.f);
+            best[1] = fmaxf(best[1] * r.y + s.y, 0.f);
+            best[2] = fmaxf(best[2] * r.z + s.z, 0.f);
+            best[3] = fmaxf(best[3] * r.w + s.w, 0.f);
+        }
         st4(y + o, best[0], best[1], best[2], best[3]);
         if (am) *reinterpret_cast<uchar4 *>(am + o) = make_uchar4(arg[0], arg[1], arg[2], arg[3]);
     }
@@ -603,9 +611,15 @@ extern "C" int ds_maxpool_bn_relu_fwd(const float *z, const float *rstd, const f
                                       int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride,
                                       int32_t pad_t, int32_t pad_l, int32_t OH, int32_t OW, int32_t y_dtype, float *amax,
                                       void *stream) {
-    DS_REQUIRE(z && rstd && shift && y && C % 4 == 0 && k == 3 && (stride == 1 || stride == 2),
-               "ds_maxpool_bn_relu_fwd: bad argument (3x3 pools, stride 1 or 2, C %% 4 == 0)");
+    DS_REQUIRE(z && rstd && shift && y && C % 4 == 0 && k >= 1 && stride >= 1, "ds_maxpool_bn_relu_fwd: bad argument (C %% 4 == 0)");
     DS_REQUIRE(y_dtype == DS_DTYPE_F32 || y_dtype == DS_DTYPE_BF16, "ds_maxpool_bn_relu_fwd: y_dtype must be DS_DTYPE_F32 or DS_DTYPE_BF16");
+    if (!(k == 3 && (stride == 1 || stride == 2))) {       // other windows (MaxPool_5a 2x2/2): the generic kernel, fp32 output
+        DS_REQUIRE(y_dtype == DS_DTYPE_F32 && !amax, "ds_maxpool_bn_relu_fwd: windows other than 3x3 write fp32 and track no maximum");
+        const int64_t total = (int64_t)N * OH * OW * (C / 4);
+        hipLaunchKernelGGL((maxpool_fwd_kernel<float, float>), dim3(ds::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           z, (float *)y, argmax, N, H, W, C, k, stride, pad_t, pad_l, OH, OW, rstd, shift);
+        return ds::check_launch("ds_maxpool_bn_relu_fwd");
+    }
     if (y_dtype == DS_DTYPE_BF16) launch_pool3(stride, (hipStream_t)stream, z, (__bf16 *)y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift, amax);
     else launch_pool3(stride, (hipStream_t)stream, z, (float *)y, argmax, N, H, W, C, pad_t, pad_l, OH, OW, rstd, shift, amax);
     return ds::check_launch("ds_maxpool_bn_relu_fwd");

@@ -264,6 +264,29 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float *x, int64_t M, 
     if (rl == 0 && c < C) partials[(int64_t)blockIdx.y * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
 
+// few row splits (M <= 512: the head biases at B <= 512): both stages in one launch, split by split in the same
+// arithmetic and order (fp32 over 4 row lanes per split, double over the splits) -- same bits, one dispatch less
+__global__ __launch_bounds__(256) void colsum_small_kernel(const float *x, int64_t M, int C, int ld, int rows_per_split,
+                                                           int RS, float *out) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double total = 0.0;
+    for (int s = 0; s < RS; ++s) {
+        const int64_t r0 = (int64_t)s * rows_per_split;
+        int64_t r1 = r0 + rows_per_split;
+        if (r1 > M) r1 = M;
+        float acc = 0.f;
+        if (c < C)
+            for (int64_t r = r0 + rl; r < r1; r += 4) acc += x[r * ld + c];
+        __syncthreads();
+        red[rl][cl] = acc;
+        __syncthreads();
+        if (rl == 0) total += (double)(red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+    }
+    if (rl == 0 && c < C) out[c] = (float)total;
+}
+
 __global__ __launch_bounds__(256) void colsum_stage2(const float *partials, int RS, int C, float *out) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
@@ -395,6 +418,10 @@ extern "C" int ds_colsum(const float *x, int64_t M, int32_t C, int32_t ld, float
     int RS = (int)((M + 63) / 64);
     if (RS > 64) RS = 64;
     const int rps = (int)((M + RS - 1) / RS);
+    if (RS <= 8) {
+        hipLaunchKernelGGL(colsum_small_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, M, C, ld, rps, RS, out);
+        return ds::check_launch("ds_colsum");
+    }
     hipLaunchKernelGGL(colsum_stage1, dim3((C + 63) / 64, RS), dim3(256), 0, (hipStream_t)stream, x, M, C, ld, rps,
                        scratch);
     hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, RS, C, out);

@@ -671,7 +671,7 @@ class MixedStage(Stage):
     def _zcat_ok(self, B):
         """Can this block leave z in its concat buffer (see alloc)?  fp32 storage, nothing trainable in this block or in
         its consumer (a weight gradient reads activations), and a consumer whose loader can normalise: a MixedStage whose
-        fused 1x1 conv runs on the wide kernel (ds_conv_igemm_norm_supported), or a 3x3 max pool."""
+        fused 1x1 conv runs on the wide kernel (ds_conv_igemm_norm_supported), or a max pool."""
         eng = self.eng
         nxt = getattr(self, "next", None)
         if not (eng.zcat and eng.dtype == "f32" and not eng.act16 and not eng.train_all):
@@ -679,7 +679,7 @@ class MixedStage(Stage):
         if any(l.trainable for l in self.layers):
             return False
         if isinstance(nxt, PoolStage):
-            return nxt.k == 3
+            return True                      # (ds_maxpool_bn_relu_fwd: 3x3 rolling kernels, any other window generic)
         if isinstance(nxt, MixedStage) and not any(l.trainable for l in nxt.layers):
             nf = nxt.b[0] + nxt.b[1] + nxt.b[3]
             probe = ConvPlan(B, self.H, self.W, self.C, self.C, 1, 1, 1, nf, nf, self.C * nf, 1, nf, flags=DS_EPI_STATS)
