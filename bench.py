@@ -185,7 +185,7 @@ def main():
                     help="A/B aid: implicit GEMM for every 3x3 layer instead of the fused Winograd F(2x2,3x3) kernel")
     ap.add_argument("--no-zcat", action="store_true",
                     help="A/B aid: every conv followed by its BatchNorm-apply pass (default: the 3x3 / Branch_3 convs of "
-                         "Mixed_3b..4e write z into the concat and the consumers normalise on load)")
+                         "Mixed_3b..4f write z into the concat and the consumers normalise on load)")
     ap.add_argument("--no-wino4", action="store_true",
                     help="A/B aid: F(2x2,3x3) also on the 56 x 56 / 28 x 28 maps instead of the F(4x4,3x3) kernel")
     ap.add_argument("--graph", action="store_true",
