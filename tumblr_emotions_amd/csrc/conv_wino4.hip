@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float *w, floa
 
 // Which kernel for a shape?  Launch-time model fitted to profiles/r03_wino4_layers.txt (B = 256 and B = 32): a launch
 // takes ceil(workgroups / CUs) rounds of one workgroup's duration,
-//     F(4x4), NB = 2: 12.5 us + 5.7 us per 16-channel K step      NB = 1: 8.5 us + 3.2 us per K step
+//     F(4x4), NB = 2: 13.5 us + 5.4 us per 16-channel K step      NB = 1: 8.5 us + 3.2 us per K step
 //     F(2x2) (conv_wino.hip): 8.7 us + 2.35 us per 8-channel K step, 128 tiles of 2x2 x 32 channels per workgroup
 // so the 14 x 14 and 7 x 7 maps (128 / 32 tile groups only) go to whichever fills the rounds best.
 struct W4Choice {
@@ -488,10 +488,10 @@ W4Choice w4_choose(int N, int H, int W, int Cin, int Cout) {
     double t[3];
     for (int nb = 1; nb <= 2; ++nb) {
         const int64_t wgs = g4 * ((Cout + 32 * nb - 1) / (32 * nb));
-        t[nb] = ceil(wgs / cus) * ((Cin / 16) * (nb == 2 ? 5.7 : 3.2) + (nb == 2 ? 12.5 : 8.5));
+        t[nb] = ceil(wgs / cus) * ((Cin / 16) * (nb == 2 ? 5.4 : 3.2) + (nb == 2 ? 13.5 : 8.5));
     }
     c.us2 = ceil(g2 * ((Cout + 31) / 32) / cus) * (8.7 + 2.35 * (Cin / 8));
-    c.nb = (forced == 1 || forced == 2) ? forced : (t[2] < t[1] ? 2 : 1);
+    c.nb = (forced == 1 || forced == 2) ? forced : (t[2] <= t[1] ? 2 : 1);
     c.us4 = t[c.nb];
     return c;
 }
