@@ -105,3 +105,19 @@ def test_no_undefined_names_in_python_sources():
             files.append(a)
     bad = [b for f in sorted(files) for b in m.check(f)]
     assert not bad, bad
+
+
+def test_winograd_f4_launch_time_model_answers_without_a_device(lib):
+    """ds_conv_wino4_supported / _prefer / _partials are pure host functions (the launch-time model that picks
+    F(4x4,3x3), with one or two channel blocks, or F(2x2,3x3) per shape): the shapes of the joint step at B = 256."""
+    L = lib.load()
+    assert L.ds_conv_wino4_supported(56, 56, 64, 192) == 1
+    assert L.ds_conv_wino4_supported(14, 14, 24, 64) == 0            # Cin % 16 != 0: ds_conv_wino / implicit GEMM
+    assert L.ds_conv_wino4_supported(14, 14, 64, 30) == 0            # Cout % 4 != 0 (16-byte output stores)
+    assert L.ds_conv_wino4_supported(7, 13, 16, 16) == 1             # partial border tiles are fine
+    for hw, ci, co in ((56, 64, 192), (56, 192, 64), (28, 96, 128), (28, 128, 192), (28, 16, 32), (14, 96, 208), (7, 160, 320)):
+        assert L.ds_conv_wino4_prefer(256, hw, hw, ci, co) > 0, (hw, ci, co)
+    assert L.ds_conv_wino4_prefer(256, 14, 14, 24, 64) == 0          # unsupported -> never preferred
+    assert L.ds_conv_wino4_prefer(256, 14, 14, 320, 160) == 0        # two rounds of long F(2x2) workgroups beat three F(4x4)
+    assert L.ds_conv_wino4_partials(256, 56, 56) == 256 * 14 * 14 // 32
+    assert L.ds_conv_wino4_partials(2, 7, 7) == 1                    # 2 x 2 x 2 tiles -> one group of 32
