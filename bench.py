@@ -183,6 +183,9 @@ def main():
                     help="--dtype bf16 / fp8: keep the activations in fp32 storage (default there: 16-bit activation storage)")
     ap.add_argument("--no-winograd", action="store_true",
                     help="A/B aid: implicit GEMM for every 3x3 layer instead of the fused Winograd F(2x2,3x3) kernel")
+    ap.add_argument("--mul3", action="store_true",
+                    help="separately labelled line (dtype f32x3): the forward 1x1 convs through ds_conv_f32x3 -- fp32 products "
+                         "from three bf16 pieces per operand on the bf16 matrix cores (fp32-MFMA accuracy, not its bits)")
     ap.add_argument("--no-zcat", action="store_true",
                     help="A/B aid: every conv followed by its BatchNorm-apply pass (default: the 3x3 / Branch_3 convs of "
                          "Mixed_3b..4f write z into the concat and the consumers normalise on load)")
@@ -260,6 +263,8 @@ def main():
         net.image.winograd4 = False
     if args.no_zcat and net.image is not None:
         net.image.zcat = False
+    if args.mul3 and net.image is not None:
+        net.image.mul3 = True
     if args.no_branch_streams and net.image is not None:
         net.image.branch_streams = False
     if args.side_mode >= 0 and net.image is not None:
@@ -408,7 +413,7 @@ def main():
             "metric": "training samples/sec (224x224 img + 32-tok text, batch 256)",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "sec_per_step": round(dt / args.steps, 5), "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "sec_per_step": round(dt / args.steps, 5), "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": ("f32x3" if args.mul3 and args.dtype == "f32" else args.dtype), "data": "synthetic",
             "config": {"workload": "%s train step (fwd+bwd+all-reduce+Adam): Inception-v1 224x224x3 + 300-d embedding + "
                                    "LSTM-512, T=32, V=10000, 15 classes, batch %d per GPU, %s, dropout 0.8, BN train mode"
                                    % (args.mode, args.batch,

@@ -354,6 +354,68 @@ def test_wide_1x1_kernel_forward_and_dgrad_match_oracle(case):
         lib.ds_debug_conv_set_wide(1)
 
 
+@pytest.mark.parametrize("case", [(2, 14, 14, 64, 96, 1), (3, 9, 10, 40, 72, 1), (2, 28, 28, 192, 176, 1), (2, 8, 8, 16, 32, 3),
+                                  (1, 7, 7, 832, 128, 1), (2, 13, 11, 48, 40, 3)])
+def test_fp32_products_from_three_bf16_pieces_match_the_oracle(case):
+    """ds_conv_f32x3 (fp32 products on the bf16 matrix cores: every operand split into three bf16 pieces, six
+    v_mfma_f32_32x32x16_bf16 per eight fp32 MFMAs) against the fp64 oracle at the bound of the fp32 kernels
+    (2e-4 of max|ref|), and against the fp32 kernel itself: its error must stay within 1.5x of the fp32 kernel's.
+    1x1 and 3x3, Cin not a multiple of 16, Cout not a multiple of 32, strided input and output rows, BatchNorm
+    statistics about a pivot; dgrad weights (flipped, transposed); BatchNorm + ReLU on load (1x1)."""
+    ops = _ops()
+    N, H, W, Ci, Co, k = case
+    rng = np.random.RandomState(N * 100 + Ci)
+    x = np.maximum(rng.normal(size=(N, H, W, Ci)), 0.0)
+    w = rng.normal(size=(k, k, Ci, Co)) * 0.1
+    ref = S.conv2d_same(x, w, 1).reshape(-1, Co)
+    M = N * H * W
+    xp = np.pad(x, ((0, 0), (0, 0), (0, 0), (0, 4)), constant_values=3.0)           # row stride Ci + 4
+    xd, wd = dev(xp), dev(w)
+    plan = ops.F32x3Plan(N, H, W, Ci, Ci + 4, k, 1, Co, Co + 4, flags=ops.DS_EPI_STATS)
+    wb = torch.empty(ops.weights_f32x3_bytes(Ci, Co, k * k, False), dtype=torch.uint8, device="cuda")
+    ops.weights_to_f32x3(ops._p(wd), wb, Ci, Co, k * k, False)
+    z = torch.full((M, Co + 4), 5.0, device="cuda")
+    stats = torch.zeros(2, Co, plan.partials, device="cuda")
+    pivot = dev(rng.normal(size=Co) * 0.1)
+    plan.run(ops._p(xd), ops._p(wb), ops._p(z), stats=ops._p(stats), pivot=ops._p(pivot))
+    torch.cuda.synchronize()
+    close(z[:, :Co], ref)
+    assert float((z[:, Co:] - 5.0).abs().max()) == 0.0
+    pv = pivot.cpu().numpy().astype(np.float64)
+    close(stats[0].sum(1), (ref - pv).sum(0), 2e-3)
+    close(stats[1].sum(1), ((ref - pv) ** 2).sum(0), 2e-3)
+    # against the fp32 kernel: the same error class
+    direct = ops.ConvPlan(N, H, W, Ci, Ci + 4, k, k, 1, Co, Co, Ci * Co, 1, Co)
+    z32 = torch.empty(M, Co, device="cuda")
+    direct.run(ops._p(xd), ops._p(wd), ops._p(z32))
+    torch.cuda.synchronize()
+    e3 = np.abs(z[:, :Co].cpu().numpy().astype(np.float64) - ref).max()
+    e32 = np.abs(z32.cpu().numpy().astype(np.float64) - ref).max()
+    assert e3 <= 1.5 * e32 + 1e-7 * np.abs(ref).max(), (e3, e32)
+    # dgrad: correlation over dz with the flipped, channel-transposed filter
+    dz = rng.normal(size=(N, H, W, Co))
+    g = ops.F32x3Plan(N, H, W, Co, Co, k, 1, Ci, Ci)
+    if Co % 8 == 0:
+        wg = torch.empty(ops.weights_f32x3_bytes(Ci, Co, k * k, True), dtype=torch.uint8, device="cuda")
+        ops.weights_to_f32x3(ops._p(wd), wg, Ci, Co, k * k, True)
+        dx = torch.empty(M, Ci, device="cuda")
+        g.run(ops._p(dev(dz)), ops._p(wg), ops._p(dx))
+        torch.cuda.synchronize()
+        close(dx, S.conv2d_same_bwd_input(dz, w, (N, H, W, Ci), 1).reshape(-1, Ci))
+    if k == 1:      # BatchNorm + ReLU on load: x holds z, channels with (1, 0) are activations already
+        r = np.abs(rng.normal(size=Ci)) + 0.5
+        sh = rng.normal(size=Ci) * 0.3
+        zin = rng.normal(size=(N, H, W, Ci))
+        yin = np.maximum(zin * r + sh, 0.0)
+        nplan = ops.F32x3Plan(N, H, W, Ci, Ci, 1, 1, Co, Co)
+        rt, st_ = dev(r), dev(sh)
+        nplan.d.norm_rstd, nplan.d.norm_shift = rt.data_ptr(), st_.data_ptr()
+        zn = torch.empty(M, Co, device="cuda")
+        nplan.run(ops._p(dev(zin)), ops._p(wb), ops._p(zn))
+        torch.cuda.synchronize()
+        close(zn, S.conv2d_same(yin, w, 1).reshape(-1, Co))
+
+
 def test_batchnorm_relu_applied_on_load_equals_the_materialised_activation():
     """The three kernel features behind InceptionV1Engine.zcat, each bit-identical to the materialised form:
     ds_conv_desc.norm_rstd / norm_shift (wide 1x1 kernel: x holds z, the loader applies relu(z*rstd + shift); channels

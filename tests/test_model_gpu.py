@@ -201,8 +201,11 @@ def test_trainable_embedding_text_step_matches_oracle():
     assert np.abs(g[used]).max() > 0 and np.abs(np.delete(g, used, axis=0)).max() == 0
 
 
-def test_image_only_step_matches_oracle():
-    """train_image_model: Inception-v1 with num_classes = nb_emotions, dropout mask injected."""
+@pytest.mark.parametrize("mul3", [False, True], ids=["fp32-mfma", "f32x3"])
+def test_image_only_step_matches_oracle(mul3):
+    """train_image_model: Inception-v1 with num_classes = nb_emotions, dropout mask injected.  mul3: the forward 1x1
+    convs through ds_conv_f32x3 (fp32 products from three bf16 pieces on the bf16 matrix cores) -- held to the SAME
+    tolerances against the fp64 oracle as the fp32-MFMA path."""
     from tumblr_emotions_amd.net import SentimentNet
     rng = np.random.RandomState(23)
     B = 3
@@ -214,8 +217,12 @@ def test_image_only_step_matches_oracle():
     mask = (rng.uniform(size=(B, 1024)) < 0.8).astype(np.float64)
     ref = R.DeepSentimentRef(params, None, "image", torch.float64)
     net = SentimentNet(mode="image", nb_emotions=15)
+    net.image.mul3 = mul3
     net.load_state_dict(params)
     _check_step(net, ref, batch, 1e-3, mask)
+    if mul3:
+        from tumblr_emotions_amd import ops
+        assert sum(1 for l in net.image.layers if isinstance(l.wino_fwd, ops.F32x3Plan)) >= 19
 
 
 def test_joint_step_matches_oracle():
@@ -450,6 +457,31 @@ def test_captured_step_matches_eager_step(mode):
     # the replayed steps are the eager steps, bit for bit
     assert l0 == l1
     assert torch.equal(z0, z1) and torch.equal(th0, th1) and torch.equal(fr0, fr1)
+
+
+def test_mul3_forward_stays_within_fp32_rounding_of_the_fp32_forward():
+    """InceptionV1Engine.mul3 (opt-in; bench.py --mul3, dtype label f32x3) at B = 16: logits and loss of the step agree
+    with the fp32-MFMA step to 1e-4 / 1e-5 -- the spread two fp32 summation orders show through this 57-layer BatchNorm
+    stack (gradients are compared with the oracle along the path's own decisions instead,
+    test_image_only_step_matches_oracle[f32x3]: a forward perturbation of any size flips ReLU / pool decisions)."""
+    from tumblr_emotions_amd import ops
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    batch = to_device(synthetic_batch_numpy(16, 10, 50, seed=4))
+    res, used = [], []
+    for on in (True, False):
+        net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10)
+        net.image.mul3 = on
+        net.initialize(seed=9)
+        net.train_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        used.append(sum(1 for l in net.image.layers if isinstance(l.wino_fwd, ops.F32x3Plan)))
+        res.append((net.logits.clone(), net.total_loss_value()))
+    assert used[0] >= 19 and used[1] == 0, used
+    dl = float((res[0][0] - res[1][0]).abs().max())
+    print("%d layers on ds_conv_f32x3; logits moved %.2e, loss %.2e" % (used[0], dl, abs(res[0][1] - res[1][1])))
+    assert dl <= 1e-4 * max(1.0, float(res[1][0].abs().max())), dl
+    assert abs(res[0][1] - res[1][1]) <= 1e-5 * max(1.0, abs(res[1][1]))
 
 
 def test_zcat_step_is_bit_identical():

@@ -1327,11 +1327,27 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
 //     fragment feeds NB MFMAs; the next step's eight A loads and NB weight DMAs are issued between the MFMA groups.
 // Epilogue: fp32 stores + BatchNorm column statistics about the pivot (flags 0 or DS_EPI_STATS).
 // ================================================================================================
-template <int NB, int KS, bool XB>      // KS x KS taps (1 or 3); XB: x is stored as bf16 (16-bit activation storage)
+// X3 (ds_conv_f32x3): fp32 PRODUCTS on the bf16 matrix cores.  Every fp32 operand is the sum of three bf16 pieces
+// (8 + 8 + 8 mantissa bits: a = a0 + a1 + a2 exactly to 2^-24 |a|); a*b is accumulated in fp32 as
+// a1*b1 + a2*b0 + a0*b2 + a1*b0 + a0*b1 + a0*b0 (the dropped terms are below 2^-24 |ab|): six v_mfma_f32_32x32x16_bf16
+// (8 passes each) per 16 reduction channels and 32x32 tile instead of eight v_mfma_f32_32x32x2_f32 (16 passes each), i.e.
+// 2.67x fewer matrix cycles at the accuracy of the fp32 MFMA (scratch/mfma_x3.hip: relative rms error against fp64
+// 3.26e-7 vs 3.22e-7 over K = 512; loop 1.6 - 1.9x faster including the splitting).  The weights are split once per
+// weight update (ds_weights_to_f32x3: three planes per K-loop iteration), the A fragment in registers (~40 VALU per 8
+// values, shared by the NB column blocks).  Measured on the 1x1 layers of the joint step (B = 256): 1.15 - 1.5x over the
+// wide fp32 kernel on twelve of fourteen shapes, up to 163 TFLOP/s of fp32-accurate GEMM -- above the fp32 MFMA peak.
+template <int NB, int KS, bool XB, bool X3 = false>      // KS x KS taps (1 or 3); XB: x is stored as bf16 (16-bit activation storage)
 __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) {
-    constexpr int BN = NB * 32, SI = 4, TAPS = KS * KS;
-    constexpr int BSZ = SI * BN * 16;                          // bf16 elements per B buffer
+    // iterations per step: X3 keeps three weight planes in LDS, so shorter steps (SI * NB % 4 == 0: whole DMA slots)
+    constexpr int BN = NB * 32, SI = !X3 ? 4 : NB == 1 ? 4 : NB <= 4 ? 2 : 1, TAPS = KS * KS;
+    constexpr int PL = X3 ? 3 : 1;                             // weight planes per iteration (X3: the three bf16 pieces)
+    constexpr int NSL = SI * PL * NB / 4;                      // 16-byte DMA slots per thread and step
+    static_assert(SI * PL * NB % 4 == 0, "a step's weight tile must be whole 256-lane DMA instructions");
+    constexpr int BSZ = SI * PL * BN * 16;                     // bf16 elements per B buffer
+    static_assert(!(X3 && XB), "ds_conv_f32x3 reads fp32 activations");
     __shared__ __attribute__((aligned(128))) __bf16 smem[2 * BSZ + 512];
+    // X3 + ds_conv_desc.norm_rstd / norm_shift (1x1 only): x holds pre-BatchNorm values, relu(x*rstd + shift) on load
+    __shared__ __attribute__((aligned(16))) float nrm[2][X3 ? 1024 + 16 : 4];
     const ds_conv_desc &d = p.d;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1363,10 +1379,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
         }
     // ---- B DMA slots of a step: slot -> (local iteration, column, 8-k half); source is linear in wb ---------------
     const int ncols = p.col_total;                              // columns of wb (Cout rounded up to 32)
-    unsigned uoff[NB];
-    int uit[NB];
+    unsigned uoff[NSL];
+    int uit[NSL];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
+    for (int i = 0; i < NSL; ++i) {
         const int sl = i * 256 + tid;
         const int itl = sl / (BN * 2), nn = (sl >> 1) % BN, half = sl & 1;
         uit[i] = itl;
@@ -1374,8 +1390,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
     }
     const unsigned it_bytes = (unsigned)ncols * 32u;            // bytes of one iteration's weights
     auto dma_b = [&](int buf, int step, int i) {
-        unsigned o = uoff[i] + (unsigned)(step * SI) * it_bytes;
-        if (step * SI + uit[i] >= iters || uoff[i] == 0x80000000u) o = 0x80000000u;     // past the reduction: zeros
+        unsigned o = uoff[i] + (unsigned)(step * SI * PL) * it_bytes;
+        if (step * SI * PL + uit[i] >= iters * PL || uoff[i] == 0x80000000u) o = 0x80000000u;     // past the reduction: zeros
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr)(smem + buf * BSZ + wave * 512 + i * 2048), 16, o, 0, 0, 0);
     };
     // A loads of one (chunk, tap) iteration
@@ -1402,7 +1418,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
 #pragma unroll
     for (int j = 0; j < SI; ++j) load_a(j, alo[j], ahi[j]);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) dma_b(0, 0, i);
+    for (int i = 0; i < NSL; ++i) dma_b(0, 0, i);
+    bool norm = false;
+    if constexpr (X3) {
+        norm = d.norm_rstd != nullptr;          // (uniform)
+        if (norm)
+            for (int c = tid; c < chunks * 16; c += 256) {
+                nrm[0][c] = c < d.Cin ? d.norm_rstd[c] : 0.f;
+                nrm[1][c] = c < d.Cin ? d.norm_shift[c] : 0.f;
+            }
+    }
     __syncthreads();
     for (int st = 0; st < nsteps; ++st) {
         const bool more = st + 1 < nsteps;
@@ -1410,25 +1435,57 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
         f32x4 nlo[SI], nhi[SI];
 #pragma unroll
         for (int j = 0; j < SI; ++j) {
-            // A fragment: 8 consecutive channels rounded to bf16
-            bf16x8 af;
+            // A fragment: 8 consecutive channels rounded to bf16 (X3: split into three bf16 pieces)
+            bf16x8 af, af1, af2;
             if (XB) {
                 af = __builtin_bit_cast(bf16x8, alo[j]);
             } else {
-                const bf16x4 l4 = __builtin_convertvector(alo[j], bf16x4), h4 = __builtin_convertvector(ahi[j], bf16x4);
+                f32x4 xl = alo[j], xh = ahi[j];
+                if constexpr (X3) {
+                    if (norm) {
+                        const int c = ((st * SI + j) / TAPS) * 16 + 8 * kh;
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        xl = __builtin_elementwise_max(__builtin_elementwise_fma(xl, *reinterpret_cast<const f32x4 *>(&nrm[0][c]),
+                                                                                 *reinterpret_cast<const f32x4 *>(&nrm[1][c])), zero);
+                        xh = __builtin_elementwise_max(__builtin_elementwise_fma(xh, *reinterpret_cast<const f32x4 *>(&nrm[0][c + 4]),
+                                                                                 *reinterpret_cast<const f32x4 *>(&nrm[1][c + 4])), zero);
+                    }
+                }
+                bf16x4 l4 = __builtin_convertvector(xl, bf16x4), h4 = __builtin_convertvector(xh, bf16x4);
                 af = __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+                if constexpr (X3) {
+                    xl -= __builtin_convertvector(l4, f32x4);
+                    xh -= __builtin_convertvector(h4, f32x4);
+                    l4 = __builtin_convertvector(xl, bf16x4);
+                    h4 = __builtin_convertvector(xh, bf16x4);
+                    af1 = __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+                    xl -= __builtin_convertvector(l4, f32x4);
+                    xh -= __builtin_convertvector(h4, f32x4);
+                    af2 = __builtin_shufflevector(__builtin_convertvector(xl, bf16x4), __builtin_convertvector(xh, bf16x4), 0, 1, 2, 3, 4, 5, 6, 7);
+                }
             }
             if (more) {             // next step's operands between the MFMA groups
                 load_a((st + 1) * SI + j, nlo[j], nhi[j]);
 #pragma unroll
-                for (int i = j; i < NB; i += SI) dma_b((st + 1) & 1, st + 1, i);
+                for (int i = j; i < NSL; i += SI) dma_b((st + 1) & 1, st + 1, i);
             }
-            bf16x8 bfr[NB];
+            bf16x8 bfr[PL][NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) bfr[b] = *reinterpret_cast<const bf16x8 *>(b_s + (j * BN + b * 32) * 16);
+            for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) bfr[pl][b] = *reinterpret_cast<const bf16x8 *>(b_s + ((j * PL + pl) * BN + b * 32) * 16);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[b], acc[b], 0, 0, 0);
+            for (int b = 0; b < NB; ++b) {
+                if constexpr (X3) {         // small terms first
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1, bfr[1][b], acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2, bfr[0][b], acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[PL - 1][b], acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1, bfr[0][b], acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[PL > 1 ? 1 : 0][b], acc[b], 0, 0, 0);
+                }
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[0][b], acc[b], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -1501,6 +1558,35 @@ __global__ __launch_bounds__(256) void weights_to_bf16_kernel(const float *w, __
             v = w[((int64_t)tp * Cin + ci) * Cout + co];
         }
         wb[i] = (__bf16)v;
+    }
+}
+
+// the three bf16 pieces of every weight, in the K-loop order of conv_bf16d_kernel<.., X3>: [iteration][piece][column][16 k]
+__global__ __launch_bounds__(256) void weights_to_f32x3_kernel(const float *w, __bf16 *wb, int Cin, int Cout, int taps,
+                                                               int dgrad) {
+    const int K = dgrad ? Cout : Cin, Ncol = dgrad ? Cin : Cout;
+    const int chunks = (K + 15) >> 4, ncols = (Ncol + 31) / 32 * 32;
+    const int64_t total = (int64_t)chunks * taps * ncols * 16;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int j = (int)(i & 15);
+        const int64_t rest = i >> 4;
+        const int col = (int)(rest % ncols);
+        const int it = (int)(rest / ncols);
+        const int chunk = it / taps, tap = it - chunk * taps;
+        const int k = chunk * 16 + j;
+        float v = 0.f;
+        if (col < Ncol && k < K) {
+            const int ci = dgrad ? col : k, co = dgrad ? k : col, tp = dgrad ? taps - 1 - tap : tap;
+            v = w[((int64_t)tp * Cin + ci) * Cout + co];
+        }
+        const __bf16 p0 = (__bf16)v;
+        const float r1 = v - (float)p0;
+        const __bf16 p1 = (__bf16)r1;
+        const __bf16 p2 = (__bf16)(r1 - (float)p1);
+        const int64_t o = (((int64_t)it * 3) * ncols + col) * 16 + j;
+        wb[o] = p0;
+        wb[o + (int64_t)ncols * 16] = p1;
+        wb[o + (int64_t)ncols * 32] = p2;
     }
 }
 
@@ -2003,4 +2089,62 @@ extern "C" int ds_conv_bf16(const ds_conv_desc *d, const void *x, const void *wb
     }
 #undef DS_B16
     return ds::check_launch("ds_conv_bf16");
+}
+
+// ---- fp32 products on the bf16 matrix cores (see conv_bf16d_kernel<.., X3>) ----------------------------------------
+extern "C" size_t ds_weights_f32x3_bytes(int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad) {
+    return 3 * ds_weights_bf16_bytes(Cin, Cout, taps, dgrad);
+}
+
+extern "C" int ds_weights_to_f32x3(const float *w, void *wb, int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad,
+                                   void *stream) {
+    DS_REQUIRE(w && wb && Cin > 0 && Cout > 0 && taps > 0, "ds_weights_to_f32x3: bad argument");
+    const int64_t total = (int64_t)ds_weights_bf16_bytes(Cin, Cout, taps, dgrad) / 2;
+    hipLaunchKernelGGL(weights_to_f32x3_kernel, dim3(ds::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (__bf16 *)wb, Cin, Cout, taps, dgrad);
+    return ds::check_launch("ds_weights_to_f32x3");
+}
+
+extern "C" int ds_conv_f32x3_supported(const ds_conv_desc *d) {
+    return d && bf16d_ok(d) && d->x_dtype == DS_DTYPE_F32 && (!d->norm_rstd || (d->KH == 1 && d->Cin <= 1024)) ? 1 : 0;
+}
+
+extern "C" int ds_conv_f32x3_partials(const ds_conv_desc *d) { return (int)((conv_M(d) + 127) / 128); }
+
+extern "C" int ds_conv_f32x3(const ds_conv_desc *d, const float *x, const void *wb, float *z, float *stats,
+                             const float *pivot, void *stream) {
+    DS_REQUIRE(d && x && wb && z, "ds_conv_f32x3: null argument");
+    DS_REQUIRE(ds_conv_f32x3_supported(d),
+               "ds_conv_f32x3: needs a 1x1 or 3x3 conv on fp32 x, Cin %% 8 == 0, ldx %% 4 == 0, flags within DS_EPI_STATS "
+               "(norm_rstd / norm_shift: 1x1 only, Cin <= 1024)");
+    DS_REQUIRE((!d->norm_rstd) == (!d->norm_shift) && !d->mask_rstd && !d->mask_shift, "ds_conv_f32x3: norm_rstd and norm_shift go together");
+    DS_REQUIRE(((((uintptr_t)x | (uintptr_t)wb) & 15) == 0) && conv_M(d) < (1ll << 31), "ds_conv_f32x3: operands must be 16-byte aligned");
+    DS_REQUIRE(!(d->flags & DS_EPI_STATS) || stats, "ds_conv_f32x3: DS_EPI_STATS without stats buffer");
+    ConvParams p = {};
+    p.d = *d;
+    p.x = x; p.w = (const float *)wb; p.z = z; p.stats = stats;
+    p.pivot = (d->flags & DS_EPI_STATS) ? pivot : nullptr;
+    p.M = (int)conv_M(d);
+    p.taps = d->KH * d->KW;
+    const int64_t x_elems = ((int64_t)d->N * d->H * d->W - 1) * d->ldx + d->Cin;
+    const int64_t wb_bytes = 3 * (int64_t)((d->Cin + 15) / 16) * p.taps * ((d->Cout + 31) / 32 * 32) * 32;
+    DS_REQUIRE(x_elems * 4 < (1ll << 31) && wb_bytes < (1ll << 31), "ds_conv_f32x3: operand larger than 2 GiB");
+    p.x_bytes = (unsigned)(x_elems * 4);
+    p.w_bytes = (unsigned)wb_bytes;
+    p.col_total = (d->Cout + 31) / 32 * 32;
+    // two column blocks per wave (one where Cout <= 32): measured best on all fourteen 1x1 layer shapes (NB = 4: the
+    // split is better amortised but two waves per SIMD no longer fit; profiles/r03_f32x3_layers.txt)
+    const int nb = d->Cout <= 32 ? 1 : 2;
+    p.row_tiles = (int)((conv_M(d) + 127) / 128);
+    p.col_tiles = (d->Cout + 32 * nb - 1) / (32 * nb);
+    const dim3 grid((unsigned)(((int64_t)p.row_tiles * p.col_tiles + 7) / 8 * 8));
+    hipStream_t st = (hipStream_t)stream;
+    if (nb == 1) {
+        if (d->KH == 1) hipLaunchKernelGGL((conv_bf16d_kernel<1, 1, false, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_bf16d_kernel<1, 3, false, true>), grid, dim3(256), 0, st, p);
+    } else {
+        if (d->KH == 1) hipLaunchKernelGGL((conv_bf16d_kernel<2, 1, false, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_bf16d_kernel<2, 3, false, true>), grid, dim3(256), 0, st, p);
+    }
+    return ds::check_launch("ds_conv_f32x3");
 }

@@ -118,6 +118,14 @@ class ConvBN:
             eng.need_stats(self.wino_fwd.partials * 2 * cout)
         self._wino_dgrad_ok = wino_ok(self.H, cout, cin)
         self._wino4_dgrad = self._wino_dgrad_ok and wino4_ok(cout, cin)
+        # mul3 (opt-in, fp32 configuration): the forward 1x1 convs through ds_conv_f32x3 -- fp32 products on the bf16 matrix
+        # cores (three bf16 pieces per operand; the fp32 MFMA's accuracy, not its bits), 1.15-1.5x over the wide fp32 kernel
+        # (profiles/r03_f32x3_layers.txt); rides the alternative-plan slot like the Winograd kernels (u_fwd = split weights)
+        if (eng.mul3 and eng.dtype == "f32" and k == 1 and self.stride == 1 and not self.fold and cin % 8 == 0 and
+                cin <= 1024 and self.wino_fwd is None):
+            self.wino_fwd = ops.F32x3Plan(B, self.H, self.W, cin, cin, 1, 1, cout, cout, flags=DS_EPI_STATS)
+            self.u_fwd = torch.empty(ops.weights_f32x3_bytes(cin, cout, 1, False), dtype=torch.uint8, device=dev)
+            eng.need_stats(self.wino_fwd.partials * 2 * cout)
         # bf16: the register-direct kernel (ds_conv_bf16, pre-converted weights) where it beats the LDS-staged one
         # (profiles/r02_bf16_layers.txt): forward from 48 output columns up, dgrad for the 1x1 layers and from 160
         # columns up; it rides the same alternative-plan slots as the Winograd kernel (u_* = its converted weights)
@@ -167,7 +175,7 @@ class ConvBN:
         layer's slices of the block's per-channel arrays."""
         self.z, self.ldz, self.rstd, self.shift, self.skip_apply = zview, ld, rstd, shift, True
         self.fwd.d.ldz = ld
-        if isinstance(self.wino_fwd, WinoPlan):
+        if isinstance(self.wino_fwd, (WinoPlan, ops.F32x3Plan)):
             self.wino_fwd.set_ldz(ld)
 
     def bind(self):
@@ -296,7 +304,9 @@ class ConvBN:
         taps = self.k * self.k
         for plan, u, dgrad in ((self.wino_fwd, getattr(self, "u_fwd", None), False),
                                (self.wino_dgrad, getattr(self, "u_dgrad", None), True)):
-            if isinstance(plan, ops.Fp8Plan):
+            if isinstance(plan, ops.F32x3Plan):
+                ops.weights_to_f32x3(self.w_ptr, u, self.cin, self.cout, taps, dgrad)
+            elif isinstance(plan, ops.Fp8Plan):
                 ops.weights_to_fp8(self.w_ptr, u, self.ws_dgrad if dgrad else self.ws_fwd, self.cin, self.cout, taps, dgrad)
             elif isinstance(plan, ops.Bf16Plan):
                 ops.weights_to_bf16(self.w_ptr, u, self.cin, self.cout, taps, dgrad)
@@ -631,8 +641,10 @@ class MixedStage(Stage):
                 n = layer.cout
                 layer.use_concat_slice(zc[:, off:off + n], Ct, self.rs_cat[0, off:off + n], self.rs_cat[1, off:off + n])
         if getattr(self.prev, "zcat", False):    # this block reads a zcat concat
-            self.fused.fwd.d.norm_rstd = self.prev.rs_cat[0].data_ptr()
-            self.fused.fwd.d.norm_shift = self.prev.rs_cat[1].data_ptr()
+            plans = [self.fused.fwd] + ([self.fused.wino_fwd] if isinstance(self.fused.wino_fwd, ops.F32x3Plan) else [])
+            for pl in plans:
+                pl.d.norm_rstd = self.prev.rs_cat[0].data_ptr()
+                pl.d.norm_shift = self.prev.rs_cat[1].data_ptr()
         self.fused.make_dgrad(cin)
         self.c1.make_dgrad(b1a)
         self.c2.make_dgrad(b2a)
@@ -834,6 +846,7 @@ class InceptionV1Engine:
         self.side = None
         self.bf16_direct = True      # dtype bf16: ds_conv_bf16 where it wins (False: the LDS-staged bf16 kernel everywhere)
         self.winograd = True         # 3x3 layers through ds_conv_wino where it wins (False: implicit GEMM everywhere)
+        self.mul3 = os.environ.get("DS_MUL3", "0") == "1"     # opt-in: forward 1x1 convs with fp32 products on the bf16 matrix cores
         self.zcat = os.environ.get("DS_ZCAT", "1") != "0"     # 3x3 / Branch_3 convs write z into the concat, consumers normalise on load
         self.winograd4 = os.environ.get("DS_WINO4", "1") != "0"      # ... and ds_conv_wino4 (F(4x4,3x3)) where it is faster
         self.weights_version = 0     # bumped by SentimentNet.after_load(): frozen layers redo their G g G^T

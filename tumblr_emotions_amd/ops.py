@@ -337,6 +337,64 @@ def weights_to_bf16(w_ptr, wb, Cin, Cout, taps, dgrad):
                "ds_weights_to_bf16")
 
 
+class F32x3Plan:
+    """1x1 / 3x3 conv (or its dgrad) through ds_conv_f32x3: fp32 products on the bf16 matrix cores (every operand split into
+    three bf16 pieces, six MFMAs per eight of the fp32 path; fp32-MFMA accuracy, not bit-identical).  Weights pre-split by
+    `weights_to_f32x3`.  Geometry arguments as Bf16Plan's; x is fp32; d.norm_rstd / norm_shift as for ConvPlan (1x1)."""
+    f4 = False
+
+    def __init__(self, N, H, W, Cin, ldx, k, stride, Cout, ldz, flags=0, pad_t=None, pad_l=None, OH=None, OW=None):
+        d = ConvDesc()
+        d.dtype = DS_DTYPE_F32
+        d.N, d.H, d.W, d.Cin, d.ldx = N, H, W, Cin, ldx
+        d.KH, d.KW, d.stride = k, k, stride
+        if OH is None:
+            OH, pt = same_pad(H, k, stride)
+            OW, pl = same_pad(W, k, stride)
+            pad_t = pt if pad_t is None else pad_t
+            pad_l = pl if pad_l is None else pad_l
+        d.pad_t, d.pad_l, d.OH, d.OW = pad_t, pad_l, OH, OW
+        d.Cout, d.ldz, d.flags, d.splits = Cout, ldz, flags, 1
+        self.d = d
+        lib = _lib.load()
+        if not lib.ds_conv_f32x3_supported(C.byref(d)):
+            raise ValueError("ds_conv_f32x3 does not take this geometry")
+        self.M = N * OH * OW
+        self.partials = lib.ds_conv_f32x3_partials(C.byref(d)) if flags & DS_EPI_STATS else 0
+        self.alg_flops = 2.0 * self.M * Cout * k * k * Cin
+
+    def set_ldx(self, ldx):
+        self.d.ldx = ldx
+
+    def set_ldz(self, ldz):
+        self.d.ldz = ldz
+
+    @property
+    def flags(self):
+        return self.d.flags
+
+    @flags.setter
+    def flags(self, v):
+        self.d.flags = v
+
+    def run(self, x, wb, z, stats=None, pivot=None):
+        t = CONV_TIMER
+        if t is not None:
+            t.begin()
+        _lib.check(_lib.load().ds_conv_f32x3(C.byref(self.d), x, wb, z, stats, pivot, _stream()), "ds_conv_f32x3")
+        if t is not None:
+            t.end(self)
+
+
+def weights_f32x3_bytes(Cin, Cout, taps, dgrad):
+    return int(_lib.load().ds_weights_f32x3_bytes(Cin, Cout, taps, int(dgrad)))
+
+
+def weights_to_f32x3(w_ptr, wb, Cin, Cout, taps, dgrad):
+    """HWIO fp32 filter -> ds_conv_f32x3's weight tensor (three bf16 pieces per weight, K-loop order)."""
+    _lib.check(_lib.load().ds_weights_to_f32x3(w_ptr, _p(wb), Cin, Cout, taps, int(dgrad), _stream()), "ds_weights_to_f32x3")
+
+
 class WgradPlan:
     """dw[tap, ci, co] = sum_m x[pixel(m)+tap, ci] * dz[m, co]; geometry given by a forward ConvPlan-like desc."""
 
