@@ -138,15 +138,16 @@ int ds_conv_bf16(const ds_conv_desc *d, const void *x, const void *wb, float *z,
  * mantissa bits) and a*b is accumulated in fp32 from the six piece products whose magnitude exceeds 2^-24 |ab| -- six
  * v_mfma_f32_32x32x16_bf16 instead of eight v_mfma_f32_32x32x2_f32 per 16 reduction channels, 2.67x fewer matrix
  * cycles.  Error against fp64 equals the fp32 MFMA's (scratch/mfma_x3.hip: 3.26e-7 vs 3.22e-7 relative rms); results
- * are NOT bit-identical to ds_conv_igemm.  Same descriptor as ds_conv_bf16 (1x1 / 3x3, Cin % 8 == 0, flags within
- * DS_EPI_STATS, fp32 x); norm_rstd / norm_shift (1x1) as for ds_conv_igemm.  wb = ds_weights_to_f32x3(w): the weights'
+ * are NOT bit-identical to ds_conv_igemm.  Same descriptor as ds_conv_bf16 (1x1 / 3x3, Cin % 8 == 0, fp32 x); flags
+ * DS_EPI_STATS, or -- for a dgrad -- DS_EPI_ACCUM and DS_EPI_BNSUMS (mask, ldmask, mask_rstd / mask_shift) exactly as
+ * ds_conv_igemm's wide kernel; norm_rstd / norm_shift (1x1) as for ds_conv_igemm.  wb = ds_weights_to_f32x3(w): the weights'
  * three pieces in the kernel's K-loop order, ds_weights_f32x3_bytes bytes, remade whenever w changes.               */
 size_t ds_weights_f32x3_bytes(int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad);
 int ds_weights_to_f32x3(const float *w, void *wb, int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad, void *stream);
 int ds_conv_f32x3_supported(const ds_conv_desc *d);
 int ds_conv_f32x3_partials(const ds_conv_desc *d);
-int ds_conv_f32x3(const ds_conv_desc *d, const float *x, const void *wb, float *z, float *stats, const float *pivot,
-                  void *stream);
+int ds_conv_f32x3(const ds_conv_desc *d, const float *x, const void *wb, float *z, const float *mask, float *stats,
+                  const float *pivot, void *stream);
 
 /* fp8 convolution path (BASELINE configs[4]: fp8 MFMA conv path on CDNA4), 1x1 and 3x3 convs, forward and
  * Conv2DBackpropInput (slim.conv2d, image_model/inception_v1.py:71-250): v_mfma_f32_32x32x16_fp8_fp8 / _bf8_fp8, OCP

@@ -399,9 +399,25 @@ def test_fp32_products_from_three_bf16_pieces_match_the_oracle(case):
         wg = torch.empty(ops.weights_f32x3_bytes(Ci, Co, k * k, True), dtype=torch.uint8, device="cuda")
         ops.weights_to_f32x3(ops._p(wd), wg, Ci, Co, k * k, True)
         dx = torch.empty(M, Ci, device="cuda")
-        g.run(ops._p(dev(dz)), ops._p(wg), ops._p(dx))
+        dzd = dev(dz)
+        g.run(ops._p(dzd), ops._p(wg), ops._p(dx))
         torch.cuda.synchronize()
         close(dx, S.conv2d_same_bwd_input(dz, w, (N, H, W, Ci), 1).reshape(-1, Ci))
+    if k == 1 and Co % 8 == 0:      # the wide kernel's dgrad epilogue: accumulate onto dx, emit the consumer's BatchNorm sums
+        yv = np.maximum(rng.normal(size=(M, Ci)), 0.0) * (rng.uniform(size=(M, Ci)) < 0.7)
+        prev = rng.normal(size=(M, Ci))
+        g.d.flags = ops.DS_EPI_ACCUM | ops.DS_EPI_BNSUMS
+        g.d.ldmask = Ci
+        P = g.partials_for_sums
+        sums = torch.full((2, Ci, P), float("nan"), device="cuda")
+        dxa, yd = dev(prev), dev(yv)
+        g.run(ops._p(dzd), ops._p(wg), ops._p(dxa), stats=ops._p(sums), mask=ops._p(yd))
+        torch.cuda.synchronize()
+        want = prev + S.conv2d_same_bwd_input(dz, w, (N, H, W, Ci), 1).reshape(-1, Ci)
+        close(dxa, want)
+        gm = want * (yv > 0)
+        close(sums[0].sum(1), gm.sum(0), 2e-3)
+        close(sums[1].sum(1), (gm * yv).sum(0), 2e-3)
     if k == 1:      # BatchNorm + ReLU on load: x holds z, channels with (1, 0) are activations already
         r = np.abs(rng.normal(size=Ci)) + 0.5
         sh = rng.normal(size=Ci) * 0.3
@@ -410,8 +426,8 @@ def test_fp32_products_from_three_bf16_pieces_match_the_oracle(case):
         nplan = ops.F32x3Plan(N, H, W, Ci, Ci, 1, 1, Co, Co)
         rt, st_ = dev(r), dev(sh)
         nplan.d.norm_rstd, nplan.d.norm_shift = rt.data_ptr(), st_.data_ptr()
-        zn = torch.empty(M, Co, device="cuda")
-        nplan.run(ops._p(dev(zin)), ops._p(wb), ops._p(zn))
+        zn, zind = torch.empty(M, Co, device="cuda"), dev(zin)
+        nplan.run(ops._p(zind), ops._p(wb), ops._p(zn))
         torch.cuda.synchronize()
         close(zn, S.conv2d_same(yin, w, 1).reshape(-1, Co))
 

@@ -65,7 +65,7 @@ SIGNATURES = {
     "ds_weights_to_f32x3": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _P]),
     "ds_conv_f32x3_supported": (C.c_int, [_CD]),
     "ds_conv_f32x3_partials": (C.c_int, [_CD]),
-    "ds_conv_f32x3": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P]),
+    "ds_conv_f32x3": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _P]),
     "ds_absmax": (C.c_int, [_P, _i64, _i32, _P, _P]),
     "ds_weights_fp8_bytes": (C.c_size_t, [_i32, _i32, _i32, _i32]),
     "ds_weights_to_fp8": (C.c_int, [_P, _P, _P, _i32, _i32, _i32, _i32, _P]),

@@ -1503,18 +1503,47 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
         const bool colok = item && col < d.Cout;
         const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
         float s = 0.f, q = 0.f;
+        if (X3 && (flags & DS_EPI_BNSUMS)) {
+            // (X3 only, as gemm_wide_kernel) dgrad whose result dy feeds a BatchNorm + ReLU backward: column sums of
+            // g = dy (y > 0) and g * y; `mask` holds y, or z with mask_rstd / mask_shift
+            float yv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row < p.M && colok) {
-                const float v = acc[b][r];
-                p.z[(int64_t)row * d.ldz + col] = v;
-                const float u = v - pv;
-                s += u;
-                q += u * u;
+            for (int r = 0; r < 16; ++r) {
+                const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                yv[r] = (row < p.M && colok) ? p.mask[(int64_t)row * d.ldmask + col] : 0.f;
+            }
+            if (d.mask_rstd && colok) {
+                const float mr = d.mask_rstd[col], ms = d.mask_shift[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[r] = fmaxf(fmaf(yv[r], mr, ms), 0.f);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < p.M && colok) {
+                    float v = acc[b][r];
+                    if (flags & DS_EPI_ACCUM) v += p.z[(int64_t)row * d.ldz + col];
+                    p.z[(int64_t)row * d.ldz + col] = v;
+                    const float u = yv[r] > 0.f ? v : 0.f;
+                    s += u;
+                    q += u * yv[r];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < p.M && colok) {
+                    float v = acc[b][r];
+                    if (X3 && (flags & DS_EPI_ACCUM)) v += p.z[(int64_t)row * d.ldz + col];
+                    p.z[(int64_t)row * d.ldz + col] = v;
+                    const float u = v - pv;
+                    s += u;
+                    q += u * u;
+                }
             }
         }
-        if (flags & DS_EPI_STATS) {
+        if (flags & (DS_EPI_STATS | (X3 ? DS_EPI_BNSUMS : 0))) {
             s += __shfl_xor(s, 32);
             q += __shfl_xor(q, 32);
             __syncthreads();
@@ -2106,23 +2135,31 @@ extern "C" int ds_weights_to_f32x3(const float *w, void *wb, int32_t Cin, int32_
 }
 
 extern "C" int ds_conv_f32x3_supported(const ds_conv_desc *d) {
-    return d && bf16d_ok(d) && d->x_dtype == DS_DTYPE_F32 && (!d->norm_rstd || (d->KH == 1 && d->Cin <= 1024)) ? 1 : 0;
+    if (!d) return 0;
+    ds_conv_desc t = *d;
+    t.flags &= ~(DS_EPI_ACCUM | DS_EPI_BNSUMS);             // (the X3 epilogue also accumulates and emits BatchNorm sums)
+    if ((d->flags & DS_EPI_BNSUMS) && (d->flags & DS_EPI_STATS)) return 0;
+    return bf16d_ok(&t) && d->x_dtype == DS_DTYPE_F32 && (!d->norm_rstd || (d->KH == 1 && d->Cin <= 1024)) ? 1 : 0;
 }
 
 extern "C" int ds_conv_f32x3_partials(const ds_conv_desc *d) { return (int)((conv_M(d) + 127) / 128); }
 
-extern "C" int ds_conv_f32x3(const ds_conv_desc *d, const float *x, const void *wb, float *z, float *stats,
-                             const float *pivot, void *stream) {
+extern "C" int ds_conv_f32x3(const ds_conv_desc *d, const float *x, const void *wb, float *z, const float *mask,
+                             float *stats, const float *pivot, void *stream) {
     DS_REQUIRE(d && x && wb && z, "ds_conv_f32x3: null argument");
     DS_REQUIRE(ds_conv_f32x3_supported(d),
-               "ds_conv_f32x3: needs a 1x1 or 3x3 conv on fp32 x, Cin %% 8 == 0, ldx %% 4 == 0, flags within DS_EPI_STATS "
-               "(norm_rstd / norm_shift: 1x1 only, Cin <= 1024)");
-    DS_REQUIRE((!d->norm_rstd) == (!d->norm_shift) && !d->mask_rstd && !d->mask_shift, "ds_conv_f32x3: norm_rstd and norm_shift go together");
+               "ds_conv_f32x3: needs a 1x1 or 3x3 conv on fp32 x, Cin %% 8 == 0, ldx %% 4 == 0, flags within DS_EPI_STATS | "
+               "DS_EPI_ACCUM | DS_EPI_BNSUMS (norm_rstd / norm_shift: 1x1 only, Cin <= 1024)");
+    DS_REQUIRE((!d->norm_rstd) == (!d->norm_shift) && (!d->mask_rstd) == (!d->mask_shift) &&
+                   (!d->mask_rstd || (d->flags & DS_EPI_BNSUMS)),
+               "ds_conv_f32x3: norm_rstd / norm_shift and mask_rstd / mask_shift come in pairs (the latter with DS_EPI_BNSUMS)");
+    DS_REQUIRE(!(d->flags & DS_EPI_BNSUMS) || (mask && stats && d->ldmask >= d->Cout),
+               "ds_conv_f32x3: DS_EPI_BNSUMS needs mask (row stride ldmask) and a partials buffer");
     DS_REQUIRE(((((uintptr_t)x | (uintptr_t)wb) & 15) == 0) && conv_M(d) < (1ll << 31), "ds_conv_f32x3: operands must be 16-byte aligned");
     DS_REQUIRE(!(d->flags & DS_EPI_STATS) || stats, "ds_conv_f32x3: DS_EPI_STATS without stats buffer");
     ConvParams p = {};
     p.d = *d;
-    p.x = x; p.w = (const float *)wb; p.z = z; p.stats = stats;
+    p.x = x; p.w = (const float *)wb; p.z = z; p.stats = stats; p.mask = mask;
     p.pivot = (d->flags & DS_EPI_STATS) ? pivot : nullptr;
     p.M = (int)conv_M(d);
     p.taps = d->KH * d->KW;

@@ -361,6 +361,7 @@ class F32x3Plan:
             raise ValueError("ds_conv_f32x3 does not take this geometry")
         self.M = N * OH * OW
         self.partials = lib.ds_conv_f32x3_partials(C.byref(d)) if flags & DS_EPI_STATS else 0
+        self.partials_for_sums = lib.ds_conv_f32x3_partials(C.byref(d))      # what a DS_EPI_BNSUMS launch would write
         self.alg_flops = 2.0 * self.M * Cout * k * k * Cin
 
     def set_ldx(self, ldx):
@@ -377,11 +378,11 @@ class F32x3Plan:
     def flags(self, v):
         self.d.flags = v
 
-    def run(self, x, wb, z, stats=None, pivot=None):
+    def run(self, x, wb, z, stats=None, pivot=None, mask=None):
         t = CONV_TIMER
         if t is not None:
             t.begin()
-        _lib.check(_lib.load().ds_conv_f32x3(C.byref(self.d), x, wb, z, stats, pivot, _stream()), "ds_conv_f32x3")
+        _lib.check(_lib.load().ds_conv_f32x3(C.byref(self.d), x, wb, z, mask, stats, pivot, _stream()), "ds_conv_f32x3")
         if t is not None:
             t.end(self)
 
