@@ -107,6 +107,9 @@ int ds_debug_conv_set_path(int path);
 /* the wide-tile register-direct kernel for plain 1x1 / GEMM shapes (flags within DS_EPI_STATS):
  * 0 = never, 1 = automatic (default), 2 = wherever the shape allows.                                      */
 int ds_debug_conv_set_wide(int mode);
+/* ds_conv_wino's kernel carries four ablation bits in `flags` (256 / 512 / 1024 / 2048: skip the pixel loads, the weight
+ * DMAs, the output stores ... -- garbage results, timing only).  They are refused (DS_ERR_ARG) unless switched on here. */
+int ds_debug_conv_wino_allow_ablation(int on);
 /* Number of row-tile blocks (P) the launch for `d` will use = number of stats partials.   */
 int ds_conv_igemm_partials(const ds_conv_desc *d);
 /* 1 if a launch for `d` can carry DS_EPI_BNSUMS (plain 1x1 stride-1 shapes that run on the wide kernel).  */
@@ -373,7 +376,9 @@ int ds_lstm_cell_bwd(const float *acts, const float *c_t, const float *c_prev, c
  * other sizes use the step-wise pair above.  All H / 16 workgroups of a row group must become resident for the
  * launch to finish; every wait is bounded, a timeout sets the direction's error word (results then invalid) and
  * ds_lstm_seq_status -- called wherever the caller synchronises anyway -- reports it instead of a hang:
- * 0 = ok, bit 0 = a forward launch timed out, bit 1 = a backward launch.  Re-entrant: no process-global state;
+ * 0 = ok, bit 0 = a forward launch timed out, bit 1 = a backward launch; a reported failure is cleared by the read
+ * (the words are sticky only until then).  The XCD-local grid is used only when min(row groups, 8) * H / 16 workgroups
+ * fit the device at once; smaller or partitioned devices get the 2-D grid.  Re-entrant: no process-global state;
  * two sequences on two streams need two workspaces.                                                        */
 int ds_lstm_seq_supported(int32_t B, int32_t H);
 size_t ds_lstm_seq_workspace(int32_t B, int32_t H);
@@ -384,7 +389,7 @@ int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float *h, float 
 int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, const float *c, const float *dh_last,
                     int32_t ld_dh, const int64_t *seq_len, int32_t T, int32_t B, int32_t H, float *dgates, int32_t rows,
                     void *ws, size_t ws_bytes, void *stream);
-int ds_lstm_seq_status(const void *ws, int32_t B);
+int ds_lstm_seq_status(void *ws, int32_t B);
 /* Debug aid (process-global, never called by the product path): device buffer of T*8 uint64; workgroup (0,0) of the
  * following ds_lstm_seq_fwd launches stamps s_memtime at its phase boundaries (scripts/lstm_phase_prof.py).  NULL = off. */
 int ds_debug_lstm_seq_set_profile(void *buf);

@@ -1,7 +1,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from tumblr_emotions_amd import ops
+from tumblr_emotions_amd import ops, _lib
+_lib.load().ds_debug_conv_wino_allow_ablation(1)
 B = 256
 def timeit(f, reps=10):
     for _ in range(2): f()

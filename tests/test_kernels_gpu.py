@@ -1018,11 +1018,14 @@ def test_lstm_sequence_is_reentrant_across_streams_and_row_settings():
     wss[0][2 * nrg] = 1
     run(pres[0], 1, wss[0])
     torch.cuda.synchronize()
-    assert lib.ds_lstm_seq_status(ops._p(wss[0]), B) == 1
     with pytest.raises(RuntimeError, match="forward"):
         ops.lstm_seq_status(wss[0], B)
+    # ... and a reported failure is cleared by the read: the next, healthy step is not blamed for it
+    assert lib.ds_lstm_seq_status(ops._p(wss[0]), B) == 0
+    wss[0][2 * nrg] = 1
     wss[0][2 * nrg + 1] = 1
     assert lib.ds_lstm_seq_status(ops._p(wss[0]), B) == 3
+    assert lib.ds_lstm_seq_status(ops._p(wss[0]), B) == 0
     # rows outside {1, 2, 4, 8} is an argument error, not a silent default
     with pytest.raises(RuntimeError, match="rows"):
         ops.lstm_seq_fwd(pres[0].clone(), ops._p(wh), 4 * H, torch.zeros(T + 1, B, H, device="cuda"),

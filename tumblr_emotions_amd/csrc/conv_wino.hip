@@ -389,6 +389,14 @@ extern "C" int ds_wino_transform_weights(const float *w, float *u, int32_t Cin, 
     return ds::check_launch("ds_wino_transform_weights");
 }
 
+namespace { int g_allow_ablation = 0; }
+
+// Debug aid (process-global, never called by the product path): let ds_conv_wino accept its ablation flag bits.
+extern "C" int ds_debug_conv_wino_allow_ablation(int on) {
+    g_allow_ablation = on ? 1 : 0;
+    return DS_OK;
+}
+
 extern "C" int ds_conv_wino_partials(int32_t N, int32_t H, int32_t W) {
     const int64_t mt = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2);
     return (int)((mt + 127) / 128);
@@ -401,7 +409,11 @@ extern "C" int ds_conv_wino(const float *x, const float *u, float *z, float *sta
     DS_REQUIRE(Cin > 0 && Cin % 8 == 0 && ldx % 4 == 0 && ldx >= Cin && Cout > 0 && ldz >= Cout &&
                    ((((uintptr_t)x | (uintptr_t)u) & 15) == 0),
                "ds_conv_wino: needs Cin %% 8 == 0, ldx %% 4 == 0 and 16-byte aligned operands");
-    DS_REQUIRE((flags & ~(DS_EPI_STATS | DS_EPI_BNSUMS | 256 | 512 | 1024 | 2048)) == 0 && (!(flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) || stats),
+    // bits 256 / 512 / 1024 / 2048 are ablation switches of the kernel (skip the pixel loads / the weight DMAs / the output
+    // stores ...: the results are garbage); they are refused unless ds_debug_conv_wino_allow_ablation(1) was called, so a
+    // stray bit in `flags` fails here instead of "succeeding" with an unwritten z (ds_conv_wino4 refuses them always)
+    const int32_t ablation = g_allow_ablation ? (256 | 512 | 1024 | 2048) : 0;
+    DS_REQUIRE((flags & ~(DS_EPI_STATS | DS_EPI_BNSUMS | ablation)) == 0 && (!(flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) || stats),
                "ds_conv_wino: only DS_EPI_STATS / DS_EPI_BNSUMS are supported (with a partials buffer)");
     DS_REQUIRE(!(flags & DS_EPI_BNSUMS) || (ymask && !(flags & DS_EPI_STATS)),
                "ds_conv_wino: DS_EPI_BNSUMS needs y (pixel stride ldz) and excludes DS_EPI_STATS");

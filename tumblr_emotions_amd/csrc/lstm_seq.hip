@@ -490,7 +490,13 @@ dim3 seq_grid(SeqParams &p, int H, int rows) {
     // rows > 1 is the setting for running BESIDE another kernel that needs whole CUs (the image tower's Winograd conv):
     // there the row groups stay spread over all XCDs -- packed onto one or two XCDs they would leave those XCDs no CU
     // for the other kernel's workgroups (joint step 17.8 -> 19.0 ms, measured)
-    p.xcd_map = (use && p.ncg <= 32 && rows == 1) ? 1 : 0;
+    // Residency: in the 1-D grid the ids interleave up to 8 row groups (id & 7 = row group, id >> 3 = unit block), so
+    // the first workgroups the dispatcher places are unit blocks 0.. of ALL of them; a device with fewer than
+    // min(nrgw, 8) * ncg CUs (one workgroup per CU, exclusive_lds) would never hold a whole row group and every
+    // workgroup would spin on peers that cannot start.  The 2-D grid dispatches row group 0 completely first and needs
+    // only ncg CUs (ds_lstm_seq_supported), so smaller / partitioned devices fall back to it.
+    const int groups_in_flight = p.nrgw < 8 ? p.nrgw : 8;
+    p.xcd_map = (use && p.ncg <= 32 && rows == 1 && device_cus() >= groups_in_flight * p.ncg) ? 1 : 0;
     if (p.xcd_map) return dim3((unsigned)(8 * p.ncg * ((p.nrgw + 7) / 8)));
     return dim3((unsigned)p.ncg, (unsigned)p.nrgw);
 }
@@ -570,13 +576,16 @@ extern "C" int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, 
     return ds::check_launch("ds_lstm_seq_bwd");
 }
 
-extern "C" int ds_lstm_seq_status(const void *ws, int32_t B) {
+extern "C" int ds_lstm_seq_status(void *ws, int32_t B) {
     // host-side read of the two error words of FINISHED launches (the caller synchronised): 0 = ok, bit 0 = a
     // hand-off wait of a forward launch timed out (a workgroup of the row group never became resident), bit 1 = the
-    // same in a backward launch; the results are invalid.  The words are sticky across launches.
+    // same in a backward launch; the results of the launches since the last call are invalid.  The words are sticky
+    // across launches and CLEARED by this call once reported, so a later, healthy step is not blamed for an old one.
     unsigned v[2] = {0, 0};
     const int nrg = (B + 31) / 32;
-    if (hipMemcpy(v, (const unsigned *)ws + 2 * nrg, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return DS_ERR_LAUNCH;
+    unsigned *err = (unsigned *)ws + 2 * nrg;
+    if (hipMemcpy(v, err, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return DS_ERR_LAUNCH;
+    if ((v[0] | v[1]) && hipMemset(err, 0, sizeof(v)) != hipSuccess) return DS_ERR_LAUNCH;
     return (int)((v[0] ? 1u : 0u) | (v[1] ? 2u : 0u));
 }
 

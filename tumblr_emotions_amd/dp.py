@@ -22,6 +22,24 @@ import torch
 import torch.distributed as dist
 
 
+def init_distributed(backend="nccl", device=None, **kwargs):
+    """`torch.distributed.init_process_group` for one rank of a data-parallel job, with the step's HIP streams bound to
+    their hardware queues FIRST (streams.reserve: RCCL's own streams must not take the queue the text tower's stream
+    would have got -- 1.4 ms per step, profiles/r03_notes.md).  Call after `torch.cuda.set_device`; `device` defaults
+    to the current one.  Extra keyword arguments go to init_process_group (rank, world_size, init_method ...)."""
+    import os
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # this driver stack only supports dmabuf IPC
+    if torch.cuda.is_available():
+        from . import streams
+        streams.reserve(device)
+        if backend == "nccl" and "device_id" not in kwargs:
+            kwargs["device_id"] = torch.device("cuda", torch.cuda.current_device() if device is None
+                                               else torch.device(device).index or 0)
+    if not dist.is_initialized():
+        dist.init_process_group(backend, **kwargs)
+    return world_info()
+
+
 def world_info(group=None):
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
@@ -49,7 +67,7 @@ class GradientReducer:
         self.overlap = overlap and self.active and flat_grad.is_cuda
         if self.overlap:
             from . import streams
-            self.stream = streams.get("comm")
+            self.stream = streams.get("comm", flat_grad.device)
         else:
             self.stream = None
         self._pending = None

@@ -45,6 +45,7 @@ TOPOLOGY = [
     ("mixed", "Mixed_5c", 384, (192, 384), (48, 128), 128),
 ]
 ENDPOINTS = [t[1] for t in TOPOLOGY]
+AMAX_RECORDS = 160     # fp8: max|.| records handed out by InceptionV1Engine.new_amax (about 91 in use)
 TRAINABLE_ENDPOINTS = ("Mixed_5c",)      # inception_v1.py:229-231; earlier scopes are trainable=False (:57-59)
 
 
@@ -888,6 +889,8 @@ class InceptionV1Engine:
         if self.amax_pool is None:
             return None
         i = self._amax_next
+        if i + ops.AMAX_FLOATS > self.amax_pool.numel():      # a short slice would let the fp8 kernels write out of bounds
+            raise RuntimeError("amax pool exhausted (%d records): raise AMAX_RECORDS" % (self.amax_pool.numel() // ops.AMAX_FLOATS))
         self._amax_next += ops.AMAX_FLOATS
         return self.amax_pool[i:i + ops.AMAX_FLOATS]
 
@@ -909,7 +912,7 @@ class InceptionV1Engine:
         self.alloc_gen = getattr(self, "alloc_gen", 0) + 1      # SentimentNet: a captured step is stale after this
         # fp8: device words that collect max|.| of the tensors the fp8 convs read (atomic max in the producing kernels,
         # zeroed at the start of every forward pass): the per-tensor scales without separate ds_absmax passes
-        self.amax_pool = torch.zeros(128 * ops.AMAX_FLOATS, device=dev) if self.dtype == "fp8" else None
+        self.amax_pool = torch.zeros(AMAX_RECORDS * ops.AMAX_FLOATS, device=dev) if self.dtype == "fp8" else None
         self._amax_next = 0
         self.input.alloc(B)
         for s in self.stages:
@@ -931,8 +934,8 @@ class InceptionV1Engine:
         self.stats, self.bwd_partials, self.ws = self.stats_set[0], self.bwdp_set[0], self.ws_set[0]
         if self.side is None and self.device.type == "cuda":
             from . import streams
-            self.side = [streams.get("side0"), streams.get("side1")]
-            self.side_w = streams.get("side0")       # free while one_side_stream == 1
+            self.side = [streams.get("side0", dev), streams.get("side1", dev)]
+            self.side_w = streams.get("side0", dev)       # free while one_side_stream == 1
         self.ws_bytes = self._ws_bytes
         self.dummy = torch.empty(1024, device=dev)
         self.ones = torch.ones(1024, device=dev)

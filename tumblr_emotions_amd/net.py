@@ -67,7 +67,7 @@ class SentimentNet:
         self.pg = process_group
         from . import streams
         streams.reserve(self.device)
-        self.text_stream = streams.get("text") if (mode == "joint" and concurrent_towers) else None
+        self.text_stream = streams.get("text", self.device) if (mode == "joint" and concurrent_towers) else None
         if self.text_stream is not None:
             # beside the image tower the persistent LSTM runs four row groups per workgroup: a quarter of the CUs for a
             # longer time instead of a 256-register wave on every SIMD that mostly waits -- the Winograd conv needs

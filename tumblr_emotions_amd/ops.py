@@ -169,7 +169,7 @@ class WinoPlan:
     def enable_bnsums(self):
         """As ConvPlan.enable_bnsums (y has the output's pixel stride)."""
         N, H, W = self.args[:3]
-        self.flags = DS_EPI_BNSUMS
+        self.flags = (self.flags & ~DS_EPI_STATS) | DS_EPI_BNSUMS      # (the two sum epilogues exclude each other)
         self.partials = self._partials(N, H, W)
         return self.partials
 
@@ -573,7 +573,7 @@ def lstm_seq_bwd(acts, wh_ptr, ldw, c, dh_last, ld_dh, seq_len, T, B, H, dgates,
 
 def lstm_seq_status(ws, B):
     """0 = ok; call after a synchronise (it copies two words to the host).  Raises on a hand-off timeout of any
-    forward (bit 0) or backward (bit 1) launch since the workspace was zeroed: the error words are sticky."""
+    forward (bit 0) or backward (bit 1) launch since the last read: the error words are sticky until reported, then cleared."""
     rc = _lib.load().ds_lstm_seq_status(_p(ws), B)
     if rc != 0:
         which = " and ".join(n for b, n in ((1, "forward"), (2, "backward")) if rc > 0 and rc & b) or "status read"
