@@ -47,3 +47,28 @@ def test_glove_loader_matches_reference_outputs(tmp_path):
     np.testing.assert_array_equal(emb.astype(np.float64), np.array(G["glove"]["embedding"]))
     w2i, table = tp.build_vocabulary(vocab, emb)
     assert w2i["<ukn>"] == len(vocab) and table.shape == (len(vocab) + 1, 3) and not table[-1].any()
+
+
+def test_preprocess_df_and_one_df_match_reference_outputs(tmp_path):
+    """preprocess_df (:107-143) / preprocess_one_df (:145-172) on the synthetic ./data set of
+    tests/golden/make_golden_preprocess_df.py against what the reference module returned for it."""
+    import importlib.util
+    P = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "preprocess_df.json")))
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(os.path.dirname(__file__), "golden",
+                                                                     "make_golden_preprocess_df.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    mk.write_inputs(str(tmp_path))
+    data_dir, text_dir = str(tmp_path / "data"), str(tmp_path / "text")
+    assert len(P["cases"]) == 2
+    for case in P["cases"]:
+        df, w2i, emb = tp.preprocess_df(text_dir, "emb", "g.txt", "glove", P["emotions"], case["post_size"], data_dir=data_dir)
+        assert mk.frame_to_json(df) == case["all"]
+        assert w2i == case["word_to_id"] and w2i["<ukn>"] == len(P["glove"])
+        np.testing.assert_array_equal(np.asarray(emb, np.float64), np.asarray(case["embedding"]))
+        assert not np.asarray(emb)[-1].any()
+        v, e = tp._load_embedding_weights_glove(text_dir, "emb", "g.txt")
+        for emotion in P["emotions"]:
+            one = tp.preprocess_one_df(v, e, emotion, case["post_size"], data_dir=data_dir)
+            assert mk.frame_to_json(one) == case["one"][emotion]
+    assert len(case["all"]["id"]) == 4          # four of the eight posts survive the hashtag / validity filters
