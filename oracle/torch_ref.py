@@ -344,6 +344,51 @@ class DeepSentimentRef:
         return dict(loss=float(total.detach()), ce=float(ce.detach()), logits=logits.detach(), grads=grads)
 
 
+    def train_step_dp(self, batches, lr, dropout_masks=None, injects=None):
+        """One data-parallel step the way slim's in-graph clones define it (slim/deployment/model_deploy.py): clone c runs
+        the forward pass on ITS sub-batch with its own BatchNorm batch statistics (:353-355), its loss is divided by the
+        number of clones (:221-223), the regularisation term is added ONCE (:301-302), the clone gradients are summed
+        (:414-444), and the BatchNorm moving averages come from the first clone's update ops (:353-355).  Then TF-Adam.
+        `injects`: per-clone decision sets (see `inject`).  Returns dict(loss, ce=[per clone], logits=[per clone], grads)."""
+        W = len(batches)
+        for n in self.trainable:
+            self.p[n].grad = None
+        total = torch.zeros((), dtype=self.dtype)
+        ces, logits_all, stats0 = [], [], None
+        keep_inject = self.inject
+        for c, batch in enumerate(batches):
+            if injects is not None:
+                self.inject = injects[c]
+            logits = self.forward(batch, None if dropout_masks is None else dropout_masks[c])
+            _, ce = self.loss(logits, batch["labels"])
+            total = total + ce / W
+            ces.append(float(ce.detach()))
+            logits_all.append(logits.detach())
+            if c == 0:
+                stats0 = dict(self.bn_batch_stats)
+        self.inject = keep_inject
+        reg, _ = self.loss(logits_all[0], batches[0]["labels"])          # (total of clone 0) - (its CE) = the L2 term
+        reg = reg - F.cross_entropy(logits_all[0], torch.as_tensor(batches[0]["labels"]), reduction="mean")
+        total = total + reg
+        total.backward()
+        grads = {n: self.p[n].grad.detach().clone() for n in self.trainable if self.p[n].grad is not None}
+        self.step += 1
+        t = self.step
+        lr_t = lr * math.sqrt(1 - S.ADAM_B2 ** t) / (1 - S.ADAM_B1 ** t)
+        with torch.no_grad():
+            for scope, (mean, var) in (stats0 or {}).items():
+                mm = self.p[scope + "/BatchNorm/moving_mean"]
+                mv = self.p[scope + "/BatchNorm/moving_variance"]
+                mm.mul_(S.BN_DECAY).add_((1 - S.BN_DECAY) * mean)
+                mv.mul_(S.BN_DECAY).add_((1 - S.BN_DECAY) * var)
+            for n, g in grads.items():
+                m, v = self.adam_m[n], self.adam_v[n]
+                m.mul_(S.ADAM_B1).add_((1 - S.ADAM_B1) * g)
+                v.mul_(S.ADAM_B2).add_((1 - S.ADAM_B2) * g * g)
+                self.p[n].sub_(lr_t * m / (v.sqrt() + S.ADAM_EPS))
+        return dict(loss=float(total.detach()), ce=ces, logits=logits_all, grads=grads)
+
+
 def make_params(mode, rng, num_classes=15, im_features_size=256, embed_dim=300, rnn_size=512,
                 fc_size=512, dtype=np.float32):
     """Random-init parameter dict with the reference's variable names/initialisers."""

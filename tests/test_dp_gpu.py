@@ -149,3 +149,109 @@ def test_rccl_single_rank_bucketed_allreduce_is_the_identity():
     assert np.array_equal(res["grad_0"], res["grad_1"])
     rep = res["report"]
     assert rep and rep["bucket1_bytes"] > 0 and rep["bucket1_allreduce_ms"] > 0.0
+
+
+# ---- DP parity of the joint (BatchNorm) model as SURVEY 8(e) defines it -------------------------------------------------
+JOINT = dict(nb_emotions=15, im_features_size=256, rnn_size=32, fc_size=512, vocab_size=60, embedding_dim=20, post_size=12)
+DP_SEED, DP_PER_RANK, DP_LR = 71, 8, 1e-3
+
+
+def _dp_parity_inputs():
+    from oracle import tf_semantics as S
+    from oracle import torch_ref as R
+    rng = np.random.RandomState(DP_SEED)
+    params = R.make_params("joint", rng, num_classes=15, im_features_size=256, embed_dim=JOINT["embedding_dim"],
+                           rnn_size=JOINT["rnn_size"], fc_size=512, dtype=np.float64)
+    for k in params:
+        if k.endswith("beta"):
+            params[k] = rng.normal(0, 0.1, size=params[k].shape)
+    emb = S.synthetic_embedding(JOINT["vocab_size"], JOINT["embedding_dim"]).astype(np.float64)
+    batch = S.synthetic_batch(2 * DP_PER_RANK, JOINT["post_size"], JOINT["vocab_size"], seed=DP_SEED + 1)
+    return params, emb, batch
+
+
+def _dp_parity_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from hip_decisions import hip_decisions, keep_activations
+        from tumblr_emotions_amd.net import SentimentNet
+        params, emb, batch = _dp_parity_inputs()
+        net = SentimentNet(mode="joint", dropout_keep_prob=1.0, **JOINT)
+        assert net.world == world and net.reducer.active
+        net.load_state_dict(dict(params, **{"Text/W_embedding": emb}))
+        lo, hi = rank * DP_PER_RANK, (rank + 1) * DP_PER_RANK
+        local = {k: torch.from_numpy(np.ascontiguousarray(v[lo:hi])).cuda() for k, v in batch.items()}
+        keep_activations(net)
+        net.train_step(local, DP_LR)
+        torch.cuda.synchronize()
+        res = dict(logits=net.logits.detach().cpu().numpy(), loss=net.total_loss_value(), decisions=hip_decisions(net),
+                   grads=net.grads_state_dict(), after=net.state_dict(),
+                   l2=[e.name for e in net.store.entries.values() if e.trainable and e.l2])
+        out.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_joint_step_matches_the_clone_oracle():
+    """SURVEY 8(e) / VERDICT r03 #7: the data-parallel JOINT step (BatchNorm inside) against the oracle run the way slim
+    defines clones (slim/deployment/model_deploy.py:221-223,301-302,353-355,414-444; oracle: DeepSentimentRef.train_step_dp):
+    every rank normalises with the batch statistics of ITS sub-batch, the two cross-entropy gradients are averaged, the L2
+    term is counted once, rank 0's moving statistics are the clone-0 update.  Two ranks on the one GPU (gloo carries the
+    all-reduce; bucketing, early bucket-1 launch, 1/world and L2 inside the Adam kernel are the RCCL run's code).  Gates as
+    in test_model_gpu._check_step: logits and loss 1e-3 per rank, every one of the 71 gradients 1e-3 (relative L2 and
+    max-norm) along the HIP ranks' own ReLU / pool decisions, the un-injected oracle within 1e-4 of the injected one, TF-Adam
+    1e-5 on resolved entries, moving statistics 1e-5."""
+    from oracle import torch_ref as R
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_parity_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(_collect(out, procs, 2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    params, emb, batch = _dp_parity_inputs()
+    subs = [{k: v[r * DP_PER_RANK:(r + 1) * DP_PER_RANK] for k, v in batch.items()} for r in range(2)]
+    ref = R.DeepSentimentRef(params, emb, "joint", torch.float64)
+    with torch.no_grad():
+        plain = [ref.forward(s).detach().clone() for s in subs]
+    o = ref.train_step_dp(subs, DP_LR, injects=[got[0]["decisions"], got[1]["decisions"]])
+    reg = o["loss"] - 0.5 * (o["ce"][0] + o["ce"][1])
+    for r in range(2):
+        assert float((o["logits"][r] - plain[r]).abs().max()) <= 1e-4
+        assert np.abs(got[r]["logits"] - o["logits"][r].numpy()).max() <= 1e-3, r
+        assert abs(got[r]["loss"] - (o["ce"][r] + reg)) <= 1e-3, r          # rank r reports ITS cross-entropy + the L2 term
+    # the reduced gradient is the same buffer on both ranks; what Adam consumes is sum / world + L2 (applied in the kernel)
+    assert len(o["grads"]) == 71
+    worst = (0.0, "")
+    for name, g_ref in o["grads"].items():
+        g_ref = g_ref.numpy()
+        assert np.array_equal(got[0]["grads"][name], got[1]["grads"][name]), name
+        g = got[0]["grads"][name].reshape(g_ref.shape) / 2.0
+        if name in got[0]["l2"]:
+            g = g + 0.00004 * params[name]
+        d = g - g_ref
+        rel = np.linalg.norm(d) / max(np.linalg.norm(g_ref), 1e-30)
+        emax = np.abs(d).max() / max(np.abs(g_ref).max(), 1e-30)
+        worst = max(worst, (rel, name))
+        assert rel <= 1e-3 and emax <= 1e-3, "gradient of %s: relative L2 %.3e, max-norm %.3e" % (name, rel, emax)
+    print("DP joint step, worst gradient relative L2 against the clone oracle: %.3e (%s)" % worst)
+    for name in ref.trainable:
+        w_ref = ref.p[name].detach().numpy()
+        assert np.array_equal(got[0]["after"][name], got[1]["after"][name]), name
+        g_ref = o["grads"][name].numpy()
+        big = np.abs(g_ref) > 1e-2 * max(np.abs(g_ref).max(), 1e-12)
+        assert (np.abs(got[0]["after"][name].reshape(w_ref.shape) - w_ref)[big] <= 1e-5).mean() >= 0.99, name
+    for name, v in got[0]["after"].items():
+        if name.endswith("moving_mean") or name.endswith("moving_variance"):
+            np.testing.assert_allclose(v, ref.p[name].numpy(), atol=1e-5, err_msg=name)
+    # per-rank statistics: rank 1 averaged ITS sub-batch, so its moving means differ from rank 0's
+    k = "InceptionV1/Conv2d_2b_1x1/BatchNorm/moving_mean"
+    assert not np.array_equal(got[0]["after"][k], got[1]["after"][k])

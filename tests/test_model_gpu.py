@@ -249,6 +249,17 @@ def test_joint_step_matches_oracle():
 
 
 def test_joint_step_b16_follows_oracle_along_same_decisions():
+    _joint_step_along_decisions(16, 60, 20, 32, 12, 41)
+
+
+def test_joint_step_b32_config3_per_gpu_share_follows_oracle():
+    """BASELINE configs[3] (joint, global batch 256 over 8 GPUs) as ONE rank sees it: B = 32 at the real dims (T = 32,
+    V = 10 000, D = 300, H = 512) -- the small-batch launch plans (partial rounds of workgroups, the launch-time model's
+    F(2x2) / F(4x4) choices at this M, the LSTM at one row group) against the fp64 oracle with the same gates as B = 16."""
+    _joint_step_along_decisions(32, 10000, 300, 512, 32, 43)
+
+
+def _joint_step_along_decisions(B, V, D, H, T, seed):
     """The tight composition check of the whole backward pass.  B = 16 joint step at 224x224; the fp64 oracle
     is evaluated along the ReLU masks and max-pool winners the HIP forward pass actually took (read back from
     its activation buffers, tests/hip_decisions.py), which removes the only ill-conditioned part of the
@@ -258,15 +269,14 @@ def test_joint_step_b16_follows_oracle_along_same_decisions():
     a mis-routed pool gradient cannot hide below that."""
     from tumblr_emotions_amd.net import SentimentNet
     from hip_decisions import hip_decisions
-    rng = np.random.RandomState(41)
-    V, D, H, T, B = 60, 20, 32, 12, 16
+    rng = np.random.RandomState(seed)
     params = R.make_params("joint", rng, num_classes=15, im_features_size=256, embed_dim=D, rnn_size=H,
                            fc_size=512, dtype=np.float64)
     for k in params:
         if k.endswith("beta"):
             params[k] = rng.normal(0, 0.1, size=params[k].shape)
     emb = S.synthetic_embedding(V, D).astype(np.float64)
-    batch = S.synthetic_batch(B, T, V, seed=14)
+    batch = S.synthetic_batch(B, T, V, seed=seed - 27)
     mask = (rng.uniform(size=(B, 1024)) < 0.8).astype(np.float64)
     net = SentimentNet(mode="joint", nb_emotions=15, im_features_size=256, rnn_size=H, fc_size=512, vocab_size=V,
                        embedding_dim=D, post_size=T)
