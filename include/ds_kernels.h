@@ -223,6 +223,75 @@ int ds_conv_wino4(const float *x, const float *u, float *z, float *stats, const 
                   int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz, int32_t flags,
                   void *stream);
 
+/* ---- ONE conv-layer interface over the kernel families above (the product path's conv entry points) ---------------
+ * slim.conv2d (image_model/inception_v1.py:63-250) and its Conv2DBackpropInput, described in TensorFlow's terms; the
+ * LIBRARY picks the kernel family for the shape -- implicit GEMM / wide 1x1 / LDS-DMA (ds_conv_igemm), fused Winograd
+ * F(2x2) / F(4x4) by the launch-time model (ds_conv_wino, ds_conv_wino4), the packed-RGB stem kernel (ds_conv_stem), the
+ * register-direct bf16 / fp8 / f32x3 kernels -- so a C, C++ or Python host gets the measured configuration from three
+ * calls.  The family-level entry points above stay exported for kernel tests and tuning scripts; the engine of this
+ * build calls only these (tests/test_abi_cpu.py checks that).
+ *   ds_conv_plan             fills a caller-owned plan (plain data, no allocation): role DS_CONV_FWD or DS_CONV_DGRAD
+ *                            (stride-1 SAME convs), arithmetic DS_ARITH_*, N / H / W of the layer INPUT, the filter's own
+ *                            channel counts and size k, pixel strides of x and z, epilogue flags (DS_EPI_*).
+ *   ds_conv_plan_set_flags   changes the epilogue flags of a plan, returns its new partial count
+ *   ds_conv_plan_enable_bnsums   dgrad whose result feeds a BatchNorm + ReLU backward: adds DS_EPI_BNSUMS (y with pixel
+ *                            stride ldy goes in as io.mask) and returns the partial count, or 0 when the chosen kernel
+ *                            cannot carry it (the caller then keeps the separate ds_bn_bwd_reduce pass)
+ *   ds_conv_plan_norm_supported   would the launch apply d.norm_rstd / d.norm_shift (BatchNorm + ReLU on load)?
+ *   ds_conv_prepare_weights  plan.w_bytes > 0: converts the HWIO filter into the form the family reads (G g G^T, bf16 /
+ *                            fp8 / three-piece K-loop order); redo whenever the filter changes.  fp8: wscale =
+ *                            float[plan.wscale_floats]
+ *   ds_conv_run              x, w (the HWIO filter when plan.w_bytes == 0, else the prepared one), z, the optional
+ *                            epilogue operands in `io` (NULL = none).  Between runs the caller may change
+ *                            plan.d.ldx / ldz / flags (within the planned epilogue set) / x_dtype / norm_* / mask_*.   */
+#define DS_CONV_FWD 0
+#define DS_CONV_DGRAD 1
+#define DS_ARITH_F32 0       /* exact fp32 MFMA, incl. fp32 Winograd: the 1e-3 parity path                              */
+#define DS_ARITH_BF16 1      /* bf16 multiplies, fp32 accumulation / storage of z                                       */
+#define DS_ARITH_FP8 2       /* e4m3 / e5m2 multiplies with per-tensor power-of-two scales; bf16 where fp8 does not apply */
+#define DS_ARITH_F32X3 3     /* fp32 arithmetic, the forward 1x1 convs with fp32 products from three bf16 pieces         */
+#define DS_FAM_IGEMM 0
+#define DS_FAM_WINO2 1
+#define DS_FAM_WINO4 2
+#define DS_FAM_STEM 3
+#define DS_FAM_BF16D 4
+#define DS_FAM_FP8D 5
+#define DS_FAM_F32X3 6
+#define DS_PLAN_NO_WINO 1u          /* A/B: implicit GEMM for every 3x3 layer                                           */
+#define DS_PLAN_NO_WINO4 2u         /* A/B: F(2x2) wherever Winograd applies                                            */
+#define DS_PLAN_NO_STEM_DIRECT 4u   /* A/B: the stem through the generic kernel on a 4-channel copy of the batch        */
+#define DS_PLAN_NO_BF16_DIRECT 8u   /* A/B: the LDS-staged bf16 kernel everywhere                                       */
+#define DS_PLAN_ACT16 16u           /* the net keeps activations in 16-bit storage (only the register-direct kernels read it) */
+#define DS_PLAN_PACKED_RGB 32u      /* Conv2d_1a_7x7: x is the packed [N, H, W, 3] batch, filter stored [7][7][4][Cout]   */
+typedef struct ds_conv_layer_plan {
+    ds_conv_desc d;          /* descriptor of the chosen launch (dgrad: channel roles swapped, flipped taps)            */
+    int32_t family;          /* DS_FAM_*                                                                                 */
+    int32_t role, arith;
+    int32_t partials;        /* P of the DS_EPI_STATS / DS_EPI_BNSUMS partials float[2][d.Cout][P] (0: none planned)     */
+    int32_t w_cin, w_cout, k; /* the filter [k][k][w_cin][w_cout]                                                         */
+    int32_t a_format;        /* fp8: format of the activation operand (DS_FP8_E4M3 forward, DS_FP8_E5M2 dgrad)           */
+    int32_t x16_ok;          /* the family reads 16-bit activation storage (d.x_dtype)                                   */
+    int64_t w_bytes;         /* bytes of the prepared filter; 0: the family reads the HWIO tensor in place               */
+    int64_t wscale_floats;   /* fp8: floats of the filter's scale record                                                 */
+    double alg_flops;        /* algorithmic FLOPs of one launch (2 M N K of the convolution, stem with Cin = 3)          */
+} ds_conv_layer_plan;
+typedef struct ds_conv_io {
+    const float *bias;       /* DS_EPI_BIAS                                                                              */
+    const float *mask;       /* DS_EPI_MASK source / DS_EPI_BNSUMS: the consumer's activation y (or z with d.mask_*)     */
+    float *stats;            /* DS_EPI_STATS / DS_EPI_BNSUMS partials                                                    */
+    const float *pivot;      /* DS_EPI_STATS pivot                                                                       */
+    const float *x_amax;     /* fp8: max|x| record of the activation operand                                             */
+    const float *wscale;     /* fp8: the filter's scale record (ds_conv_prepare_weights)                                 */
+} ds_conv_io;
+int ds_conv_plan(ds_conv_layer_plan *plan, int32_t role, int32_t arith, uint32_t options, int32_t N, int32_t H, int32_t W,
+                 int32_t w_cin, int32_t w_cout, int32_t k, int32_t stride, int32_t ldx, int32_t ldz, int32_t flags);
+int ds_conv_plan_set_flags(ds_conv_layer_plan *plan, int32_t flags);
+int ds_conv_plan_enable_bnsums(ds_conv_layer_plan *plan, int32_t ldy);
+int ds_conv_plan_norm_supported(const ds_conv_layer_plan *plan);
+int ds_conv_prepare_weights(const ds_conv_layer_plan *plan, const float *w_hwio, void *w_prepared, float *wscale,
+                            void *stream);
+int ds_conv_run(const ds_conv_layer_plan *plan, const void *x, const void *w, float *z, const ds_conv_io *io, void *stream);
+
 /* Conv2DBackpropFilter / MatMul-transposed (wgrad), split over pixels.
  *   dw[tap, ci, co] = sum_m x[pixel(m)+tap, ci] * dz[m, co]
  * only reached for the trainable scope image_model/inception_v1.py:229-250,302-303 and the

@@ -222,7 +222,7 @@ def test_image_only_step_matches_oracle(mul3):
     _check_step(net, ref, batch, 1e-3, mask)
     if mul3:
         from tumblr_emotions_amd import ops
-        assert sum(1 for l in net.image.layers if isinstance(l.wino_fwd, ops.F32x3Plan)) >= 19
+        assert sum(1 for l in net.image.layers if l.fwd.family == ops.DS_FAM_F32X3) >= 19
 
 
 def test_joint_step_matches_oracle():
@@ -389,8 +389,8 @@ def test_joint_step_fp8_conv_path_matches_fp8_emulating_oracle():
     net.train_step(_dev_batch(batch), 1e-3)
     torch.cuda.synchronize()
     from tumblr_emotions_amd import ops
-    n_fp8 = sum(isinstance(l.wino_fwd, ops.Fp8Plan) for l in net.image.layers)
-    n_fp8d = sum(isinstance(l.wino_dgrad, ops.Fp8Plan) for l in net.image.layers)
+    n_fp8 = sum(l.fwd.family == ops.DS_FAM_FP8D for l in net.image.layers)
+    n_fp8d = sum(l.dgrad is not None and l.dgrad.family == ops.DS_FAM_FP8D for l in net.image.layers)
     assert n_fp8 == 38 and n_fp8d == 38, (n_fp8, n_fp8d)       # every conv but the stem (fused 1x1s count once)
     logits = net.logits.detach().cpu().numpy()
     assert np.isfinite(logits).all()
@@ -485,7 +485,7 @@ def test_mul3_forward_stays_within_fp32_rounding_of_the_fp32_forward():
         net.initialize(seed=9)
         net.train_step(batch, 1e-3)
         torch.cuda.synchronize()
-        used.append(sum(1 for l in net.image.layers if isinstance(l.wino_fwd, ops.F32x3Plan)))
+        used.append(sum(1 for l in net.image.layers if l.fwd.family == ops.DS_FAM_F32X3))
         res.append((net.logits.clone(), net.total_loss_value()))
     assert used[0] >= 19 and used[1] == 0, used
     dl = float((res[0][0] - res[1][0]).abs().max())

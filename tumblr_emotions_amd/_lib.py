@@ -12,6 +12,10 @@ LIB_PATH = os.path.join(_HERE, "libds_kernels.so")
 DS_EPI_BIAS, DS_EPI_RELU, DS_EPI_ACCUM, DS_EPI_STATS, DS_EPI_MASK, DS_EPI_BNSUMS = 1, 2, 4, 8, 16, 32
 DS_DTYPE_F32, DS_DTYPE_BF16 = 0, 1
 DS_FP8_E4M3, DS_FP8_E5M2 = 0, 1
+DS_CONV_FWD, DS_CONV_DGRAD = 0, 1
+DS_ARITH_F32, DS_ARITH_BF16, DS_ARITH_FP8, DS_ARITH_F32X3 = 0, 1, 2, 3
+DS_FAM_IGEMM, DS_FAM_WINO2, DS_FAM_WINO4, DS_FAM_STEM, DS_FAM_BF16D, DS_FAM_FP8D, DS_FAM_F32X3 = range(7)
+DS_PLAN_NO_WINO, DS_PLAN_NO_WINO4, DS_PLAN_NO_STEM_DIRECT, DS_PLAN_NO_BF16_DIRECT, DS_PLAN_ACT16, DS_PLAN_PACKED_RGB = 1, 2, 4, 8, 16, 32
 
 
 class ConvDesc(C.Structure):
@@ -26,6 +30,19 @@ class ConvDesc(C.Structure):
         ("partials", C.c_int32),
         ("norm_rstd", C.c_void_p), ("norm_shift", C.c_void_p), ("mask_rstd", C.c_void_p), ("mask_shift", C.c_void_p),
     ]
+
+
+class LayerPlanStruct(C.Structure):
+    """ds_conv_layer_plan"""
+    _fields_ = [("d", ConvDesc), ("family", C.c_int32), ("role", C.c_int32), ("arith", C.c_int32), ("partials", C.c_int32),
+                ("w_cin", C.c_int32), ("w_cout", C.c_int32), ("k", C.c_int32), ("a_format", C.c_int32), ("x16_ok", C.c_int32),
+                ("w_bytes", C.c_int64), ("wscale_floats", C.c_int64), ("alg_flops", C.c_double)]
+
+
+class ConvIO(C.Structure):
+    """ds_conv_io"""
+    _fields_ = [("bias", C.c_void_p), ("mask", C.c_void_p), ("stats", C.c_void_p), ("pivot", C.c_void_p),
+                ("x_amax", C.c_void_p), ("wscale", C.c_void_p)]
 
 
 class Segments(C.Structure):
@@ -44,6 +61,8 @@ _i32, _i64, _f32, _u64 = C.c_int32, C.c_int64, C.c_float, C.c_uint64
 _CD = C.POINTER(ConvDesc)
 _SG = C.POINTER(Segments)
 _SS = C.POINTER(SumSegments)
+_LP = C.POINTER(LayerPlanStruct)
+_IO = C.POINTER(ConvIO)
 
 # name -> (restype, argtypes); mirrors include/ds_kernels.h one to one
 SIGNATURES = {
@@ -83,6 +102,12 @@ SIGNATURES = {
     "ds_wino4_transform_weights": (C.c_int, [_P, _P, _i32, _i32, _i32, _P]),
     "ds_conv_wino4_partials": (C.c_int, [_i32, _i32, _i32]),
     "ds_conv_wino4": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
+    "ds_conv_plan": (C.c_int, [_LP, _i32, _i32, C.c_uint32] + [_i32] * 10),
+    "ds_conv_plan_set_flags": (C.c_int, [_LP, _i32]),
+    "ds_conv_plan_enable_bnsums": (C.c_int, [_LP, _i32]),
+    "ds_conv_plan_norm_supported": (C.c_int, [_LP]),
+    "ds_conv_prepare_weights": (C.c_int, [_LP, _P, _P, _P, _P]),
+    "ds_conv_run": (C.c_int, [_LP, _P, _P, _P, _IO, _P]),
     "ds_conv_wgrad_workspace": (C.c_size_t, [_CD]),
     "ds_conv_wgrad": (C.c_int, [_CD, _P, _P, _i32, _P, _P, C.c_size_t, _P]),
     "ds_bn_finalize": (C.c_int, [_P, _i32, _i64, _i32, _P, _P, _f32, _f32, _P, _P, _P, _P, _P, _P]),

@@ -14,7 +14,7 @@ namespace {
 // per-element integer division.  Four rows are fetched before the first is stored (memory-level parallelism:
 // the 12 MB table is cache resident, the stores are the HBM stream) and the stores are non-temporal -- the
 // rows are next read by the projection GEMM, long after they left the caches at 2^20 tokens.
-template <int VEC, bool NT = true>
+template <int VEC, bool NT = true, bool OUTORDER = false>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *table, const int64_t *ids, float *out, int B,
                                                           int T, int D, int64_t rows, int time_major, int rpw) {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
@@ -25,7 +25,12 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *table, co
     const int64_t r1 = r + rpw < total ? r + rpw : total;
     if (r >= r1) return;
     const int DV = D / VEC;
-    int b = (int)(r / T), t = (int)(r - (int64_t)b * T);           // once per wave; then incremented
+    // OUTORDER (time-major output): r walks the OUTPUT rows t * B + b, so a wave's stores -- and the stores of
+    // consecutive waves -- form one linear stream (the ids are then read with stride T: 8 MB of scattered 8-byte reads
+    // against 1.26 GB of row stores); otherwise r walks the id list and a time-major row lands B * D floats from the next
+    int b, t;
+    if (OUTORDER) { t = (int)(r / B); b = (int)(r - (int64_t)t * B); }
+    else { b = (int)(r / T); t = (int)(r - (int64_t)b * T); }     // once per wave; then incremented
     constexpr int U = 4;                                           // rows in flight
     for (; r < r1; r += U) {
         const float *src[U];
@@ -34,11 +39,12 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *table, co
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool in = r + u < r1;
-            const int64_t id = in ? ids[r + u] : -1;               // wave-uniform
+            const int64_t id = in ? ids[OUTORDER ? (int64_t)b * T + t : r + u] : -1;               // wave-uniform
             ok[u] = id >= 0 && id < rows;                          // out-of-range id -> zero row
             src[u] = table + (ok[u] ? id : 0) * D;
-            dst[u] = in ? out + (time_major ? (int64_t)t * B + b : r + u) * D : nullptr;
-            if (++t == T) { t = 0; ++b; }
+            dst[u] = in ? out + (OUTORDER ? r + u : (time_major ? (int64_t)t * B + b : r + u)) * D : nullptr;
+            if (OUTORDER) { if (++b == B) { b = 0; ++t; } }
+            else if (++t == T) { t = 0; ++b; }
         }
         for (int v0 = 0; v0 < DV; v0 += 64) {
             const int v = v0 + lane;
@@ -337,7 +343,16 @@ extern "C" int ds_gather_rows(const float *table, const int64_t *ids, float *out
         const char *e = getenv("DS_GATHER_PLAIN_STORES");      // A/B aid
         plain = e ? atoi(e) : 0;
     }
-    if (D % 4 == 0 && a16 && plain) {
+    static int outorder = -1;
+    if (outorder < 0) {
+        const char *e = getenv("DS_GATHER_OUTORDER");          // A/B aid
+        outorder = e ? atoi(e) : 1;
+    }
+    if (D % 4 == 0 && a16 && !plain && time_major && outorder == 1) {
+        hipLaunchKernelGGL((gather_rows_kernel<4, true, true>), grid, dim3(256), 0, s, table, ids, out, B, T, D, table_rows, time_major, rpw);
+    } else if (D % 4 == 0 && a16 && time_major && outorder == 2) {
+        hipLaunchKernelGGL((gather_rows_kernel<4, false, true>), grid, dim3(256), 0, s, table, ids, out, B, T, D, table_rows, time_major, rpw);
+    } else if (D % 4 == 0 && a16 && plain) {
         hipLaunchKernelGGL((gather_rows_kernel<4, false>), grid, dim3(256), 0, s, table, ids, out, B, T, D, table_rows, time_major, rpw);
     } else if (D % 4 == 0 && a16) {
         hipLaunchKernelGGL(gather_rows_kernel<4>, grid, dim3(256), 0, s, table, ids, out, B, T, D, table_rows, time_major, rpw);

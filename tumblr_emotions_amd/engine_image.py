@@ -19,7 +19,7 @@ import os
 import torch
 
 from . import ops
-from .ops import ConvPlan, WgradPlan, WinoPlan, gemm_plan, make_segments, same_pad, DS_EPI_BIAS, DS_EPI_STATS
+from .ops import WgradPlan, gemm_plan, make_segments, same_pad, DS_EPI_BIAS, DS_EPI_STATS
 
 BN_EPS = 0.001         # slim/nets/inception_utils.py:35
 BN_DECAY = 0.9997      # slim/nets/inception_utils.py:34
@@ -88,67 +88,24 @@ class ConvBN:
         self.rstd = torch.empty(cout, device=dev)
         self.shift = torch.empty(cout, device=dev)
         self.coef = torch.empty(2, cout, device=dev)
-        if self.fold:
-            # Conv2d_1a_7x7: KW folded into the channel axis (28 contiguous floats per kernel row)
-            self.fwd = ConvPlan(B, self.H, self.W, 7 * 4, 4, 7, 1, self.stride, cout, cout, 28 * cout, 1, cout,
-                                fold_cin=4, flags=DS_EPI_STATS, dtype=eng.conv_dtype)
+        # The library plans the launch (ds_conv_plan): kernel family per shape and arithmetic -- implicit GEMM / wide 1x1,
+        # fused Winograd F(2x2) / F(4x4) by its launch-time model, the packed-RGB stem kernel, the register-direct bf16 /
+        # fp8 / f32x3 kernels -- the BatchNorm partial count and the prepared filter form.  The engine only says what the
+        # layer is (one conv entry point; the selection rules live next to the kernels).
+        opts = eng.plan_options()
+        if self.fold:      # Conv2d_1a_7x7 reads the packed RGB batch (or, generic kernel, its zero-padded 4-channel copy)
+            self.fwd = ops.LayerPlan(ops.DS_CONV_FWD, eng.arith, opts | ops.DS_PLAN_PACKED_RGB, B, self.H, self.W, 4, cout,
+                                     k, self.stride, 4, cout, DS_EPI_STATS)
         else:
-            self.fwd = ConvPlan(B, self.H, self.W, cin, 0, k, k, self.stride, cout, cout, cin * cout, 1, cout,
-                                flags=DS_EPI_STATS, dtype=eng.conv_dtype)
-        # 3x3 stride-1 layers: fused Winograd F(2x2,3x3) where it beats the implicit GEMM (measured per shape,
-        # profiles/r02_wino_layers.txt: 1.3-1.8x on every 56x56 / 28x28 / 14x14 layer): needs 8-channel K steps;
-        # on the 7x7 maps (half-empty border tiles, 16 tiles per image) only the wide layers gain
-        def wino_ok(H, cin_k, cout_k):
-            return (eng.winograd and eng.conv_dtype == ops.DS_DTYPE_F32 and k == 3 and self.stride == 1 and
-                    cin_k % 8 == 0 and (H >= 14 or cout_k >= 128))
-        self.wino_fwd = self.wino_dgrad = None
-        # the stem straight from the packed RGB batch (ds_conv_stem); rides the alternative-plan slot, its "u" is
-        # the HWIO filter itself
-        self.stem_direct = self.fold and eng.stem_direct and eng.conv_dtype == ops.DS_DTYPE_F32 and cout == 64
-        if self.stem_direct:
-            self.wino_fwd = ops.StemPlan(B, self.H, self.W, 4, cout, cout)
-            eng.need_stats(self.wino_fwd.partials * 2 * cout)
-        # ... and F(4x4,3x3) (ds_conv_wino4) where the library's launch-time model prefers it: 1.3-1.6x over F(2x2) on
-        # the 56 x 56 / 28 x 28 maps, and those 14 x 14 / 7 x 7 layers whose workgroups fill the chip better that way
-        # (profiles/r03_wino4_layers.txt)
-        def wino4_ok(cin_k, cout_k):
-            return eng.winograd4 and ops.wino4_prefer(B, self.H, self.W, cin_k, cout_k)
-        if wino_ok(self.H, cin, cout):
-            self.wino_fwd = WinoPlan(B, self.H, self.W, cin, 0, cout, cout, flags=DS_EPI_STATS, f4=wino4_ok(cin, cout))
-            self.u_fwd = torch.empty(self.wino_fwd.u_elems, device=dev)
-            eng.need_stats(self.wino_fwd.partials * 2 * cout)
-        self._wino_dgrad_ok = wino_ok(self.H, cout, cin)
-        self._wino4_dgrad = self._wino_dgrad_ok and wino4_ok(cout, cin)
-        # mul3 (opt-in, fp32 configuration): the forward 1x1 convs through ds_conv_f32x3 -- fp32 products on the bf16 matrix
-        # cores (three bf16 pieces per operand; the fp32 MFMA's accuracy, not its bits), 1.15-1.5x over the wide fp32 kernel
-        # (profiles/r03_f32x3_layers.txt); rides the alternative-plan slot like the Winograd kernels (u_fwd = split weights)
-        if (eng.mul3 and eng.dtype == "f32" and k == 1 and self.stride == 1 and not self.fold and cin % 8 == 0 and
-                cin <= 1024 and self.wino_fwd is None):
-            self.wino_fwd = ops.F32x3Plan(B, self.H, self.W, cin, cin, 1, 1, cout, cout, flags=DS_EPI_STATS)
-            self.u_fwd = torch.empty(ops.weights_f32x3_bytes(cin, cout, 1, False), dtype=torch.uint8, device=dev)
-            eng.need_stats(self.wino_fwd.partials * 2 * cout)
-        # bf16: the register-direct kernel (ds_conv_bf16, pre-converted weights) where it beats the LDS-staged one
-        # (profiles/r02_bf16_layers.txt): forward from 48 output columns up, dgrad for the 1x1 layers and from 160
-        # columns up; it rides the same alternative-plan slots as the Winograd kernel (u_* = its converted weights)
-        bf16 = eng.dtype == "bf16" and not self.fold and k in (1, 3) and eng.bf16_direct
-        self._bf16_dgrad_ok = bf16 and cout % 8 == 0 and (k == 1 or cin >= 160)
-        if bf16 and cin % 8 == 0 and (cout >= 48 or eng.act16):
-            self.wino_fwd = ops.Bf16Plan(B, self.H, self.W, cin, cin, k, self.stride, cout, cout, flags=DS_EPI_STATS)
-            self.u_fwd = torch.empty(ops.weights_bf16_bytes(cin, cout, k * k, False), dtype=torch.uint8, device=dev)
-            eng.need_stats(self.wino_fwd.partials * 2 * cout)
-        # fp8: ds_conv_fp8 wherever it applies (same alternative-plan slots; u_* = the e4m3 filter, ws_* its scale
-        # record, amax = device words with max|x| of the forward input / of dz, taken by ds_absmax right before the conv)
+            self.fwd = ops.LayerPlan(ops.DS_CONV_FWD, eng.arith, opts, B, self.H, self.W, cin, cout, k, self.stride, 0, cout,
+                                     DS_EPI_STATS)
+        self.fwd.alloc_weights(dev)
+        self.stem_direct = self.fwd.family == ops.DS_FAM_STEM
+        # fp8: device records with max|x| of the forward input / of dz for the layers ds_conv_fp8 can take
         fp8 = eng.dtype == "fp8" and not self.fold and k in (1, 3) and self.stride == 1
-        self._fp8_dgrad_ok = fp8 and cout % 8 == 0
         if fp8:
             self.amax = torch.zeros(2, ops.AMAX_FLOATS, device=dev)      # fallback records for ds_absmax passes
             self.dz_amax = eng.new_amax()                # max|dz|, collected by ds_bn_bwd_apply
-        if fp8 and cin % 8 == 0:
-            self.wino_fwd = ops.Fp8Plan(B, self.H, self.W, cin, cin, k, self.stride, cout, cout, flags=DS_EPI_STATS,
-                                        a_format=ops.DS_FP8_E4M3)
-            self.u_fwd = torch.empty(ops.weights_fp8_bytes(cin, cout, k * k, False), dtype=torch.uint8, device=dev)
-            self.ws_fwd = torch.zeros(ops.WSCALE_FLOATS, device=dev)
-            eng.need_stats(self.wino_fwd.partials * 2 * cout)
         self.u_version = -1
         eng.need_stats(self.fwd.partials * 2 * cout)
         self.bwd_P = ops.bn_bwd_partials(self.M, cout)
@@ -176,8 +133,6 @@ class ConvBN:
         layer's slices of the block's per-channel arrays."""
         self.z, self.ldz, self.rstd, self.shift, self.skip_apply = zview, ld, rstd, shift, True
         self.fwd.d.ldz = ld
-        if isinstance(self.wino_fwd, (WinoPlan, ops.F32x3Plan)):
-            self.wino_fwd.set_ldz(ld)
 
     def bind(self):
         st = self.eng.store
@@ -210,12 +165,7 @@ class ConvBN:
         eng = self.eng
         if not eng.bwd_sums or self.dgrad is None:
             return None
-        if isinstance(self.wino_dgrad, WinoPlan):
-            P = self.wino_dgrad.enable_bnsums()
-        elif self.wino_dgrad is None and self.k == 1:
-            P = self.dgrad.enable_bnsums(self.dgrad.d.ldz)
-        else:
-            P = 0
+        P = self.dgrad.enable_bnsums(self.dgrad.d.ldz)
         if not P:
             return None
         self.dx_sums = torch.empty(2 * self.cin * P, device=eng.device)
@@ -276,89 +226,56 @@ class ConvBN:
         ops.bn_bwd_finalize_segs(self._sum_segs, M, Cc, self.beta, self.gbeta, self.coef)
 
     def make_dgrad(self, lddx):
-        """Conv2DBackpropInput as a forward conv over dz with flipped taps (stride-1 SAME convs only)."""
+        """Conv2DBackpropInput as a forward conv over dz with flipped taps (stride-1 SAME convs only); the library picks
+        the kernel family for the swapped shape."""
         assert self.stride == 1
-        k, cin, cout = self.k, self.cin, self.cout
-        self.dgrad = ConvPlan(self.B, self.H, self.W, cout, self.ldz, k, k, 1, cin, lddx, cin * cout, cout, 1, flip=1,
-                              dtype=self.eng.conv_dtype)
-        if self._wino_dgrad_ok:
-            self.wino_dgrad = WinoPlan(self.B, self.H, self.W, cout, self.ldz, cin, lddx, f4=self._wino4_dgrad)
-            self.u_dgrad = torch.empty(self.wino_dgrad.u_elems, device=self.eng.device)
-        elif self._bf16_dgrad_ok:
-            self.wino_dgrad = ops.Bf16Plan(self.B, self.H, self.W, cout, cout, k, 1, cin, lddx)
-            self.u_dgrad = torch.empty(ops.weights_bf16_bytes(cin, cout, k * k, True), dtype=torch.uint8,
-                                       device=self.eng.device)
-        elif self._fp8_dgrad_ok:
-            self.wino_dgrad = ops.Fp8Plan(self.B, self.H, self.W, cout, cout, k, 1, cin, lddx, a_format=ops.DS_FP8_E5M2)
-            self.u_dgrad = torch.empty(ops.weights_fp8_bytes(cin, cout, k * k, True), dtype=torch.uint8,
-                                       device=self.eng.device)
-            self.ws_dgrad = torch.zeros(ops.WSCALE_FLOATS, device=self.eng.device)
-
-    def _refresh_wino(self):
-        """G g G^T of the filter for the Winograd kernels: redone when the weights changed -- every step for a
-        trainable layer (Adam moves them), once per load for a frozen one."""
         eng = self.eng
-        if (self.wino_fwd is None and self.wino_dgrad is None) or self.stem_direct:
-            return
+        self.dgrad = ops.LayerPlan(ops.DS_CONV_DGRAD, eng.arith, eng.plan_options(), self.B, self.H, self.W, self.cin,
+                                   self.cout, self.k, 1, self.ldz, lddx, 0)
+        self.dgrad.alloc_weights(eng.device)
+
+    def _refresh_weights(self):
+        """The prepared filter forms (G g G^T for the Winograd kernels, the bf16 / fp8 / three-piece K-loop orders):
+        redone when the weights changed -- every step for a trainable layer (Adam moves them), once per load for a
+        frozen one."""
+        eng = self.eng
         if not self.trainable and self.u_version == eng.weights_version:
             return
-        taps = self.k * self.k
-        for plan, u, dgrad in ((self.wino_fwd, getattr(self, "u_fwd", None), False),
-                               (self.wino_dgrad, getattr(self, "u_dgrad", None), True)):
-            if isinstance(plan, ops.F32x3Plan):
-                ops.weights_to_f32x3(self.w_ptr, u, self.cin, self.cout, taps, dgrad)
-            elif isinstance(plan, ops.Fp8Plan):
-                ops.weights_to_fp8(self.w_ptr, u, self.ws_dgrad if dgrad else self.ws_fwd, self.cin, self.cout, taps, dgrad)
-            elif isinstance(plan, ops.Bf16Plan):
-                ops.weights_to_bf16(self.w_ptr, u, self.cin, self.cout, taps, dgrad)
-            elif plan is not None:
-                ops.wino_transform_weights(self.w_ptr, u, self.cin, self.cout, dgrad, f4=plan.f4)
+        for plan in (self.fwd, self.dgrad):
+            if plan is not None:
+                plan.prepare(self.w_ptr)
         self.u_version = eng.weights_version
 
     # x_ptr: input activations [B,H,W,ldx]; segs: where relu(bn(conv)) is scattered (None: the consumer, a max
     # pool, applies BatchNorm + ReLU to its own output instead -- PoolStage.forward)
     def forward(self, x_ptr, ldx, segs, x_dtype=ops.DS_DTYPE_F32, x_amax=None):
         eng = self.eng
+        plan = self.fwd
         if not self.fold:
-            self.fwd.d.ldx = ldx
-        if x_dtype != ops.DS_DTYPE_F32 and not isinstance(self.wino_fwd, ops.Bf16Plan):
+            plan.d.ldx = ldx
+        if x_dtype != ops.DS_DTYPE_F32 and not plan.x16_ok:
             raise RuntimeError("16-bit activation storage needs ds_conv_bf16 / ds_conv_fp8 for %s" % self.key)
-        if isinstance(self.wino_fwd, ops.Bf16Plan):
-            self.wino_fwd.d.x_dtype = x_dtype
-        self._refresh_wino()
-        wino = self.wino_fwd
+        plan.d.x_dtype = x_dtype if plan.x16_ok else ops.DS_DTYPE_F32
+        self._refresh_weights()
         if self.stem_direct:
-            x_ptr, u_ptr = ops._p(eng.images), self.w_ptr
-        elif wino is not None:
-            wino.set_ldx(ldx)
-            u_ptr = ops._p(self.u_fwd)
-        fp8_kw = {}
-        if isinstance(wino, ops.Fp8Plan):      # per-tensor scale of the input from max|x| in a device word
+            x_ptr = ops._p(eng.images)
+        amax_p = None
+        if plan.family == ops.DS_FAM_FP8D:      # per-tensor scale of the input from max|x| in a device word
             if x_amax is None:                  # no producer tracked it: one pass over x
                 x_amax = self.amax[0]
                 ops.absmax(x_ptr, self.B * self.H * self.W * ldx, x_amax, x_dtype)
-            fp8_kw = dict(x_amax=ops._p(x_amax), wscale=ops._p(self.ws_fwd))
+            amax_p = ops._p(x_amax)
         if eng.training:       # batch statistics (slim.batch_norm is_training=True)
             # the column sums are taken about a pivot near the mean -- the previous step's batch mean, the
             # moving mean before the first step (bind) -- so channels with |mean| >> std keep their variance
-            if wino is not None:
-                wino.flags = DS_EPI_STATS
-                wino.run(x_ptr, u_ptr, ops._p(self.z), stats=ops._p(self.stats_buf), pivot=ops._p(self.mean), **fp8_kw)
-                P = wino.partials
-            else:
-                self.fwd.d.flags = DS_EPI_STATS
-                self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z), stats=ops._p(self.stats_buf), pivot=ops._p(self.mean))
-                P = self.fwd.partials
-            ops.bn_finalize(self.stats_buf, P, self.M, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
+            plan.d.flags = DS_EPI_STATS
+            plan.run(x_ptr, self.w_ptr, ops._p(self.z), stats=ops._p(self.stats_buf), pivot=ops._p(self.mean), x_amax=amax_p)
+            ops.bn_finalize(self.stats_buf, plan.partials, self.M, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
                             self.rstd, self.shift, self.mm if eng.update_moving else None,
                             self.mv if eng.update_moving else None, pivot=self.mean)
         else:                  # moving statistics (is_training=False: evaluate_* on the validation split)
-            if wino is not None:
-                wino.flags = 0
-                wino.run(x_ptr, u_ptr, ops._p(self.z), **fp8_kw)
-            else:
-                self.fwd.d.flags = 0
-                self.fwd.run(x_ptr, self.w_ptr, ops._p(self.z))
+            plan.d.flags = 0
+            plan.run(x_ptr, self.w_ptr, ops._p(self.z), x_amax=amax_p)
             ops.bn_infer_prepare(self.beta, self.mm, self.mv, BN_EPS, self.cout, self.rstd, self.shift)
         if segs is not None and not self.skip_apply:
             ops.bn_apply_relu(self.z, self.M, self.cout, self.rstd, self.shift, segs)
@@ -392,18 +309,12 @@ class ConvBN:
     def _run_dgrad(self, dx_ptr):
         sums = ops._p(self.dx_sums) if self.dx_sums is not None else None
         y = ops._p(self.dx_y) if self.dx_sums is not None else None
-        if isinstance(self.wino_dgrad, ops.Fp8Plan):
+        am = None
+        if self.dgrad.family == ops.DS_FAM_FP8D:
             am = self.dz_amax if self._dz_amax_live else self.amax[1]
             if not self._dz_amax_live:          # dz came from a kernel that does not track max|dz| (pooled BatchNorm backward)
                 ops.absmax(self.z, self.M * self.cout, am)
-            self.wino_dgrad.run(ops._p(self.z), ops._p(self.u_dgrad), dx_ptr, x_amax=ops._p(am), wscale=ops._p(self.ws_dgrad))
-        elif self.wino_dgrad is not None:
-            if sums is not None:
-                self.wino_dgrad.run(ops._p(self.z), ops._p(self.u_dgrad), dx_ptr, stats=sums, ymask=y)
-            else:
-                self.wino_dgrad.run(ops._p(self.z), ops._p(self.u_dgrad), dx_ptr)
-        else:
-            self.dgrad.run(ops._p(self.z), self.w_ptr, dx_ptr, mask=y, stats=sums)
+        self.dgrad.run(ops._p(self.z), self.w_ptr, dx_ptr, mask=y, stats=sums, x_amax=ops._p(am))
 
     def backward(self, x_ptr=None, ldx=0, dx_ptr=None, need_dx=True):
         eng = self.eng
@@ -419,7 +330,7 @@ class ConvBN:
                                 self.coef)
         if not (need_dx or self.trainable):
             return
-        track = isinstance(self.wino_dgrad, ops.Fp8Plan)
+        track = self.dgrad is not None and self.dgrad.family == ops.DS_FAM_FP8D
         ops.bn_bwd_apply(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.coef, self.z,    # dz over z
                          amax=self.dz_amax if track else None, ldz=self.ldz)
         self._dz_amax_live = track
@@ -642,10 +553,8 @@ class MixedStage(Stage):
                 n = layer.cout
                 layer.use_concat_slice(zc[:, off:off + n], Ct, self.rs_cat[0, off:off + n], self.rs_cat[1, off:off + n])
         if getattr(self.prev, "zcat", False):    # this block reads a zcat concat
-            plans = [self.fused.fwd] + ([self.fused.wino_fwd] if isinstance(self.fused.wino_fwd, ops.F32x3Plan) else [])
-            for pl in plans:
-                pl.d.norm_rstd = self.prev.rs_cat[0].data_ptr()
-                pl.d.norm_shift = self.prev.rs_cat[1].data_ptr()
+            self.fused.fwd.d.norm_rstd = self.prev.rs_cat[0].data_ptr()
+            self.fused.fwd.d.norm_shift = self.prev.rs_cat[1].data_ptr()
         self.fused.make_dgrad(cin)
         self.c1.make_dgrad(b1a)
         self.c2.make_dgrad(b2a)
@@ -660,7 +569,7 @@ class MixedStage(Stage):
         #  * the fused 1x1 dgrad writes (last, accumulating onto the pool path: pool_first) the gradient of the block
         #    input = the previous block's concat output, i.e. one part of each of ITS four layers.
         p = self.prev
-        self.pool_first = bool(eng.pool_first and self.fused.wino_dgrad is None)
+        self.pool_first = bool(eng.pool_first and self.fused.dgrad.family == ops.DS_FAM_IGEMM)      # (kernels with an accumulate epilogue)
         if isinstance(p, MixedStage) and self.pool_first:
             src = self.fused.emit_dx_sums(p.out)
             if src is not None and getattr(p, "zcat", False):      # the epilogue rebuilds y from the concat's z
@@ -695,8 +604,9 @@ class MixedStage(Stage):
             return True                      # (ds_maxpool_bn_relu_fwd: 3x3 rolling kernels, any other window generic)
         if isinstance(nxt, MixedStage) and not any(l.trainable for l in nxt.layers):
             nf = nxt.b[0] + nxt.b[1] + nxt.b[3]
-            probe = ConvPlan(B, self.H, self.W, self.C, self.C, 1, 1, 1, nf, nf, self.C * nf, 1, nf, flags=DS_EPI_STATS)
-            return ops.conv_norm_supported(probe)
+            probe = ops.LayerPlan(ops.DS_CONV_FWD, eng.arith, eng.plan_options(), B, self.H, self.W, self.C, nf, 1, 1, self.C,
+                                  nf, DS_EPI_STATS)
+            return probe.norm_supported()
         return False
 
     def _pool_fwd(self):
@@ -883,6 +793,28 @@ class InceptionV1Engine:
         self.lg = lg
         # first stage (from the top) below which nothing is trainable -> backward can stop there
         self.layers = [l for s in self.stages for l in s.layers]
+
+    @property
+    def arith(self):
+        """DS_ARITH_* of the 57 convs' forward / dgrad multiplies (ds_conv_plan)."""
+        if self.dtype == "f32":
+            return ops.DS_ARITH_F32X3 if self.mul3 else ops.DS_ARITH_F32
+        return ops.DS_ARITH_BF16 if self.dtype == "bf16" else ops.DS_ARITH_FP8
+
+    def plan_options(self):
+        """The A/B switches of this engine as ds_conv_plan option bits."""
+        o = 0
+        if not self.winograd:
+            o |= ops.DS_PLAN_NO_WINO
+        if not self.winograd4:
+            o |= ops.DS_PLAN_NO_WINO4
+        if not self.stem_direct:
+            o |= ops.DS_PLAN_NO_STEM_DIRECT
+        if not self.bf16_direct:
+            o |= ops.DS_PLAN_NO_BF16_DIRECT
+        if self.act16:
+            o |= ops.DS_PLAN_ACT16
+        return o
 
     def new_amax(self):
         """One word of the amax pool (None outside the fp8 configuration)."""

@@ -11,7 +11,10 @@ import torch
 from . import _lib
 from ._lib import (ConvDesc, Segments, SumSegments, DS_EPI_ACCUM, DS_EPI_BIAS, DS_EPI_BNSUMS, DS_EPI_MASK, DS_EPI_RELU,  # noqa: F401
                    DS_EPI_STATS,
-                   DS_DTYPE_BF16, DS_DTYPE_F32, DS_FP8_E4M3, DS_FP8_E5M2)
+                   DS_DTYPE_BF16, DS_DTYPE_F32, DS_FP8_E4M3, DS_FP8_E5M2, DS_CONV_FWD, DS_CONV_DGRAD, DS_ARITH_F32, DS_ARITH_BF16,
+                   DS_ARITH_FP8, DS_ARITH_F32X3, DS_FAM_IGEMM, DS_FAM_WINO2, DS_FAM_WINO4, DS_FAM_STEM, DS_FAM_BF16D, DS_FAM_FP8D,
+                   DS_FAM_F32X3, DS_PLAN_NO_WINO, DS_PLAN_NO_WINO4, DS_PLAN_NO_STEM_DIRECT, DS_PLAN_NO_BF16_DIRECT, DS_PLAN_ACT16,
+                   DS_PLAN_PACKED_RGB)
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -185,6 +188,69 @@ class WinoPlan:
             t.begin()
         N, H, W, Cin, ldx, Cout, ldz = self.args
         _lib.check(self._run(x, u, z, stats, pivot, ymask, N, H, W, Cin, ldx, Cout, ldz, self.flags, _stream()), self._name)
+        if t is not None:
+            t.end(self)
+
+
+class LayerPlan:
+    """One conv layer launch planned BY THE LIBRARY (ds_conv_plan): the engine says what the layer is -- role (forward /
+    Conv2DBackpropInput), arithmetic, filter [k][k][w_cin][w_cout], map, strides of x and z, epilogue flags -- and the
+    library picks the kernel family (implicit GEMM / wide 1x1, Winograd F(2x2) / F(4x4), packed-RGB stem, register-direct
+    bf16 / fp8 / f32x3), sizes the BatchNorm partials and names the prepared filter form.  `d` is the live descriptor
+    (ldx, ldz, flags, norm_* / mask_* may change between runs)."""
+
+    def __init__(self, role, arith, options, N, H, W, w_cin, w_cout, k, stride, ldx, ldz, flags=0):
+        self.p = _lib.LayerPlanStruct()
+        _lib.check(_lib.load().ds_conv_plan(C.byref(self.p), role, arith, options, N, H, W, w_cin, w_cout, k, stride, ldx,
+                                            ldz, flags), "ds_conv_plan")
+        self.d = self.p.d                    # a view into self.p
+        self.family = self.p.family
+        self.M = N * self.d.OH * self.d.OW
+        self.alg_flops = self.p.alg_flops
+        self.u = None                        # the prepared filter (alloc_weights), None: the family reads HWIO in place
+        self.wscale = None
+        self.io = _lib.ConvIO()
+        self._run = _lib.load().ds_conv_run
+        self._ref = C.byref(self.p)
+        self._io_ref = C.byref(self.io)
+
+    @property
+    def partials(self):
+        return self.p.partials
+
+    @property
+    def x16_ok(self):
+        return bool(self.p.x16_ok)
+
+    def alloc_weights(self, device):
+        if self.p.w_bytes:
+            self.u = torch.empty(self.p.w_bytes, dtype=torch.uint8, device=device)
+        if self.p.wscale_floats:
+            self.wscale = torch.zeros(self.p.wscale_floats, device=device)
+            self.io.wscale = self.wscale.data_ptr()
+
+    def prepare(self, w_hwio):
+        """Filter -> the form the chosen family reads (no-op for the families that read HWIO in place)."""
+        if self.u is not None:
+            _lib.check(_lib.load().ds_conv_prepare_weights(self._ref, w_hwio, _p(self.u), _p(self.wscale), _stream()),
+                       "ds_conv_prepare_weights")
+
+    def enable_bnsums(self, ldy):
+        """Conv2DBackpropInput whose result feeds a BatchNorm + ReLU backward: that layer's column sums from the epilogue
+        (y with pixel stride ldy goes in as `mask`).  Returns the partial count, 0 when the chosen kernel cannot."""
+        return int(_lib.load().ds_conv_plan_enable_bnsums(self._ref, ldy))
+
+    def norm_supported(self):
+        return bool(_lib.load().ds_conv_plan_norm_supported(self._ref))
+
+    def run(self, x, w_hwio, z, stats=None, pivot=None, mask=None, bias=None, x_amax=None):
+        t = CONV_TIMER
+        if t is not None:
+            t.begin()
+        io = self.io
+        io.stats, io.pivot, io.mask, io.bias, io.x_amax = stats, pivot, mask, bias, x_amax
+        _lib.check(self._run(self._ref, x, w_hwio if self.u is None else self.u.data_ptr(), z, self._io_ref, _stream()),
+                   "ds_conv_run")
         if t is not None:
             t.end(self)
 
