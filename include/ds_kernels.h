@@ -140,7 +140,7 @@ int ds_conv_bf16(const ds_conv_desc *d, const void *x, const void *wb, float *z,
 /* fp32 PRODUCTS on the bf16 matrix cores ("bf16x3").  Every fp32 operand is split into three bf16 pieces (8 + 8 + 8
  * mantissa bits) and a*b is accumulated in fp32 from the six piece products whose magnitude exceeds 2^-24 |ab| -- six
  * v_mfma_f32_32x32x16_bf16 instead of eight v_mfma_f32_32x32x2_f32 per 16 reduction channels, 2.67x fewer matrix
- * cycles.  Error against fp64 equals the fp32 MFMA's (scratch/mfma_x3.hip: 3.26e-7 vs 3.22e-7 relative rms); results
+ * cycles.  Error against fp64 equals the fp32 MFMA's (scripts/microbench/mfma_x3.hip: 3.26e-7 vs 3.22e-7 relative rms); results
  * are NOT bit-identical to ds_conv_igemm.  Same descriptor as ds_conv_bf16 (1x1 / 3x3, Cin % 8 == 0, fp32 x); flags
  * DS_EPI_STATS, or -- for a dgrad -- DS_EPI_ACCUM and DS_EPI_BNSUMS (mask, ldmask, mask_rstd / mask_shift) exactly as
  * ds_conv_igemm's wide kernel; norm_rstd / norm_shift (1x1) as for ds_conv_igemm.  wb = ds_weights_to_f32x3(w): the weights'

@@ -3,7 +3,7 @@
 // replace eight v_mfma_f32_32x32x2_f32 (16 passes each) per 16 reduction channels and 32x32 tile: 2.67x fewer matrix
 // cycles -- IF the splitting VALU work (per A fragment, shared by NB column blocks; B pre-split) does not eat it.
 // Measures both loops (one wave per SIMD x 4, 256 workgroups, registers only) and checks the accuracy of one tile.
-//   hipcc --offload-arch=gfx950 -O3 -o scratch/mfma_x3 scratch/mfma_x3.hip && scratch/mfma_x3
+//   hipcc --offload-arch=gfx950 -O3 -o scripts/microbench/mfma_x3 scripts/microbench/mfma_x3.hip && scripts/microbench/mfma_x3
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>

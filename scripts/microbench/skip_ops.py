@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Upper bounds for restructuring the non-MFMA passes: run bench.py with some op wrappers turned into no-ops (results are
-garbage, only the step time matters).   SKIP=apply,bwd_apply,finalize,bwd_finalize,pool_fwd,pool_bwd python scratch/skip_ops.py [bench args]"""
+garbage, only the step time matters).   SKIP=apply,bwd_apply,finalize,bwd_finalize,pool_fwd,pool_bwd python scripts/microbench/skip_ops.py [bench args]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
 // VGPRs (buffer_load -> s_waitcnt -> ds_write_b128): 12 staging registers per thread, three 13-cycle
 // LDS stores per K-tile and a vmcnt(0) in the middle of every K-step.  Here each lane's 16 bytes land
 // directly in LDS (a wave-instruction fills 1 KiB at M0 + lane*16; out-of-range lanes write zeros --
-// probed in scratch/glds/glds_test.hip), so there are no staging registers and no LDS stores, and the
+// probed in scripts/microbench/glds_test.hip), so there are no staging registers and no LDS stores, and the
 // freed registers pay for a 32-deep K-tile: half as many barriers and fragment-read restarts per MFMA.
 // Rows are 128 bytes and unpadded (the DMA destination is lane-linear), so the bank-conflict-free layout
 // is an XOR swizzle applied on the SOURCE side: LDS slot (row, pc) holds the row's logical 16-byte chunk
@@ -1331,7 +1331,7 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
 // (8 + 8 + 8 mantissa bits: a = a0 + a1 + a2 exactly to 2^-24 |a|); a*b is accumulated in fp32 as
 // a1*b1 + a2*b0 + a0*b2 + a1*b0 + a0*b1 + a0*b0 (the dropped terms are below 2^-24 |ab|): six v_mfma_f32_32x32x16_bf16
 // (8 passes each) per 16 reduction channels and 32x32 tile instead of eight v_mfma_f32_32x32x2_f32 (16 passes each), i.e.
-// 2.67x fewer matrix cycles at the accuracy of the fp32 MFMA (scratch/mfma_x3.hip: relative rms error against fp64
+// 2.67x fewer matrix cycles at the accuracy of the fp32 MFMA (scripts/microbench/mfma_x3.hip: relative rms error against fp64
 // 3.26e-7 vs 3.22e-7 over K = 512; loop 1.6 - 1.9x faster including the splitting).  The weights are split once per
 // weight update (ds_weights_to_f32x3: three planes per K-loop iteration), the A fragment in registers (~40 VALU per 8
 // values, shared by the NB column blocks).  Measured on the 1x1 layers of the joint step (B = 256): 1.15 - 1.5x over the

@@ -61,7 +61,7 @@ typedef __attribute__((address_space(3))) void *lds_ptr;
 
 // a - b on four floats as two v_pk_add_f32 with the second operand negated.  hipcc packs fp32 adds into
 // v_pk_add_f32 by itself but leaves subtractions as four v_sub_f32, and with one wave per SIMD every VALU issue
-// slot of the transform is a slot the matrix pipe idles (scratch/mfma_mix.hip: 64 MFMAs alone 1.73 us, with the K
+// slot of the transform is a slot the matrix pipe idles (scripts/microbench/mfma_mix.hip: 64 MFMAs alone 1.73 us, with the K
 // step's 128 VALU ops, 16 LDS reads and barrier 2.15 us): 112 -> 64 VALU instructions per K step, -4 % kernel time.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {

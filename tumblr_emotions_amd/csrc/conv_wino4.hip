@@ -35,7 +35,7 @@
 // dgrad: the same kernel with U built from the flipped, transposed filter.
 // Numerics: fp32 throughout, ordered reductions (deterministic).  The F(4x4) transforms carry constants up to 8 and
 // cost about one decimal digit against F(2x2): relative rms error 2.4e-6 instead of 3.7e-7 on post-ReLU activations
-// with 192 input channels (scratch/wino4_numerics.py), against 2.6e-7 for a direct fp32 sum.
+// with 192 input channels (scripts/microbench/wino4_numerics.py), against 2.6e-7 for a direct fp32 sum.
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
