@@ -94,7 +94,25 @@ typedef struct ds_conv_desc {
                               /* that are already activations carry (1, 0): relu(y) = y.                               */
     const float *mask_rstd;   /* DS_EPI_BNSUMS: `mask` holds z of the consumer layer(s) instead of y; y is rebuilt as */
     const float *mask_shift;  /* relu(mask*mask_rstd[n] + mask_shift[n]) per output column n (Cout floats each)        */
+    const struct ds_bn_bwd_on_load *bnb;   /* HOST pointer, nullable: BatchNorm + ReLU backward applied ON LOAD (below)  */
 } ds_conv_desc;
+
+/* Conv2DBackpropInput of a 1x1 conv + BatchNorm + ReLU layer WITHOUT the separate ds_bn_bwd_apply pass (wide 1x1 kernel
+ * only, ds_conv_igemm_bnb_supported): x holds the layer's pre-BatchNorm output z (pixel stride ldx, Cin = the layer's
+ * output channels), and the reduction operand is formed as it is loaded,
+ *     dz = rstd (g - coef[0] - xhat coef[1]),  g = dy (z rstd + shift > 0),  xhat = (z - mean) rstd
+ * -- slim.batch_norm's gradient (scale = False; slim/nets/inception_utils.py:48-70) with coef = the two column means that
+ * ds_bn_bwd_finalize* produce; bit-identical to ds_bn_bwd_apply followed by the plain dgrad.  dy may live in up to three
+ * channel ranges (the slices of a fused 1x1 layer's output gradient): ascending, boundaries multiples of 16.  z is left
+ * untouched (a weight gradient that needs dz keeps the separate pass).                                               */
+typedef struct ds_bn_bwd_on_load {
+    const float *mean, *rstd, *shift;   /* Cin floats each                                                        */
+    const float *coef;                  /* float[2][Cin]                                                          */
+    int32_t nseg;                       /* 1..3                                                                   */
+    int32_t c_end[3];                   /* range i covers channels [c_end[i-1], c_end[i]); c_end[nseg-1] == Cin   */
+    int32_t ld[3];                      /* pixel stride of each range's dy (floats)                               */
+    const float *dy[3];                 /* channel c_end[i-1] of pixel 0 of range i                               */
+} ds_bn_bwd_on_load;
 
 /* DEBUG / A-B AIDS (ds_debug_*): process-global switches for tests and tuning scripts.  They are NOT re-entrant,
  * are never called by the product path (tests/test_abi_cpu.py checks that) and none is needed for correct results;
@@ -116,6 +134,8 @@ int ds_conv_igemm_partials(const ds_conv_desc *d);
 int ds_conv_igemm_bnsums_supported(const ds_conv_desc *d);
 /* ... and whether ds_conv_igemm would apply norm_rstd / norm_shift for this descriptor (same kernel, same rule).   */
 int ds_conv_igemm_norm_supported(const ds_conv_desc *d);
+/* ... and whether it takes ds_conv_desc.bnb (k-contiguous weights, i.e. a dgrad, on the wide kernel; Cin <= 1024).     */
+int ds_conv_igemm_bnb_supported(const ds_conv_desc *d);
 /* stats (DS_EPI_STATS): float[2][Cout][P] partial column sums of (z - pivot) and (z - pivot)^2.
  * pivot (nullable = 0): float[Cout], any value near the column mean -- the build passes the previous step's
  * batch mean (the moving mean after a restore) -- so that the fp32 partial sums carry the spread of z rather
@@ -238,6 +258,7 @@ int ds_conv_wino4(const float *x, const float *u, float *z, float *stats, const 
  *                            stride ldy goes in as io.mask) and returns the partial count, or 0 when the chosen kernel
  *                            cannot carry it (the caller then keeps the separate ds_bn_bwd_reduce pass)
  *   ds_conv_plan_norm_supported   would the launch apply d.norm_rstd / d.norm_shift (BatchNorm + ReLU on load)?
+ *   ds_conv_plan_bnb_supported    dgrad: would it apply the layer's BatchNorm backward on load (d.bnb)?
  *   ds_conv_prepare_weights  plan.w_bytes > 0: converts the HWIO filter into the form the family reads (G g G^T, bf16 /
  *                            fp8 / three-piece K-loop order); redo whenever the filter changes.  fp8: wscale =
  *                            float[plan.wscale_floats]
@@ -288,6 +309,7 @@ int ds_conv_plan(ds_conv_layer_plan *plan, int32_t role, int32_t arith, uint32_t
 int ds_conv_plan_set_flags(ds_conv_layer_plan *plan, int32_t flags);
 int ds_conv_plan_enable_bnsums(ds_conv_layer_plan *plan, int32_t ldy);
 int ds_conv_plan_norm_supported(const ds_conv_layer_plan *plan);
+int ds_conv_plan_bnb_supported(const ds_conv_layer_plan *plan);      /* would ds_conv_run take plan.d.bnb?                 */
 int ds_conv_prepare_weights(const ds_conv_layer_plan *plan, const float *w_hwio, void *w_prepared, float *wscale,
                             void *stream);
 int ds_conv_run(const ds_conv_layer_plan *plan, const void *x, const void *w, float *z, const ds_conv_io *io, void *stream);

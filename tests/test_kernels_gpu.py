@@ -354,6 +354,80 @@ def test_wide_1x1_kernel_forward_and_dgrad_match_oracle(case):
         lib.ds_debug_conv_set_wide(1)
 
 
+@pytest.mark.parametrize("case", [(1000, 176, 192, (64, 160, 176)), (777, 304, 480, (192, 288, 304)), (513, 296, 512, (160, 272, 296)),
+                                  (300, 64, 224, (64,)), (4100, 448, 832, (256, 416, 448)), (260, 32, 96, (32,))])
+def test_wide_dgrad_applies_batchnorm_backward_on_load(case):
+    """ds_conv_desc.bnb: the wide 1x1 dgrad reads the layer's z and the activation gradient dy (one to three channel
+    ranges with their own pixel strides, boundaries multiples of 16, last range ending off the 16-channel step) and forms
+    dz = rstd (g - mean g - xhat mean(g xhat)) as it loads.  Against the fp64 formula + GEMM at 2e-4, and BIT-identical
+    to ds_bn_bwd_apply followed by the plain dgrad (plain, DS_EPI_ACCUM and DS_EPI_BNSUMS epilogues)."""
+    ops = _ops()
+    from tumblr_emotions_amd import _lib
+    lib = _lib.load()
+    M, K, N, ends = case            # K = the layer's output channels (reduction of the dgrad), N = its input channels
+    rng = np.random.RandomState(M + K)
+    ldz = K + 8
+    z = rng.normal(size=(M, K)) * 1.5 + rng.normal(size=K)
+    w = rng.normal(size=(N, K)) * 0.1                   # HWIO [1][1][N][K]: the dgrad reads it k-contiguous
+    mean, var = z.mean(0), z.var(0)
+    rstd = 1.0 / np.sqrt(var + 1e-3)
+    beta = rng.normal(size=K) * 0.3
+    shift = beta - mean * rstd
+    dy = rng.normal(size=(M, K))
+    g = dy * (z * rstd + shift > 0)
+    xh = (z - mean) * rstd
+    a1, a2 = g.mean(0), (g * xh).mean(0)
+    dz = rstd * (g - a1 - xh * a2)
+    zd = dev(np.pad(z, ((0, 0), (0, 8)), constant_values=5.0))
+    parts, keep, c0 = [], [], 0
+    for i, c1 in enumerate(ends):                       # each range in its own buffer with its own row stride
+        ld = (c1 - c0) + 4 * i
+        t = dev(np.pad(dy[:, c0:c1], ((0, 0), (0, ld - (c1 - c0))), constant_values=9.0))
+        keep.append(t)
+        parts.append((c0, c1, t.data_ptr(), ld))
+        c0 = c1
+    md, rd, sd = dev(mean), dev(rstd), dev(shift)
+    coef = dev(np.stack([a1, a2]))
+    wd = dev(w)
+    lib.ds_debug_conv_set_wide(2)
+    try:
+        plan = ops.LayerPlan(ops.DS_CONV_DGRAD, ops.DS_ARITH_F32, 0, 1, M, 1, N, K, 1, 1, ldz, N, 0)
+        assert plan.family == ops.DS_FAM_IGEMM
+        assert plan.enable_bn_backward_on_load(md, rd, sd, coef, parts)
+        dx = torch.full((M, N), float("nan"), device="cuda")
+        plan.run(ops._p(zd), ops._p(wd), ops._p(dx))
+        torch.cuda.synchronize()
+        close(dx, dz @ w.T)
+        # the separate pass + plain dgrad on the same inputs: same bits
+        segs = ops.make_segments(parts)
+        dzd = zd.clone()
+        ops.bn_bwd_apply(dzd, segs, M, K, md, rd, sd, coef, dzd, ldz=ldz)
+        ref_plan = ops.LayerPlan(ops.DS_CONV_DGRAD, ops.DS_ARITH_F32, 0, 1, M, 1, N, K, 1, 1, ldz, N, 0)
+        dx2 = torch.full((M, N), float("nan"), device="cuda")
+        ref_plan.run(ops._p(dzd), ops._p(wd), ops._p(dx2))
+        torch.cuda.synchronize()
+        close(dzd[:, :K], dz)
+        assert torch.equal(dx, dx2)
+        # with the accumulate + BatchNorm-sums epilogues (the fused block-input dgrad's form)
+        if N >= 32 and N % 8 == 0:
+            prev = dev(rng.normal(size=(M, N)))
+            yv = dev(np.maximum(rng.normal(size=(M, N)), 0.0))
+            outs = []
+            for pl, xin in ((plan, zd), (ref_plan, dzd)):
+                P = pl.enable_bnsums(N)
+                assert P > 0
+                pl.d.flags |= ops.DS_EPI_ACCUM
+                sums = torch.zeros(2, N, P, device="cuda")
+                o = prev.clone()
+                pl.run(ops._p(xin), ops._p(wd), ops._p(o), mask=ops._p(yv), stats=ops._p(sums))
+                torch.cuda.synchronize()
+                outs.append((o, sums))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+            close(outs[0][0], prev.cpu().numpy().astype(np.float64) + dz @ w.T)
+    finally:
+        lib.ds_debug_conv_set_wide(1)
+
+
 @pytest.mark.parametrize("case", [(2, 14, 14, 64, 96, 1), (3, 9, 10, 40, 72, 1), (2, 28, 28, 192, 176, 1), (2, 8, 8, 16, 32, 3),
                                   (1, 7, 7, 832, 128, 1), (2, 13, 11, 48, 40, 3)])
 def test_fp32_products_from_three_bf16_pieces_match_the_oracle(case):

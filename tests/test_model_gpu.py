@@ -522,6 +522,36 @@ def test_zcat_step_is_bit_identical():
         assert torch.equal(a, b) if torch.is_tensor(a) else a == b
 
 
+def test_bn_backward_on_load_step_is_bit_identical():
+    """InceptionV1Engine.bnb_on_load = 2: the frozen 1x1 layers -- every block's fused Branch_0/1/2 conv, Branch_3's conv,
+    Conv2d_2b -- run no ds_bn_bwd_apply pass; their wide dgrad forms dz = rstd (g - mean g - xhat mean(g xhat)) from z and
+    the activation gradient as it loads its A operand (ds_conv_desc.bnb, up to three channel ranges of dy).  One
+    definition of the per-element arithmetic (ds::bn_bwd_dz) in both kernels: logits, loss, every gradient and the updated
+    parameters of two training steps are BIT-identical to the separate-pass form, and the switch really changes the path.
+    (The default, 1, keeps it for Conv2d_2b only: elsewhere it is slower, profiles/r04_bnb_layers.txt.)"""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    batch = to_device(synthetic_batch_numpy(32, 10, 50, seed=5))
+    res, used = [], []
+    for on in (2, 0, 1):
+        net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10)
+        net.image.bnb_on_load = on
+        net.initialize(seed=7)
+        net.train_step(batch, 1e-3)
+        g1 = net.store.grad.clone()
+        net.train_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        used.append(sorted(l.key for l in net.image.layers if l.bnb))
+        res.append((net.logits.clone(), net.total_loss_value(), g1, net.store.grad.clone(), net.store.theta.clone(),
+                    net.store.frozen.clone()))
+    assert len(used[0]) >= 15 and used[1] == [] and used[2] == ["InceptionV1/Conv2d_2b_1x1"], used
+    assert "InceptionV1/Conv2d_2b_1x1" in used[0] and "InceptionV1/Mixed_3b/fused_1x1" in used[0]
+    assert not any("Mixed_5c" in k for k in used[0])          # trainable: the weight gradient reads dz
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+
+
 def test_bn_sums_from_dgrad_epilogues_equal_the_separate_reduce_pass():
     """InceptionV1Engine.bwd_sums: the BatchNorm backward sums of most layers come out of the epilogue of the dgrad
     that produces their output gradient (DS_EPI_BNSUMS: wide 1x1 and Winograd kernels) instead of a ds_bn_bwd_reduce

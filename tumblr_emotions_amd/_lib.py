@@ -29,7 +29,14 @@ class ConvDesc(C.Structure):
         ("tile_nt", C.c_int32), ("grid_x", C.c_int32), ("dtype", C.c_int32), ("x_dtype", C.c_int32),
         ("partials", C.c_int32),
         ("norm_rstd", C.c_void_p), ("norm_shift", C.c_void_p), ("mask_rstd", C.c_void_p), ("mask_shift", C.c_void_p),
+        ("bnb", C.c_void_p),
     ]
+
+
+class BnBwdOnLoad(C.Structure):
+    """ds_bn_bwd_on_load"""
+    _fields_ = [("mean", C.c_void_p), ("rstd", C.c_void_p), ("shift", C.c_void_p), ("coef", C.c_void_p),
+                ("nseg", C.c_int32), ("c_end", C.c_int32 * 3), ("ld", C.c_int32 * 3), ("dy", C.c_void_p * 3)]
 
 
 class LayerPlanStruct(C.Structure):
@@ -75,6 +82,7 @@ SIGNATURES = {
     "ds_conv_igemm_partials": (C.c_int, [_CD]),
     "ds_conv_igemm_bnsums_supported": (C.c_int, [_CD]),
     "ds_conv_igemm_norm_supported": (C.c_int, [_CD]),
+    "ds_conv_igemm_bnb_supported": (C.c_int, [_CD]),
     "ds_conv_igemm": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ds_weights_bf16_bytes": (C.c_size_t, [_i32, _i32, _i32, _i32]),
     "ds_weights_to_bf16": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _P]),
@@ -106,6 +114,7 @@ SIGNATURES = {
     "ds_conv_plan_set_flags": (C.c_int, [_LP, _i32]),
     "ds_conv_plan_enable_bnsums": (C.c_int, [_LP, _i32]),
     "ds_conv_plan_norm_supported": (C.c_int, [_LP]),
+    "ds_conv_plan_bnb_supported": (C.c_int, [_LP]),
     "ds_conv_prepare_weights": (C.c_int, [_LP, _P, _P, _P, _P]),
     "ds_conv_run": (C.c_int, [_LP, _P, _P, _P, _IO, _P]),
     "ds_conv_wgrad_workspace": (C.c_size_t, [_CD]),

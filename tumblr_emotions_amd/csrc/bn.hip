@@ -337,9 +337,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, int l
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float g = (zz[j] * rr[j] + ss[j] > 0.f) ? dd[j] : 0.f;
-            const float xh = (zz[j] - mm[j]) * rr[j];
-            o[j] = rr[j] * (g - a1[j] - xh * a2[j]);
+            o[j] = ds::bn_bwd_dz(zz[j], dd[j], rr[j], ss[j], mm[j], a1[j], a2[j]);
         }
         *reinterpret_cast<float4 *>(dz + row * ldz + c) = make_float4(o[0], o[1], o[2], o[3]);
         am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));

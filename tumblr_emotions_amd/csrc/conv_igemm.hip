@@ -52,6 +52,7 @@ struct ConvParams {
     int prio_mode;               // 1: staggered static wave priorities (see kernel)
     int col_tiles;               // > 0: 1-D XCD-aware launch (see TileId); 0: (row, column) = (blockIdx.x, blockIdx.y)
     int col_total;               // conv_bf16d_kernel: columns of the converted weight tensor (Cout rounded up to 32)
+    ds_bn_bwd_on_load bnb;       // gemm_wide_kernel<.., BNB = true>: copy of *d.bnb (the descriptor's pointer is a host pointer)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *p, unsigned bytes) {
@@ -1109,14 +1110,19 @@ __global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void conv_bf16_kernel(const C
 // MFMA groups (conv_wino.hip: a burst of row-scattered loads stalls the in-order wave behind the texture path).
 // Epilogue: stores (DS_EPI_ACCUM: z += result) + BatchNorm column statistics about the pivot (DS_EPI_STATS).
 // ================================================================================================
-template <int NB, bool BNMAJOR>
+// BNB (dgrad of a 1x1 conv + BatchNorm + ReLU layer, ds_conv_desc.bnb): x holds the layer's z and the A fragment becomes
+// dz = bn_bwd_dz(z, dy, ...) as it is loaded -- a second float4 (dy, from up to three channel ranges whose boundaries are
+// multiples of the 16-channel K step, so a step's range is wave-uniform) and five per-channel values from LDS per A
+// float4, ~8 VALU per element against NB MFMAs: the layer's ds_bn_bwd_apply pass (12 B per element) disappears.
+template <int NB, bool BNMAJOR, bool BNB = false>
 __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const ConvParams p) {
     constexpr int BN = NB * 32, WK = 16;                       // K step: 16 channels = two float4 per lane
     constexpr int DJ = (WK * BN / 4 + 255) / 256;              // 16-byte DMA slots per thread per K step: ceil(NB / 2)
     constexpr int BSZ = DJ * 1024;                             // floats per B buffer (odd NB: the last DMA is half used)
     __shared__ __attribute__((aligned(128))) float smem[2 * BSZ + 256];
-    // BatchNorm + ReLU on load (ds_conv_desc.norm_rstd / norm_shift): rstd and shift of all Cin reduction channels
-    __shared__ __attribute__((aligned(16))) float nrm[2][1024 + WK];
+    // BatchNorm + ReLU on load (ds_conv_desc.norm_rstd / norm_shift): rstd and shift of all Cin reduction channels;
+    // BNB: rstd, shift, mean, coef[0], coef[1]
+    __shared__ __attribute__((aligned(16))) float nrm[BNB ? 5 : 2][1024 + WK];
     const ds_conv_desc &d = p.d;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1167,6 +1173,32 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
 
     f32x4 a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, 0, 0));
     f32x4 a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, 32, 0));
+    // BNB: the gradient dy of the layer's activation, per channel range its own descriptor and row offset
+    const ds_bn_bwd_on_load &bb = p.bnb;
+    __amdgpu_buffer_rsrc_t srd_dy[3];
+    unsigned vdy[3];
+    if (BNB) {
+#pragma unroll
+        for (int sg = 0; sg < 3; ++sg) {
+            const bool has = sg < bb.nseg;
+            const int cb = sg == 0 ? 0 : bb.c_end[sg - 1];
+            const int ld = has ? bb.ld[sg] : 0;
+            srd_dy[sg] = make_srd(has ? bb.dy[sg] : bb.dy[0], has ? (unsigned)(((int64_t)(p.M - 1) * ld + (bb.c_end[sg] - cb)) * 4) : 0u);
+            vdy[sg] = (has && item && m < p.M) ? ((unsigned)m * (unsigned)ld + 4u * kh) * 4u : kOOB;
+        }
+    }
+    auto load_dy = [&](int c0, int half) -> f32x4 {          // channels c0 + 8 half + 4 kh ... of the step that starts at c0
+        const int sg = (c0 < bb.c_end[0] || bb.nseg == 1) ? 0 : ((c0 < bb.c_end[1] || bb.nseg == 2) ? 1 : 2);     // (uniform)
+        const int cb = sg == 0 ? 0 : bb.c_end[sg - 1];
+        const __amdgpu_buffer_rsrc_t r = sg == 0 ? srd_dy[0] : (sg == 1 ? srd_dy[1] : srd_dy[2]);
+        const unsigned v = sg == 0 ? vdy[0] : (sg == 1 ? vdy[1] : vdy[2]);
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, v, (c0 - cb) * 4 + 32 * half, 0));
+    };
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    if (BNB) {
+        d0 = load_dy(0, 0);
+        d1 = load_dy(0, 1);
+    }
 #pragma unroll
     for (int i = 0; i < DJ; ++i) dma_b(0, 0, i);
     const int ksteps = (K + WK - 1) / WK;
@@ -1184,10 +1216,30 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         a = __builtin_elementwise_max(__builtin_elementwise_fma(a, r, sh), zero);
     };
+    if (BNB) {          // channels past Cin get zeros: dz = 0 there (and the weights read as zeros anyway)
+        for (int c = tid; c < ksteps * WK; c += 256) {
+            nrm[0][c] = c < K ? bb.rstd[c] : 0.f;
+            nrm[1][c] = c < K ? bb.shift[c] : 0.f;
+            nrm[BNB ? 2 : 0][c] = c < K ? bb.mean[c] : 0.f;
+            nrm[BNB ? 3 : 0][c] = c < K ? bb.coef[c] : 0.f;
+            nrm[BNB ? 4 : 0][c] = c < K ? bb.coef[K + c] : 0.f;
+        }
+    }
+    auto apply_bnb = [&](f32x4 &a, const f32x4 &dy, int c) {      // a holds z of channels c .. c + 3
+        const f32x4 r = *reinterpret_cast<const f32x4 *>(&nrm[0][c]), sh = *reinterpret_cast<const f32x4 *>(&nrm[1][c]);
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(&nrm[BNB ? 2 : 0][c]);
+        const f32x4 k1 = *reinterpret_cast<const f32x4 *>(&nrm[BNB ? 3 : 0][c]), k2 = *reinterpret_cast<const f32x4 *>(&nrm[BNB ? 4 : 0][c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = ds::bn_bwd_dz(a[j], dy[j], r[j], sh[j], mu[j], k1[j], k2[j]);
+    };
     __syncthreads();
     if (norm) {
         apply_norm(a0, 4 * kh);
         apply_norm(a1, 8 + 4 * kh);
+    }
+    if (BNB) {
+        apply_bnb(a0, d0, 4 * kh);
+        apply_bnb(a1, d1, 8 + 4 * kh);
     }
     for (int ks = 0; ks < ksteps; ++ks) {
         const bool more = ks + 1 < ksteps;
@@ -1212,8 +1264,14 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
                 for (int j = 0; j < 4; ++j) { bf[j] = lo[j]; bf[4 + j] = hi[j]; }
             }
             if (more) {                                    // next K step's operands, spread over the column blocks
-                if (b == 0) n0v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, cn * 4, 0));
-                if (b == (NB > 1 ? 1 : 0)) n1v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, cn * 4 + 32, 0));
+                if (b == 0) {
+                    n0v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, cn * 4, 0));
+                    if (BNB) d0 = load_dy(cn, 0);
+                }
+                if (b == (NB > 1 ? 1 : 0)) {
+                    n1v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, cn * 4 + 32, 0));
+                    if (BNB) d1 = load_dy(cn, 1);
+                }
                 if (b < DJ) dma_b((ks + 1) & 1, cn, b);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1232,6 +1290,10 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
         if (norm && more) {
             apply_norm(a0, cn + 4 * kh);
             apply_norm(a1, cn + 8 + 4 * kh);
+        }
+        if (BNB && more) {
+            apply_bnb(a0, d0, cn + 4 * kh);
+            apply_bnb(a1, d1, cn + 8 + 4 * kh);
         }
         __syncthreads();
     }
@@ -1716,11 +1778,12 @@ KernelFn bf16_kernel(int nt, Variant v) {
     }
 }
 
-void launch_wide(int nb, bool bnmajor, dim3 grid, hipStream_t st, const ConvParams &p) {
-#define DS_WIDE(NBV)                                                                                   \
-    case NBV:                                                                                          \
-        if (bnmajor) hipLaunchKernelGGL((gemm_wide_kernel<NBV, true>), grid, dim3(256), 0, st, p);     \
-        else hipLaunchKernelGGL((gemm_wide_kernel<NBV, false>), grid, dim3(256), 0, st, p);            \
+void launch_wide(int nb, bool bnmajor, bool bnb, dim3 grid, hipStream_t st, const ConvParams &p) {
+#define DS_WIDE(NBV)                                                                                      \
+    case NBV:                                                                                             \
+        if (bnmajor) hipLaunchKernelGGL((gemm_wide_kernel<NBV, true>), grid, dim3(256), 0, st, p);        \
+        else if (bnb) hipLaunchKernelGGL((gemm_wide_kernel<NBV, false, true>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((gemm_wide_kernel<NBV, false>), grid, dim3(256), 0, st, p);               \
         break;
     switch (nb) {
         DS_WIDE(1)
@@ -1956,6 +2019,12 @@ extern "C" int ds_conv_igemm_norm_supported(const ds_conv_desc *d) {
     return wide_nb(d, dims_vec(d)) > 0 ? 1 : 0;
 }
 
+extern "C" int ds_conv_igemm_bnb_supported(const ds_conv_desc *d) {
+    // BatchNorm backward on load lives in the wide 1x1 kernel's loader, k-contiguous-weights (dgrad) instantiation
+    if (!d || d->Cin > 1024 || (d->w_n_stride == 1 && d->w_k_stride != 1) || d->norm_rstd) return 0;
+    return wide_nb(d, dims_vec(d)) > 0 ? 1 : 0;
+}
+
 extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float *w, float *z, const float *bias,
                              const float *mask, float *stats, const float *pivot, void *stream) {
     DS_REQUIRE(d && x && w && z, "ds_conv_igemm: null argument");
@@ -2028,7 +2097,22 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
         p.col_tiles = gy;
         grid = dim3((rt * gy + 7) / 8 * 8, 1, splits);
     }
-    if (c.wide) launch_wide(c.wide, v.bnmajor, grid, (hipStream_t)stream, p);
+    if (d->bnb) {
+        const ds_bn_bwd_on_load &b = *d->bnb;
+        DS_REQUIRE(c.wide && !v.bnmajor && d->Cin <= 1024 && !d->norm_rstd,
+                   "ds_conv_igemm: ds_conv_desc.bnb is implemented by the wide 1x1 kernel for k-contiguous weights only "
+                   "(ds_conv_igemm_bnb_supported)");
+        DS_REQUIRE(b.mean && b.rstd && b.shift && b.coef && b.nseg >= 1 && b.nseg <= 3 && b.c_end[b.nseg - 1] == d->Cin,
+                   "ds_conv_igemm: bnb needs mean / rstd / shift / coef and 1..3 channel ranges that end at Cin");
+        for (int i = 0; i < b.nseg; ++i) {
+            const int cb = i ? b.c_end[i - 1] : 0;
+            DS_REQUIRE(b.dy[i] && (((uintptr_t)b.dy[i]) & 15) == 0 && b.ld[i] % 4 == 0 && b.c_end[i] > cb && cb % 16 == 0 &&
+                           b.ld[i] >= b.c_end[i] - cb && ((int64_t)(p.M - 1) * b.ld[i] + (b.c_end[i] - cb)) * 4 < (1ll << 31),
+                       "ds_conv_igemm: bnb channel range %d (16-byte aligned dy, ld %% 4 == 0, boundaries %% 16 == 0)", i);
+        }
+        p.bnb = b;
+    }
+    if (c.wide) launch_wide(c.wide, v.bnmajor, d->bnb != nullptr, grid, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(kernel_for(c, v), grid, dim3(256), 0, (hipStream_t)stream, p);
     return ds::check_launch("ds_conv_igemm");
 }

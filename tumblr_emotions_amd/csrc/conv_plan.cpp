@@ -189,6 +189,13 @@ extern "C" int ds_conv_plan_norm_supported(const ds_conv_layer_plan *p) {
     return p->family == DS_FAM_F32X3 && p->k == 1 && p->d.Cin <= 1024 ? 1 : 0;
 }
 
+extern "C" int ds_conv_plan_bnb_supported(const ds_conv_layer_plan *p) {
+    if (p == nullptr || p->role != DS_CONV_DGRAD || p->family != DS_FAM_IGEMM || p->k != 1) return 0;
+    ds_conv_desc t = p->d;
+    t.partials = 0;
+    return ds_conv_igemm_bnb_supported(&t);
+}
+
 extern "C" int ds_conv_prepare_weights(const ds_conv_layer_plan *p, const float *w_hwio, void *w_prepared, float *wscale,
                                        void *stream) {
     PLAN_REQUIRE(p != nullptr, "ds_conv_prepare_weights: null plan");

@@ -59,6 +59,15 @@ __device__ __forceinline__ float amax_read(const float *record) {
     return m;
 }
 
+// slim.batch_norm (scale = False) + ReLU backward for one element: dz from the layer's pre-BatchNorm z, the gradient dy of
+// its activation and the per-channel rstd r, shift s, mean mu, column means a1 = mean(g), a2 = mean(g xhat).  ONE
+// definition, explicit fused multiply-adds: ds_bn_bwd_apply and the wide dgrad's on-load form give the same bits.
+__device__ __forceinline__ float bn_bwd_dz(float z, float dy, float r, float s, float mu, float a1, float a2) {
+    const float g = __builtin_fmaf(z, r, s) > 0.f ? dy : 0.f;
+    const float xh = (z - mu) * r;
+    return r * __builtin_fmaf(-xh, a2, g - a1);
+}
+
 }  // namespace ds
 
 #define DS_REQUIRE(cond, ...)                 \

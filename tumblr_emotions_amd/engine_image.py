@@ -117,6 +117,7 @@ class ConvBN:
         self.dy_parts = None          # set_dy_parts(): where the gradient of this layer's output lives
         self._dz_amax_live = False
         self.dx_sums = None           # this layer's dgrad emits the consumer's BatchNorm sums (emit_dx_sums)
+        self.bnb = False              # the dgrad forms dz from z and dy as it loads (enable_bnb): no ds_bn_bwd_apply pass
         self.dx_y = None
         self._sum_segs = None
         if self.trainable:
@@ -233,6 +234,16 @@ class ConvBN:
         self.dgrad = ops.LayerPlan(ops.DS_CONV_DGRAD, eng.arith, eng.plan_options(), self.B, self.H, self.W, self.cin,
                                    self.cout, self.k, 1, self.ldz, lddx, 0)
         self.dgrad.alloc_weights(eng.device)
+        # BatchNorm + ReLU backward APPLIED ON LOAD by the wide 1x1 dgrad (ds_conv_desc.bnb): the layer skips its
+        # ds_bn_bwd_apply pass and the dgrad reads z and the activation gradient instead of dz (frozen layers only: a weight
+        # gradient needs dz).  Bit-identical, but it pays only where the dgrad is HBM-bound with ONE column tile -- Conv2d_2b
+        # (219 -> 190 us): the second A stream and ~8 VALU per element are redone for every column tile and cost the
+        # matrix-bound dgrads 25-65 % (profiles/r04_bnb_layers.txt: all fifteen 1x1 shapes; the whole step 15.2 -> 16.0 ms
+        # with it everywhere).  bnb_on_load: 1 = where it wins (default), 2 = every frozen 1x1 layer (tests), 0 = off
+        auto = self.cin <= 64 and self.cout <= 64
+        if (eng.bnb_on_load == 2 or (eng.bnb_on_load == 1 and auto)) and not self.trainable and self.k == 1 \
+                and self.dy_parts is not None:
+            self.bnb = self.dgrad.enable_bn_backward_on_load(self.mean, self.rstd, self.shift, self.coef, self.dy_parts)
 
     def _refresh_weights(self):
         """The prepared filter forms (G g G^T for the Winograd kernels, the bf16 / fp8 / three-piece K-loop orders):
@@ -329,6 +340,9 @@ class ConvBN:
             ops.bn_bwd_finalize(self.bwdp_buf, self.bwd_P, M, Cc, self.gbeta if self.gbeta is not None else eng.dummy,
                                 self.coef)
         if not (need_dx or self.trainable):
+            return
+        if self.bnb:              # z stays as it is: the dgrad's loader forms dz
+            self._run_dgrad(dx_ptr)
             return
         track = self.dgrad is not None and self.dgrad.family == ops.DS_FAM_FP8D
         ops.bn_bwd_apply(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.coef, self.z,    # dz over z
@@ -758,6 +772,7 @@ class InceptionV1Engine:
         self.bf16_direct = True      # dtype bf16: ds_conv_bf16 where it wins (False: the LDS-staged bf16 kernel everywhere)
         self.winograd = True         # 3x3 layers through ds_conv_wino where it wins (False: implicit GEMM everywhere)
         self.mul3 = os.environ.get("DS_MUL3", "0") == "1"     # opt-in: forward 1x1 convs with fp32 products on the bf16 matrix cores
+        self.bnb_on_load = int(os.environ.get("DS_BNB", "1"))      # BatchNorm backward formed by the 1x1 dgrad's loader: see ConvBN.make_dgrad
         self.zcat = os.environ.get("DS_ZCAT", "1") != "0"     # 3x3 / Branch_3 convs write z into the concat, consumers normalise on load
         self.winograd4 = os.environ.get("DS_WINO4", "1") != "0"      # ... and ds_conv_wino4 (F(4x4,3x3)) where it is faster
         self.weights_version = 0     # bumped by SentimentNet.after_load(): frozen layers redo their G g G^T

@@ -243,6 +243,24 @@ class LayerPlan:
     def norm_supported(self):
         return bool(_lib.load().ds_conv_plan_norm_supported(self._ref))
 
+    def enable_bn_backward_on_load(self, mean, rstd, shift, coef, parts):
+        """Conv2DBackpropInput of a 1x1 conv + BatchNorm + ReLU layer straight from z and the activation gradient: the
+        layer's ds_bn_bwd_apply pass is formed on load (ds_conv_desc.bnb).  parts: [(c0, c1, address, ld)] of dy.
+        Returns False when the chosen kernel cannot (the caller keeps the separate pass)."""
+        if not _lib.load().ds_conv_plan_bnb_supported(self._ref) or len(parts) > 3:
+            return False
+        if any(c0 % 16 for (c0, _, _, _) in parts):
+            return False
+        b = _lib.BnBwdOnLoad()
+        b.mean, b.rstd, b.shift, b.coef = mean.data_ptr(), rstd.data_ptr(), shift.data_ptr(), coef.data_ptr()
+        b.nseg = len(parts)
+        for i, (c0, c1, ptr, ld) in enumerate(parts):
+            assert c0 == (parts[i - 1][1] if i else 0)
+            b.c_end[i], b.ld[i], b.dy[i] = c1, ld, ptr
+        self.bnb = b                         # (kept alive: the descriptor holds its address)
+        self.d.bnb = C.addressof(b)
+        return True
+
     def run(self, x, w_hwio, z, stats=None, pivot=None, mask=None, bias=None, x_amax=None):
         t = CONV_TIMER
         if t is not None:
