@@ -255,3 +255,92 @@ def test_two_rank_joint_step_matches_the_clone_oracle():
     # per-rank statistics: rank 1 averaged ITS sub-batch, so its moving means differ from rank 0's
     k = "InceptionV1/Conv2d_2b_1x1/BatchNorm/moving_mean"
     assert not np.array_equal(got[0]["after"][k], got[1]["after"][k])
+
+
+def _sync_bn_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tumblr_emotions_amd.net import SentimentNet
+        from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+        net = SentimentNet(mode="joint", dropout_keep_prob=1.0, sync_bn=True, **TEXT)
+        assert net.sync_bn and net.image.sync_world == world
+        net.initialize(seed=3)
+        local = to_device(synthetic_batch_numpy(8, 10, 50, seed=4, with_images=True), "cuda", rank, world)
+        net.train_step(local, 1e-3)
+        torch.cuda.synchronize()
+        res = dict(logits=net.logits.detach().cpu().numpy(), ce=float(net.loss_buf.item()), grads=net.grads_state_dict(),
+                   after=net.state_dict())
+        # second run: BOTH ranks get the same four samples.  Doubling every partial sum and the count is exact in floating
+        # point, so the synchronised step must give the bits of one process on those four samples -- any partial-sum
+        # region left out of an all-reduce, or a count not multiplied by the world size, breaks that
+        net2 = SentimentNet(mode="joint", dropout_keep_prob=1.0, sync_bn=True, **TEXT)
+        net2.initialize(seed=5)
+        same = to_device(synthetic_batch_numpy(4, 10, 50, seed=6, with_images=True))
+        for _ in range(2):
+            net2.train_step(same, 1e-3)
+        torch.cuda.synchronize()
+        res["theta_same"] = net2.store.theta.detach().cpu().numpy()
+        res["frozen_same"] = net2.store.frozen.detach().cpu().numpy()
+        out.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_bn_reproduces_the_single_process_step():
+    """SURVEY 8(e), optional `sync_bn=True`: BatchNorm statistics and the two column means of its backward formula are
+    all-reduced per layer, so two ranks x 4 samples compute what one process computes on the 8 samples (slim's default --
+    and this build's -- is per-clone statistics; see test_two_rank_joint_step_matches_the_clone_oracle).  Same function,
+    different summation order: logits 1e-4, cross-entropy 1e-5, moving statistics 1e-5, the head gradients that follow the
+    logits 1e-4 / 1e-3; every other gradient to 3e-2 (median 2e-2): below a ReLU two fp32 evaluations with different summation
+    orders differ by ~1e-2 at any batch size (profiles/r02_oracle_fp32_spread.txt), which is what is seen here."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_bn_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(_collect(out, procs, 2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    net = SentimentNet(mode="joint", dropout_keep_prob=1.0, **TEXT)
+    net.initialize(seed=3)
+    net.train_step(to_device(synthetic_batch_numpy(8, 10, 50, seed=4, with_images=True)), 1e-3)
+    torch.cuda.synchronize()
+    logits = net.logits.detach().cpu().numpy()
+    both = np.concatenate([got[0]["logits"], got[1]["logits"]])
+    assert np.abs(both - logits).max() <= 1e-4, np.abs(both - logits).max()
+    assert abs(0.5 * (got[0]["ce"] + got[1]["ce"]) - float(net.loss_buf.item())) <= 1e-5
+    single = net.grads_state_dict()
+    rels, by_name = [], {}
+    for name, g in single.items():
+        assert np.array_equal(got[0]["grads"][name], got[1]["grads"][name]), name
+        d = got[0]["grads"][name] / 2.0 - g                      # reduced sum / world
+        rels.append(np.linalg.norm(d) / max(np.linalg.norm(g), 1e-30))
+        by_name[name] = rels[-1]
+        assert rels[-1] <= 3e-2, (name, rels[-1])
+    print(sorted(by_name.items(), key=lambda kv: kv[1])[:8])
+    # what sits above every ReLU of the image tower follows the logits: tight
+    assert by_name["b_softmax"] <= 1e-4 and by_name["W_softmax"] <= 1e-3, (by_name["b_softmax"], by_name["W_softmax"])
+    assert np.median(rels) <= 2e-2, np.median(rels)
+    after = net.state_dict()
+    for name, v in after.items():
+        if name.endswith("moving_mean") or name.endswith("moving_variance"):
+            np.testing.assert_allclose(got[0]["after"][name], v, atol=1e-5, err_msg=name)
+            assert np.array_equal(got[0]["after"][name], got[1]["after"][name]), name
+    # identical shards on both ranks: bit-identical to one process on that shard (see the worker)
+    net2 = SentimentNet(mode="joint", dropout_keep_prob=1.0, **TEXT)
+    net2.initialize(seed=5)
+    same = to_device(synthetic_batch_numpy(4, 10, 50, seed=6, with_images=True))
+    for _ in range(2):
+        net2.train_step(same, 1e-3)
+    torch.cuda.synchronize()
+    for r in range(2):
+        assert np.array_equal(got[r]["theta_same"], net2.store.theta.detach().cpu().numpy())
+        assert np.array_equal(got[r]["frozen_same"], net2.store.frozen.detach().cpu().numpy())      # (moving statistics)
+    print("sync_bn: max|dlogits| %.2e, median gradient rel L2 %.2e, worst %.2e" % (np.abs(both - logits).max(), np.median(rels), max(rels)))

@@ -182,6 +182,7 @@ class ConvBN:
             sg = ops.SumSegments()
             sg.nseg = len(self.dy_parts)
             self._reduce_jobs = []
+            self._sync_views = []          # sync_bn: the partial-sum regions to all-reduce before the finalize
             scratch, P0 = self.bwdp_buf.data_ptr(), self.bwd_P
             for i, (c0, c1, _, _) in enumerate(self.dy_parts):
                 sg.c_begin[i], sg.c_end[i] = c0, c1
@@ -191,6 +192,8 @@ class ConvBN:
                     sg.P[i], sg.kind[i] = P, 1
                     sg.s[i] = buf.data_ptr() + 4 * off * P
                     sg.q[i] = buf.data_ptr() + 4 * (ctot + off) * P
+                    n = c1 - c0
+                    self._sync_views += [buf[off * P:(off + n) * P], buf[(ctot + off) * P:(ctot + off + n) * P]]
                 elif self.part_pool[i] is not None:
                     # The part feeds only a max pool.  Every window hands its gradient to ONE input pixel p*, whose
                     # activation is the pooled value, so   sum_pixels g = sum_windows dpool (ypool > 0)   and
@@ -203,6 +206,8 @@ class ConvBN:
                     Pp = ops.bn_bwd_partials(Mp, n)
                     sg.P[i], sg.kind[i] = Pp, 0
                     sg.s[i], sg.q[i] = scratch, scratch + 4 * n * Pp
+                    o0 = (scratch - self.bwdp_buf.data_ptr()) // 4
+                    self._sync_views.append(self.bwdp_buf[o0:o0 + 2 * n * Pp])
                     seg = make_segments([(0, n, pool.dout.data_ptr() + 4 * off, pool.C)])
                     self._reduce_jobs.append(("pool", seg, Mp, n, _vp(pool.out.data_ptr() + pool.out.element_size() * off),
                                               pool.C, _vp(self.beta.data_ptr() + 4 * c0), _vp(scratch),
@@ -212,6 +217,8 @@ class ConvBN:
                     n = c1 - c0
                     sg.P[i], sg.kind[i] = P0, 0
                     sg.s[i], sg.q[i] = scratch, scratch + 4 * n * P0
+                    o0 = (scratch - self.bwdp_buf.data_ptr()) // 4
+                    self._sync_views.append(self.bwdp_buf[o0:o0 + 2 * n * P0])
                     self._reduce_jobs.append(("full", i, c0, n, _vp(scratch)))
                     scratch += 4 * 2 * n * P0
             self._sum_segs = sg
@@ -224,7 +231,29 @@ class ConvBN:
             off = 4 * c0
             ops.bn_bwd_reduce(_vp(self.z.data_ptr() + off), self.part_segs[i], M, n, _vp(self.mean.data_ptr() + off),
                               _vp(self.rstd.data_ptr() + off), _vp(self.shift.data_ptr() + off), dst, ldz=self.ldz)
+        if eng.sync_bn:
+            # beta's gradient stays this rank's own sum (the gradient all-reduce adds the ranks); the two column MEANS of the
+            # backward formula are over the global batch: finalize once locally for dbeta, all-reduce, finalize again
+            if self.gbeta is not None:
+                ops.bn_bwd_finalize_segs(self._sum_segs, M, Cc, self.beta, self.gbeta, self.coef)
+            for v in self._sync_views:
+                eng.all_reduce(v)
+            ops.bn_bwd_finalize_segs(self._sum_segs, M * eng.sync_world, Cc, self.beta, None, self.coef)
+            return
         ops.bn_bwd_finalize_segs(self._sum_segs, M, Cc, self.beta, self.gbeta, self.coef)
+
+    def _finalize_plain(self, P):
+        """ds_bn_bwd_finalize of bwdp_buf [2][C][P] (sync_bn: as in _bn_bwd_sums)."""
+        eng = self.eng
+        M, Cc = self.M, self.cout
+        gb = self.gbeta if self.gbeta is not None else eng.dummy
+        if not eng.sync_bn:
+            ops.bn_bwd_finalize(self.bwdp_buf, P, M, Cc, gb, self.coef)
+            return
+        if self.gbeta is not None:
+            ops.bn_bwd_finalize(self.bwdp_buf, P, M, Cc, gb, self.coef)
+        eng.all_reduce(self.bwdp_buf[:2 * Cc * P])
+        ops.bn_bwd_finalize(self.bwdp_buf, P, M * eng.sync_world, Cc, eng.dummy, self.coef)
 
     def make_dgrad(self, lddx):
         """Conv2DBackpropInput as a forward conv over dz with flipped taps (stride-1 SAME convs only); the library picks
@@ -281,7 +310,11 @@ class ConvBN:
             # moving mean before the first step (bind) -- so channels with |mean| >> std keep their variance
             plan.d.flags = DS_EPI_STATS
             plan.run(x_ptr, self.w_ptr, ops._p(self.z), stats=ops._p(self.stats_buf), pivot=ops._p(self.mean), x_amax=amax_p)
-            ops.bn_finalize(self.stats_buf, plan.partials, self.M, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
+            count = self.M
+            if eng.sync_bn:       # statistics of the GLOBAL batch: every rank's partials are about the same pivot, so they add
+                eng.all_reduce(self.stats_buf[:2 * self.cout * plan.partials])
+                count = self.M * eng.sync_world
+            ops.bn_finalize(self.stats_buf, plan.partials, count, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
                             self.rstd, self.shift, self.mm if eng.update_moving else None,
                             self.mv if eng.update_moving else None, pivot=self.mean)
         else:                  # moving statistics (is_training=False: evaluate_* on the validation split)
@@ -304,8 +337,7 @@ class ConvBN:
         else:
             ops.bn_pool_bwd_reduce(self.z, pool.dout, pool.argmax, B, H, W, Cc, self.mean, self.rstd, self.shift,
                                    self.bwdp_buf)
-            ops.bn_bwd_finalize(self.bwdp_buf, self.pool_P, M, Cc, self.gbeta if self.gbeta is not None else eng.dummy,
-                                self.coef)
+            self._finalize_plain(self.pool_P)
         if not (need_dx or self.trainable):
             return
         ops.bn_pool_bwd_apply(self.z, pool.dout, pool.argmax, B, H, W, Cc, self.mean, self.rstd, self.shift, self.coef,
@@ -337,8 +369,7 @@ class ConvBN:
             self._bn_bwd_sums()
         else:
             ops.bn_bwd_reduce(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.bwdp_buf, ldz=self.ldz)
-            ops.bn_bwd_finalize(self.bwdp_buf, self.bwd_P, M, Cc, self.gbeta if self.gbeta is not None else eng.dummy,
-                                self.coef)
+            self._finalize_plain(self.bwd_P)
         if not (need_dx or self.trainable):
             return
         if self.bnb:              # z stays as it is: the dgrad's loader forms dz
@@ -751,6 +782,12 @@ class InceptionV1Engine:
         self.update_moving = True
         self.training = True         # False: BatchNorm uses moving statistics, dropout is the identity
         self.reducer = None          # dp.GradientReducer, set by SentimentNet
+        # sync_bn (optional; slim keeps statistics per clone): BatchNorm statistics and the two column means of
+        # its backward formula over the GLOBAL batch -- one small all-reduce per layer and direction, W-rank numerics =
+        # the one-process step on the whole batch.  Set by SentimentNet(sync_bn=True) under data parallelism.
+        self.sync_bn = False
+        self.sync_world = 1
+        self.sync_group = None
         self.seed_dev = None         # device int64 added to the dropout seed (hipGraph replay draws fresh masks)
         # 1 (default): the Branch_3 chain, then the Branch_2 chain, on ONE side stream -- one cross-queue join per block (a join
         # costs ~17 us of idle GPU: 17.74 -> 17.58 ms/step against two side streams); 0: a side stream each; 2: Branch_3 only
@@ -830,6 +867,10 @@ class InceptionV1Engine:
         if self.act16:
             o |= ops.DS_PLAN_ACT16
         return o
+
+    def all_reduce(self, t):
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.sync_group)
 
     def new_amax(self):
         """One word of the amax pool (None outside the fp8 configuration)."""

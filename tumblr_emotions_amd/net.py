@@ -30,7 +30,7 @@ class SentimentNet:
                  vocab_size=10000, embedding_dim=300, post_size=32, image_size=224, dropout_keep_prob=0.8,
                  trainable_bn_beta=True, device="cuda", process_group=None, overlap_comm=True,
                  concurrent_towers=True, train_all=False, trainable_embedding=False, dtype="f32",
-                 force_dp_buckets=False):
+                 force_dp_buckets=False, sync_bn=False):
         assert mode in ("joint", "image", "text")
         self.dtype = dtype
         if not torch.cuda.is_available():
@@ -82,6 +82,13 @@ class SentimentNet:
         for e in (self.image, self.text, self.head):
             if e is not None:
                 e.reducer = self.reducer
+        # sync_bn: BatchNorm over the global batch (off by default: slim's clones -- and the DP parity tests -- keep the
+        # statistics per rank, model_deploy.py:353-355)
+        self.sync_bn = bool(sync_bn and self.world > 1 and self.image is not None)
+        if self.sync_bn:
+            if dtype != "f32":
+                raise ValueError("sync_bn is implemented for the fp32 configuration")
+            self.image.sync_bn, self.image.sync_world, self.image.sync_group = True, self.world, process_group
         self.logits = None
         self._graph = None           # captured training step (capture_step)
         self._graph_key = None
