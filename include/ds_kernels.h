@@ -95,6 +95,8 @@ typedef struct ds_conv_desc {
     const float *mask_rstd;   /* DS_EPI_BNSUMS: `mask` holds z of the consumer layer(s) instead of y; y is rebuilt as */
     const float *mask_shift;  /* relu(mask*mask_rstd[n] + mask_shift[n]) per output column n (Cout floats each)        */
     const struct ds_bn_bwd_on_load *bnb;   /* HOST pointer, nullable: BatchNorm + ReLU backward applied ON LOAD (below)  */
+    int32_t mask_dtype;       /* DS_EPI_BNSUMS in ds_conv_bf16 / ds_conv_fp8: storage type of `mask` (DS_DTYPE_F32 or, under     */
+                              /* 16-bit activation storage, DS_DTYPE_BF16: ldmask then counts bf16 elements)                    */
 } ds_conv_desc;
 
 /* Conv2DBackpropInput of a 1x1 conv + BatchNorm + ReLU layer WITHOUT the separate ds_bn_bwd_apply pass (wide 1x1 kernel
@@ -148,14 +150,16 @@ int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float *w, float *
  * convs (forward and Conv2DBackpropInput), fp32 accumulation and storage.  wb = the filter converted once per
  * weight update by ds_weights_to_bf16 into the kernel's own order ([channel chunk x tap][column][16 k] bf16, zero
  * padded; ds_weights_bf16_bytes gives its size; dgrad = 1: flipped taps, channel roles swapped -- the conv then
- * runs over dz with Cin = Cout_w, Cout = Cin_w).  `d` as for ds_conv_igemm (geometry, ldx, ldz, flags 0 or
- * DS_EPI_STATS; the weight strides are ignored); partials float[2][Cout][ds_conv_bf16_partials(d)].          */
+ * runs over dz with Cin = Cout_w, Cout = Cin_w).  `d` as for ds_conv_igemm (geometry, ldx, ldz; the weight strides are
+ * ignored); flags DS_EPI_STATS (forward), or -- a dgrad -- DS_EPI_ACCUM and DS_EPI_BNSUMS exactly as ds_conv_igemm's wide
+ * kernel, with `mask` = the consumer layer's activation in fp32 or bf16 storage (d.mask_dtype, ldmask);
+ * partials float[2][Cout][ds_conv_bf16_partials(d)].                                                          */
 size_t ds_weights_bf16_bytes(int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad);
 int ds_weights_to_bf16(const float *w, void *wb, int32_t Cin, int32_t Cout, int32_t taps, int32_t dgrad, void *stream);
 int ds_conv_bf16_supported(const ds_conv_desc *d);
 int ds_conv_bf16_partials(const ds_conv_desc *d);
-int ds_conv_bf16(const ds_conv_desc *d, const void *x, const void *wb, float *z, float *stats, const float *pivot,
-                 void *stream);
+int ds_conv_bf16(const ds_conv_desc *d, const void *x, const void *wb, float *z, const void *mask, float *stats,
+                 const float *pivot, void *stream);
 
 /* fp32 PRODUCTS on the bf16 matrix cores ("bf16x3").  Every fp32 operand is split into three bf16 pieces (8 + 8 + 8
  * mantissa bits) and a*b is accumulated in fp32 from the six piece products whose magnitude exceeds 2^-24 |ab| -- six
@@ -182,7 +186,7 @@ int ds_conv_f32x3(const ds_conv_desc *d, const float *x, const void *wb, float *
  *   activations  a_format DS_FP8_E4M3 (forward x) or DS_FP8_E5M2 (FMAX 57344: dgrad's dz); the scale is derived in the
  *                kernel from the device record x_amax (max |x|: ds_absmax, or a producer that tracks it): nothing
  *                crosses to the host.  Values are scaled, saturated to +-FMAX and rounded to nearest even.
- * z = acc / (s_a s_w); `d` as for ds_conv_bf16 (flags 0 or DS_EPI_STATS, partials float[2][Cout][ds_conv_fp8_partials]).
+ * z = acc / (s_a s_w); `d`, flags and `mask` as for ds_conv_bf16 (partials float[2][Cout][ds_conv_fp8_partials]).
  * Not the fp32 parity path: separately labelled, tolerance documented in tests/test_kernels_gpu.py / DESIGN.md.     */
 #define DS_FP8_E4M3 0
 #define DS_FP8_E5M2 1
@@ -198,7 +202,7 @@ int ds_weights_to_fp8(const float *w, void *wq, float *wscale, int32_t Cin, int3
 int ds_conv_fp8_supported(const ds_conv_desc *d);
 int ds_conv_fp8_partials(const ds_conv_desc *d);
 int ds_conv_fp8(const ds_conv_desc *d, const void *x, const float *x_amax, int32_t a_format, const void *wq,
-                const float *wscale, float *z, float *stats, const float *pivot, void *stream);
+                const float *wscale, float *z, const void *mask, float *stats, const float *pivot, void *stream);
 
 /* Conv2d_1a_7x7 (inception_v1.py:63): 7x7 stride-2 SAME conv 3 -> 64 read from the PACKED RGB images
  * x [N, H, W, 3] (no 4-channel copy), w = HWIO [7][7][cin_store][64] (cin_store 3 or 4: the store keeps the stem
@@ -269,7 +273,7 @@ int ds_conv_wino4(const float *x, const float *u, float *z, float *stats, const 
 #define DS_CONV_DGRAD 1
 #define DS_ARITH_F32 0       /* exact fp32 MFMA, incl. fp32 Winograd: the 1e-3 parity path                              */
 #define DS_ARITH_BF16 1      /* bf16 multiplies, fp32 accumulation / storage of z                                       */
-#define DS_ARITH_FP8 2       /* e4m3 / e5m2 multiplies with per-tensor power-of-two scales; bf16 where fp8 does not apply */
+#define DS_ARITH_FP8 2       /* e4m3 / e5m2 multiplies with per-tensor power-of-two scales where they beat bf16, bf16 elsewhere */
 #define DS_ARITH_F32X3 3     /* fp32 arithmetic, the forward 1x1 convs with fp32 products from three bf16 pieces         */
 #define DS_FAM_IGEMM 0
 #define DS_FAM_WINO2 1
@@ -283,6 +287,7 @@ int ds_conv_wino4(const float *x, const float *u, float *z, float *stats, const 
 #define DS_PLAN_NO_STEM_DIRECT 4u   /* A/B: the stem through the generic kernel on a 4-channel copy of the batch        */
 #define DS_PLAN_NO_BF16_DIRECT 8u   /* A/B: the LDS-staged bf16 kernel everywhere                                       */
 #define DS_PLAN_ACT16 16u           /* the net keeps activations in 16-bit storage (only the register-direct kernels read it) */
+#define DS_PLAN_FP8_EVERYWHERE 64u  /* A/B: ds_conv_fp8 wherever it applies (default: only where it beats the bf16 kernels) */
 #define DS_PLAN_PACKED_RGB 32u      /* Conv2d_1a_7x7: x is the packed [N, H, W, 3] batch, filter stored [7][7][4][Cout]   */
 typedef struct ds_conv_layer_plan {
     ds_conv_desc d;          /* descriptor of the chosen launch (dgrad: channel roles swapped, flipped taps)            */

@@ -116,6 +116,41 @@ def conv2d_same_fp8_multiply(x, w_hwio, stride):
     return _ConvFp8Multiply.apply(_same_pad_nchw(x, k, stride, 0.0), w_hwio.permute(3, 2, 0, 1), stride)
 
 
+class _ConvMixedMultiply(torch.autograd.Function):
+    """The fp8 configuration as the build ships it since round 4: a layer's forward / input-gradient multiplies are fp8
+    only where ds_conv_plan picks ds_conv_fp8 (fp8_where_it_wins below), bf16 otherwise -- chosen per direction."""
+
+    @staticmethod
+    def forward(ctx, xp, w_oihw, stride, fwd_fp8, bwd_fp8):
+        ctx.save_for_backward(xp, w_oihw)
+        ctx.stride, ctx.bwd_fp8 = stride, bwd_fp8
+        if fwd_fp8:
+            xq, sx = fp8_quantize(xp, FP8_E4M3)
+            wq, sw = fp8_quantize(w_oihw, FP8_E4M3)
+            return F.conv2d(xq, wq, stride=stride) / (sx * sw)
+        return F.conv2d(_bf16(xp), _bf16(w_oihw), stride=stride)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, w = ctx.saved_tensors
+        if ctx.bwd_fp8:
+            wq, sw = fp8_quantize(w, FP8_E4M3)
+            dq, sd = fp8_quantize(dy, FP8_E5M2)
+            dx = torch.nn.grad.conv2d_input(xp.shape, wq, dq, stride=ctx.stride) / (sd * sw)
+        else:
+            dx = torch.nn.grad.conv2d_input(xp.shape, _bf16(w), _bf16(dy), stride=ctx.stride)
+        dw = torch.nn.grad.conv2d_weight(xp, w.shape, dy, stride=ctx.stride)
+        return dx, dw, None, None, None
+
+
+def fp8_where_it_wins(reduction, columns):
+    """The launch rule of the build's fp8 configuration (tumblr_emotions_amd/csrc/conv_plan.cpp, measured per layer in
+    profiles/r04_fp8_layers_b128.txt): ds_conv_fp8 for reductions of >= 64 channels into >= 96 columns, bf16 elsewhere.
+    Forward: (Cin, Cout) of the launch -- the horizontally fused Branch_0/1/2 1x1 convs count their SUMMED columns;
+    input gradient: (Cout, Cin)."""
+    return reduction >= 64 and columns >= 96
+
+
 def conv2d_same_bf16_multiply(x, w_hwio, stride):
     k = w_hwio.shape[0]
     return _ConvBf16Multiply.apply(_same_pad_nchw(x, k, stride, 0.0), w_hwio.permute(3, 2, 0, 1), stride)
@@ -205,11 +240,18 @@ class DeepSentimentRef:
         return True                                 # Text/rnn/*, W_fc, b_fc, W_softmax, b_softmax
 
     # -- towers -------------------------------------------------------------------------------
-    def _cbr(self, x, scope, stride=1):
-        if self.conv_multiply == "fp8" and self.p[scope + "/weights"].shape[0] in (1, 3) and stride == 1 \
-                and x.shape[1] % 8 == 0:
+    def _cbr(self, x, scope, stride=1, launch_cout=None):
+        w_ = self.p[scope + "/weights"]
+        fp8_ok = w_.shape[0] in (1, 3) and stride == 1 and x.shape[1] % 8 == 0
+        if self.conv_multiply == "fp8" and fp8_ok:
             # the layers ds_conv_fp8 takes (1x1 / 3x3, stride 1, Cin % 8 == 0); the rest -- the stem -- multiplies in bf16
             z = conv2d_same_fp8_multiply(x, self.p[scope + "/weights"], stride)
+        elif self.conv_multiply == "fp8_auto":
+            # fp8 only where the build's launch rule picks it (launch_cout: the fused 1x1 launch's summed columns)
+            cin, cout = w_.shape[2], (launch_cout or w_.shape[3])
+            k = w_.shape[0]
+            z = _ConvMixedMultiply.apply(_same_pad_nchw(x, k, stride, 0.0), w_.permute(3, 2, 0, 1), stride,
+                                         fp8_ok and fp8_where_it_wins(cin, cout), fp8_ok and cout % 8 == 0 and fp8_where_it_wins(cout, cin))
         elif self.conv_multiply in ("bf16", "fp8"):
             z = conv2d_same_bf16_multiply(x, self.p[scope + "/weights"], stride)
         else:
@@ -257,9 +299,11 @@ class DeepSentimentRef:
             else:
                 pre = "InceptionV1/%s/" % name
                 nm = [n for (n, _, _, _) in S.mixed_conv_names(name)]
-                b0 = self._cbr(net, pre + nm[0])
-                b1 = self._cbr(self._cbr(net, pre + nm[1]), pre + nm[2])
-                b2 = self._cbr(self._cbr(net, pre + nm[3]), pre + nm[4])
+                # (the build runs Branch_0/1/2's 1x1 convs as ONE launch: its column count decides the fp8 rule)
+                nf = sum(self.p[pre + nm[i] + "/weights"].shape[3] for i in (0, 1, 3))
+                b0 = self._cbr(net, pre + nm[0], launch_cout=nf)
+                b1 = self._cbr(self._cbr(net, pre + nm[1], launch_cout=nf), pre + nm[2])
+                b2 = self._cbr(self._cbr(net, pre + nm[3], launch_cout=nf), pre + nm[4])
                 b3 = self._cbr(self._pool(net, 3, 1, name + "/Branch_3"), pre + nm[5])
                 net = torch.cat([b0, b1, b2, b3], dim=1)
         self.last_mixed_5c = net

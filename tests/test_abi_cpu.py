@@ -154,7 +154,9 @@ def test_conv_plan_picks_the_kernel_family_without_a_device(lib):
     rc, p = plan(L.DS_CONV_DGRAD, L.DS_ARITH_F32, 0, B, 28, 28, 96, 128, 3, 1, 0, ldx=128, ldz=96)
     assert p.family in (L.DS_FAM_WINO2, L.DS_FAM_WINO4) and l.ds_conv_plan_enable_bnsums(C.byref(p), 96) > 0
     rc, p = plan(L.DS_CONV_DGRAD, L.DS_ARITH_BF16, 0, B, 28, 28, 192, 176, 1, 1, 0, ldx=176, ldz=192)
-    assert p.family == L.DS_FAM_BF16D and l.ds_conv_plan_enable_bnsums(C.byref(p), 192) == 0 and p.w_bytes > 0
+    assert p.family == L.DS_FAM_BF16D and l.ds_conv_plan_enable_bnsums(C.byref(p), 192) > 0 and p.w_bytes > 0
+    rc, p = plan(L.DS_CONV_DGRAD, L.DS_ARITH_BF16, 0, B, 28, 28, 96, 128, 3, 1, 0, ldx=128, ldz=96)      # LDS-staged bf16 kernel
+    assert p.family == L.DS_FAM_IGEMM and l.ds_conv_plan_enable_bnsums(C.byref(p), 96) == 0
     # stem: the packed-RGB kernel, or the generic kernel with KW folded into the channel axis
     rc, p = plan(L.DS_CONV_FWD, L.DS_ARITH_F32, L.DS_PLAN_PACKED_RGB, B, 224, 224, 4, 64, 7, 2, L.DS_EPI_STATS)
     assert rc == 0 and p.family == L.DS_FAM_STEM and (p.d.OH, p.d.pad_t) == (112, 2) and p.partials > 0
@@ -174,6 +176,10 @@ def test_conv_plan_picks_the_kernel_family_without_a_device(lib):
     assert p.family == L.DS_FAM_FP8D and p.a_format == L.DS_FP8_E4M3 and p.wscale_floats == 4 + 512 and p.partials > 0
     rc, p = plan(L.DS_CONV_DGRAD, L.DS_ARITH_FP8, 0, B, 14, 14, 96, 208, 3, 1, ldx=208, ldz=96)
     assert p.family == L.DS_FAM_FP8D and p.a_format == L.DS_FP8_E5M2
+    # ... only where fp8 beats the bf16 kernels (narrow reductions / few columns take the bf16 rules), unless forced
+    assert plan(L.DS_CONV_FWD, L.DS_ARITH_FP8, L.DS_PLAN_ACT16, B, 14, 14, 16, 48, 3, 1)[1].family == L.DS_FAM_BF16D
+    assert plan(L.DS_CONV_FWD, L.DS_ARITH_FP8, L.DS_PLAN_FP8_EVERYWHERE, B, 14, 14, 16, 48, 3, 1)[1].family == L.DS_FAM_FP8D
+    assert plan(L.DS_CONV_DGRAD, L.DS_ARITH_FP8, 0, B, 56, 56, 64, 192, 3, 1, ldx=192, ldz=64)[1].family == L.DS_FAM_IGEMM
     # zcat probe: BatchNorm + ReLU on load is the wide 1x1 kernel's (and the f32x3 kernel's)
     rc, p = plan(L.DS_CONV_FWD, L.DS_ARITH_F32, 0, B, 28, 28, 256, 288, 1, 1, L.DS_EPI_STATS)
     assert l.ds_conv_plan_norm_supported(C.byref(p)) == 1

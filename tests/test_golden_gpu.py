@@ -135,3 +135,60 @@ def test_full_size_step_matches_committed_golden_vector(which):
         assert rel <= gate, "gradient of %s: relative L2 %.3e above %.3e" % (n, rel, gate)
     print("%s B=%d: max|dlogits| %.2e, |dloss| %.2e; %s" % (which, cfg["B"], dl, dloss,
           "; ".join("%s %.1e/%.1e" % (n.split("/")[-3] if n.count("/") > 2 else n, r, gt) for r, gt, n in report)))
+
+
+def test_joint_fp8_config5_share_vs_emulating_oracle():
+    """BASELINE configs[4] ("fp16 joint with fp8 (CDNA4) MFMA conv path, batch 1024, 8 GPUs") as ONE rank sees it: the
+    joint step at B = 128 and the real dims in the fp8 configuration AS IT SHIPS -- ds_conv_fp8 (e4m3 x e4m3 forward,
+    e5m2 x e4m3 input gradient, per-tensor power-of-two scales) on the layers where it beats the bf16 kernels, bf16
+    multiplies on the others, 16-bit (bf16) activation storage, fp32 accumulation / BatchNorm / weight gradients / text
+    tower -- against the committed fp64 oracle vector that EMULATES those multiplies (tests/golden/make_golden_fp8.py,
+    DeepSentimentRef.conv_multiply = "fp8_auto").  Not the 1e-3 parity path.  TOLERANCE of this configuration, stated
+    here: logits within 0.6 and total loss within 0.1 of the emulating oracle (measured on MI355X: printed below; e4m3
+    carries 3 mantissa bits and this randomly initialised 57-layer BatchNorm stack amplifies a forward perturbation
+    ~100x -- the oracle with EXACT multiplies sits 0.41 from the emulating one itself, recorded in the fixture); the
+    gradient of b_softmax within 0.05 relative L2, the other head / LSTM / Logits gradients reported (0.2-0.6)."""
+    import sys
+    GOLD = os.path.join(os.path.dirname(__file__), "golden")
+    sys.path.insert(0, GOLD)
+    from make_golden_fullsize import build
+    from make_golden_fp8 import CFG
+    from tumblr_emotions_amd import ops
+    from tumblr_emotions_amd.net import SentimentNet
+    G = np.load(os.path.join(GOLD, CFG["file"]))
+    params, emb, batch, mask = build(CFG, np.float32)
+    net = SentimentNet(mode="joint", nb_emotions=15, im_features_size=256, rnn_size=CFG["H"], fc_size=512,
+                       vocab_size=CFG["V"], embedding_dim=CFG["D"], post_size=CFG["T"], dtype="fp8")
+    assert net.image.act16 and not net.image.fp8_everywhere
+    net.load_state_dict(dict(params, **{"Text/W_embedding": emb}))
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in batch.items()}
+    net.train_step(dev, CFG["lr"], dropout_mask=torch.tensor(mask, dtype=torch.float32).cuda())
+    torch.cuda.synchronize()
+    n_fp8 = sum(l.fwd.family == ops.DS_FAM_FP8D for l in net.image.layers)
+    n_b16 = sum(l.fwd.family == ops.DS_FAM_BF16D for l in net.image.layers)
+    assert 15 <= n_fp8 <= 30 and n_b16 >= 8, (n_fp8, n_b16)          # fp8 where it wins, bf16 on the narrow layers
+    logits = net.logits.detach().cpu().numpy()
+    assert np.isfinite(logits).all()
+    d_emul = float(np.abs(logits - G["logits/fp8_auto"]).max())
+    d_exact = float(np.abs(logits - G["logits/f32"]).max())
+    oracle_gap = float(np.abs(G["logits/fp8_auto"] - G["logits/f32"]).max())
+    dloss = abs(net.total_loss_value() - float(G["loss/fp8_auto"]))
+    grads = net.grads_state_dict()
+    rels = []
+    for key in G.files:
+        if key.startswith("grad/") and not key.endswith("/BatchNorm/beta"):     # (below the tower's ReLUs fp8 noise is O(1): not gated)
+            name = key[5:]
+            g = grads[name].reshape(-1)
+            g = g[::CFG["stride"]] if g.size > CFG["big"] else g
+            ref = G[key].reshape(-1)
+            rels.append((float(np.linalg.norm(g - ref) / max(np.linalg.norm(ref), 1e-30)), name))
+    rels.sort()
+    print("fp8 configuration at B = 128 (%d fp8 / %d bf16 forward layers): max|dlogits| %.3f vs the emulating oracle, %.3f vs "
+          "the exact one (the two oracles: %.3f apart); |dloss| %.4f; gradient relative L2 median %.3f, worst %.3f (%s)"
+          % (n_fp8, n_b16, d_emul, d_exact, oracle_gap, dloss, rels[len(rels) // 2][0], rels[-1][0], rels[-1][1]))
+    assert d_emul <= 0.6 and dloss <= 0.1
+    # gradients: b_softmax follows the logits alone (mean softmax - one-hot): tight; the others multiply features that
+    # already carry the forward fp8 noise, so a PLAIN comparison (no decision injection is possible against a committed
+    # vector) shows 0.2-0.6 -- reported, bounded for sanity
+    by = {n: r for r, n in rels}
+    assert by["b_softmax"] <= 0.05 and rels[-1][0] <= 0.9

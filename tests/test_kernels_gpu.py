@@ -825,6 +825,15 @@ def test_fp8_conv_forward_and_dgrad_match_quantising_oracle(case):
         g.run(ops._p(dyd), ops._p(wqd), ops._p(dx), x_amax=ops._p(amax), wscale=ops._p(wsd))
         torch.cuda.synchronize()
         close(dx, dref.reshape(M, Ci), 1e-4)
+
+        def run(flags, ldmask, mask_dtype, out, mask):
+            g2 = ops.Fp8Plan(N, H, W, Co, Co, k, 1, Ci, Ci, flags=flags, a_format=ops.DS_FP8_E5M2)
+            g2.d.ldmask, g2.d.mask_dtype = ldmask, mask_dtype
+            P = (M + 127) // 128
+            sums = torch.full((2, Ci, P), float("nan"), device="cuda")
+            g2.run(ops._p(dyd), ops._p(wqd), ops._p(out), stats=ops._p(sums), x_amax=ops._p(amax), wscale=ops._p(wsd), mask=ops._p(mask))
+            return sums, P
+        _check_accum_bnsums_epilogue(run, dref.reshape(M, Ci), M, Ci, rng, 1e-4)
         e_bwd = np.linalg.norm(dx.cpu().numpy().reshape(dexact.shape) - dexact) / np.linalg.norm(dexact)
         print("fp8 conv %s: relative L2 against the unquantised convolution: forward %.3f, dgrad %.3f" % (case, e_fwd, e_bwd))
         assert e_fwd <= 0.08 and e_bwd <= 0.15
@@ -887,6 +896,28 @@ def test_conv_bf16_forward_dgrad_match_oracle(case):
         close(dx, S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1).reshape(-1, Ci), 1e-2)
 
 
+def _check_accum_bnsums_epilogue(run, dx_ref, M, C_, rng, tol):
+    """The dgrad epilogue of the register-direct bf16 / fp8 kernels (the wide fp32 kernel's): dx += result next to
+    DS_EPI_BNSUMS -- column sums of g = dx_final (y > 0) and g y -- with y in fp32 and in bf16 storage.
+    run(flags, ldmask, mask_dtype, dx, mask, sums) launches; dx_ref is the plain dgrad result (fp64)."""
+    ops = _ops()
+    prev = rng.normal(size=(M, C_)) * np.abs(dx_ref).max()
+    yv = np.maximum(rng.normal(size=(M, C_)), 0.0) * (rng.uniform(size=(M, C_)) < 0.7)
+    full = prev + dx_ref
+    for dt in (ops.DS_DTYPE_F32, ops.DS_DTYPE_BF16):
+        ld = C_ + 8
+        ypad = np.pad(yv, ((0, 0), (0, 8)), constant_values=3.0)
+        yd = dev(ypad) if dt == ops.DS_DTYPE_F32 else dev(ypad, torch.bfloat16)
+        y_seen = yd.float().cpu().numpy().astype(np.float64)[:, :C_]          # (bf16 storage rounds y)
+        dx = dev(prev)
+        sums, P = run(ops.DS_EPI_ACCUM | ops.DS_EPI_BNSUMS, ld, dt, dx, yd)
+        torch.cuda.synchronize()
+        close(dx, full, tol)
+        gm = dx.cpu().numpy().astype(np.float64) * (y_seen > 0)               # sums of what the kernel stored
+        close(sums[0].sum(1), gm.sum(0), 2e-3)
+        close(sums[1].sum(1), (gm * y_seen).sum(0), 2e-3)
+
+
 BF16D_CASES = [
     # (N, H, W, Cin, Cout, k, stride)
     (2, 9, 9, 16, 32, 1, 1),
@@ -945,8 +976,18 @@ def test_conv_bf16_register_direct_forward_dgrad_match_oracle(case):
         dyd = dev(dy)
         g.run(ops._p(dyd), ops._p(wbt), ops._p(dx))
         torch.cuda.synchronize()
-        close(dx, S.conv2d_same_bwd_input(_bf16_round(dy), _bf16_round(w), (N, H, W, Ci), 1).reshape(-1, Ci), 2e-4)
+        dref = S.conv2d_same_bwd_input(_bf16_round(dy), _bf16_round(w), (N, H, W, Ci), 1).reshape(-1, Ci)
+        close(dx, dref, 2e-4)
         close(dx, S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1).reshape(-1, Ci), 1e-2)
+
+        def run(flags, ldmask, mask_dtype, out, mask):
+            g2 = ops.Bf16Plan(N, H, W, Co, Co, k, 1, Ci, Ci, flags=flags)
+            g2.d.ldmask, g2.d.mask_dtype = ldmask, mask_dtype
+            P = (g2.M + 127) // 128
+            sums = torch.full((2, Ci, P), float("nan"), device="cuda")
+            g2.run(ops._p(dyd), ops._p(wbt), ops._p(out), stats=ops._p(sums), mask=ops._p(mask))
+            return sums, P
+        _check_accum_bnsums_epilogue(run, dref, g.M, Ci, rng, 2e-4)
 
 
 def test_conv_bf16_folded_stem_and_epilogues():

@@ -16,6 +16,7 @@ DS_CONV_FWD, DS_CONV_DGRAD = 0, 1
 DS_ARITH_F32, DS_ARITH_BF16, DS_ARITH_FP8, DS_ARITH_F32X3 = 0, 1, 2, 3
 DS_FAM_IGEMM, DS_FAM_WINO2, DS_FAM_WINO4, DS_FAM_STEM, DS_FAM_BF16D, DS_FAM_FP8D, DS_FAM_F32X3 = range(7)
 DS_PLAN_NO_WINO, DS_PLAN_NO_WINO4, DS_PLAN_NO_STEM_DIRECT, DS_PLAN_NO_BF16_DIRECT, DS_PLAN_ACT16, DS_PLAN_PACKED_RGB = 1, 2, 4, 8, 16, 32
+DS_PLAN_FP8_EVERYWHERE = 64
 
 
 class ConvDesc(C.Structure):
@@ -29,7 +30,7 @@ class ConvDesc(C.Structure):
         ("tile_nt", C.c_int32), ("grid_x", C.c_int32), ("dtype", C.c_int32), ("x_dtype", C.c_int32),
         ("partials", C.c_int32),
         ("norm_rstd", C.c_void_p), ("norm_shift", C.c_void_p), ("mask_rstd", C.c_void_p), ("mask_shift", C.c_void_p),
-        ("bnb", C.c_void_p),
+        ("bnb", C.c_void_p), ("mask_dtype", C.c_int32),
     ]
 
 
@@ -88,7 +89,7 @@ SIGNATURES = {
     "ds_weights_to_bf16": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _P]),
     "ds_conv_bf16_supported": (C.c_int, [_CD]),
     "ds_conv_bf16_partials": (C.c_int, [_CD]),
-    "ds_conv_bf16": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P]),
+    "ds_conv_bf16": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _P]),
     "ds_weights_f32x3_bytes": (C.c_size_t, [_i32, _i32, _i32, _i32]),
     "ds_weights_to_f32x3": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _P]),
     "ds_conv_f32x3_supported": (C.c_int, [_CD]),
@@ -99,7 +100,7 @@ SIGNATURES = {
     "ds_weights_to_fp8": (C.c_int, [_P, _P, _P, _i32, _i32, _i32, _i32, _P]),
     "ds_conv_fp8_supported": (C.c_int, [_CD]),
     "ds_conv_fp8_partials": (C.c_int, [_CD]),
-    "ds_conv_fp8": (C.c_int, [_CD, _P, _P, _i32, _P, _P, _P, _P, _P, _P]),
+    "ds_conv_fp8": (C.c_int, [_CD, _P, _P, _i32, _P, _P, _P, _P, _P, _P, _P]),
     "ds_conv_stem_partials": (C.c_int, [_i32, _i32, _i32]),
     "ds_conv_stem": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "ds_wino_transform_weights": (C.c_int, [_P, _P, _i32, _i32, _i32, _P]),

@@ -34,6 +34,7 @@ struct Fp8Params {
     const float *x_amax;         // device word: max |x|
     const float *wscale;         // float[4]: amax, s_w, 1 / s_w, -
     float *z;
+    const float *mask;           // DS_EPI_BNSUMS: the consumer layer's activation (fp32 or bf16 storage, d.mask_dtype)
     float *stats;
     const float *pivot;
     int M, row_tiles, col_tiles, ncols;
@@ -206,18 +207,48 @@ __global__ __launch_bounds__(256, 2) void conv_fp8d_kernel(const Fp8Params p) {
         const bool colok = item && col < d.Cout;
         const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
         float s = 0.f, q = 0.f;
+        float zv[16];                                    // DS_EPI_ACCUM: previous values requested up front (gemm_wide_kernel)
 #pragma unroll
         for (int r2 = 0; r2 < 16; ++r2) {
             const int row = mrow0 + (r2 & 3) + 8 * (r2 >> 2) + 4 * kh;
-            if (row < p.M && colok) {
-                const float v = acc[b][r2] * inv;
-                p.z[(int64_t)row * d.ldz + col] = v;
-                const float u = v - pv;
-                s += u;
-                q += u * u;
+            zv[r2] = ((flags & DS_EPI_ACCUM) && row < p.M && colok) ? p.z[(int64_t)row * d.ldz + col] : 0.f;
+        }
+        if (flags & DS_EPI_BNSUMS) {
+            // (as gemm_wide_kernel) dgrad whose result dy feeds a BatchNorm + ReLU backward: column sums of g = dy (y > 0)
+            // and g * y next to the stores; y = the consumer layer's activation in fp32 or bf16 storage
+            float yv[16];
+            const bool m16 = d.mask_dtype == DS_DTYPE_BF16;      // (uniform)
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) {
+                const int row = mrow0 + (r2 & 3) + 8 * (r2 >> 2) + 4 * kh;
+                const int64_t at = (int64_t)row * d.ldmask + col;
+                yv[r2] = !(row < p.M && colok) ? 0.f : m16 ? (float)reinterpret_cast<const __bf16 *>(p.mask)[at] : p.mask[at];
+            }
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) {
+                const int row = mrow0 + (r2 & 3) + 8 * (r2 >> 2) + 4 * kh;
+                if (row < p.M && colok) {
+                    const float v = acc[b][r2] * inv + zv[r2];
+                    p.z[(int64_t)row * d.ldz + col] = v;
+                    const float u = yv[r2] > 0.f ? v : 0.f;
+                    s += u;
+                    q += u * yv[r2];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) {
+                const int row = mrow0 + (r2 & 3) + 8 * (r2 >> 2) + 4 * kh;
+                if (row < p.M && colok) {
+                    const float v = acc[b][r2] * inv + zv[r2];
+                    p.z[(int64_t)row * d.ldz + col] = v;
+                    const float u = v - pv;
+                    s += u;
+                    q += u * u;
+                }
             }
         }
-        if (flags & DS_EPI_STATS) {
+        if (flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) {
             s += __shfl_xor(s, 32);
             q += __shfl_xor(q, 32);
             __syncthreads();
@@ -315,7 +346,8 @@ int fp8_nb(int Cout) {
 
 bool fp8_ok(const ds_conv_desc *d) {
     return (d->KH == d->KW) && (d->KH == 1 || d->KH == 3) && d->fold_cin == 0 && d->Cin % 8 == 0 && d->ldx % 4 == 0 &&
-           !(d->flags & ~DS_EPI_STATS) && d->splits <= 1;
+           !(d->flags & ~(DS_EPI_STATS | DS_EPI_ACCUM | DS_EPI_BNSUMS)) &&
+           !((d->flags & DS_EPI_BNSUMS) && (d->flags & DS_EPI_STATS)) && d->splits <= 1;
 }
 
 int64_t fp8_M(const ds_conv_desc *d) { return (int64_t)d->N * d->OH * d->OW; }
@@ -372,17 +404,23 @@ extern "C" int ds_conv_fp8_supported(const ds_conv_desc *d) { return d && fp8_ok
 extern "C" int ds_conv_fp8_partials(const ds_conv_desc *d) { return (int)((fp8_M(d) + 127) / 128); }
 
 extern "C" int ds_conv_fp8(const ds_conv_desc *d, const void *x, const float *x_amax, int32_t a_format, const void *wq,
-                           const float *wscale, float *z, float *stats, const float *pivot, void *stream) {
+                           const float *wscale, float *z, const void *mask, float *stats, const float *pivot, void *stream) {
     DS_REQUIRE(d && x && x_amax && wq && wscale && z, "ds_conv_fp8: null argument");
+    DS_REQUIRE(!(d->flags & DS_EPI_BNSUMS) || (mask && stats && d->ldmask >= d->Cout &&
+                                               (d->mask_dtype == DS_DTYPE_F32 || d->mask_dtype == DS_DTYPE_BF16)),
+               "ds_conv_fp8: DS_EPI_BNSUMS needs mask (row stride ldmask, mask_dtype) and a partials buffer");
+    DS_REQUIRE(!d->mask_rstd && !d->norm_rstd && !d->bnb, "ds_conv_fp8: the on-load transforms belong to the fp32 kernels");
     DS_REQUIRE(d->x_dtype == DS_DTYPE_F32 || (d->x_dtype == DS_DTYPE_BF16 && a_format == DS_FP8_E4M3 && d->ldx % 8 == 0),
                "ds_conv_fp8: x_dtype DS_DTYPE_BF16 is for forward activations (e4m3) with ldx %% 8 == 0");
-    DS_REQUIRE(fp8_ok(d), "ds_conv_fp8: needs a 1x1 or 3x3 conv, Cin %% 8 == 0, ldx %% 4 == 0, flags within DS_EPI_STATS");
+    DS_REQUIRE(fp8_ok(d), "ds_conv_fp8: needs a 1x1 or 3x3 conv, Cin %% 8 == 0, ldx %% 4 == 0, flags within DS_EPI_STATS, or "
+                          "DS_EPI_ACCUM | DS_EPI_BNSUMS for a dgrad");
     DS_REQUIRE(a_format == DS_FP8_E4M3 || a_format == DS_FP8_E5M2, "ds_conv_fp8: a_format must be DS_FP8_E4M3 or DS_FP8_E5M2");
     DS_REQUIRE(((((uintptr_t)x | (uintptr_t)wq) & 15) == 0) && fp8_M(d) < (1ll << 31), "ds_conv_fp8: operands must be 16-byte aligned");
     DS_REQUIRE(!(d->flags & DS_EPI_STATS) || stats, "ds_conv_fp8: DS_EPI_STATS without stats buffer");
     Fp8Params p = {};
     p.d = *d;
     p.x = (const float *)x; p.w = (const unsigned char *)wq; p.x_amax = x_amax; p.wscale = wscale; p.z = z; p.stats = stats;
+    p.mask = (const float *)mask;
     p.pivot = (d->flags & DS_EPI_STATS) ? pivot : nullptr;
     p.M = (int)fp8_M(d);
     const int taps = d->KH * d->KW;

@@ -1308,6 +1308,14 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
         const bool colok = item && col < d.Cout;
         const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
         float s = 0.f, q = 0.f;
+        // DS_EPI_ACCUM: the sixteen previous values are requested UP FRONT.  Read inside the store loop, every read waited
+        // for the store before it (one in-order memory counter): sixteen round trips per column block
+        float zv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            zv[r] = ((flags & DS_EPI_ACCUM) && row < p.M && colok) ? p.z[(int64_t)row * d.ldz + col] : 0.f;
+        }
         if (flags & DS_EPI_BNSUMS) {
             // dgrad whose result dy feeds a BatchNorm + ReLU backward: column sums of g = dy (y > 0) and g * y, y = the
             // consumer layer's forward activation (same rows / columns as dy).  The y values are requested up front so
@@ -1327,8 +1335,7 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
             for (int r = 0; r < 16; ++r) {
                 const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row < p.M && colok) {
-                    float v = acc[b][r];
-                    if (flags & DS_EPI_ACCUM) v += p.z[(int64_t)row * d.ldz + col];
+                    const float v = acc[b][r] + zv[r];
                     p.z[(int64_t)row * d.ldz + col] = v;
                     const float u = yv[r] > 0.f ? v : 0.f;
                     s += u;
@@ -1340,8 +1347,7 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
             for (int r = 0; r < 16; ++r) {
                 const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row < p.M && colok) {
-                    float v = acc[b][r];
-                    if (flags & DS_EPI_ACCUM) v += p.z[(int64_t)row * d.ldz + col];
+                    const float v = acc[b][r] + zv[r];
                     p.z[(int64_t)row * d.ldz + col] = v;
                     const float u = v - pv;
                     s += u;
@@ -1565,14 +1571,23 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
         const bool colok = item && col < d.Cout;
         const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
         float s = 0.f, q = 0.f;
-        if (X3 && (flags & DS_EPI_BNSUMS)) {
-            // (X3 only, as gemm_wide_kernel) dgrad whose result dy feeds a BatchNorm + ReLU backward: column sums of
-            // g = dy (y > 0) and g * y; `mask` holds y, or z with mask_rstd / mask_shift
+        float zv[16];                                    // DS_EPI_ACCUM: previous values requested up front (gemm_wide_kernel)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            zv[r] = ((flags & DS_EPI_ACCUM) && row < p.M && colok) ? p.z[(int64_t)row * d.ldz + col] : 0.f;
+        }
+        if (flags & DS_EPI_BNSUMS) {
+            // (as gemm_wide_kernel) dgrad whose result dy feeds a BatchNorm + ReLU backward: column sums of
+            // g = dy (y > 0) and g * y; `mask` holds y (fp32, or bf16 under 16-bit activation storage), or z with
+            // mask_rstd / mask_shift
             float yv[16];
+            const bool m16 = d.mask_dtype == DS_DTYPE_BF16;      // (uniform)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                yv[r] = (row < p.M && colok) ? p.mask[(int64_t)row * d.ldmask + col] : 0.f;
+                const int64_t at = (int64_t)row * d.ldmask + col;
+                yv[r] = !(row < p.M && colok) ? 0.f : m16 ? (float)reinterpret_cast<const __bf16 *>(p.mask)[at] : p.mask[at];
             }
             if (d.mask_rstd && colok) {
                 const float mr = d.mask_rstd[col], ms = d.mask_shift[col];
@@ -1583,8 +1598,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
             for (int r = 0; r < 16; ++r) {
                 const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row < p.M && colok) {
-                    float v = acc[b][r];
-                    if (flags & DS_EPI_ACCUM) v += p.z[(int64_t)row * d.ldz + col];
+                    const float v = acc[b][r] + zv[r];
                     p.z[(int64_t)row * d.ldz + col] = v;
                     const float u = yv[r] > 0.f ? v : 0.f;
                     s += u;
@@ -1596,8 +1610,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
             for (int r = 0; r < 16; ++r) {
                 const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row < p.M && colok) {
-                    float v = acc[b][r];
-                    if (X3 && (flags & DS_EPI_ACCUM)) v += p.z[(int64_t)row * d.ldz + col];
+                    const float v = acc[b][r] + zv[r];
                     p.z[(int64_t)row * d.ldz + col] = v;
                     const float u = v - pv;
                     s += u;
@@ -1605,7 +1618,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
                 }
             }
         }
-        if (flags & (DS_EPI_STATS | (X3 ? DS_EPI_BNSUMS : 0))) {
+        if (flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) {
             s += __shfl_xor(s, 32);
             q += __shfl_xor(q, 32);
             __syncthreads();
@@ -2131,7 +2144,8 @@ int bf16d_nb(int Cout) {
 }
 bool bf16d_ok(const ds_conv_desc *d) {
     return (d->KH == d->KW) && (d->KH == 1 || d->KH == 3) && d->fold_cin == 0 && d->Cin % 8 == 0 && d->ldx % 4 == 0 &&
-           !(d->flags & ~DS_EPI_STATS) && d->splits <= 1;
+           !(d->flags & ~(DS_EPI_STATS | DS_EPI_ACCUM | DS_EPI_BNSUMS)) &&
+           !((d->flags & DS_EPI_BNSUMS) && (d->flags & DS_EPI_STATS)) && d->splits <= 1;
 }
 }  // namespace
 
@@ -2153,18 +2167,23 @@ extern "C" int ds_conv_bf16_supported(const ds_conv_desc *d) { return d && bf16d
 
 extern "C" int ds_conv_bf16_partials(const ds_conv_desc *d) { return (int)((conv_M(d) + 127) / 128); }
 
-extern "C" int ds_conv_bf16(const ds_conv_desc *d, const void *x, const void *wb, float *z, float *stats,
+extern "C" int ds_conv_bf16(const ds_conv_desc *d, const void *x, const void *wb, float *z, const void *mask, float *stats,
                             const float *pivot, void *stream) {
     DS_REQUIRE(d && x && wb && z, "ds_conv_bf16: null argument");
+    DS_REQUIRE(!(d->flags & DS_EPI_BNSUMS) || (mask && stats && d->ldmask >= d->Cout &&
+                                               (d->mask_dtype == DS_DTYPE_F32 || d->mask_dtype == DS_DTYPE_BF16)),
+               "ds_conv_bf16: DS_EPI_BNSUMS needs mask (row stride ldmask, mask_dtype) and a partials buffer");
+    DS_REQUIRE(!d->mask_rstd && !d->norm_rstd && !d->bnb, "ds_conv_bf16: the on-load transforms belong to the fp32 kernels");
     DS_REQUIRE(d->x_dtype == DS_DTYPE_F32 || (d->x_dtype == DS_DTYPE_BF16 && d->ldx % 8 == 0),
                "ds_conv_bf16: x_dtype must be DS_DTYPE_F32 or DS_DTYPE_BF16 (then ldx %% 8 == 0)");
     const bool xb = d->x_dtype == DS_DTYPE_BF16;
-    DS_REQUIRE(bf16d_ok(d), "ds_conv_bf16: needs a 1x1 or 3x3 conv, Cin %% 8 == 0, ldx %% 4 == 0, flags within DS_EPI_STATS");
+    DS_REQUIRE(bf16d_ok(d), "ds_conv_bf16: needs a 1x1 or 3x3 conv, Cin %% 8 == 0, ldx %% 4 == 0, flags within DS_EPI_STATS, or "
+                            "DS_EPI_ACCUM | DS_EPI_BNSUMS for a dgrad");
     DS_REQUIRE(((((uintptr_t)x | (uintptr_t)wb) & 15) == 0) && conv_M(d) < (1ll << 31), "ds_conv_bf16: operands must be 16-byte aligned");
     DS_REQUIRE(!(d->flags & DS_EPI_STATS) || stats, "ds_conv_bf16: DS_EPI_STATS without stats buffer");
     ConvParams p = {};
     p.d = *d;
-    p.x = (const float *)x; p.w = (const float *)wb; p.z = z; p.stats = stats;
+    p.x = (const float *)x; p.w = (const float *)wb; p.z = z; p.stats = stats; p.mask = (const float *)mask;
     p.pivot = (d->flags & DS_EPI_STATS) ? pivot : nullptr;
     p.M = (int)conv_M(d);
     p.taps = d->KH * d->KW;

@@ -117,9 +117,14 @@ extern "C" int ds_conv_plan(ds_conv_layer_plan *out, int32_t role, int32_t arith
         else if (arith == DS_ARITH_F32X3 && !dgrad && k == 1 && stride == 1 && cin % 8 == 0 && cin <= 1024)
             fam = DS_FAM_F32X3;      // fp32 products from three bf16 pieces: the forward 1x1 convs (opt-in, own label)
     } else if (k == 1 || k == 3) {
-        if (arith == DS_ARITH_FP8) {
-            // ds_conv_fp8 wherever it applies; what it does not take falls back to the LDS-staged bf16 kernel
-            if (stride == 1 && cin % 8 == 0) fam = DS_FAM_FP8D;
+        // ds_conv_fp8 on the layers where it beats the bf16 kernels (profiles/r04_fp8_layers_b128.txt, every conv shape of
+        // the tower at cfg5's per-GPU batch): reductions of at least 64 channels into at least 96 columns -- 1.3-1.5x on
+        // the 14x14 3x3 layers, 1.0-1.09x on the wide 1x1 layers; it is 3x SLOWER on the 16 / 24 / 32-channel 3x3 layers
+        // and 5-30 % slower into 64 columns (Conv2d_2c's dgrad: 375 against 283 us).  The rest takes the bf16 rules.
+        const bool fp8 = arith == DS_ARITH_FP8 && stride == 1 && cin % 8 == 0 &&
+                         ((options & DS_PLAN_FP8_EVERYWHERE) || (cin >= 64 && cout >= 96));
+        if (fp8) {
+            fam = DS_FAM_FP8D;
         } else if (!(options & DS_PLAN_NO_BF16_DIRECT)) {
             // register-direct bf16 where it beats the staged kernel (profiles/r02_bf16_layers.txt): forward from 48 output
             // columns up (always under 16-bit activation storage, which only it reads), dgrad for the 1x1 layers and
@@ -170,8 +175,11 @@ extern "C" int ds_conv_plan_enable_bnsums(ds_conv_layer_plan *p, int32_t ldy) {
         if (!ds_conv_igemm_bnsums_supported(&t)) return 0;
         p->d.flags |= DS_EPI_BNSUMS;
         p->d.ldmask = ldy;
+    } else if (p->family == DS_FAM_BF16D || p->family == DS_FAM_FP8D) {
+        p->d.flags |= DS_EPI_BNSUMS;          // register-direct bf16 / fp8 dgrads carry the wide kernel's epilogue
+        p->d.ldmask = ldy;
     } else {
-        return 0;      // implicit-GEMM fallbacks of other shapes, bf16 / fp8 dgrads: the separate reduce pass stays
+        return 0;      // implicit-GEMM fallbacks of other shapes (LDS-staged kernels): the separate reduce pass stays
     }
     p->d.partials = 0;
     p->partials = plan_partials(p);
@@ -233,10 +241,10 @@ extern "C" int ds_conv_run(const ds_conv_layer_plan *p, const void *x, const voi
     case DS_FAM_STEM:
         return ds_conv_stem((const float *)x, (const float *)w, z, (d.flags & DS_EPI_STATS) ? io->stats : nullptr,
                             io->pivot, d.N, d.H, d.W, p->w_cin, d.Cout, d.ldz, stream);
-    case DS_FAM_BF16D: return ds_conv_bf16(&d, x, w, z, io->stats, io->pivot, stream);
+    case DS_FAM_BF16D: return ds_conv_bf16(&d, x, w, z, io->mask, io->stats, io->pivot, stream);
     case DS_FAM_F32X3: return ds_conv_f32x3(&d, (const float *)x, w, z, io->mask, io->stats, io->pivot, stream);
     case DS_FAM_FP8D:
-        return ds_conv_fp8(&d, x, io->x_amax, p->a_format, w, io->wscale, z, io->stats, io->pivot, stream);
+        return ds_conv_fp8(&d, x, io->x_amax, p->a_format, w, io->wscale, z, io->mask, io->stats, io->pivot, stream);
     default: break;
     }
     PLAN_REQUIRE(false, "ds_conv_run: family %d", p->family);

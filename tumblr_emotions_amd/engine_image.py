@@ -169,6 +169,7 @@ class ConvBN:
         P = self.dgrad.enable_bnsums(self.dgrad.d.ldz)
         if not P:
             return None
+        self.dgrad.d.mask_dtype = ops.act_dtype(y)          # (bf16 under 16-bit activation storage)
         self.dx_sums = torch.empty(2 * self.cin * P, device=eng.device)
         self.dx_y = y
         return self.dx_sums, P
@@ -614,7 +615,9 @@ class MixedStage(Stage):
         #  * the fused 1x1 dgrad writes (last, accumulating onto the pool path: pool_first) the gradient of the block
         #    input = the previous block's concat output, i.e. one part of each of ITS four layers.
         p = self.prev
-        self.pool_first = bool(eng.pool_first and self.fused.dgrad.family == ops.DS_FAM_IGEMM)      # (kernels with an accumulate epilogue)
+        # (the register-direct bf16 / fp8 dgrads have the accumulate epilogue too, but at their two workgroups per CU its
+        # dependent read-add-store chain costs more than the pass it saves: bf16 step 12.5 -> 14.0 ms, profiles/r04_notes.md)
+        self.pool_first = bool(eng.pool_first and self.fused.dgrad.family == ops.DS_FAM_IGEMM)
         if isinstance(p, MixedStage) and self.pool_first:
             src = self.fused.emit_dx_sums(p.out)
             if src is not None and getattr(p, "zcat", False):      # the epilogue rebuilds y from the concat's z
@@ -806,6 +809,7 @@ class InceptionV1Engine:
         self.stem_direct = True      # Conv2d_1a_7x7 from the packed RGB batch (ds_conv_stem; False: generic kernel on a 4-channel copy)
         self.branch_streams = True   # Mixed blocks: Branch_2 and Branch_3 on side streams next to Branch_0/1 (False: one stream)
         self.side = None
+        self.fp8_everywhere = os.environ.get("DS_FP8_EVERYWHERE", "0") == "1"      # A/B: ds_conv_fp8 also where the bf16 kernels are faster
         self.bf16_direct = True      # dtype bf16: ds_conv_bf16 where it wins (False: the LDS-staged bf16 kernel everywhere)
         self.winograd = True         # 3x3 layers through ds_conv_wino where it wins (False: implicit GEMM everywhere)
         self.mul3 = os.environ.get("DS_MUL3", "0") == "1"     # opt-in: forward 1x1 convs with fp32 products on the bf16 matrix cores
@@ -866,6 +870,8 @@ class InceptionV1Engine:
             o |= ops.DS_PLAN_NO_BF16_DIRECT
         if self.act16:
             o |= ops.DS_PLAN_ACT16
+        if self.fp8_everywhere:
+            o |= ops.DS_PLAN_FP8_EVERYWHERE
         return o
 
     def all_reduce(self, t):

@@ -14,7 +14,7 @@ from ._lib import (ConvDesc, Segments, SumSegments, DS_EPI_ACCUM, DS_EPI_BIAS, D
                    DS_DTYPE_BF16, DS_DTYPE_F32, DS_FP8_E4M3, DS_FP8_E5M2, DS_CONV_FWD, DS_CONV_DGRAD, DS_ARITH_F32, DS_ARITH_BF16,
                    DS_ARITH_FP8, DS_ARITH_F32X3, DS_FAM_IGEMM, DS_FAM_WINO2, DS_FAM_WINO4, DS_FAM_STEM, DS_FAM_BF16D, DS_FAM_FP8D,
                    DS_FAM_F32X3, DS_PLAN_NO_WINO, DS_PLAN_NO_WINO4, DS_PLAN_NO_STEM_DIRECT, DS_PLAN_NO_BF16_DIRECT, DS_PLAN_ACT16,
-                   DS_PLAN_PACKED_RGB)
+                   DS_PLAN_PACKED_RGB, DS_PLAN_FP8_EVERYWHERE)
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -351,11 +351,11 @@ class Bf16Plan:
     def flags(self, v):
         self.d.flags = v
 
-    def run(self, x, wb, z, stats=None, pivot=None):
+    def run(self, x, wb, z, stats=None, pivot=None, mask=None):
         t = CONV_TIMER
         if t is not None:
             t.begin()
-        _lib.check(_lib.load().ds_conv_bf16(C.byref(self.d), x, wb, z, stats, pivot, _stream()), "ds_conv_bf16")
+        _lib.check(_lib.load().ds_conv_bf16(C.byref(self.d), x, wb, z, mask, stats, pivot, _stream()), "ds_conv_bf16")
         if t is not None:
             t.end(self)
 
@@ -373,11 +373,11 @@ class Fp8Plan(Bf16Plan):
         self.a_format = a_format
         self.partials = lib.ds_conv_fp8_partials(C.byref(self.d)) if flags & DS_EPI_STATS else 0
 
-    def run(self, x, wq, z, stats=None, pivot=None, x_amax=None, wscale=None):
+    def run(self, x, wq, z, stats=None, pivot=None, x_amax=None, wscale=None, mask=None):
         t = CONV_TIMER
         if t is not None:
             t.begin()
-        _lib.check(_lib.load().ds_conv_fp8(C.byref(self.d), x, x_amax, self.a_format, wq, wscale, z, stats, pivot,
+        _lib.check(_lib.load().ds_conv_fp8(C.byref(self.d), x, x_amax, self.a_format, wq, wscale, z, mask, stats, pivot,
                                            _stream()), "ds_conv_fp8")
         if t is not None:
             t.end(self)
