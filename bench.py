@@ -82,6 +82,8 @@ def cpu_baseline(post_size, vocab, dim, rnn, warmup=3, steps=10):
         timed("joint", 2, 1)
         for threads in sorted({min(16, phys), phys}):
             timed("joint", 16, threads)
+        steps, warmup = max(3, steps // 2), 2      # the larger batch, bounded: ~64 / 45 s per step
+        timed("joint", 64, min(16, phys))
     finally:
         torch.set_num_threads(prev)
     joint = [r for r in runs if r["workload"].startswith("joint")]
@@ -89,7 +91,7 @@ def cpu_baseline(post_size, vocab, dim, rnn, warmup=3, steps=10):
     return dict(value=best["samples_per_s"], unit="samples/s", cores=best["threads"], kind="port",
                 sample="joint train step (fwd+bwd+TF-Adam), fp32, batch %d, %d timed steps after %d warm-up, PyTorch-CPU "
                        "restatement of the TF1 step (reference-equivalent CPU path: TensorFlow 1.x is not installable "
-                       "here); best of the joint runs listed in `runs`" % (best["batch"], steps, warmup),
+                       "here); best of the joint runs listed in `runs`" % (best["batch"], best["steps"], best["warmup"]),
                 runs=runs, host=dict(logical_cpus=os.cpu_count(), physical_cores=phys, model=cpu_model()))
 
 
@@ -133,14 +135,63 @@ def cpu_model():
     return "unknown"
 
 
-def pmc_traffic(args):
-    """HBM bytes per conv_igemm launch from the committed rocprofv3 PMC passes of THIS workload
-    (profiles/rNN_pmc.json, made by scripts/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs,
-    FETCH doubled as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the timed
-    process, so the figure is null unless a profile of the default workload is present."""
+CONV_FAMILY = ("conv_igemm_kernel", "conv_glds_kernel", "gemm_wide_kernel", "conv_wino_kernel", "conv_wino4_kernel",
+               "conv_stem_kernel", "conv_bf16_kernel", "conv_bf16d_kernel", "conv_fp8d_kernel")
+
+
+def pmc_traffic_live(steps=3, timeout=150):
+    """HBM bytes per conv-family launch measured NOW: two rocprofv3 sub-runs of this same bench (default workload,
+    `steps` steps, Mixed-block branches on one stream as in the roofline timing pass), one per counter -- FETCH_SIZE and
+    WRITE_SIZE in SEPARATE passes with --kernel-trace only, FETCH doubled for gfx950, exactly as MI355X_MICROARCH.md
+    prescribes -- summed over the launches the roofline brackets.  Returns (bytes per launch, description) or None when
+    rocprofv3 is missing, a pass fails or times out (the caller then falls back to the committed profile)."""
     import glob
-    if args.batch != 256 or args.mode != "joint" or args.gpus != 1 or args.train_all or args.dtype != "f32":
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    tot, calls = {}, 0
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="ds_pmc_", dir="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "0", "--no-cpu-baseline", "--no-conv-timing",
+                   "--no-gather", "--no-branch-streams", "--no-live-traffic"]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            cur = sqlite3.connect(dbs[0]).cursor()
+            n, b = 0, 0.0
+            for name, val in cur.execute("select kernel_name, value from counters_collection where counter_name=?", (counter,)):
+                short = name.replace("(anonymous namespace)::", "").replace("void ", "", 1)
+                if short.startswith(CONV_FAMILY):
+                    n += 1
+                    b += val * 1024.0          # KB -> bytes
+            shutil.rmtree(d, ignore_errors=True)
+            if n == 0:
+                return None
+            tot[counter], calls = b, n
+        hbm = 2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]
+        return round(hbm / calls), ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only; FETCH x 2 "
+                                    "for gfx950) over %d steps of this workload, %d bracketed launches" % (steps, calls))
+    except Exception as e:      # missing counters, a crashed pass, a timeout: never fail the benchmark over this
+        sys.stderr.write("bench.py: live PMC traffic pass failed (%s); using the committed profile\n" % (e,))
+        return None
+
+
+def pmc_traffic(args):
+    """HBM bytes per conv-family launch: measured live (pmc_traffic_live) for the default workload, else read from the
+    committed rocprofv3 PMC passes of THIS workload (profiles/rNN_pmc.json, made by scripts/pmc_summary.py the same
+    way), else null.  `traffic_source` says which."""
+    import glob
+    if args.batch != 256 or args.mode != "joint" or args.gpus != 1 or args.train_all or args.dtype != "f32" or args.mul3:
         return None, None
+    if not args.no_live_traffic:
+        live = pmc_traffic_live()
+        if live is not None:
+            return live
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
         return None, None
@@ -210,6 +261,8 @@ def main():
     ap.add_argument("--cpu-warmup", type=int, default=3)
     ap.add_argument("--no-conv-timing", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the embedding-gather bandwidth measurement")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed profile instead of two rocprofv3 --pmc sub-runs (about 40 s)")
     args = ap.parse_args()
 
     import torch
