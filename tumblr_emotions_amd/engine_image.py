@@ -617,7 +617,10 @@ class MixedStage(Stage):
         p = self.prev
         # (the register-direct bf16 / fp8 dgrads have the accumulate epilogue too, but at their two workgroups per CU its
         # dependent read-add-store chain costs more than the pass it saves: bf16 step 12.5 -> 14.0 ms, profiles/r04_notes.md)
-        self.pool_first = bool(eng.pool_first and self.fused.dgrad.family == ops.DS_FAM_IGEMM)
+        # DS_POOL_FIRST_16=1 (A/B): also for the register-direct bf16 / fp8 dgrads -- 12.98 -> 13.45 ms at bf16 even with the
+        # accumulate reads requested up front (14.0 before that): two waves per SIMD cannot hide a read-modify-write epilogue
+        fams = (ops.DS_FAM_IGEMM, ops.DS_FAM_BF16D, ops.DS_FAM_FP8D) if os.environ.get("DS_POOL_FIRST_16") == "1" else (ops.DS_FAM_IGEMM,)
+        self.pool_first = bool(eng.pool_first and self.fused.dgrad.family in fams)
         if isinstance(p, MixedStage) and self.pool_first:
             src = self.fused.emit_dx_sums(p.out)
             if src is not None and getattr(p, "zcat", False):      # the epilogue rebuilds y from the concat's z
