@@ -143,12 +143,12 @@ class _ConvMixedMultiply(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
-def fp8_where_it_wins(reduction, columns):
+def fp8_where_it_wins(k, cin, height, dgrad):
     """The launch rule of the build's fp8 configuration (tumblr_emotions_amd/csrc/conv_plan.cpp, measured per layer in
-    profiles/r04_fp8_layers_b128.txt): ds_conv_fp8 for reductions of >= 64 channels into >= 96 columns, bf16 elsewhere.
-    Forward: (Cin, Cout) of the launch -- the horizontally fused Branch_0/1/2 1x1 convs count their SUMMED columns;
-    input gradient: (Cout, Cin)."""
-    return reduction >= 64 and columns >= 96
+    profiles/r04_fp8_layers_b128.txt): ds_conv_fp8 for the FORWARD 3x3 convs with at least 96 input channels on maps of
+    14 x 14 and larger (1.09-1.5x over the bf16 kernel); everything else -- every 1x1 conv, the narrow and the 7 x 7 3x3
+    convs, every input gradient -- multiplies in bf16."""
+    return (not dgrad) and k == 3 and cin >= 96 and height >= 14
 
 
 def conv2d_same_bf16_multiply(x, w_hwio, stride):
@@ -248,10 +248,10 @@ class DeepSentimentRef:
             z = conv2d_same_fp8_multiply(x, self.p[scope + "/weights"], stride)
         elif self.conv_multiply == "fp8_auto":
             # fp8 only where the build's launch rule picks it (launch_cout: the fused 1x1 launch's summed columns)
-            cin, cout = w_.shape[2], (launch_cout or w_.shape[3])
-            k = w_.shape[0]
+            k, cin = w_.shape[0], w_.shape[2]
             z = _ConvMixedMultiply.apply(_same_pad_nchw(x, k, stride, 0.0), w_.permute(3, 2, 0, 1), stride,
-                                         fp8_ok and fp8_where_it_wins(cin, cout), fp8_ok and cout % 8 == 0 and fp8_where_it_wins(cout, cin))
+                                         fp8_ok and fp8_where_it_wins(k, cin, x.shape[2], False),
+                                         fp8_ok and fp8_where_it_wins(k, cin, x.shape[2], True))
         elif self.conv_multiply in ("bf16", "fp8"):
             z = conv2d_same_bf16_multiply(x, self.p[scope + "/weights"], stride)
         else:

@@ -174,9 +174,12 @@ def test_conv_plan_picks_the_kernel_family_without_a_device(lib):
     assert plan(L.DS_CONV_FWD, L.DS_ARITH_BF16, L.DS_PLAN_NO_BF16_DIRECT, B, 28, 28, 192, 176, 1, 1)[1].family == L.DS_FAM_IGEMM
     rc, p = plan(L.DS_CONV_FWD, L.DS_ARITH_FP8, 0, B, 14, 14, 96, 208, 3, 1, L.DS_EPI_STATS)
     assert p.family == L.DS_FAM_FP8D and p.a_format == L.DS_FP8_E4M3 and p.wscale_floats == 4 + 512 and p.partials > 0
-    rc, p = plan(L.DS_CONV_DGRAD, L.DS_ARITH_FP8, 0, B, 14, 14, 96, 208, 3, 1, ldx=208, ldz=96)
+    rc, p = plan(L.DS_CONV_DGRAD, L.DS_ARITH_FP8, L.DS_PLAN_FP8_EVERYWHERE, B, 14, 14, 96, 208, 3, 1, ldx=208, ldz=96)
     assert p.family == L.DS_FAM_FP8D and p.a_format == L.DS_FP8_E5M2
-    # ... only where fp8 beats the bf16 kernels (narrow reductions / few columns take the bf16 rules), unless forced
+    # ... only where fp8 beats the bf16 kernels (forward 3x3, >= 96 input channels, 14 x 14 and larger), unless forced
+    assert plan(L.DS_CONV_DGRAD, L.DS_ARITH_FP8, 0, B, 14, 14, 96, 208, 3, 1, ldx=208, ldz=96)[1].family != L.DS_FAM_FP8D
+    assert plan(L.DS_CONV_FWD, L.DS_ARITH_FP8, 0, B, 7, 7, 192, 384, 3, 1)[1].family == L.DS_FAM_BF16D
+    assert plan(L.DS_CONV_FWD, L.DS_ARITH_FP8, 0, B, 28, 28, 256, 288, 1, 1)[1].family == L.DS_FAM_BF16D
     assert plan(L.DS_CONV_FWD, L.DS_ARITH_FP8, L.DS_PLAN_ACT16, B, 14, 14, 16, 48, 3, 1)[1].family == L.DS_FAM_BF16D
     assert plan(L.DS_CONV_FWD, L.DS_ARITH_FP8, L.DS_PLAN_FP8_EVERYWHERE, B, 14, 14, 16, 48, 3, 1)[1].family == L.DS_FAM_FP8D
     assert plan(L.DS_CONV_DGRAD, L.DS_ARITH_FP8, 0, B, 56, 56, 64, 192, 3, 1, ldx=192, ldz=64)[1].family == L.DS_FAM_IGEMM

@@ -140,14 +140,15 @@ def test_full_size_step_matches_committed_golden_vector(which):
 def test_joint_fp8_config5_share_vs_emulating_oracle():
     """BASELINE configs[4] ("fp16 joint with fp8 (CDNA4) MFMA conv path, batch 1024, 8 GPUs") as ONE rank sees it: the
     joint step at B = 128 and the real dims in the fp8 configuration AS IT SHIPS -- ds_conv_fp8 (e4m3 x e4m3 forward,
-    e5m2 x e4m3 input gradient, per-tensor power-of-two scales) on the layers where it beats the bf16 kernels, bf16
-    multiplies on the others, 16-bit (bf16) activation storage, fp32 accumulation / BatchNorm / weight gradients / text
+    per-tensor power-of-two scales) on the layers where it beats the bf16 kernels (the forward 3x3 convs with >= 96 input
+    channels on 14 x 14 and larger maps), bf16 multiplies on the others, 16-bit (bf16) activation storage, fp32 accumulation / BatchNorm / weight gradients / text
     tower -- against the committed fp64 oracle vector that EMULATES those multiplies (tests/golden/make_golden_fp8.py,
     DeepSentimentRef.conv_multiply = "fp8_auto").  Not the 1e-3 parity path.  TOLERANCE of this configuration, stated
-    here: logits within 0.6 and total loss within 0.1 of the emulating oracle (measured on MI355X: printed below; e4m3
+    here: logits within 0.35 and total loss within 0.05 of the emulating oracle, and CLOSER to it than to the exact-multiply
+    oracle (measured on MI355X, printed below: 0.16 against 0.25; e4m3
     carries 3 mantissa bits and this randomly initialised 57-layer BatchNorm stack amplifies a forward perturbation
-    ~100x -- the oracle with EXACT multiplies sits 0.41 from the emulating one itself, recorded in the fixture); the
-    gradient of b_softmax within 0.05 relative L2, the other head / LSTM / Logits gradients reported (0.2-0.6)."""
+    ~100x -- the oracle with EXACT multiplies sits 0.25 from the emulating one itself, recorded in the fixture); the
+    gradient of b_softmax within 0.05 relative L2, the other head / LSTM / Logits gradients reported (0.1-0.35)."""
     import sys
     GOLD = os.path.join(os.path.dirname(__file__), "golden")
     sys.path.insert(0, GOLD)
@@ -166,7 +167,8 @@ def test_joint_fp8_config5_share_vs_emulating_oracle():
     torch.cuda.synchronize()
     n_fp8 = sum(l.fwd.family == ops.DS_FAM_FP8D for l in net.image.layers)
     n_b16 = sum(l.fwd.family == ops.DS_FAM_BF16D for l in net.image.layers)
-    assert 15 <= n_fp8 <= 30 and n_b16 >= 8, (n_fp8, n_b16)          # fp8 where it wins, bf16 on the narrow layers
+    n_fp8d = sum(l.dgrad is not None and l.dgrad.family == ops.DS_FAM_FP8D for l in net.image.layers)
+    assert 5 <= n_fp8 <= 8 and n_fp8d == 0 and n_b16 >= 25, (n_fp8, n_fp8d, n_b16)      # fp8 where it wins, bf16 elsewhere
     logits = net.logits.detach().cpu().numpy()
     assert np.isfinite(logits).all()
     d_emul = float(np.abs(logits - G["logits/fp8_auto"]).max())
@@ -186,9 +188,9 @@ def test_joint_fp8_config5_share_vs_emulating_oracle():
     print("fp8 configuration at B = 128 (%d fp8 / %d bf16 forward layers): max|dlogits| %.3f vs the emulating oracle, %.3f vs "
           "the exact one (the two oracles: %.3f apart); |dloss| %.4f; gradient relative L2 median %.3f, worst %.3f (%s)"
           % (n_fp8, n_b16, d_emul, d_exact, oracle_gap, dloss, rels[len(rels) // 2][0], rels[-1][0], rels[-1][1]))
-    assert d_emul <= 0.6 and dloss <= 0.1
+    assert d_emul <= 0.35 and dloss <= 0.05 and d_emul < d_exact
     # gradients: b_softmax follows the logits alone (mean softmax - one-hot): tight; the others multiply features that
     # already carry the forward fp8 noise, so a PLAIN comparison (no decision injection is possible against a committed
     # vector) shows 0.2-0.6 -- reported, bounded for sanity
     by = {n: r for r, n in rels}
-    assert by["b_softmax"] <= 0.05 and rels[-1][0] <= 0.9
+    assert by["b_softmax"] <= 0.05 and rels[-1][0] <= 0.6

@@ -7,6 +7,7 @@
 // register-direct bf16 / fp8 / f32x3 kernels), how many BatchNorm partials it writes, and which prepared form of the
 // filter it reads.  The selection rules that used to live in the Python engine (isinstance chains over five plan
 // classes) are here, next to the launch-time model they consult.  Host code only: no kernel in this file.
+#include <stdlib.h>
 #include <string.h>
 
 #include "ds_kernels.h"
@@ -118,11 +119,19 @@ extern "C" int ds_conv_plan(ds_conv_layer_plan *out, int32_t role, int32_t arith
             fam = DS_FAM_F32X3;      // fp32 products from three bf16 pieces: the forward 1x1 convs (opt-in, own label)
     } else if (k == 1 || k == 3) {
         // ds_conv_fp8 on the layers where it beats the bf16 kernels (profiles/r04_fp8_layers_b128.txt, every conv shape of
-        // the tower at cfg5's per-GPU batch): reductions of at least 64 channels into at least 96 columns -- 1.3-1.5x on
-        // the 14x14 3x3 layers, 1.0-1.09x on the wide 1x1 layers; it is 3x SLOWER on the 16 / 24 / 32-channel 3x3 layers
-        // and 5-30 % slower into 64 columns (Conv2d_2c's dgrad: 375 against 283 us).  The rest takes the bf16 rules.
-        const bool fp8 = arith == DS_ARITH_FP8 && stride == 1 && cin % 8 == 0 &&
-                         ((options & DS_PLAN_FP8_EVERYWHERE) || (cin >= 64 && cout >= 96));
+        // the tower at cfg5's per-GPU batch): both kernels are fetch / conversion-bound, so fp8 is within +-5 % of bf16 on
+        // most shapes, 3x SLOWER on the 16 / 24 / 32-channel 3x3 layers, 5-30 % slower into 64 columns (Conv2d_2c's dgrad:
+        // 375 against 283 us) -- and 1.09-1.5x FASTER on the forward 3x3 layers with >= 96 input channels on 14 x 14 and
+        // larger maps.  Only those run in fp8; the rest takes the bf16 rules.  In-box, ms/step at B = 256: bf16 13.02,
+        // fp8 by this rule 13.07, by the wider rule (>= 64 channels into >= 96 columns, DS_FP8_RULE=1) 13.46, everywhere 13.8.
+        static int fp8_rule = -1;
+        if (fp8_rule < 0) {
+            const char *e = getenv("DS_FP8_RULE");        // A/B aid: 1 = the wider round-4 rule (reduction >= 64 into >= 96 columns)
+            fp8_rule = e ? atoi(e) : 0;
+        }
+        const bool wins = fp8_rule == 1 ? (cin >= 64 && cout >= 96)
+                                        : (!dgrad && k == 3 && cin >= 96 && H >= 14);      // the 1.09-1.5x layers only
+        const bool fp8 = arith == DS_ARITH_FP8 && stride == 1 && cin % 8 == 0 && ((options & DS_PLAN_FP8_EVERYWHERE) || wins);
         if (fp8) {
             fam = DS_FAM_FP8D;
         } else if (!(options & DS_PLAN_NO_BF16_DIRECT)) {

@@ -502,7 +502,7 @@ class PoolStage(Stage):
         p = self.prev
         if getattr(p, "fused_into_pool", False):
             ops.maxpool_bn_relu_fwd(p.layer.z, p.layer.rstd, p.layer.shift, self.out, self.argmax, self.B, p.H, p.W, p.C,
-                                    self.k, self.stride, amax=self._own_amax)
+                                    self.k, self.stride, amax=self._own_amax if getattr(self, "track_amax", True) else None)
         elif getattr(p, "zcat", False):      # the block's concat holds pre-BatchNorm values: normalise on load
             ops.maxpool_bn_relu_fwd(p.out, p.rs_cat[0], p.rs_cat[1], self.out, self.argmax, self.B, p.H, p.W, p.C,
                                     self.k, self.stride)
@@ -881,6 +881,38 @@ class InceptionV1Engine:
         import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.sync_group)
 
+    def _prune_amax(self):
+        """fp8: a producer raises a tensor's max|.| record (an atomic per wave in the BatchNorm-apply / pool kernels) only
+        when a conv that READS the tensor runs on the fp8 kernels -- with fp8 restricted to the layers where it wins
+        (ds_conv_plan) that is a handful of reduce outputs, not every activation of the tower."""
+        def fp8(layer):
+            return layer.fwd.family == ops.DS_FAM_FP8D
+
+        def consumers(st):
+            nxt = getattr(st, "next", None)
+            if isinstance(nxt, ConvStage):
+                return [nxt.layer]
+            if isinstance(nxt, MixedStage):
+                return [nxt.fused, nxt.c3]
+            if isinstance(nxt, PoolStage):
+                return consumers(nxt)
+            return []
+
+        for st in self.stages:
+            need_out = any(fp8(l) for l in consumers(st))
+            if isinstance(st, ConvStage) and not need_out:
+                st.segs.amax[0] = None
+            elif isinstance(st, PoolStage):
+                st.track_amax = need_out
+            elif isinstance(st, MixedStage):
+                if not need_out:
+                    for sg in (st.seg_f, st.seg_1, st.seg_2, st.seg_3):
+                        sg.amax[0] = None
+                if not fp8(st.c1):
+                    st.seg_f.amax[1] = None
+                if not fp8(st.c2):
+                    st.seg_f.amax[2] = None
+
     def new_amax(self):
         """One word of the amax pool (None outside the fp8 configuration)."""
         if self.amax_pool is None:
@@ -914,6 +946,8 @@ class InceptionV1Engine:
         self.input.alloc(B)
         for s in self.stages:
             s.alloc(B)
+        if self.amax_pool is not None:
+            self._prune_amax()
         nc, F = self.num_classes, self.feat
         self.pooled = torch.empty(B, F, device=dev)
         self.dpooled = torch.empty(B, F, device=dev)
