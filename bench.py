@@ -139,7 +139,7 @@ CONV_FAMILY = ("conv_igemm_kernel", "conv_glds_kernel", "gemm_wide_kernel", "con
                "conv_stem_kernel", "conv_bf16_kernel", "conv_bf16d_kernel", "conv_fp8d_kernel")
 
 
-def pmc_traffic_live(steps=3, timeout=150):
+def pmc_traffic_live(steps=3, timeout=90):
     """HBM bytes per conv-family launch measured NOW: two rocprofv3 sub-runs of this same bench (default workload,
     `steps` steps, Mixed-block branches on one stream as in the roofline timing pass), one per counter -- FETCH_SIZE and
     WRITE_SIZE in SEPARATE passes with --kernel-trace only, FETCH doubled for gfx950, exactly as MI355X_MICROARCH.md
@@ -160,7 +160,17 @@ def pmc_traffic_live(steps=3, timeout=150):
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "0", "--no-cpu-baseline", "--no-conv-timing",
                    "--no-gather", "--no-branch-streams", "--no-live-traffic"]
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            # own process group: on a timeout the profiler AND the bench it wraps are killed, nothing lingers on the GPU
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                raise
+            if rc != 0:
+                raise RuntimeError("rocprofv3 exited with %d" % rc)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             cur = sqlite3.connect(dbs[0]).cursor()
             n, b = 0, 0.0
