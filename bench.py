@@ -25,6 +25,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# kernel arguments in device memory (this image's default; measured: forcing it OFF costs 0.3 ms per step at B = 256 and
+# 0.35 ms at B = 32, profiles/r04_notes.md) -- pinned so that a differently configured runtime measures the same thing
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 GFLOP_PER_SAMPLE = 6.169          # fwd+bwd, reference-faithful freeze (BASELINE.md section 2 / SURVEY 8d)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md
