@@ -108,32 +108,50 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *z, int6
     const int C4 = C >> 2;
     const int64_t total = M * C4;
     float smax[4] = {0.f, 0.f, 0.f, 0.f};      // max(y) per destination segment (y >= 0), for the segments that ask
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t row = i / C4;
-        const int c = (int)(i - row * C4) * 4;
-        const float4 v = *reinterpret_cast<const float4 *>(z + row * C + c);
-        const float4 r = *reinterpret_cast<const float4 *>(rstd + c);
-        const float4 s = *reinterpret_cast<const float4 *>(shift + c);
-        float4 y;
-        y.x = fmaxf(v.x * r.x + s.x, 0.f);
-        y.y = fmaxf(v.y * r.y + s.y, 0.f);
-        y.z = fmaxf(v.z * r.z + s.z, 0.f);
-        y.w = fmaxf(v.w * r.w + s.w, 0.f);
-        // destination segment: fp32, or bf16 (16-bit activation storage; round to nearest even)
+    // two elements per pass, both loads before either store (see bn_bwd_apply_kernel)
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 2 * stride) {
+        float4 vv[2], rr[2], ss[2];
+        int64_t rows[2];
+        int cs[2];
+        bool ok[2];
 #pragma unroll
-        for (int sgi = 0; sgi < 4; ++sgi)
-            if (sgi < dst.nseg && c >= dst.c_begin[sgi] && c < dst.c_end[sgi]) {
-                smax[sgi] = fmaxf(smax[sgi], fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w)));
-                const int64_t e = row * dst.ld[sgi] + (c - dst.c_begin[sgi]);
-                if (dst.dtype[sgi] == DS_DTYPE_BF16) {
-                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                    typedef float f32x4v __attribute__((ext_vector_type(4)));
-                    const f32x4v yv = {y.x, y.y, y.z, y.w};
-                    *reinterpret_cast<bf16x4 *>(reinterpret_cast<__bf16 *>(dst.ptr[sgi]) + e) = __builtin_convertvector(yv, bf16x4);
-                } else {
-                    *reinterpret_cast<float4 *>(dst.ptr[sgi] + e) = y;
+        for (int u = 0; u < 2; ++u) {
+            const int64_t i = i0 + u * stride;
+            ok[u] = i < total;
+            rows[u] = (ok[u] ? i : 0) / C4;
+            cs[u] = (int)((ok[u] ? i : 0) - rows[u] * C4) * 4;
+            vv[u] = *reinterpret_cast<const float4 *>(z + rows[u] * C + cs[u]);
+            rr[u] = *reinterpret_cast<const float4 *>(rstd + cs[u]);
+            ss[u] = *reinterpret_cast<const float4 *>(shift + cs[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!ok[u]) continue;
+            const int64_t row = rows[u];
+            const int c = cs[u];
+            const float4 v = vv[u], r = rr[u], s = ss[u];
+            float4 y;
+            y.x = fmaxf(v.x * r.x + s.x, 0.f);
+            y.y = fmaxf(v.y * r.y + s.y, 0.f);
+            y.z = fmaxf(v.z * r.z + s.z, 0.f);
+            y.w = fmaxf(v.w * r.w + s.w, 0.f);
+            // destination segment: fp32, or bf16 (16-bit activation storage; round to nearest even)
+#pragma unroll
+            for (int sgi = 0; sgi < 4; ++sgi)
+                if (sgi < dst.nseg && c >= dst.c_begin[sgi] && c < dst.c_end[sgi]) {
+                    smax[sgi] = fmaxf(smax[sgi], fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w)));
+                    const int64_t e = row * dst.ld[sgi] + (c - dst.c_begin[sgi]);
+                    if (dst.dtype[sgi] == DS_DTYPE_BF16) {
+                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                        typedef float f32x4v __attribute__((ext_vector_type(4)));
+                        const f32x4v yv = {y.x, y.y, y.z, y.w};
+                        *reinterpret_cast<bf16x4 *>(reinterpret_cast<__bf16 *>(dst.ptr[sgi]) + e) = __builtin_convertvector(yv, bf16x4);
+                    } else {
+                        *reinterpret_cast<float4 *>(dst.ptr[sgi] + e) = y;
+                    }
                 }
-            }
+        }
     }
 #pragma unroll
     for (int sgi = 0; sgi < 4; ++sgi)
@@ -321,26 +339,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, int l
     const int C4 = C >> 2;
     const int64_t total = M * C4;
     float am = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t row = i / C4;
-        const int c = (int)(i - row * C4) * 4;
-        const float4 zv = *reinterpret_cast<const float4 *>(z + row * ldz + c);
-        const float4 dv = *reinterpret_cast<const float4 *>(seg_addr(dy, row, c));
-        const float4 r = *reinterpret_cast<const float4 *>(rstd + c);
-        const float4 s = *reinterpret_cast<const float4 *>(shift + c);
-        const float4 mu = *reinterpret_cast<const float4 *>(mean + c);
-        const float4 k1 = *reinterpret_cast<const float4 *>(coef + c);
-        const float4 k2 = *reinterpret_cast<const float4 *>(coef + C + c);
-        const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
-        const float rr[4] = {r.x, r.y, r.z, r.w}, ss[4] = {s.x, s.y, s.z, s.w}, mm[4] = {mu.x, mu.y, mu.z, mu.w};
-        const float a1[4] = {k1.x, k1.y, k1.z, k1.w}, a2[4] = {k2.x, k2.y, k2.z, k2.w};
-        float o[4];
+    // TWO elements per pass, all loads of both before either store: a load issued behind a store waits for it (one
+    // in-order memory counter), so the one-element loop was a chain of memory round trips
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 2 * stride) {
+        float4 zv[2], dv[2], r[2], s[2], mu[2], k1[2], k2[2];
+        int64_t at[2];
+        bool ok[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            o[j] = ds::bn_bwd_dz(zz[j], dd[j], rr[j], ss[j], mm[j], a1[j], a2[j]);
+        for (int u = 0; u < 2; ++u) {
+            const int64_t i = i0 + u * stride;
+            ok[u] = i < total;
+            const int64_t row = (ok[u] ? i : 0) / C4;
+            const int c = (int)((ok[u] ? i : 0) - row * C4) * 4;
+            at[u] = row * ldz + c;
+            zv[u] = *reinterpret_cast<const float4 *>(z + at[u]);
+            dv[u] = *reinterpret_cast<const float4 *>(seg_addr(dy, row, c));
+            r[u] = *reinterpret_cast<const float4 *>(rstd + c);
+            s[u] = *reinterpret_cast<const float4 *>(shift + c);
+            mu[u] = *reinterpret_cast<const float4 *>(mean + c);
+            k1[u] = *reinterpret_cast<const float4 *>(coef + c);
+            k2[u] = *reinterpret_cast<const float4 *>(coef + C + c);
         }
-        *reinterpret_cast<float4 *>(dz + row * ldz + c) = make_float4(o[0], o[1], o[2], o[3]);
-        am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!ok[u]) continue;
+            const float zz[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w}, dd[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+            const float rr[4] = {r[u].x, r[u].y, r[u].z, r[u].w}, ss[4] = {s[u].x, s[u].y, s[u].z, s[u].w};
+            const float mm[4] = {mu[u].x, mu[u].y, mu[u].z, mu[u].w};
+            const float a1[4] = {k1[u].x, k1[u].y, k1[u].z, k1[u].w}, a2[4] = {k2[u].x, k2[u].y, k2[u].z, k2[u].w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = ds::bn_bwd_dz(zz[j], dd[j], rr[j], ss[j], mm[j], a1[j], a2[j]);
+            *reinterpret_cast<float4 *>(dz + at[u]) = make_float4(o[0], o[1], o[2], o[3]);
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+        }
     }
     if (amax) {
 #pragma unroll

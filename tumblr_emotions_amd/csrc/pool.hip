@@ -160,6 +160,51 @@ __device__ __forceinline__ RowMax row_max3(const TI *x, int64_t row_base, int iw
     return r;
 }
 
+// The same in two halves, so that a row can be REQUESTED iterations before it is reduced: each thread's walk down the
+// rows is one dependent chain (load -> max -> store, and a load behind a store waits for it: one in-order memory counter),
+// i.e. the kernel's time was rows x memory latency -- 4.9 TB/s.  With the next rows' loads issued two rows ahead, before
+// the stores of the current one, twice the bytes are in flight per thread.
+struct RawRow3 {
+    float4 v[3];
+    bool ok[3];
+};
+
+template <typename TI>
+__device__ __forceinline__ RawRow3 load_row3(const TI *x, int64_t row_base, int iw0, int W, int C, int c, bool row_ok) {
+    RawRow3 q;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int iw = iw0 + kw;
+        q.ok[kw] = row_ok && (unsigned)iw < (unsigned)W;
+        q.v[kw] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q.ok[kw]) q.v[kw] = ld4<TI>(x + (row_base + iw) * C + c);
+    }
+    return q;
+}
+
+__device__ __forceinline__ RowMax reduce_row3(const RawRow3 &q) {      // = row_max3 on the loaded values
+    RowMax r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r.v[j] = -INFINITY;
+        r.k[j] = 0;
+    }
+    bool any = false;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        if (!q.ok[kw]) continue;
+        const float vv[4] = {q.v[kw].x, q.v[kw].y, q.v[kw].z, q.v[kw].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (!any || vv[j] > r.v[j]) {
+                r.v[j] = vv[j];
+                r.k[j] = kw;
+            }
+        any = true;
+    }
+    return r;
+}
+
 // rstd/shift != nullptr: x is the PRE-BatchNorm conv output z and the pooled value is stored as
 // relu(rstd*max(z) + shift).  With rstd > 0 the affine map and the ReLU are monotone, so this equals the max of
 // relu(bn(z)) over the window (and ties only appear among positions whose ReLU gradient is zero anyway): the
@@ -179,10 +224,20 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_rolling(const TI *x, TO *y, 
         const int64_t img = (int64_t)n * H;
         RowMax r0, r1, r2;      // input rows ih0, ih0+1, ih0+2 of the current output row
         int ih0 = -pad_t;
+        auto req = [&](int ih) { return load_row3(x, (img + ih) * W, iw0, W, C, c, (unsigned)ih < (unsigned)H); };
         r0 = row_max3(x, (img + ih0) * W, iw0, W, C, c, (unsigned)ih0 < (unsigned)H);
         r1 = row_max3(x, (img + ih0 + 1) * W, iw0, W, C, c, (unsigned)(ih0 + 1) < (unsigned)H);
+        // STRIDE 1: rows requested ahead of their use -- qa = row ih0 + 2 (this output row's new row), qb = ih0 + 3 (the next one's)
+        RawRow3 qa, qb;
+        if (STRIDE == 1) { qa = req(ih0 + 2); qb = req(ih0 + 3); }
         for (int oh = 0; oh < OH; ++oh) {
-            r2 = row_max3(x, (img + ih0 + 2) * W, iw0, W, C, c, (unsigned)(ih0 + 2) < (unsigned)H);
+            RawRow3 na;
+            if (STRIDE == 1) {
+                na = req(ih0 + 4);         // the load of a LATER output row goes out before this one's stores
+                r2 = reduce_row3(qa);
+            } else {                       // (3x3/2: measured mixed -- 112x112 and 28x28 gain, 56x56 loses: kept as it was)
+                r2 = row_max3(x, (img + ih0 + 2) * W, iw0, W, C, c, (unsigned)(ih0 + 2) < (unsigned)H);
+            }
             float best[4];
             int arg[4];
 #pragma unroll
@@ -207,6 +262,8 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_rolling(const TI *x, TO *y, 
             if (STRIDE == 1) {
                 r0 = r1;
                 r1 = r2;
+                qa = qb;          // row ih0 + 3 becomes the next output row's new row ...
+                qb = na;          // ... and row ih0 + 4, requested above, the one after
             } else {
                 r0 = r2;
                 r1 = row_max3(x, (img + ih0 + 3) * W, iw0, W, C, c, (unsigned)(ih0 + 3) < (unsigned)H);
