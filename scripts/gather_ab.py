@@ -8,7 +8,10 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tumblr_emotions_amd import ops  # noqa: E402
+from tumblr_emotions_amd import _lib, ops  # noqa: E402
+
+if os.environ.get("DS_LIB"):        # A/B runs of kernel variants on one box
+    _lib.LIB_PATH = os.environ["DS_LIB"]
 
 V, D, B, T = 10000, 300, 8192, 128
 table = torch.randn(V + 1, D, device="cuda")

@@ -32,6 +32,57 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *table, co
     if (OUTORDER) { t = (int)(r / B); b = (int)(r - (int64_t)t * B); }
     else { b = (int)(r / T); t = (int)(r - (int64_t)b * T); }     // once per wave; then incremented
     constexpr int U = 4;                                           // rows in flight
+    if (VEC == 4 && DV <= 128) {
+        // Rows of at most 128 float4 (two chunks per lane), software pipelined: the id reads and the eight row loads of
+        // the NEXT four rows go out before the stores of the current four.  In the plain loop below every load sits
+        // behind the previous chunk's stores and waits for them (one in-order memory counter): two round trips per group.
+        const float *srcA[U], *srcB[U];
+        float *dstA[U], *dstB[U];
+        bool okA[U], okB[U];
+        vec_t a0[U], a1[U], b0[U], b1[U];
+        auto fetch = [&](int64_t rr, const float *(&src)[U], float *(&dst)[U], bool (&ok)[U], vec_t (&v0)[U], vec_t (&v1)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool in = rr + u < r1;
+                const int64_t id = in ? ids[OUTORDER ? (int64_t)b * T + t : rr + u] : -1;               // wave-uniform
+                ok[u] = id >= 0 && id < rows;                          // out-of-range id -> zero row
+                src[u] = table + (ok[u] ? id : 0) * D;
+                dst[u] = in ? out + (OUTORDER ? rr + u : (time_major ? (int64_t)t * B + b : rr + u)) * D : nullptr;
+                if (OUTORDER) { if (++b == B) { b = 0; ++t; } }
+                else if (++t == T) { t = 0; ++b; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                v0[u] = vec_t(0.f);
+                v1[u] = vec_t(0.f);
+                if (lane < DV && ok[u]) v0[u] = *reinterpret_cast<const vec_t *>(src[u] + lane * VEC);
+                if (64 + lane < DV && ok[u]) v1[u] = *reinterpret_cast<const vec_t *>(src[u] + (64 + lane) * VEC);
+            }
+        };
+        auto put = [&](float *(&dst)[U], vec_t (&v0)[U], vec_t (&v1)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!dst[u]) continue;
+                if (lane < DV) {
+                    if (NT) __builtin_nontemporal_store(v0[u], reinterpret_cast<vec_t *>(dst[u] + lane * VEC));
+                    else *reinterpret_cast<vec_t *>(dst[u] + lane * VEC) = v0[u];
+                }
+                if (64 + lane < DV) {
+                    if (NT) __builtin_nontemporal_store(v1[u], reinterpret_cast<vec_t *>(dst[u] + (64 + lane) * VEC));
+                    else *reinterpret_cast<vec_t *>(dst[u] + (64 + lane) * VEC) = v1[u];
+                }
+            }
+        };
+        fetch(r, srcA, dstA, okA, a0, a1);
+        for (; r < r1; r += 2 * U) {
+            if (r + U < r1) fetch(r + U, srcB, dstB, okB, b0, b1);
+            put(dstA, a0, a1);
+            if (r + U >= r1) break;
+            if (r + 2 * U < r1) fetch(r + 2 * U, srcA, dstA, okA, a0, a1);
+            put(dstB, b0, b1);
+        }
+        return;
+    }
     for (; r < r1; r += U) {
         const float *src[U];
         float *dst[U];
