@@ -1299,27 +1299,32 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
     }
 
     // ---- epilogue: store, BatchNorm column statistics ---------------------------------------------------------------
+    // Two phases.  (1) per column block: the accumulate / mask reads, the sums, the LDS combine -- results stay in the
+    // accumulator registers; (2) all stores.  With the stores of block b in front of the reads of block b + 1 every
+    // block cost a memory round trip (a load behind a store waits for it: one in-order counter).
     const int flags = d.flags;
     float *red = smem + 2 * BSZ;
     const int mrow0 = t0.row * 128 + wave * 32;
+    float pss[NB], pqq[NB];                          // (threads 0..31) this workgroup's partials of column block b
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int col = n0 + 32 * b + li;
         const bool colok = item && col < d.Cout;
         const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
         float s = 0.f, q = 0.f;
-        // DS_EPI_ACCUM: the sixteen previous values are requested UP FRONT.  Read inside the store loop, every read waited
-        // for the store before it (one in-order memory counter): sixteen round trips per column block
-        float zv[16];
+        if (flags & DS_EPI_ACCUM) {                  // the sixteen previous values, requested together
+            float zv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            zv[r] = ((flags & DS_EPI_ACCUM) && row < p.M && colok) ? p.z[(int64_t)row * d.ldz + col] : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                zv[r] = (row < p.M && colok) ? p.z[(int64_t)row * d.ldz + col] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] += zv[r];
         }
         if (flags & DS_EPI_BNSUMS) {
             // dgrad whose result dy feeds a BatchNorm + ReLU backward: column sums of g = dy (y > 0) and g * y, y = the
-            // consumer layer's forward activation (same rows / columns as dy).  The y values are requested up front so
-            // they arrive under the accumulate reads and the stores.
+            // consumer layer's forward activation (same rows / columns as dy)
             float yv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1335,26 +1340,23 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
             for (int r = 0; r < 16; ++r) {
                 const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row < p.M && colok) {
-                    const float v = acc[b][r] + zv[r];
-                    p.z[(int64_t)row * d.ldz + col] = v;
-                    const float u = yv[r] > 0.f ? v : 0.f;
+                    const float u = yv[r] > 0.f ? acc[b][r] : 0.f;
                     s += u;
                     q += u * yv[r];
                 }
             }
-        } else {
+        } else if (flags & DS_EPI_STATS) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row < p.M && colok) {
-                    const float v = acc[b][r] + zv[r];
-                    p.z[(int64_t)row * d.ldz + col] = v;
-                    const float u = v - pv;
+                    const float u = acc[b][r] - pv;
                     s += u;
                     q += u * u;
                 }
             }
         }
+        pss[b] = pqq[b] = 0.f;
         if (flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) {
             s += __shfl_xor(s, 32);
             q += __shfl_xor(q, 32);
@@ -1364,16 +1366,27 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
                 red[(wave * 32 + li) * 2 + 1] = q;
             }
             __syncthreads();
-            if (tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
-                float ss = 0.f, qq = 0.f;
+            if (tid < 32) {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    ss += red[(w * 32 + tid) * 2 + 0];
-                    qq += red[(w * 32 + tid) * 2 + 1];
+                    pss[b] += red[(w * 32 + tid) * 2 + 0];
+                    pqq[b] += red[(w * 32 + tid) * 2 + 1];
                 }
-                p.stats[(int64_t)(n0 + 32 * b + tid) * t0.stride + t0.row] = ss;
-                p.stats[((int64_t)d.Cout + n0 + 32 * b + tid) * t0.stride + t0.row] = qq;
             }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int col = n0 + 32 * b + li;
+        const bool colok = item && col < d.Cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row < p.M && colok) p.z[(int64_t)row * d.ldz + col] = acc[b][r];
+        }
+        if ((flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) && tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
+            p.stats[(int64_t)(n0 + 32 * b + tid) * t0.stride + t0.row] = pss[b];
+            p.stats[((int64_t)d.Cout + n0 + 32 * b + tid) * t0.stride + t0.row] = pqq[b];
         }
     }
 }
