@@ -197,25 +197,29 @@ __global__ __launch_bounds__(256, 2) void conv_fp8d_kernel(const Fp8Params p) {
         __syncthreads();
     }
 
-    // ---- epilogue: unscale, store, BatchNorm column statistics ----------------------------------------------------
+    // ---- epilogue: unscale, store, BatchNorm column statistics (two phases as gemm_wide_kernel: reads and sums for
+    // every column block first, all stores last -- a read behind a store waits for it) ----------------------------------
     const int flags = d.flags;
     float *red = reinterpret_cast<float *>(smem + 2 * DJ * 4096);
     const int mrow0 = trow * 128 + wave * 32;
+    float pss[NB], pqq[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int col = n0 + 32 * b + li;
         const bool colok = item && col < d.Cout;
         const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
         float s = 0.f, q = 0.f;
-        float zv[16];                                    // DS_EPI_ACCUM: previous values requested up front (gemm_wide_kernel)
+        float zv[16];                                    // DS_EPI_ACCUM: the previous values
 #pragma unroll
         for (int r2 = 0; r2 < 16; ++r2) {
             const int row = mrow0 + (r2 & 3) + 8 * (r2 >> 2) + 4 * kh;
             zv[r2] = ((flags & DS_EPI_ACCUM) && row < p.M && colok) ? p.z[(int64_t)row * d.ldz + col] : 0.f;
         }
+#pragma unroll
+        for (int r2 = 0; r2 < 16; ++r2) acc[b][r2] = acc[b][r2] * inv + zv[r2];
         if (flags & DS_EPI_BNSUMS) {
             // (as gemm_wide_kernel) dgrad whose result dy feeds a BatchNorm + ReLU backward: column sums of g = dy (y > 0)
-            // and g * y next to the stores; y = the consumer layer's activation in fp32 or bf16 storage
+            // and g * y; y = the consumer layer's activation in fp32 or bf16 storage
             float yv[16];
             const bool m16 = d.mask_dtype == DS_DTYPE_BF16;      // (uniform)
 #pragma unroll
@@ -228,26 +232,23 @@ __global__ __launch_bounds__(256, 2) void conv_fp8d_kernel(const Fp8Params p) {
             for (int r2 = 0; r2 < 16; ++r2) {
                 const int row = mrow0 + (r2 & 3) + 8 * (r2 >> 2) + 4 * kh;
                 if (row < p.M && colok) {
-                    const float v = acc[b][r2] * inv + zv[r2];
-                    p.z[(int64_t)row * d.ldz + col] = v;
-                    const float u = yv[r2] > 0.f ? v : 0.f;
+                    const float u = yv[r2] > 0.f ? acc[b][r2] : 0.f;
                     s += u;
                     q += u * yv[r2];
                 }
             }
-        } else {
+        } else if (flags & DS_EPI_STATS) {
 #pragma unroll
             for (int r2 = 0; r2 < 16; ++r2) {
                 const int row = mrow0 + (r2 & 3) + 8 * (r2 >> 2) + 4 * kh;
                 if (row < p.M && colok) {
-                    const float v = acc[b][r2] * inv + zv[r2];
-                    p.z[(int64_t)row * d.ldz + col] = v;
-                    const float u = v - pv;
+                    const float u = acc[b][r2] - pv;
                     s += u;
                     q += u * u;
                 }
             }
         }
+        pss[b] = pqq[b] = 0.f;
         if (flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) {
             s += __shfl_xor(s, 32);
             q += __shfl_xor(q, 32);
@@ -257,16 +258,27 @@ __global__ __launch_bounds__(256, 2) void conv_fp8d_kernel(const Fp8Params p) {
                 red[(wave * 32 + li) * 2 + 1] = q;
             }
             __syncthreads();
-            if (tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
-                float ss = 0.f, qq = 0.f;
+            if (tid < 32) {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    ss += red[(w * 32 + tid) * 2 + 0];
-                    qq += red[(w * 32 + tid) * 2 + 1];
+                    pss[b] += red[(w * 32 + tid) * 2 + 0];
+                    pqq[b] += red[(w * 32 + tid) * 2 + 1];
                 }
-                p.stats[(int64_t)(n0 + 32 * b + tid) * p.row_tiles + trow] = ss;
-                p.stats[((int64_t)d.Cout + n0 + 32 * b + tid) * p.row_tiles + trow] = qq;
             }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int col = n0 + 32 * b + li;
+        const bool colok = item && col < d.Cout;
+#pragma unroll
+        for (int r2 = 0; r2 < 16; ++r2) {
+            const int row = mrow0 + (r2 & 3) + 8 * (r2 >> 2) + 4 * kh;
+            if (row < p.M && colok) p.z[(int64_t)row * d.ldz + col] = acc[b][r2];
+        }
+        if ((flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) && tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
+            p.stats[(int64_t)(n0 + 32 * b + tid) * p.row_tiles + trow] = pss[b];
+            p.stats[((int64_t)d.Cout + n0 + 32 * b + tid) * p.row_tiles + trow] = pqq[b];
         }
     }
 }

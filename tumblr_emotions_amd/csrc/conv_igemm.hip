@@ -1574,21 +1574,26 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
         __syncthreads();
     }
 
-    // ---- epilogue: store, BatchNorm column statistics ---------------------------------------------------------------
+    // ---- epilogue: store, BatchNorm column statistics (two phases as gemm_wide_kernel: reads and sums, then stores) -----
     const int flags = d.flags;
     float *red = reinterpret_cast<float *>(smem + 2 * BSZ);
     const int mrow0 = t0.row * 128 + wave * 32;
+    float pss[NB], pqq[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int col = n0 + 32 * b + li;
         const bool colok = item && col < d.Cout;
         const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
         float s = 0.f, q = 0.f;
-        float zv[16];                                    // DS_EPI_ACCUM: previous values requested up front (gemm_wide_kernel)
+        if (flags & DS_EPI_ACCUM) {
+            float zv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            zv[r] = ((flags & DS_EPI_ACCUM) && row < p.M && colok) ? p.z[(int64_t)row * d.ldz + col] : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                zv[r] = (row < p.M && colok) ? p.z[(int64_t)row * d.ldz + col] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] += zv[r];
         }
         if (flags & DS_EPI_BNSUMS) {
             // (as gemm_wide_kernel) dgrad whose result dy feeds a BatchNorm + ReLU backward: column sums of
@@ -1611,26 +1616,23 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
             for (int r = 0; r < 16; ++r) {
                 const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row < p.M && colok) {
-                    const float v = acc[b][r] + zv[r];
-                    p.z[(int64_t)row * d.ldz + col] = v;
-                    const float u = yv[r] > 0.f ? v : 0.f;
+                    const float u = yv[r] > 0.f ? acc[b][r] : 0.f;
                     s += u;
                     q += u * yv[r];
                 }
             }
-        } else {
+        } else if (flags & DS_EPI_STATS) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row < p.M && colok) {
-                    const float v = acc[b][r] + zv[r];
-                    p.z[(int64_t)row * d.ldz + col] = v;
-                    const float u = v - pv;
+                    const float u = acc[b][r] - pv;
                     s += u;
                     q += u * u;
                 }
             }
         }
+        pss[b] = pqq[b] = 0.f;
         if (flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) {
             s += __shfl_xor(s, 32);
             q += __shfl_xor(q, 32);
@@ -1640,16 +1642,27 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
                 red[(wave * 32 + li) * 2 + 1] = q;
             }
             __syncthreads();
-            if (tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
-                float ss = 0.f, qq = 0.f;
+            if (tid < 32) {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    ss += red[(w * 32 + tid) * 2 + 0];
-                    qq += red[(w * 32 + tid) * 2 + 1];
+                    pss[b] += red[(w * 32 + tid) * 2 + 0];
+                    pqq[b] += red[(w * 32 + tid) * 2 + 1];
                 }
-                p.stats[(int64_t)(n0 + 32 * b + tid) * t0.stride + t0.row] = ss;
-                p.stats[((int64_t)d.Cout + n0 + 32 * b + tid) * t0.stride + t0.row] = qq;
             }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int col = n0 + 32 * b + li;
+        const bool colok = item && col < d.Cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row < p.M && colok) p.z[(int64_t)row * d.ldz + col] = acc[b][r];
+        }
+        if ((flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) && tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
+            p.stats[(int64_t)(n0 + 32 * b + tid) * t0.stride + t0.row] = pss[b];
+            p.stats[((int64_t)d.Cout + n0 + 32 * b + tid) * t0.stride + t0.row] = pqq[b];
         }
     }
 }
