@@ -254,9 +254,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
         constexpr bool bns = true;
         const __amdgpu_buffer_rsrc_t srd_y = wsrd(bns ? p.y : p.z, p.z_bytes);
         // DS_EPI_BNSUMS (this launch is a dgrad whose result dy feeds a BatchNorm + ReLU backward): per column, the sums
-        // of g = dy (y > 0) and g * y.  y sits at the offsets of the stores; element e + 1's four values are requested
-        // while element e is transformed (out-of-range offsets read zeros: y = 0 drops the element from both sums).
-        float ycur[4] = {0.f, 0.f, 0.f, 0.f}, ynxt[4] = {0.f, 0.f, 0.f, 0.f};
+        // of g = dy (y > 0) and g * y.  y sits at the offsets of the stores; (out-of-range
+        // offsets read zeros: y = 0 drops the element from both sums).
+        float yall[16][4];         // all sixty-four requested BEFORE the first store (a load behind a store waits for it)
         auto offsets_of = [&](int e, unsigned *off, bool *ok) {
             const int row0 = (e & 3) + 8 * (e >> 2);
             const unsigned ob0 = __builtin_amdgcn_readlane(obase, row0), ob1 = __builtin_amdgcn_readlane(obase, row0 + 4);
@@ -269,31 +269,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
             ok[0] = live; ok[1] = live && (of & 1); ok[2] = live && (of & 2); ok[3] = live && (of & 3) == 3;
             off[0] = ob; off[1] = ob + right; off[2] = ob + below; off[3] = ob + below + right;
         };
-        if (bns) {
+    #pragma unroll
+        for (int e = 0; e < 16; ++e) {
             unsigned off[4];
             bool ok[4];
-            offsets_of(0, off, ok);
+            offsets_of(e, off, ok);
     #pragma unroll
             for (int k = 0; k < 4; ++k)
-                ynxt[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_y, ok[k] ? off[k] + cbyte : kOOB, 0, 0));
+                yall[e][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_y, ok[k] ? off[k] + cbyte : kOOB, 0, 0));
         }
     #pragma unroll
         for (int e = 0; e < 16; ++e) {
             unsigned off[4];
             bool ok[4];
             offsets_of(e, off, ok);
-            if (bns) {
-    #pragma unroll
-                for (int k = 0; k < 4; ++k) ycur[k] = ynxt[k];
-                if (e < 15) {
-                    unsigned offn[4];
-                    bool okn[4];
-                    offsets_of(e + 1, offn, okn);
-    #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        ynxt[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_y, okn[k] ? offn[k] + cbyte : kOOB, 0, 0));
-                }
-            }
+            const float *ycur = yall[e];
             float mm[16];
     #pragma unroll
             for (int xi = 0; xi < 16; ++xi) mm[xi] = acc[xi][e];
