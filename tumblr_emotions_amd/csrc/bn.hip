@@ -49,7 +49,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <typename T>
 __device__ __forceinline__ float4 ldz4(const T *p);
 template <>
-__device__ __forceinline__ float4 ldz4<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 ldz4<float>(const float *p) { return ds::ld_stream4(p); }
 template <>
 __device__ __forceinline__ float4 ldz4<__bf16>(const __bf16 *p) {
     const f32x4_t v = __builtin_convertvector(*reinterpret_cast<const bf16x4_t *>(p), f32x4_t);
@@ -103,64 +103,61 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *stats, in
     }
 }
 
+// Streaming kernels (bn_apply_relu, bn_bwd_apply): the launch has gridDim.x * 256 = drow * (C / 4) threads, so a thread
+// keeps ONE float4 column group for its whole walk down the rows (row += drow): the per-channel values and the
+// segment lookup happen once, the loop has no division, and consecutive threads still read consecutive addresses.  Tensors
+// that are read once come in with the non-temporal hint (scripts/microbench/stream_bw.hip: 5.3 -> 6.4 TB/s for "two in,
+// one out"); two rows per pass with both rows' loads before either store (a load behind a store waits for it).
 __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *z, int64_t M, int C, const float *rstd,
-                                                            const float *shift, SegDev dst) {
+                                                            const float *shift, SegDev dst, int drow) {
     const int C4 = C >> 2;
-    const int64_t total = M * C4;
-    float smax[4] = {0.f, 0.f, 0.f, 0.f};      // max(y) per destination segment (y >= 0), for the segments that ask
-    // two elements per pass, both loads before either store (see bn_bwd_apply_kernel)
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 2 * stride) {
-        float4 vv[2], rr[2], ss[2];
-        int64_t rows[2];
-        int cs[2];
-        bool ok[2];
+    const int t0 = blockIdx.x * 256 + threadIdx.x;
+    const int row0 = t0 / C4, c = (t0 - row0 * C4) * 4;
+    const float4 r = *reinterpret_cast<const float4 *>(rstd + c), s = *reinterpret_cast<const float4 *>(shift + c);
+    int sgi = 0;                                 // this column group's destination segment
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < dst.nseg && c >= dst.c_begin[i] && c < dst.c_end[i]) sgi = i;
+    const bool to16 = dst.dtype[sgi] == DS_DTYPE_BF16;
+    float *const dptr = dst.ptr[sgi];
+    const int64_t dld = dst.ld[sgi];
+    const int dc = c - dst.c_begin[sgi];
+    float smax = 0.f;                            // max(y) of this segment (y >= 0), if it asks
+    for (int64_t row = row0; row < M; row += 2 * (int64_t)drow) {
+        const bool ok1 = row + drow < M;
+        const float4 v0 = ds::ld_stream4(z + row * C + c);
+        const float4 v1 = ds::ld_stream4(z + (ok1 ? row + drow : row) * C + c);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int64_t i = i0 + u * stride;
-            ok[u] = i < total;
-            rows[u] = (ok[u] ? i : 0) / C4;
-            cs[u] = (int)((ok[u] ? i : 0) - rows[u] * C4) * 4;
-            vv[u] = *reinterpret_cast<const float4 *>(z + rows[u] * C + cs[u]);
-            rr[u] = *reinterpret_cast<const float4 *>(rstd + cs[u]);
-            ss[u] = *reinterpret_cast<const float4 *>(shift + cs[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (!ok[u]) continue;
-            const int64_t row = rows[u];
-            const int c = cs[u];
-            const float4 v = vv[u], r = rr[u], s = ss[u];
+            if (u == 1 && !ok1) break;
+            const float4 v = u ? v1 : v0;
             float4 y;
             y.x = fmaxf(v.x * r.x + s.x, 0.f);
             y.y = fmaxf(v.y * r.y + s.y, 0.f);
             y.z = fmaxf(v.z * r.z + s.z, 0.f);
             y.w = fmaxf(v.w * r.w + s.w, 0.f);
+            smax = fmaxf(smax, fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w)));
+            const int64_t e = (row + u * (int64_t)drow) * dld + dc;
             // destination segment: fp32, or bf16 (16-bit activation storage; round to nearest even)
-#pragma unroll
-            for (int sgi = 0; sgi < 4; ++sgi)
-                if (sgi < dst.nseg && c >= dst.c_begin[sgi] && c < dst.c_end[sgi]) {
-                    smax[sgi] = fmaxf(smax[sgi], fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w)));
-                    const int64_t e = row * dst.ld[sgi] + (c - dst.c_begin[sgi]);
-                    if (dst.dtype[sgi] == DS_DTYPE_BF16) {
-                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                        typedef float f32x4v __attribute__((ext_vector_type(4)));
-                        const f32x4v yv = {y.x, y.y, y.z, y.w};
-                        *reinterpret_cast<bf16x4 *>(reinterpret_cast<__bf16 *>(dst.ptr[sgi]) + e) = __builtin_convertvector(yv, bf16x4);
-                    } else {
-                        *reinterpret_cast<float4 *>(dst.ptr[sgi] + e) = y;
-                    }
-                }
+            if (to16) {
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                typedef float f32x4v __attribute__((ext_vector_type(4)));
+                const f32x4v yv = {y.x, y.y, y.z, y.w};
+                *reinterpret_cast<bf16x4 *>(reinterpret_cast<__bf16 *>(dptr) + e) = __builtin_convertvector(yv, bf16x4);
+            } else {
+                *reinterpret_cast<float4 *>(dptr + e) = y;
+            }
         }
     }
+    // non-negative floats order like unsigned integers.  (A wave may span two segments: every segment is reduced.)
 #pragma unroll
-    for (int sgi = 0; sgi < 4; ++sgi)
-        if (sgi < dst.nseg && dst.amax[sgi]) {      // (uniform) non-negative floats order like unsigned integers
-            float m = smax[sgi];
+    for (int i = 0; i < 4; ++i) {
+        if (i >= dst.nseg || !dst.amax[i]) continue;          // (uniform)
+        float m = sgi == i ? smax : 0.f;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            if ((threadIdx.x & 63) == 0) ds::atomic_max_nonneg(dst.amax[sgi], m);
-        }
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) ds::atomic_max_nonneg(dst.amax[i], m);
+    }
 }
 
 // ---- backward -----------------------------------------------------------------------------------
@@ -211,7 +208,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const TZ *z, int ldz
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 zv[u] = ldz4<TZ>(z + (row + u * RG) * ldz + c);
-                dv[u] = *reinterpret_cast<const float4 *>(seg_addr(dy, row + u * RG, c));
+                dv[u] = ds::ld_stream4(seg_addr(dy, row + u * RG, c));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -226,7 +223,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const TZ *z, int ldz
         }
         for (; row < r1; row += RG) {
             const float4 zv = ldz4<TZ>(z + row * ldz + c);
-            const float4 dv = *reinterpret_cast<const float4 *>(seg_addr(dy, row, c));
+            const float4 dv = ds::ld_stream4(seg_addr(dy, row, c));
             const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -335,43 +332,36 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_segs_kernel(SumSegDev sg,
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, int ldz, SegDev dy, int64_t M, int C,
                                                            const float *mean, const float *rstd, const float *shift,
-                                                           const float *coef, float *dz, float *amax) {
+                                                           const float *coef, float *dz, float *amax, int drow) {
+    // (thread = one float4 column group, rows row0, row0 + drow, ...: see bn_apply_relu_kernel)
     const int C4 = C >> 2;
-    const int64_t total = M * C4;
+    const int t0 = blockIdx.x * 256 + threadIdx.x;
+    const int row0 = t0 / C4, c = (t0 - row0 * C4) * 4;
+    const float4 r4 = *reinterpret_cast<const float4 *>(rstd + c), s4 = *reinterpret_cast<const float4 *>(shift + c);
+    const float4 m4 = *reinterpret_cast<const float4 *>(mean + c);
+    const float4 k14 = *reinterpret_cast<const float4 *>(coef + c), k24 = *reinterpret_cast<const float4 *>(coef + C + c);
+    const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+    const float a1[4] = {k14.x, k14.y, k14.z, k14.w}, a2[4] = {k24.x, k24.y, k24.z, k24.w};
+    int sgi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < dy.nseg && c >= dy.c_begin[i] && c < dy.c_end[i]) sgi = i;
+    const float *const dyp = dy.ptr[sgi] + (c - dy.c_begin[sgi]);
+    const int64_t dyld = dy.ld[sgi];
     float am = 0.f;
-    // TWO elements per pass, all loads of both before either store: a load issued behind a store waits for it (one
-    // in-order memory counter), so the one-element loop was a chain of memory round trips
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 2 * stride) {
-        float4 zv[2], dv[2], r[2], s[2], mu[2], k1[2], k2[2];
-        int64_t at[2];
-        bool ok[2];
+    for (int64_t row = row0; row < M; row += 2 * (int64_t)drow) {
+        const bool ok1 = row + drow < M;
+        const int64_t row1 = ok1 ? row + drow : row;
+        const float4 zv[2] = {ds::ld_stream4(z + row * ldz + c), ds::ld_stream4(z + row1 * ldz + c)};
+        const float4 dv[2] = {ds::ld_stream4(dyp + row * dyld), ds::ld_stream4(dyp + row1 * dyld)};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int64_t i = i0 + u * stride;
-            ok[u] = i < total;
-            const int64_t row = (ok[u] ? i : 0) / C4;
-            const int c = (int)((ok[u] ? i : 0) - row * C4) * 4;
-            at[u] = row * ldz + c;
-            zv[u] = *reinterpret_cast<const float4 *>(z + at[u]);
-            dv[u] = *reinterpret_cast<const float4 *>(seg_addr(dy, row, c));
-            r[u] = *reinterpret_cast<const float4 *>(rstd + c);
-            s[u] = *reinterpret_cast<const float4 *>(shift + c);
-            mu[u] = *reinterpret_cast<const float4 *>(mean + c);
-            k1[u] = *reinterpret_cast<const float4 *>(coef + c);
-            k2[u] = *reinterpret_cast<const float4 *>(coef + C + c);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (!ok[u]) continue;
+            if (u == 1 && !ok1) break;
             const float zz[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w}, dd[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
-            const float rr[4] = {r[u].x, r[u].y, r[u].z, r[u].w}, ss[4] = {s[u].x, s[u].y, s[u].z, s[u].w};
-            const float mm[4] = {mu[u].x, mu[u].y, mu[u].z, mu[u].w};
-            const float a1[4] = {k1[u].x, k1[u].y, k1[u].z, k1[u].w}, a2[4] = {k2[u].x, k2[u].y, k2[u].z, k2[u].w};
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = ds::bn_bwd_dz(zz[j], dd[j], rr[j], ss[j], mm[j], a1[j], a2[j]);
-            *reinterpret_cast<float4 *>(dz + at[u]) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4 *>(dz + (u ? row1 : row) * ldz + c) = make_float4(o[0], o[1], o[2], o[3]);
             am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
         }
     }
@@ -380,6 +370,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, int l
         for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
         if ((threadIdx.x & 63) == 0) ds::atomic_max_nonneg(amax, am);
     }
+}
+
+// Launch shape of the fixed-column streaming kernels: gridDim.x * 256 threads = drow rows of C4 column groups each, i.e. the
+// grid is a multiple of C4 / gcd(C4, 256); about DS_STREAM_BPC (default 4) workgroups per CU, fewer for small tensors
+// (two rows per thread and pass).
+int column_grid(int64_t M, int C4, int *drow) {
+    static int bpc = -1;
+    if (bpc < 0) {
+        const char *e = getenv("DS_STREAM_BPC");
+        bpc = e && atoi(e) > 0 ? atoi(e) : 4;
+    }
+    int g = C4, b = 256;
+    while (b) { const int t = g % b; g = b; b = t; }          // gcd(C4, 256)
+    const int q = C4 / g;                                      // grid granule
+    int64_t want = (M * C4 + 511) / 512;                       // workgroups if every thread took two rows
+    if (want > (int64_t)ds::kCUs * bpc) want = (int64_t)ds::kCUs * bpc;
+    int64_t k = (want + q - 1) / q;
+    if (k < 1) k = 1;
+    const int64_t grid = k * q;
+    *drow = (int)(grid * 256 / C4);
+    return (int)grid;
 }
 
 int check_segments(const ds_segments *s, int C, const char *who, bool allow_bf16 = false) {
@@ -430,8 +441,10 @@ extern "C" int ds_bn_apply_relu(const float *z, int64_t M, int32_t C, const floa
                                 const ds_segments *dst, void *stream) {
     DS_REQUIRE(z && rstd && shift && M > 0 && C > 0 && C % 4 == 0, "ds_bn_apply_relu: bad argument (C %% 4 != 0?)");
     if (int e = check_segments(dst, C, "ds_bn_apply_relu", true)) return e;
-    hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(ds::stream_grid(M * (C / 4), 256 * 4)), dim3(256), 0,
-                       (hipStream_t)stream, z, M, C, rstd, shift, to_dev(dst));
+    int drow;
+    const int grid = column_grid(M, C / 4, &drow);
+    hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, M, C, rstd, shift, to_dev(dst),
+                       drow);
     return ds::check_launch("ds_bn_apply_relu");
 }
 
@@ -499,7 +512,9 @@ extern "C" int ds_bn_bwd_apply(const float *z, int32_t ldz, const ds_segments *d
                    ((((uintptr_t)z) | ((uintptr_t)dz)) & 15) == 0,
                "ds_bn_bwd_apply: bad argument (need C %% 4 == 0, ldz >= C, ldz %% 4 == 0, 16-byte aligned z / dz)");
     if (int e = check_segments(dy, C, "ds_bn_bwd_apply")) return e;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ds::stream_grid(M * (C / 4), 256 * 4)), dim3(256), 0,
-                       (hipStream_t)stream, z, ldz, to_dev(dy), M, C, mean, rstd, shift, coef, dz, amax);
+    int drow;
+    const int grid = column_grid(M, C / 4, &drow);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, ldz, to_dev(dy), M, C, mean, rstd,
+                       shift, coef, dz, amax, drow);
     return ds::check_launch("ds_bn_bwd_apply");
 }

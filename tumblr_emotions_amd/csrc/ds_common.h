@@ -30,6 +30,14 @@ inline int stream_grid(int64_t work_items, int per_block) {
     return (int)b;
 }
 
+// 16-byte load of data that is read once (streaming): non-temporal hint, so the lines do not displace what the
+// neighbouring kernels keep in L2 / the Infinity Cache (scripts/microbench/stream_bw.hip)
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream4(const float *p) {
+    const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
