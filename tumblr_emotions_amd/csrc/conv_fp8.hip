@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8d_kernel(const Fp8Params p) {
 #pragma unroll
         for (int r2 = 0; r2 < 16; ++r2) {
             const int row = mrow0 + (r2 & 3) + 8 * (r2 >> 2) + 4 * kh;
-            if (row < p.M && colok) p.z[(int64_t)row * d.ldz + col] = acc[b][r2];
+            if (row < p.M && colok) __builtin_nontemporal_store(acc[b][r2], p.z + (int64_t)row * d.ldz + col);
         }
         if ((flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) && tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
             p.stats[(int64_t)(n0 + 32 * b + tid) * p.row_tiles + trow] = pss[b];

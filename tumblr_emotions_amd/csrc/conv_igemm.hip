@@ -1382,7 +1382,7 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row < p.M && colok) p.z[(int64_t)row * d.ldz + col] = acc[b][r];
+            if (row < p.M && colok) __builtin_nontemporal_store(acc[b][r], p.z + (int64_t)row * d.ldz + col);
         }
         if ((flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) && tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
             p.stats[(int64_t)(n0 + 32 * b + tid) * t0.stride + t0.row] = pss[b];
@@ -1658,7 +1658,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row < p.M && colok) p.z[(int64_t)row * d.ldz + col] = acc[b][r];
+            if (row < p.M && colok) __builtin_nontemporal_store(acc[b][r], p.z + (int64_t)row * d.ldz + col);
         }
         if ((flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) && tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
             p.stats[(int64_t)(n0 + 32 * b + tid) * t0.stride + t0.row] = pss[b];

@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemParams p) {
                 const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * kh;
                 if (row < p.M) {
                     const float v0 = acc[a][0][e], v1 = acc[a][1][e];
-                    p.z[(int64_t)row * p.ldz + li] = v0;
-                    p.z[(int64_t)row * p.ldz + 32 + li] = v1;
+                    __builtin_nontemporal_store(v0, p.z + (int64_t)row * p.ldz + li);
+                    __builtin_nontemporal_store(v1, p.z + (int64_t)row * p.ldz + 32 + li);
                     const float u0 = v0 - pv0, u1 = v1 - pv1;
                     s0 += u0; q0 += u0 * u0;
                     s1 += u1; q1 += u1 * u1;

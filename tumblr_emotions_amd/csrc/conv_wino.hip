@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (!(p.flags & 1024))
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[k]), srd_z, ok[k] ? off[k] + cbyte : kOOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[k]), srd_z, ok[k] ? off[k] + cbyte : kOOB, 0, 2 /* nt */);
                 const float u = ok[k] ? y[k] - pv : 0.f;
                 s += u;
                 q += u * u;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (!(p.flags & 1024))
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[k]), srd_z, ok[k] ? off[k] + cbyte : kOOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[k]), srd_z, ok[k] ? off[k] + cbyte : kOOB, 0, 2 /* nt */);
                 if (bns) {
                     const float u = (ok[k] && ycur[k] > 0.f) ? y[k] : 0.f;
                     s += u;

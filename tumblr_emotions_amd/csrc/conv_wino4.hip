@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
             out1d(P[rr][0], P[rr][1], P[rr][2], P[rr][3], P[rr][4], P[rr][5], y[0], y[1], y[2], y[3]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[k]), srd_z, vof[k], rr * orow + k * opix, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[k]), srd_z, vof[k], rr * orow + k * opix, 2 /* nt */);
                 if constexpr (BNS) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
