@@ -465,7 +465,11 @@ int ds_lstm_cell_bwd(const float *acts, const float *c_t, const float *c_prev, c
  *          one row group's hand-off wait covered by work on the others (beside a concurrent kernel that needs
  *          whole CUs).  Scheduling only: every cell's arithmetic and summation order are the same.  With rows = 1
  *          and H <= 512 the launch is XCD-local: the H / 16 workgroups of a row group share one XCD, so the per-step
- *          exchange stays inside its L2 (text-only step at B = 256: 1.67 -> 1.27 ms).
+ *          exchange stays inside its L2 (text-only step at B = 256: 1.67 -> 1.27 ms).  With rows = 1, H = 64 ... 512
+ *          and a batch whose ceil(B / 16) * H / 16 workgroups all fit the device, the row groups are 16 rows
+ *          (v_mfma_f32_16x16x4_f32 instead of 32x32x2: another summation order of the recurrent product, same
+ *          accuracy): a 32-row step is bound by one CU's matrix rate, so a small batch spreads over twice the CUs
+ *          (text-only step at B = 64: 0.89 -> 0.75 ms).
  *   ws     ds_lstm_seq_workspace(B, H) bytes of device scratch, ZEROED ONCE BY THE CALLER: forward and backward
  *          arrival counters (each launch re-zeroes its own) and one sticky error word per direction.
  * Supported: H in {32, 64, 128, 256, 512, 1024} with H / 16 <= the device's compute units (ds_lstm_seq_supported);

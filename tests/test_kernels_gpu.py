@@ -1078,10 +1078,13 @@ def test_lstm_sequence_kernels_match_oracle(case):
     ops.lstm_seq_bwd(gates, ops._p(whd), 4 * H, c, dhd, dhd.stride(0), seqd, T, B, H, dg2, ws)
     torch.cuda.synchronize()
     assert torch.equal(dg, dg2)
-    # `rows`: R row groups per workgroup (fewer, longer workgroups) changes scheduling only: the forward
-    # pass gives the same bits, the backward pass the same values to the last bit or two (hipcc contracts the gate
-    # derivatives' multiply-adds differently in the R > 1 instantiations of the small hidden sizes); a last workgroup
-    # with fewer than R row groups is included
+    # `rows`: R row groups per workgroup (fewer, longer workgroups) changes scheduling only: among the R > 1 launches
+    # the forward pass gives the same bits, the backward pass the same values to the last bit or two (hipcc contracts
+    # the gate derivatives' multiply-adds differently in the R > 1 instantiations of the small hidden sizes); a last
+    # workgroup with fewer than R row groups is included.  Against the rows = 1 launch above the agreement is to
+    # rounding only where that one ran 16-row groups (small batches, H = 64 ... 512: the 16x16x4 MFMA sums the
+    # reduction in another order than the 32x32x2 one).
+    ref = None
     for rows in (2, 4, 8):
         g2, h2, c2 = dev(pre), torch.zeros_like(h), torch.zeros_like(c)
         ops.lstm_seq_fwd(g2, ops._p(whd), 4 * H, h2, c2, seqd, T, B, H, S.FORGET_BIAS, ws, rows=rows)
@@ -1089,8 +1092,13 @@ def test_lstm_sequence_kernels_match_oracle(case):
         ops.lstm_seq_bwd(g2, ops._p(whd), 4 * H, c2, dhd, dhd.stride(0), seqd, T, B, H, dg3, ws, rows=rows)
         torch.cuda.synchronize()
         ops.lstm_seq_status(ws, B)
-        assert torch.equal(h2, h) and torch.equal(c2, c) and torch.equal(g2, gates), rows
-        assert float((dg3 - dg).abs().max()) <= 4e-7 * float(dg.abs().max()), rows
+        if ref is None:
+            ref = (h2, c2, g2, dg3)
+        assert torch.equal(h2, ref[0]) and torch.equal(c2, ref[1]) and torch.equal(g2, ref[2]), rows
+        assert float((dg3 - ref[3]).abs().max()) <= 4e-7 * float(dg.abs().max()), rows
+        for got, want in ((h2, h), (c2, c), (g2, gates)):
+            assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), rows
+        assert float((dg3 - dg).abs().max()) <= 2e-6 * float(dg.abs().max()), rows
 
 
 def test_lstm_sequence_is_reentrant_across_streams_and_row_settings():
@@ -1129,7 +1137,7 @@ def test_lstm_sequence_is_reentrant_across_streams_and_row_settings():
             ops.lstm_seq_status(wss[i], B)
             assert torch.equal(both[i][0], alone[i][0]) and torch.equal(both[i][1], alone[i][1]), (rep, i)
     # sticky, separate error words: poke the forward word, run a backward launch, the status still reports bit 0
-    nrg = (B + 31) // 32
+    nrg = (B + 15) // 16             # the two error words sit behind one counter per 16-row group and direction
     wss[0][2 * nrg] = 1
     run(pres[0], 1, wss[0])
     torch.cuda.synchronize()

@@ -110,16 +110,21 @@ __device__ __forceinline__ void store_sc1(float *p, const float *v) {
 // ================================================================================================
 // forward: H = 8 * NCH * NW; workgroup tile 32 rows x 64 gate columns (16 units x i,j,f,o), K = H split over NW waves
 // ================================================================================================
-template <int NCH, int NW, int R>      // R row groups per workgroup (the `rows` argument)
+// RB = rows of a row group.  32: v_mfma_f32_32x32x2_f32, two 32-column blocks.  16 (small batches, H <= 512): v_mfma_f32_16x16x4_f32,
+// four 16-column blocks -- the step of a 32-row group is bound by ONE CU's matrix rate (32 x 64 x H x 2 flops: 3.4 us at
+// H = 512, scripts/lstm_phase_prof.py: 6.1 of an 8.6 us step are fragment loads + MFMAs); with 16-row groups a batch that
+// leaves CUs idle spreads over twice as many of them and every workgroup's loads and MFMAs halve.
+template <int NCH, int NW, int R, int RB = 32>      // R row groups per workgroup (the `rows` argument)
 __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const SeqParams p) {
     constexpr int H = 8 * NCH * NW, KQ = 8 * NCH;
-    constexpr int UPT = 8 / NW;                    // hidden units per thread in the cell phase (512 cells / threads)
+    constexpr int UPT = RB * 16 / (64 * NW);       // hidden units per thread in the cell phase (RB x 16 cells / threads)
+    static_assert(UPT >= 1, "16-row groups need four waves");
     constexpr int LDR = 68;                        // padded row of the reduction buffer
-    __shared__ __attribute__((aligned(16))) float red[NW * 32 * LDR];
+    __shared__ __attribute__((aligned(16))) float red[NW * RB * LDR];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, kh = lane >> 5;
+    const int li = RB == 32 ? lane & 31 : lane & 15, kh = RB == 32 ? lane >> 5 : lane >> 4;     // RB = 16: kh = k quarter
     int cg, yb;
     if (!wg_coords(p, cg, yb)) return;                  // (uniform) surplus workgroup of the XCD-local launch
     const int rg0 = yb * R;
@@ -129,16 +134,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
     unsigned *err = p.err;
 
     // ---- this wave's slice of Wh as MFMA B fragments: column c64 = 16 g + u  <->  Wh column g H + u0 + u ------
-    float bfr[2][NCH][4];
+    // RB = 32: bfr[cb][q][j] = Wh[wave KQ + 8 q + 4 kh + j][column 32 cb + li]      (q < NCH, two column blocks)
+    // RB = 16: bfr[cb][q][j] = Wh[wave KQ + 16 q + 4 kh + j][column 16 cb + li]     (q < NCH / 2, four column blocks)
+    constexpr int NCB = RB == 32 ? 2 : 4, NQ = RB == 32 ? NCH : NCH / 2;
+    float bfr[NCB][NQ][4];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int c64 = 32 * cb + li;
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int c64 = (RB == 32 ? 32 : 16) * cb + li;
         const int col = (c64 >> 4) * H + u0 + (c64 & 15);
 #pragma unroll
-        for (int q = 0; q < NCH; ++q)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                bfr[cb][q][j] = p.wh[(int64_t)(wave * KQ + 8 * q + 4 * kh + j) * p.ldw + col];
+                bfr[cb][q][j] = p.wh[(int64_t)(wave * KQ + (RB == 32 ? 8 : 16) * q + 4 * kh + j) * p.ldw + col];
     }
 
     // ---- cell ownership: thread -> (row, UPT consecutive units), for each of the R row groups ----------------
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
     float cst[R][UPT], hst[R][UPT];
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
-        const int r0 = (rg0 + rr) * 32;
+        const int r0 = (rg0 + rr) * RB;
         grow[rr] = r0 + crow;
         valid[rr] = grow[rr] < B;
         sl[rr] = valid[rr] ? p.seq_len[grow[rr]] : 0;
@@ -184,29 +192,47 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
             }
             if (rr == 0) DS_STAMP(1);
             // ---- A fragments straight from h[t] (sc1: past the L1, which other CUs' stores never refresh) --------
-            f32x4 a[NCH];
+            f32x4 a[NQ];
             const unsigned abase = (unsigned)((((int64_t)t * B + arow[rr]) * H + wave * KQ + 4 * kh) * 4);
 #pragma unroll
-            for (int q = 0; q < NCH; ++q)
-                a[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_h, abase + 32u * q, 0, kSC1));
-            f32x16 acc[2];
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
-#pragma unroll
-            for (int q = 0; q < NCH; ++q)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
-                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], bfr[cb][q][j], acc[cb], 0, 0, 0);
+            for (int q = 0; q < NQ; ++q)
+                a[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_h, abase + (RB == 32 ? 32u : 64u) * q, 0, kSC1));
             // ---- K slices of the NW waves -> LDS, summed in wave order by the cell threads ------------------------
+            if constexpr (RB == 32) {
+                f32x16 acc[2];
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * LDR + 32 * cb + li] = acc[cb][r];
+                    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+                            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], bfr[cb][q][j], acc[cb], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * LDR + 32 * cb + li] = acc[cb][r];
+            } else {
+                f32x4 acc[4];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb)
+                            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][j], bfr[cb][q][j], acc[cb], 0, 0, 0);
+                // C layout of the 16x16 MFMA: lane (li, kh) holds rows 4 kh .. 4 kh + 3 of column li
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * kh + r) * LDR + 16 * cb + li] = acc[cb][r];
+            }
             if (rr == 0) DS_STAMP(2);
             __syncthreads();
             if (rr == 0) DS_STAMP(3);
@@ -217,7 +243,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
-                        for (int e = 0; e < UPT; ++e) gp[k][e] += red[(w * 32 + crow) * LDR + 16 * k + cu + e];
+                        for (int e = 0; e < UPT; ++e) gp[k][e] += red[(w * RB + crow) * LDR + 16 * k + cu + e];
                 const bool live = (int64_t)t < sl[rr];
 #pragma unroll
                 for (int e = 0; e < UPT; ++e) {
@@ -256,13 +282,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
 // ================================================================================================
 // backward: d(h_t)[rows, own 16 units] = carried part + dgates_{t+1}[rows, :] * Wh[own units, :]^T  (K = 4H)
 // ================================================================================================
-template <int NQ, int NW, int R>       // 4H = 16 * NQ * NW; R row groups per workgroup
+template <int NQ, int NW, int R, int RB = 32>       // 4H = 16 * NQ * NW; R row groups of RB = 32 / 16 rows per workgroup
 __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const SeqParams p) {
     constexpr int H4 = 16 * NQ * NW, H = H4 / 4, KQ = 16 * NQ;
-    constexpr int UPT = 8 / NW;
+    constexpr int UPT = RB * 16 / (64 * NW);
+    static_assert(UPT >= 1, "16-row groups need four waves");
+    constexpr int NRB = RB / 16;                            // 16-row blocks of the 16x16x4 MFMA
     constexpr int GQ = NQ < 8 ? NQ : (NW == 8 ? 4 : 8);     // A chunks in flight per register group
     constexpr int LDR = 20;
-    __shared__ __attribute__((aligned(16))) float red[NW * 32 * LDR];
+    __shared__ __attribute__((aligned(16))) float red[NW * RB * LDR];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -282,13 +310,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
         bfr[q] = *reinterpret_cast<const f32x4 *>(p.wh + (int64_t)(u0 + li) * p.ldw + wave * KQ + 16 * q + 4 * kb);
 
     const int crow = tid / (16 / UPT), cu = (tid % (16 / UPT)) * UPT;
-    int grow[R], arow[R][2];
+    int grow[R], arow[R][NRB];
     bool valid[R];
     int64_t sl[R];
     float dcs[R][UPT], dhc[R][UPT];
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
-        const int r0 = (rg0 + rr) * 32;
+        const int r0 = (rg0 + rr) * RB;
         grow[rr] = r0 + crow;
         valid[rr] = grow[rr] < B;
         sl[rr] = valid[rr] ? p.seq_len[grow[rr]] : 0;
@@ -298,7 +326,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
             dhc[rr][e] = valid[rr] ? p.dh_last[(int64_t)grow[rr] * p.ld_dh + u0 + cu + e] : 0.f;      // gradient of h[T]
         }
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) arow[rr][rb] = (r0 + 16 * rb + li < B) ? r0 + 16 * rb + li : B - 1;
+        for (int rb = 0; rb < NRB; ++rb) arow[rr][rb] = (r0 + 16 * rb + li < B) ? r0 + 16 * rb + li : B - 1;
     }
 
     const __amdgpu_buffer_rsrc_t srd_g = srd_of(p.dgates, (unsigned)((int64_t)T * B * H4 * 4));
@@ -328,19 +356,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
             if (t < T - 1) {
                 if (tid == 0) wait_counter(cnt, (unsigned)(T - 1 - t) * ncg, err);
                 __syncthreads();
-                f32x4 acc[2];
+                f32x4 acc[NRB];
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                unsigned abase[2];
+                for (int rb = 0; rb < NRB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                unsigned abase[NRB];
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < NRB; ++rb)
                     abase[rb] = (unsigned)((((int64_t)(t + 1) * B + arow[rr][rb]) * H4 + wave * KQ + 4 * kb) * 4);
-                f32x4 a[2][2][GQ];                              // [buffer][row block][chunk]
+                f32x4 a[2][NRB][GQ];                            // [buffer][row block][chunk]
                 auto load_group = [&](int buf, int g0) {
 #pragma unroll
                     for (int q = 0; q < GQ; ++q)
 #pragma unroll
-                        for (int rb = 0; rb < 2; ++rb)
+                        for (int rb = 0; rb < NRB; ++rb)
                             a[buf][rb][q] = __builtin_bit_cast(
                                 f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_g, abase[rb] + 64u * (g0 + q), 0, kSC1));
                 };
@@ -353,20 +381,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int rb = 0; rb < 2; ++rb)
+                            for (int rb = 0; rb < NRB; ++rb)
                                 acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g & 1][rb][q][j], bfr[g * GQ + q][j], acc[rb],
                                                                                0, 0, 0);
                 }
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) red[(wave * 32 + 16 * rb + 4 * kb + r) * LDR + li] = acc[rb][r];
+                    for (int r = 0; r < 4; ++r) red[(wave * RB + 16 * rb + 4 * kb + r) * LDR + li] = acc[rb][r];
                 __syncthreads();
                 if (valid[rr]) {
 #pragma unroll
                     for (int w = 0; w < NW; ++w)
 #pragma unroll
-                        for (int e = 0; e < UPT; ++e) rec[e] += red[(w * 32 + crow) * LDR + cu + e];
+                        for (int e = 0; e < UPT; ++e) rec[e] += red[(w * RB + crow) * LDR + cu + e];
                 }
             }
             if (valid[rr]) {
@@ -415,25 +443,36 @@ struct SeqCfg {
 // beside them.  R > 1: a workgroup walks R row groups per time step with the same register-resident Wh slice; the
 // hand-off wait of one row group is covered by the work on the others and the launch occupies 1/R of the CUs.
 
-template <int R>
+template <int R, int RB>
 bool seq_cfg_r(int H, SeqCfg *c) {
     switch (H) {
-        case 32: *c = {lstm_seq_fwd_kernel<1, 4, R>, lstm_seq_bwd_kernel<2, 4, R>, 4}; return true;
-        case 64: *c = {lstm_seq_fwd_kernel<2, 4, R>, lstm_seq_bwd_kernel<4, 4, R>, 4}; return true;
-        case 128: *c = {lstm_seq_fwd_kernel<4, 4, R>, lstm_seq_bwd_kernel<8, 4, R>, 4}; return true;
-        case 256: *c = {lstm_seq_fwd_kernel<8, 4, R>, lstm_seq_bwd_kernel<16, 4, R>, 4}; return true;
-        case 512: *c = {lstm_seq_fwd_kernel<16, 4, R>, lstm_seq_bwd_kernel<32, 4, R>, 4}; return true;
-        case 1024: *c = {lstm_seq_fwd_kernel<16, 8, R>, lstm_seq_bwd_kernel<32, 8, R>, 8}; return true;
+        case 32:            // (one 8-channel K chunk per wave: no 16-channel chunk for the 16x16x4 form)
+            if constexpr (RB == 32) {
+                *c = {lstm_seq_fwd_kernel<1, 4, R, 32>, lstm_seq_bwd_kernel<2, 4, R, 32>, 4};
+                return true;
+            }
+            return false;
+        case 64: *c = {lstm_seq_fwd_kernel<2, 4, R, RB>, lstm_seq_bwd_kernel<4, 4, R, RB>, 4}; return true;
+        case 128: *c = {lstm_seq_fwd_kernel<4, 4, R, RB>, lstm_seq_bwd_kernel<8, 4, R, RB>, 4}; return true;
+        case 256: *c = {lstm_seq_fwd_kernel<8, 4, R, RB>, lstm_seq_bwd_kernel<16, 4, R, RB>, 4}; return true;
+        case 512: *c = {lstm_seq_fwd_kernel<16, 4, R, RB>, lstm_seq_bwd_kernel<32, 4, R, RB>, 4}; return true;
+        case 1024:
+            if constexpr (RB == 32) {
+                *c = {lstm_seq_fwd_kernel<16, 8, R, 32>, lstm_seq_bwd_kernel<32, 8, R, 32>, 8};
+                return true;
+            }
+            return false;
         default: return false;
     }
 }
 
-bool seq_cfg(int H, SeqCfg *c, int rows = 1) {
+bool seq_cfg(int H, SeqCfg *c, int rows = 1, int rb = 32) {
+    if (rb == 16) return H >= 64 && seq_cfg_r<1, 16>(H, c);        // (16-row groups: rows = 1 only; H = 32 has NQ / NCH too small)
     switch (rows) {
-        case 2: return seq_cfg_r<2>(H, c);
-        case 4: return seq_cfg_r<4>(H, c);
-        case 8: return seq_cfg_r<8>(H, c);
-        default: return seq_cfg_r<1>(H, c);
+        case 2: return seq_cfg_r<2, 32>(H, c);
+        case 4: return seq_cfg_r<4, 32>(H, c);
+        case 8: return seq_cfg_r<8, 32>(H, c);
+        default: return seq_cfg_r<1, 32>(H, c);
     }
 }
 
@@ -465,17 +504,35 @@ int device_cus() {
 // late, and the whole row group waits for its slowest member (measured: ~3.5 us of a 15 us step was this skew).
 // Residency is limited through the LDS request: static reduction buffer + this dynamic pad > half of 160 KiB.
 // DS_LSTM_SHARED_CU=1 switches the pad off (A/B aid).
-size_t exclusive_lds(int nw, bool fwd) {
+size_t exclusive_lds(int nw, bool fwd, int rb = 32) {
     static int shared_cu = -1;
     if (shared_cu < 0) {
         const char *e = getenv("DS_LSTM_SHARED_CU");
         shared_cu = e ? atoi(e) : 0;
     }
     if (shared_cu) return 0;
-    const size_t stat = (size_t)nw * 32 * (fwd ? 68 : 20) * 4;
+    const size_t stat = (size_t)nw * rb * (fwd ? 68 : 20) * 4;
     const size_t want = 84 * 1024;
     return stat >= want ? 0 : want - stat;
 }
+
+// Rows per row group: 16 where the batch leaves CUs idle (rows = 1, H = 64 ... 512, and all ceil(B / 16) * H / 16 workgroups
+// resident at one per CU), else 32.  DS_LSTM_RB = 16 / 32 forces it (A/B aid; 16 only where the kernels exist).
+int pick_rb(int B, int H, int rows) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = getenv("DS_LSTM_RB");
+        forced = e ? atoi(e) : 0;
+    }
+    const bool can16 = rows == 1 && H >= 64 && H <= 512;
+    if (!can16 || forced == 32) return 32;
+    if (forced == 16) return 16;
+    return ((B + 15) / 16) * (H / 16) <= device_cus() ? 16 : 32;
+}
+
+// workspace words: G = ceil(B / 16) arrival counters per direction (a launch with 32-row groups uses the first half of
+// its G), then the forward and the backward error word
+inline int ws_groups(int B) { return (B + 15) / 16; }
 
 // launch geometry: XCD-local 1-D grid when a row group's H / 16 workgroups fit one XCD (32 CUs, one workgroup each);
 // DS_LSTM_XCD=0 switches back to the 2-D grid (A/B aid)
@@ -521,13 +578,13 @@ extern "C" int ds_lstm_seq_supported(int32_t B, int32_t H) {
     return B > 0 && seq_cfg(H, &c) && H / 16 <= device_cus() ? 1 : 0;
 }
 
-// workspace words: [0, nrg) forward arrival counters, [nrg, 2 nrg) backward arrival counters, then the forward and
-// the backward error word.  A launch re-zeroes ITS counters only; the error words are sticky until the caller
-// clears the workspace (it is zero-initialised once by the caller).
+// workspace words: [0, G) forward arrival counters, [G, 2 G) backward arrival counters (G = ceil(B / 16): one per 16-row
+// group; launches with 32-row groups use the first half), then the forward and the backward error word.  A launch
+// re-zeroes ITS counters only; the error words are sticky until ds_lstm_seq_status reports them (the workspace is
+// zero-initialised once by the caller).
 extern "C" size_t ds_lstm_seq_workspace(int32_t B, int32_t H) {
     (void)H;
-    const int nrg = (B + 31) / 32;
-    return (size_t)(2 * nrg + 2 + 3) / 4 * 16;
+    return (size_t)(2 * ws_groups(B) + 2 + 3) / 4 * 16;
 }
 
 extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float *h, float *c, const int64_t *seq_len,
@@ -537,20 +594,21 @@ extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float
     DS_REQUIRE(c && seq_len, "ds_lstm_seq_fwd: null argument");
     SeqCfg cfg;
     const int rows = rows_for(rows_arg, (B + 31) / 32);
-    seq_cfg(H, &cfg, rows);
+    const int rb = pick_rb(B, H, rows);
+    seq_cfg(H, &cfg, rows, rb);
     SeqParams p = {};
     p.gates = gates; p.wh = wh; p.ldw = ldw; p.h = h; p.c = c; p.seq_len = seq_len;
     p.T = T; p.B = B; p.H = H; p.forget_bias = forget_bias;
-    p.nrg = (B + 31) / 32;
+    p.nrg = (B + rb - 1) / rb;
     p.sync = (unsigned *)ws;
-    p.err = (unsigned *)ws + 2 * p.nrg;
+    p.err = (unsigned *)ws + 2 * ws_groups(B);
     p.prof = g_prof;
     // every polled word is re-initialised by a memset node in front of the launch (Guideline 16); the error words
     // are left alone
     if (hipMemsetAsync(p.sync, 0, (size_t)p.nrg * sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
         return ds::check_launch("ds_lstm_seq_fwd(memset)");
     const dim3 grid = seq_grid(p, H, rows);
-    hipLaunchKernelGGL(cfg.fwd, grid, dim3(64 * cfg.nw), exclusive_lds(cfg.nw, true), (hipStream_t)stream, p);
+    hipLaunchKernelGGL(cfg.fwd, grid, dim3(64 * cfg.nw), exclusive_lds(cfg.nw, true, rb), (hipStream_t)stream, p);
     return ds::check_launch("ds_lstm_seq_fwd");
 }
 
@@ -561,18 +619,19 @@ extern "C" int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, 
     DS_REQUIRE(dh_last && seq_len && dgates && ld_dh >= H, "ds_lstm_seq_bwd: bad argument");
     SeqCfg cfg;
     const int rows = rows_for(rows_arg, (B + 31) / 32);
-    seq_cfg(H, &cfg, rows);
+    const int rb = pick_rb(B, H, rows);
+    seq_cfg(H, &cfg, rows, rb);
     SeqParams p = {};
     p.gates = const_cast<float *>(acts); p.wh = wh; p.ldw = ldw; p.c = const_cast<float *>(c);
     p.dh_last = dh_last; p.ld_dh = ld_dh; p.dgates = dgates; p.seq_len = seq_len;
     p.T = T; p.B = B; p.H = H;
-    p.nrg = (B + 31) / 32;
-    p.sync = (unsigned *)ws + p.nrg;
-    p.err = (unsigned *)ws + 2 * p.nrg + 1;
+    p.nrg = (B + rb - 1) / rb;
+    p.sync = (unsigned *)ws + ws_groups(B);
+    p.err = (unsigned *)ws + 2 * ws_groups(B) + 1;
     if (hipMemsetAsync(p.sync, 0, (size_t)p.nrg * sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
         return ds::check_launch("ds_lstm_seq_bwd(memset)");
     const dim3 grid = seq_grid(p, H, rows);
-    hipLaunchKernelGGL(cfg.bwd, grid, dim3(64 * cfg.nw), exclusive_lds(cfg.nw, false), (hipStream_t)stream, p);
+    hipLaunchKernelGGL(cfg.bwd, grid, dim3(64 * cfg.nw), exclusive_lds(cfg.nw, false, rb), (hipStream_t)stream, p);
     return ds::check_launch("ds_lstm_seq_bwd");
 }
 
@@ -582,8 +641,7 @@ extern "C" int ds_lstm_seq_status(void *ws, int32_t B) {
     // same in a backward launch; the results of the launches since the last call are invalid.  The words are sticky
     // across launches and CLEARED by this call once reported, so a later, healthy step is not blamed for an old one.
     unsigned v[2] = {0, 0};
-    const int nrg = (B + 31) / 32;
-    unsigned *err = (unsigned *)ws + 2 * nrg;
+    unsigned *err = (unsigned *)ws + 2 * ws_groups(B);
     if (hipMemcpy(v, err, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return DS_ERR_LAUNCH;
     if ((v[0] | v[1]) && hipMemset(err, 0, sizeof(v)) != hipSuccess) return DS_ERR_LAUNCH;
     return (int)((v[0] ? 1u : 0u) | (v[1] ? 2u : 0u));
