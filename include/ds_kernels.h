@@ -493,6 +493,7 @@ int ds_lstm_seq_status(void *ws, int32_t B);
 /* Debug aid (process-global, never called by the product path): device buffer of T*8 uint64; workgroup (0,0) of the
  * following ds_lstm_seq_fwd launches stamps s_memtime at its phase boundaries (scripts/lstm_phase_prof.py).  NULL = off. */
 int ds_debug_lstm_seq_set_profile(void *buf);
+int ds_debug_lstm_seq_set_profile_bwd(void *buf);      /* the same for the ds_lstm_seq_bwd launches (row t = time step t) */
 
 /* slim.losses.softmax_cross_entropy + its gradient (im_text_rnn_model.py:124-125):
  * loss[0] = mean_b(logsumexp(z_b) - z_b[y_b]); dlogits = (softmax - onehot) * grad_scale / B;

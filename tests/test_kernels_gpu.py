@@ -1137,7 +1137,7 @@ def test_lstm_sequence_is_reentrant_across_streams_and_row_settings():
             ops.lstm_seq_status(wss[i], B)
             assert torch.equal(both[i][0], alone[i][0]) and torch.equal(both[i][1], alone[i][1]), (rep, i)
     # sticky, separate error words: poke the forward word, run a backward launch, the status still reports bit 0
-    nrg = (B + 15) // 16             # the two error words sit behind one counter per 16-row group and direction
+    nrg = 65 * ((B + 15) // 16)      # the two error words sit behind the two directions' blocks of 65 * ceil(B / 16) words each
     wss[0][2 * nrg] = 1
     run(pres[0], 1, wss[0])
     torch.cuda.synchronize()

@@ -146,6 +146,7 @@ SIGNATURES = {
     "ds_lstm_seq_bwd": (C.c_int, [_P, _P, _i32, _P, _P, _i32, _P, _i32, _i32, _i32, _P, _i32, _P, C.c_size_t, _P]),
     "ds_lstm_seq_status": (C.c_int, [_P, _i32]),
     "ds_debug_lstm_seq_set_profile": (C.c_int, [_P]),
+    "ds_debug_lstm_seq_set_profile_bwd": (C.c_int, [_P]),
     "ds_softmax_ce": (C.c_int, [_P, _P, _i32, _i32, _f32, _P, _P, _P, _P]),
     "ds_adam_tf": (C.c_int, [_P, _P, _P, _P, _i64, _i64, _f32, _f32, _f32, _P, _f32, _f32, _f32, _P]),
     "ds_sumsq": (C.c_int, [_P, _i64, _P, _P, _P]),

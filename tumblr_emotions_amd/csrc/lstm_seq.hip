@@ -45,6 +45,8 @@ struct SeqParams {
     int T, B, H;
     float forget_bias;
     unsigned *sync;            // this direction's [row groups] arrival counters
+    unsigned *xcc;             // this direction's [row groups][64] placement words (group_on_one_xcd), zeroed per launch
+    float *xchg;               // bwd: two-slot exchange ring in fragment order, 2 x B' x 4H floats (B' = B rounded up to the row groups)
     unsigned *err;             // this direction's error word (sticky: launches never clear it)
     int nrg;
     int ncg, nrgw;             // unit blocks (H / 16); workgroup rows (ceil(nrg / R))
@@ -104,6 +106,51 @@ __device__ __forceinline__ void store_sc1(float *p, const float *v) {
     } else {
         __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v[0]), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Do all `ncg` workgroups of a row group run on ONE XCD?  Then the per-step payload can stay in that XCD's L2: plain
+// stores keep their lines there (an sc1 store writes through AND drops the line: the readers then fetch at the cross-XCD
+// rate, MI355X_MICROARCH.md hand-off table -- 128 KB per workgroup and step took 8.8 of the backward step's 10.8 us),
+// `s_waitcnt vmcnt(0)` = acknowledged by the L2, and the readers' sc1 loads bypass only their L1.  The launch geometry
+// aims at that placement (wg_coords) but nothing guarantees it, so it is MEASURED: every workgroup publishes its XCC id
+// and reads the others' (write-through words, bounded spin).  All members read the same table, so they take the same
+// decision; a row group that is spread over XCDs keeps the write-through payload.  Called by all threads.
+__device__ __forceinline__ bool group_on_one_xcd(unsigned *tab, int cg, int ncg, unsigned *err) {
+    __shared__ int verdict;
+    unsigned me;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(me));
+    me = (me & 15u) + 1u;
+    const int tid = threadIdx.x;
+    if (tid == 0) __hip_atomic_store(tab + cg, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+        bool same = true;
+        if (tid < ncg) {
+            unsigned v = 0, spins = 0;
+            while ((v = __hip_atomic_load(tab + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kSpinLimit) {
+                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            same = v == me;
+        }
+        const bool all_same = __all(same);
+        if (tid == 0) verdict = all_same ? 1 : 0;
+    }
+    __syncthreads();
+    return verdict != 0;
+}
+
+// the hand-off payload: write-through, or plain when the row group shares an L2 (group_on_one_xcd)
+template <int N>
+__device__ __forceinline__ void store_payload(float *p, const float *v, bool l2_local) {
+    if (l2_local) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) p[e] = v[e];
+    } else {
+        store_sc1<N>(p, v);
     }
 }
 
@@ -170,6 +217,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
     }
 
     const __amdgpu_buffer_rsrc_t srd_h = srd_of(p.h, (unsigned)((int64_t)(T + 1) * B * H * 4));
+    bool l2_local = false;                              // (uniform over the row group)
+    if (R == 1 && p.xcd_map && ncg <= 64) l2_local = group_on_one_xcd(p.xcc + rg0 * 64, cg, ncg, err);
 
     for (int t = 0; t < T; ++t) {
 #pragma unroll
@@ -256,7 +305,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
                     hst[rr][e] = hn[e] = live ? h_new : hst[rr][e];
                 }
                 const int64_t o = ((int64_t)(t + 1) * B + grow[rr]) * H + u0 + cu;
-                store_sc1<UPT>(p.h + o, hn);                     // the hand-off payload goes first ...
+                store_payload<UPT>(p.h + o, hn, l2_local);       // the hand-off payload goes first ...
             }
             if (rr == 0) DS_STAMP(4);
             // ---- publish: every storing wave drains, then one lane counts this workgroup in ----------------------
@@ -330,6 +379,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
     }
 
     const __amdgpu_buffer_rsrc_t srd_g = srd_of(p.dgates, (unsigned)((int64_t)T * B * H4 * 4));
+    bool l2_local = false;                              // (uniform over the row group)
+    if (R == 1 && p.xcd_map && ncg <= 64) l2_local = group_on_one_xcd(p.xcc + rg0 * 64, cg, ncg, err);
+    // l2_local: the exchange goes through a two-slot ring in FRAGMENT order, X[t & 1][row group][k / 4][row][4]: lane
+    // (li, kb)'s 16-byte A chunk of K quad 4 q + kb sits next to its neighbours', so a wave's load instruction reads 1 KB of
+    // consecutive bytes -- out of the [B, 4H] tensor it touched sixteen half-used lines of sixteen rows, and the 128 KB a
+    // workgroup reads per step took 9 of the step's 11 us.  Slot parity is safe: a workgroup writes X[t - 1] only after
+    // every member has published step t, i.e. after they have all read X[t + 1].  dgates itself is still written for the
+    // weight-gradient GEMMs, behind the publish.
+    const __amdgpu_buffer_rsrc_t srd_x = srd_of(p.xchg, (unsigned)((int64_t)2 * p.nrg * RB * H4 * 4));
+    constexpr unsigned kSlot = (unsigned)(H4 / 4) * RB * 16u;          // bytes of one row group's slot
 
     for (int t = T - 1; t >= 0; --t) {
 #pragma unroll
@@ -353,16 +412,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
                 a_ct[e] = valid[rr] ? p.c[ci + e] : 0.f;
                 a_cp[e] = valid[rr] ? p.c[ci - (int64_t)B * H + e] : 0.f;
             }
+            if (rr == 0) DS_STAMP(0);
             if (t < T - 1) {
                 if (tid == 0) wait_counter(cnt, (unsigned)(T - 1 - t) * ncg, err);
                 __syncthreads();
+                if (rr == 0) DS_STAMP(1);
                 f32x4 acc[NRB];
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
                 unsigned abase[NRB];
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
-                    abase[rb] = (unsigned)((((int64_t)(t + 1) * B + arow[rr][rb]) * H4 + wave * KQ + 4 * kb) * 4);
+                    abase[rb] = l2_local ? ((unsigned)((t + 1) & 1) * (unsigned)p.nrg + (unsigned)(rg0 + rr)) * kSlot +
+                                               (unsigned)(((wave * (KQ / 4) + kb) * RB + 16 * rb + li) * 16)
+                                         : (unsigned)((((int64_t)(t + 1) * B + arow[rr][rb]) * H4 + wave * KQ + 4 * kb) * 4);
+                const unsigned qstep = l2_local ? 4u * RB * 16u : 64u;       // bytes between 16-channel chunks
                 f32x4 a[2][NRB][GQ];                            // [buffer][row block][chunk]
                 auto load_group = [&](int buf, int g0) {
 #pragma unroll
@@ -370,7 +434,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
 #pragma unroll
                         for (int rb = 0; rb < NRB; ++rb)
                             a[buf][rb][q] = __builtin_bit_cast(
-                                f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_g, abase[rb] + 64u * (g0 + q), 0, kSC1));
+                                f32x4, l2_local ? __builtin_amdgcn_raw_buffer_load_b128(srd_x, abase[rb] + qstep * (g0 + q), 0, kSC1)
+                                                : __builtin_amdgcn_raw_buffer_load_b128(srd_g, abase[rb] + qstep * (g0 + q), 0, kSC1));
                 };
                 load_group(0, 0);
 #pragma unroll
@@ -389,7 +454,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
                 for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) red[(wave * RB + 16 * rb + 4 * kb + r) * LDR + li] = acc[rb][r];
+                if (rr == 0) DS_STAMP(2);
                 __syncthreads();
+                if (rr == 0) DS_STAMP(3);
                 if (valid[rr]) {
 #pragma unroll
                     for (int w = 0; w < NW; ++w)
@@ -397,9 +464,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
                         for (int e = 0; e < UPT; ++e) rec[e] += red[(w * RB + crow) * LDR + cu + e];
                 }
             }
+            float dg[4][UPT];
             if (valid[rr]) {
                 const bool live = (int64_t)t < sl[rr];
-                float dg[4][UPT];
 #pragma unroll
                 for (int e = 0; e < UPT; ++e) {
                     const float dhv = dhc[rr][e] + rec[e];
@@ -419,18 +486,38 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
                         dhc[rr][e] = dhv;
                     }
                 }
+                if (l2_local) {         // the hand-off payload, in fragment order
+                    float *xs = p.xchg + ((int64_t)((t & 1) * p.nrg + rg0 + rr) * (H4 / 4) * RB) * 4;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) store_sc1<UPT>(p.dgates + gi + k * H, dg[k]);
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int e = 0; e < UPT; ++e) {
+                            const int col = k * H + u0 + cu + e;
+                            xs[((col >> 2) * RB + crow) * 4 + (col & 3)] = dg[k][e];
+                        }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) store_sc1<UPT>(p.dgates + gi + k * H, dg[k]);
+                }
             }
+            if (rr == 0) DS_STAMP(4);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (rr == 0) DS_STAMP(5);
             __syncthreads();
             if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rr == 0) DS_STAMP(6);
+            if (l2_local && valid[rr]) {        // ... and dgates for the kernels behind this one, off the hand-off's path
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < UPT; ++e) p.dgates[gi + k * H + e] = dg[k][e];
+            }
         }
     }
 }
 
 typedef void (*SeqFn)(const SeqParams);
-unsigned long long *g_prof = nullptr;
+unsigned long long *g_prof = nullptr, *g_prof_bwd = nullptr;
 
 struct SeqCfg {
     SeqFn fwd, bwd;
@@ -530,9 +617,14 @@ int pick_rb(int B, int H, int rows) {
     return ((B + 15) / 16) * (H / 16) <= device_cus() ? 16 : 32;
 }
 
-// workspace words: G = ceil(B / 16) arrival counters per direction (a launch with 32-row groups uses the first half of
-// its G), then the forward and the backward error word
+// workspace words: per direction a block of G = ceil(B / 16) arrival counters (a launch with 32-row groups uses the first
+// half) and G x 64 placement words (group_on_one_xcd); behind the two blocks the forward and the backward error word
 inline int ws_groups(int B) { return (B + 15) / 16; }
+// words of one direction's block: G arrival counters + G x 64 placement words (re-zeroed by every launch of that direction)
+inline size_t dir_words(int B) { return (size_t)ws_groups(B) * 65; }
+inline size_t ctl_bytes(int B) { return (2 * dir_words(B) + 2 + 63) / 64 * 256; }          // control words, 256-byte aligned
+// the backward launch's exchange ring (two slots of dgates_t in fragment order; rows rounded up to 32)
+inline size_t ring_bytes(int B, int H) { return (size_t)2 * ((B + 31) / 32 * 32) * 4 * H * sizeof(float); }
 
 // launch geometry: XCD-local 1-D grid when a row group's H / 16 workgroups fit one XCD (32 CUs, one workgroup each);
 // DS_LSTM_XCD=0 switches back to the 2-D grid (A/B aid)
@@ -578,13 +670,13 @@ extern "C" int ds_lstm_seq_supported(int32_t B, int32_t H) {
     return B > 0 && seq_cfg(H, &c) && H / 16 <= device_cus() ? 1 : 0;
 }
 
-// workspace words: [0, G) forward arrival counters, [G, 2 G) backward arrival counters (G = ceil(B / 16): one per 16-row
-// group; launches with 32-row groups use the first half), then the forward and the backward error word.  A launch
-// re-zeroes ITS counters only; the error words are sticky until ds_lstm_seq_status reports them (the workspace is
+// workspace: [forward block][backward block][forward error word][backward error word]; a block = G arrival counters
+// (G = ceil(B / 16): one per 16-row group; launches with 32-row groups use the first half) + G x 64 placement words.  A
+// launch re-zeroes ITS block only; the error words are sticky until ds_lstm_seq_status reports them (the workspace is
 // zero-initialised once by the caller).
 extern "C" size_t ds_lstm_seq_workspace(int32_t B, int32_t H) {
     (void)H;
-    return (size_t)(2 * ws_groups(B) + 2 + 3) / 4 * 16;
+    return ctl_bytes(B) + ring_bytes(B, H);
 }
 
 extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float *h, float *c, const int64_t *seq_len,
@@ -601,11 +693,12 @@ extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float
     p.T = T; p.B = B; p.H = H; p.forget_bias = forget_bias;
     p.nrg = (B + rb - 1) / rb;
     p.sync = (unsigned *)ws;
-    p.err = (unsigned *)ws + 2 * ws_groups(B);
+    p.xcc = p.sync + ws_groups(B);
+    p.err = (unsigned *)ws + 2 * dir_words(B);
     p.prof = g_prof;
     // every polled word is re-initialised by a memset node in front of the launch (Guideline 16); the error words
     // are left alone
-    if (hipMemsetAsync(p.sync, 0, (size_t)p.nrg * sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
+    if (hipMemsetAsync(p.sync, 0, dir_words(B) * sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
         return ds::check_launch("ds_lstm_seq_fwd(memset)");
     const dim3 grid = seq_grid(p, H, rows);
     hipLaunchKernelGGL(cfg.fwd, grid, dim3(64 * cfg.nw), exclusive_lds(cfg.nw, true, rb), (hipStream_t)stream, p);
@@ -626,9 +719,12 @@ extern "C" int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, 
     p.dh_last = dh_last; p.ld_dh = ld_dh; p.dgates = dgates; p.seq_len = seq_len;
     p.T = T; p.B = B; p.H = H;
     p.nrg = (B + rb - 1) / rb;
-    p.sync = (unsigned *)ws + ws_groups(B);
-    p.err = (unsigned *)ws + 2 * ws_groups(B) + 1;
-    if (hipMemsetAsync(p.sync, 0, (size_t)p.nrg * sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
+    p.sync = (unsigned *)ws + dir_words(B);
+    p.xcc = p.sync + ws_groups(B);
+    p.err = (unsigned *)ws + 2 * dir_words(B) + 1;
+    p.xchg = reinterpret_cast<float *>((char *)ws + ctl_bytes(B));
+    p.prof = g_prof_bwd;
+    if (hipMemsetAsync(p.sync, 0, dir_words(B) * sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
         return ds::check_launch("ds_lstm_seq_bwd(memset)");
     const dim3 grid = seq_grid(p, H, rows);
     hipLaunchKernelGGL(cfg.bwd, grid, dim3(64 * cfg.nw), exclusive_lds(cfg.nw, false, rb), (hipStream_t)stream, p);
@@ -641,7 +737,7 @@ extern "C" int ds_lstm_seq_status(void *ws, int32_t B) {
     // same in a backward launch; the results of the launches since the last call are invalid.  The words are sticky
     // across launches and CLEARED by this call once reported, so a later, healthy step is not blamed for an old one.
     unsigned v[2] = {0, 0};
-    unsigned *err = (unsigned *)ws + 2 * ws_groups(B);
+    unsigned *err = (unsigned *)ws + 2 * dir_words(B);
     if (hipMemcpy(v, err, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return DS_ERR_LAUNCH;
     if ((v[0] | v[1]) && hipMemset(err, 0, sizeof(v)) != hipSuccess) return DS_ERR_LAUNCH;
     return (int)((v[0] ? 1u : 0u) | (v[1] ? 2u : 0u));
@@ -651,5 +747,11 @@ extern "C" int ds_lstm_seq_status(void *ws, int32_t B) {
 // workgroup (0,0) of the NEXT ds_lstm_seq_fwd launches stamps s_memtime at its phase boundaries; NULL switches it off.
 extern "C" int ds_debug_lstm_seq_set_profile(void *buf) {
     g_prof = (unsigned long long *)buf;
+    return DS_OK;
+}
+
+// the same for the NEXT ds_lstm_seq_bwd launches (stamp row t of step t; the walk goes from T - 1 down to 0)
+extern "C" int ds_debug_lstm_seq_set_profile_bwd(void *buf) {
+    g_prof_bwd = (unsigned long long *)buf;
     return DS_OK;
 }
