@@ -82,7 +82,7 @@ def test_lstm_seq_entry_points_take_rows_and_keep_no_global(lib):
     assert not hasattr(dll, "ds_lstm_seq_set_rows")
     l = lib.load()
     # workspace: forward + backward counters per 32-row group and two error words, 16-byte granules
-    assert l.ds_lstm_seq_workspace(256, 512) == (2 * 16 * 65 + 2 + 63) // 64 * 256 + 2 * 256 * 2048 * 4      # control words (two blocks of 16 counters + 16 x 64 placement words, two error words) + the backward exchange ring
+    assert l.ds_lstm_seq_workspace(256, 512) == (2 * 16 * 65 + 2 + 63) // 64 * 256 + 2 * 256 * (2048 + 512) * 4      # control words (two blocks of 16 counters + 16 x 64 placement words, two error words) + the backward and the forward exchange ring
     assert l.ds_lstm_seq_supported(256, 512) == 1 and l.ds_lstm_seq_supported(256, 48) == 0
     # argument errors are reported before anything is launched (no device needed)
     assert l.ds_lstm_seq_fwd(None, None, 0, None, None, None, 1, 1, 32, 1.0, 1, None, 0, None) == -1

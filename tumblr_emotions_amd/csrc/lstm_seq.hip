@@ -46,7 +46,7 @@ struct SeqParams {
     float forget_bias;
     unsigned *sync;            // this direction's [row groups] arrival counters
     unsigned *xcc;             // this direction's [row groups][64] placement words (group_on_one_xcd), zeroed per launch
-    float *xchg;               // bwd: two-slot exchange ring in fragment order, 2 x B' x 4H floats (B' = B rounded up to the row groups)
+    float *xchg;               // two-slot exchange ring in fragment order: fwd 2 x B' x H floats, bwd 2 x B' x 4H (B' = B rounded up to 32)
     unsigned *err;             // this direction's error word (sticky: launches never clear it)
     int nrg;
     int ncg, nrgw;             // unit blocks (H / 16); workgroup rows (ceil(nrg / R))
@@ -143,17 +143,6 @@ __device__ __forceinline__ bool group_on_one_xcd(unsigned *tab, int cg, int ncg,
     return verdict != 0;
 }
 
-// the hand-off payload: write-through, or plain when the row group shares an L2 (group_on_one_xcd)
-template <int N>
-__device__ __forceinline__ void store_payload(float *p, const float *v, bool l2_local) {
-    if (l2_local) {
-#pragma unroll
-        for (int e = 0; e < N; ++e) p[e] = v[e];
-    } else {
-        store_sc1<N>(p, v);
-    }
-}
-
 // ================================================================================================
 // forward: H = 8 * NCH * NW; workgroup tile 32 rows x 64 gate columns (16 units x i,j,f,o), K = H split over NW waves
 // ================================================================================================
@@ -219,6 +208,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
     const __amdgpu_buffer_rsrc_t srd_h = srd_of(p.h, (unsigned)((int64_t)(T + 1) * B * H * 4));
     bool l2_local = false;                              // (uniform over the row group)
     if (R == 1 && p.xcd_map && ncg <= 64) l2_local = group_on_one_xcd(p.xcc + rg0 * 64, cg, ncg, err);
+    // l2_local: h_t travels through a two-slot ring in fragment order, X[t & 1][row group][k / 4][row][4] (see the backward
+    // kernel): a wave's A load reads 1 KB of consecutive bytes instead of 16 / 32 row pieces.  h itself is written behind
+    // the publish (the head, the weight gradient and the caller read it); step 0 reads the initial state from h[0].
+    const __amdgpu_buffer_rsrc_t srd_x = srd_of(p.xchg, (unsigned)((int64_t)2 * p.nrg * RB * H * 4));
+    constexpr unsigned kSlot = (unsigned)(H / 4) * RB * 16u;           // bytes of one row group's slot
+    constexpr unsigned kQuads = RB == 32 ? 2u : 4u;                    // K quads per A chunk (8 / 16 channels)
 
     for (int t = 0; t < T; ++t) {
 #pragma unroll
@@ -242,10 +237,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
             if (rr == 0) DS_STAMP(1);
             // ---- A fragments straight from h[t] (sc1: past the L1, which other CUs' stores never refresh) --------
             f32x4 a[NQ];
-            const unsigned abase = (unsigned)((((int64_t)t * B + arow[rr]) * H + wave * KQ + 4 * kh) * 4);
+            const bool ring = l2_local && t > 0;                // (uniform)
+            const unsigned abase = ring ? ((unsigned)(t & 1) * (unsigned)p.nrg + (unsigned)(rg0 + rr)) * kSlot +
+                                              (unsigned)(((wave * (KQ / 4) + kh) * RB + li) * 16)
+                                        : (unsigned)((((int64_t)t * B + arow[rr]) * H + wave * KQ + 4 * kh) * 4);
+            const unsigned qstep = ring ? kQuads * RB * 16u : (RB == 32 ? 32u : 64u);
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
-                a[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_h, abase + (RB == 32 ? 32u : 64u) * q, 0, kSC1));
+                a[q] = __builtin_bit_cast(f32x4, ring ? __builtin_amdgcn_raw_buffer_load_b128(srd_x, abase + qstep * q, 0, kSC1)
+                                                      : __builtin_amdgcn_raw_buffer_load_b128(srd_h, abase + qstep * q, 0, kSC1));
             // ---- K slices of the NW waves -> LDS, summed in wave order by the cell threads ------------------------
             if constexpr (RB == 32) {
                 f32x16 acc[2];
@@ -304,8 +304,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
                     cst[rr][e] = live ? c_new : cst[rr][e];      // dynamic_rnn copies the state through past seq_len
                     hst[rr][e] = hn[e] = live ? h_new : hst[rr][e];
                 }
-                const int64_t o = ((int64_t)(t + 1) * B + grow[rr]) * H + u0 + cu;
-                store_payload<UPT>(p.h + o, hn, l2_local);       // the hand-off payload goes first ...
+                // the hand-off payload goes first ...
+                if (l2_local) {
+                    float *xs = p.xchg + ((int64_t)(((t + 1) & 1) * p.nrg + rg0 + rr) * (H / 4) * RB) * 4;
+#pragma unroll
+                    for (int e = 0; e < UPT; ++e) {
+                        const int col = u0 + cu + e;
+                        xs[((col >> 2) * RB + crow) * 4 + (col & 3)] = hn[e];
+                    }
+                } else {
+                    store_sc1<UPT>(p.h + ((int64_t)(t + 1) * B + grow[rr]) * H + u0 + cu, hn);
+                }
             }
             if (rr == 0) DS_STAMP(4);
             // ---- publish: every storing wave drains, then one lane counts this workgroup in ----------------------
@@ -323,6 +332,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
                     for (int e = 0; e < UPT; ++e) g[k * H + e] = act[k][e];
 #pragma unroll
                 for (int e = 0; e < UPT; ++e) p.c[o + e] = cst[rr][e];
+                if (l2_local) {
+#pragma unroll
+                    for (int e = 0; e < UPT; ++e) p.h[o + e] = hn[e];
+                }
             }
         }
     }
@@ -625,6 +638,8 @@ inline size_t dir_words(int B) { return (size_t)ws_groups(B) * 65; }
 inline size_t ctl_bytes(int B) { return (2 * dir_words(B) + 2 + 63) / 64 * 256; }          // control words, 256-byte aligned
 // the backward launch's exchange ring (two slots of dgates_t in fragment order; rows rounded up to 32)
 inline size_t ring_bytes(int B, int H) { return (size_t)2 * ((B + 31) / 32 * 32) * 4 * H * sizeof(float); }
+// ... and the forward launch's (h_t), behind it
+inline size_t ring_bytes_fwd(int B, int H) { return (size_t)2 * ((B + 31) / 32 * 32) * H * sizeof(float); }
 
 // launch geometry: XCD-local 1-D grid when a row group's H / 16 workgroups fit one XCD (32 CUs, one workgroup each);
 // DS_LSTM_XCD=0 switches back to the 2-D grid (A/B aid)
@@ -676,7 +691,7 @@ extern "C" int ds_lstm_seq_supported(int32_t B, int32_t H) {
 // zero-initialised once by the caller).
 extern "C" size_t ds_lstm_seq_workspace(int32_t B, int32_t H) {
     (void)H;
-    return ctl_bytes(B) + ring_bytes(B, H);
+    return ctl_bytes(B) + ring_bytes(B, H) + ring_bytes_fwd(B, H);
 }
 
 extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float *h, float *c, const int64_t *seq_len,
@@ -695,6 +710,7 @@ extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float
     p.sync = (unsigned *)ws;
     p.xcc = p.sync + ws_groups(B);
     p.err = (unsigned *)ws + 2 * dir_words(B);
+    p.xchg = reinterpret_cast<float *>((char *)ws + ctl_bytes(B) + ring_bytes(B, H));
     p.prof = g_prof;
     // every polled word is re-initialised by a memset node in front of the launch (Guideline 16); the error words
     // are left alone
