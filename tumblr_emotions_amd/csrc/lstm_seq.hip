@@ -237,7 +237,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
             if (rr == 0) DS_STAMP(1);
             // ---- A fragments straight from h[t] (sc1: past the L1, which other CUs' stores never refresh) --------
             f32x4 a[NQ];
-            const bool ring = l2_local && t > 0;                // (uniform)
+            // (uniform) step 0 reads the initial state from h[0]; row groups spread over XCDs keep the [B, H] exchange (their
+            // write-through ring stores would be 8-byte pieces 512 bytes apart: forward launch 0.91 -> 1.08 ms beside the
+            // image tower; the backward launch, which reads four times the bytes, gains even so)
+            const bool ring = l2_local && t > 0;
             const unsigned abase = ring ? ((unsigned)(t & 1) * (unsigned)p.nrg + (unsigned)(rg0 + rr)) * kSlot +
                                               (unsigned)(((wave * (KQ / 4) + kh) * RB + li) * 16)
                                         : (unsigned)((((int64_t)t * B + arow[rr]) * H + wave * KQ + 4 * kh) * 4);
@@ -306,12 +309,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
                 }
                 // the hand-off payload goes first ...
                 if (l2_local) {
-                    float *xs = p.xchg + ((int64_t)(((t + 1) & 1) * p.nrg + rg0 + rr) * (H / 4) * RB) * 4;
+                    float *xs = p.xchg + ((int64_t)(((t + 1) & 1) * p.nrg + rg0 + rr) * (H / 4) * RB) * 4 +
+                                (((u0 + cu) >> 2) * RB + crow) * 4 + ((u0 + cu) & 3);
 #pragma unroll
-                    for (int e = 0; e < UPT; ++e) {
-                        const int col = u0 + cu + e;
-                        xs[((col >> 2) * RB + crow) * 4 + (col & 3)] = hn[e];
-                    }
+                    for (int e = 0; e < UPT; ++e) xs[e] = hn[e];
                 } else {
                     store_sc1<UPT>(p.h + ((int64_t)(t + 1) * B + grow[rr]) * H + u0 + cu, hn);
                 }
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
         bfr[q] = *reinterpret_cast<const f32x4 *>(p.wh + (int64_t)(u0 + li) * p.ldw + wave * KQ + 16 * q + 4 * kb);
 
     const int crow = tid / (16 / UPT), cu = (tid % (16 / UPT)) * UPT;
-    int grow[R], arow[R][NRB];
+    int grow[R];
     bool valid[R];
     int64_t sl[R];
     float dcs[R][UPT], dhc[R][UPT];
@@ -387,11 +388,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
             dcs[rr][e] = 0.f;
             dhc[rr][e] = valid[rr] ? p.dh_last[(int64_t)grow[rr] * p.ld_dh + u0 + cu + e] : 0.f;      // gradient of h[T]
         }
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) arow[rr][rb] = (r0 + 16 * rb + li < B) ? r0 + 16 * rb + li : B - 1;
     }
 
-    const __amdgpu_buffer_rsrc_t srd_g = srd_of(p.dgates, (unsigned)((int64_t)T * B * H4 * 4));
     bool l2_local = false;                              // (uniform over the row group)
     if (R == 1 && p.xcd_map && ncg <= 64) l2_local = group_on_one_xcd(p.xcc + rg0 * 64, cg, ncg, err);
     // l2_local: the exchange goes through a two-slot ring in FRAGMENT order, X[t & 1][row group][k / 4][row][4]: lane
@@ -436,10 +434,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
                 unsigned abase[NRB];
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
-                    abase[rb] = l2_local ? ((unsigned)((t + 1) & 1) * (unsigned)p.nrg + (unsigned)(rg0 + rr)) * kSlot +
-                                               (unsigned)(((wave * (KQ / 4) + kb) * RB + 16 * rb + li) * 16)
-                                         : (unsigned)((((int64_t)(t + 1) * B + arow[rr][rb]) * H4 + wave * KQ + 4 * kb) * 4);
-                const unsigned qstep = l2_local ? 4u * RB * 16u : 64u;       // bytes between 16-channel chunks
+                    abase[rb] = ((unsigned)((t + 1) & 1) * (unsigned)p.nrg + (unsigned)(rg0 + rr)) * kSlot +
+                                (unsigned)(((wave * (KQ / 4) + kb) * RB + 16 * rb + li) * 16);
+                constexpr unsigned qstep = 4u * RB * 16u;                    // bytes between 16-channel chunks
                 f32x4 a[2][NRB][GQ];                            // [buffer][row block][chunk]
                 auto load_group = [&](int buf, int g0) {
 #pragma unroll
@@ -447,8 +444,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
 #pragma unroll
                         for (int rb = 0; rb < NRB; ++rb)
                             a[buf][rb][q] = __builtin_bit_cast(
-                                f32x4, l2_local ? __builtin_amdgcn_raw_buffer_load_b128(srd_x, abase[rb] + qstep * (g0 + q), 0, kSC1)
-                                                : __builtin_amdgcn_raw_buffer_load_b128(srd_g, abase[rb] + qstep * (g0 + q), 0, kSC1));
+                                f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, abase[rb] + qstep * (g0 + q), 0, kSC1));
                 };
                 load_group(0, 0);
 #pragma unroll
@@ -499,18 +495,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
                         dhc[rr][e] = dhv;
                     }
                 }
-                if (l2_local) {         // the hand-off payload, in fragment order
-                    float *xs = p.xchg + ((int64_t)((t & 1) * p.nrg + rg0 + rr) * (H4 / 4) * RB) * 4;
+                // the hand-off payload, in fragment order: plain stores where the row group shares an L2, else write-through
+                float *xs = p.xchg + ((int64_t)((t & 1) * p.nrg + rg0 + rr) * (H4 / 4) * RB) * 4;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < 4; ++k) {
+                    const int col = k * H + u0 + cu;                    // (UPT = 2: cu is even, one 8-byte piece)
+                    float *q = xs + ((col >> 2) * RB + crow) * 4 + (col & 3);
+                    if (l2_local) {
 #pragma unroll
-                        for (int e = 0; e < UPT; ++e) {
-                            const int col = k * H + u0 + cu + e;
-                            xs[((col >> 2) * RB + crow) * 4 + (col & 3)] = dg[k][e];
-                        }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) store_sc1<UPT>(p.dgates + gi + k * H, dg[k]);
+                        for (int e = 0; e < UPT; ++e) q[e] = dg[k][e];
+                    } else {
+                        store_sc1<UPT>(q, dg[k]);
+                    }
                 }
             }
             if (rr == 0) DS_STAMP(4);
@@ -519,7 +515,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
             __syncthreads();
             if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (rr == 0) DS_STAMP(6);
-            if (l2_local && valid[rr]) {        // ... and dgates for the kernels behind this one, off the hand-off's path
+            if (valid[rr]) {                    // ... and dgates for the kernels behind this one, off the hand-off's path
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
