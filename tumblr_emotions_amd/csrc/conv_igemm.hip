@@ -1869,6 +1869,15 @@ int wide_nb(const ds_conv_desc *d, bool vec) {
         const int64_t cost = rounds * (2 * nb + cA);
         if (cost < best_cost) { best_cost = cost; best = nb; best_pad = tiles * 32 * nb; }
     }
+    static int pin_nb = -1;                                      // tuning aid: DS_WIDE_NB pins the column blocks per wave
+    if (pin_nb < 0) {
+        const char *e = getenv("DS_WIDE_NB");
+        pin_nb = e ? atoi(e) : 0;
+    }
+    if (pin_nb >= 1 && pin_nb <= 8) {
+        best = pin_nb;
+        best_pad = (N + 32 * best - 1) / (32 * best) * 32 * best;
+    }
     const int64_t wgs = (M + 127) / 128 * ((N + 32 * best - 1) / (32 * best));
     // measured per shape (profiles/r02_wide_layers.txt): wins 1.1-1.4x except with one mostly padded column tile or too
     // few workgroups to cover the CUs (7x7 maps with N <= 128)
