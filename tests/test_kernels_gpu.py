@@ -1613,3 +1613,51 @@ def test_split_k_gemm_slabs_feed_lstm_cell():
 
 def S_sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
+
+
+_LSTM_PLACEMENT_SCRIPT = r"""
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from tumblr_emotions_amd import ops
+out = []
+for (B, T, H) in ((48, 7, 128), (64, 9, 512), (256, 5, 512)):
+    rng = np.random.RandomState(B + H)
+    pre = torch.from_numpy((rng.normal(size=(T, B, 4 * H)) * 0.7).astype(np.float32)).cuda()
+    wh = torch.from_numpy((rng.normal(size=(H, 4 * H)) * (0.5 / np.sqrt(H))).astype(np.float32)).cuda()
+    seq = torch.from_numpy(rng.randint(1, T + 1, size=B).astype(np.int64)).cuda()
+    dh = torch.from_numpy(rng.normal(size=(B, H)).astype(np.float32)).cuda()
+    h, c = torch.zeros(T + 1, B, H, device="cuda"), torch.zeros(T + 1, B, H, device="cuda")
+    dg = torch.empty(T, B, 4 * H, device="cuda")
+    ws = torch.zeros(max(ops.lstm_seq_workspace(B, H) // 4, 4), dtype=torch.int32, device="cuda")
+    for rep in range(2):          # the second pass runs on a used workspace / ring
+        g = pre.clone()
+        ops.lstm_seq_fwd(g, ops._p(wh), 4 * H, h, c, seq, T, B, H, 1.0, ws)
+        ops.lstm_seq_bwd(g, ops._p(wh), 4 * H, c, dh, H, seq, T, B, H, dg, ws)
+        torch.cuda.synchronize()
+        ops.lstm_seq_status(ws, B)
+    for t in (h, c, g, dg):
+        out.append(hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest())
+print("DIGEST " + " ".join(out))
+"""
+
+
+def test_lstm_exchange_is_placement_independent():
+    """The persistent LSTM picks its hand-off form from the MEASURED placement (row group on one XCD: plain stores into the
+    fragment-order ring; spread over XCDs: write-through).  Both forms -- the XCD-local 1-D launch and the plain 2-D grid
+    (DS_LSTM_XCD=0, which spreads a row group over all XCDs) -- must give the same bits, for the 16-row (B = 48, 64) and the
+    32-row (B = 256) groups, also on a re-used workspace."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for xcd in ("1", "0"):
+        env = dict(os.environ, DS_LSTM_XCD=xcd)
+        r = subprocess.run([sys.executable, "-c", _LSTM_PLACEMENT_SCRIPT % root], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("DIGEST ")]
+        assert line, r.stdout[-2000:]
+        digests.append(line[-1])
+    assert digests[0] == digests[1]
