@@ -516,6 +516,13 @@ int ds_adam_tf(float *theta, const float *g, float *m, float *v, int64_t n, int6
 int ds_sumsq(const float *x, int64_t n, float *scratch, float *out, void *stream);
 /* BiasAddGrad: out[c] = sum_m x[m*ld + c]; scratch >= 64*C floats                            */
 int ds_colsum(const float *x, int64_t M, int32_t C, int32_t ld, float *scratch, float *out, void *stream);
+/* Second half of a split-K GEMM (ds_conv_igemm with ds_conv_desc.splits > 1 leaves slab s of partial sums at
+ * z + s * z_split_stride, row stride lds): out[m][n] = epilogue(sum_s slabs[s][m][n]), slabs added in index order
+ * (deterministic); flags: DS_EPI_BIAS / DS_EPI_ACCUM / DS_EPI_MASK / DS_EPI_RELU, applied in ds_conv_igemm's order.
+ * For the batch x features GEMMs of the heads (MatMul + BiasAdd + Relu, im_text_rnn_model.py:95-105; Logits,
+ * image_model/inception_v1.py:302), whose single row tile would otherwise walk K serially. */
+int ds_slab_epilogue(const float *slabs, int32_t splits, int64_t slab_stride, int32_t lds, int64_t M, int32_t N, float *out,
+                     int32_t ldo, const float *bias, const float *mask, int32_t ldmask, int32_t flags, void *stream);
 int ds_copy2d(const float *src, int32_t lds, float *dst, int32_t ldd, int64_t rows, int32_t cols,
               void *stream);
 int ds_pad_channels(const float *src, int32_t cs, float *dst, int32_t cd, int64_t pixels, void *stream);

@@ -1661,3 +1661,44 @@ def test_lstm_exchange_is_placement_independent():
         assert line, r.stdout[-2000:]
         digests.append(line[-1])
     assert digests[0] == digests[1]
+
+
+@pytest.mark.parametrize("case", [(256, 1024, 256, False), (32, 512, 15, False), (256, 512, 512, True), (64, 768, 512, False),
+                                  (300, 256, 40, True)])
+def test_split_gemm_with_slab_epilogue_matches_the_single_launch(case):
+    """head_gemm_plan: split-K ds_conv_igemm + ds_slab_epilogue (bias / accumulate / mask / relu in ds_conv_igemm's order) for the
+    batch x features GEMMs of the heads -- against fp64 and against the single launch; strided input and output rows; two
+    runs give the same bits (slabs combined in index order)."""
+    ops = _ops()
+    M, K, N, transposed = case
+    rng = np.random.RandomState(M + K + N)
+    a = rng.normal(size=(M, K))
+    w = rng.normal(size=(N, K) if transposed else (K, N)) * 0.05
+    bias, prev = rng.normal(size=N), rng.normal(size=(M, N))
+    mask = (rng.uniform(size=(M, N)) < 0.6).astype(np.float64)
+    ad = dev(np.pad(a, ((0, 0), (0, 8))))                       # row stride K + 8
+    wd, biasd, maskd = dev(w), dev(bias), dev(np.pad(mask, ((0, 0), (0, 4))))
+    core = a @ (w.T if transposed else w)
+    for flags, want in ((ops.DS_EPI_BIAS | ops.DS_EPI_RELU, np.maximum(core + bias, 0)),
+                        (ops.DS_EPI_ACCUM | ops.DS_EPI_BIAS | ops.DS_EPI_RELU, np.maximum(core + bias + prev, 0)),
+                        (ops.DS_EPI_MASK, core * mask), (0, core)):
+        plan = ops.head_gemm_plan(M, K, N, K + 8, N + 4, K if transposed else N, transposed_w=transposed, flags=flags,
+                                  ldmask=N + 4)
+        assert isinstance(plan, ops.SplitGemm)
+        outs = []
+        for rep in range(2):
+            out = dev(np.pad(prev, ((0, 0), (0, 4)), constant_values=5.0))
+            plan.run(ops._p(ad), ops._p(wd), ops._p(out), bias=ops._p(biasd), mask=ops._p(maskd))
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1])
+        close(outs[0][:, :N], want, 2e-4)
+        assert bool((outs[0][:, N:] == 5.0).all())              # the row padding is untouched
+        single = ops.gemm_plan(M, K, N, K + 8, N + 4, K if transposed else N, transposed_w=transposed, flags=flags, ldmask=N + 4)
+        ref = dev(np.pad(prev, ((0, 0), (0, 4)), constant_values=5.0))
+        single.run(ops._p(ad), ops._p(wd), ops._p(ref), bias=ops._p(biasd), mask=ops._p(maskd))
+        torch.cuda.synchronize()
+        assert float((outs[0] - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    # below the thresholds the plain plan is returned
+    assert not isinstance(ops.head_gemm_plan(4096, 512, 64, 512, 64, 64), ops.SplitGemm)
+    assert not isinstance(ops.head_gemm_plan(64, 15, 512, 15, 512, 15, transposed_w=True), ops.SplitGemm)

@@ -151,6 +151,7 @@ SIGNATURES = {
     "ds_adam_tf": (C.c_int, [_P, _P, _P, _P, _i64, _i64, _f32, _f32, _f32, _P, _f32, _f32, _f32, _P]),
     "ds_sumsq": (C.c_int, [_P, _i64, _P, _P, _P]),
     "ds_colsum": (C.c_int, [_P, _i64, _i32, _i32, _P, _P, _P]),
+    "ds_slab_epilogue": (C.c_int, [_P, _i32, _i64, _i32, _i64, _i32, _P, _i32, _P, _P, _i32, _i32, _P]),
     "ds_copy2d": (C.c_int, [_P, _i32, _P, _i32, _i64, _i32, _P]),
     "ds_pad_channels": (C.c_int, [_P, _i32, _P, _i32, _i64, _P]),
     "ds_fill": (C.c_int, [_P, _i64, _f32, _P]),

@@ -494,6 +494,40 @@ extern "C" int ds_colsum(const float *x, int64_t M, int32_t C, int32_t ld, float
     return ds::check_launch("ds_colsum");
 }
 
+// out[m][n] = epilogue(sum_s slabs[s][m][n]): the second half of a split-K GEMM (ds_conv_igemm with splits > 1 writes slab s at
+// z + s * z_split_stride).  The M <= 512 GEMMs of the heads are ONE row tile or two: a single launch walks K = 512 ... 1024
+// serially in a handful of workgroups (40-57 us each, on the chain between the towers' forward and backward passes);
+// split eight ways and combined here in a fixed order (deterministic) they take a third of that.
+__global__ __launch_bounds__(256) void slab_epilogue_kernel(const float *slabs, int splits, int64_t slab_stride, int lds,
+                                                            int64_t M, int N, float *out, int ldo, const float *bias,
+                                                            const float *mask, int ldmask, int flags) {
+    const int64_t total = M * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / N;
+        const int n = (int)(i - m * N);
+        float v = 0.f;
+        for (int k = 0; k < splits; ++k) v += slabs[(int64_t)k * slab_stride + m * lds + n];
+        if (flags & DS_EPI_BIAS) v += bias[n];
+        const int64_t o = m * ldo + n;
+        if (flags & DS_EPI_ACCUM) v += out[o];
+        if (flags & DS_EPI_MASK) v = mask[m * ldmask + n] > 0.f ? v : 0.f;
+        if (flags & DS_EPI_RELU) v = fmaxf(v, 0.f);
+        out[o] = v;
+    }
+}
+
+extern "C" int ds_slab_epilogue(const float *slabs, int32_t splits, int64_t slab_stride, int32_t lds, int64_t M, int32_t N,
+                                float *out, int32_t ldo, const float *bias, const float *mask, int32_t ldmask, int32_t flags,
+                                void *stream) {
+    DS_REQUIRE(slabs && out && splits >= 1 && M > 0 && N > 0 && lds >= N && ldo >= N, "ds_slab_epilogue: bad argument");
+    DS_REQUIRE((flags & ~(DS_EPI_BIAS | DS_EPI_ACCUM | DS_EPI_MASK | DS_EPI_RELU)) == 0 && (!(flags & DS_EPI_BIAS) || bias) &&
+                   (!(flags & DS_EPI_MASK) || (mask && ldmask >= N)),
+               "ds_slab_epilogue: flags are BIAS / ACCUM / MASK / RELU (with their operands)");
+    hipLaunchKernelGGL(slab_epilogue_kernel, dim3(ds::stream_grid(M * N, 256)), dim3(256), 0, (hipStream_t)stream, slabs, splits,
+                       slab_stride, lds, M, N, out, ldo, bias, mask, ldmask, flags);
+    return ds::check_launch("ds_slab_epilogue");
+}
+
 extern "C" int ds_copy2d(const float *src, int32_t lds, float *dst, int32_t ldd, int64_t rows, int32_t cols,
                          void *stream) {
     DS_REQUIRE(src && dst && rows > 0 && cols > 0, "ds_copy2d: bad argument");

@@ -953,8 +953,8 @@ class InceptionV1Engine:
         self.dpooled = torch.empty(B, F, device=dev)
         self.mask = torch.ones(B, F, device=dev)
         self.logits = torch.empty(B, nc, device=dev)
-        self.fc = gemm_plan(B, F, nc, F, nc, nc, flags=DS_EPI_BIAS)
-        self.fc_dgrad = gemm_plan(B, nc, F, nc, F, nc, transposed_w=True)
+        self.fc = ops.head_gemm_plan(B, F, nc, F, nc, nc, flags=DS_EPI_BIAS)
+        self.fc_dgrad = ops.head_gemm_plan(B, nc, F, nc, F, nc, transposed_w=True)
         self.fc_wgrad = WgradPlan(B, 1, 1, F, F, 1, 1, 1, nc, nc, pad_t=0, pad_l=0, OH=1, OW=1)
         self.need_ws(self.fc_wgrad.ws_bytes)
         self.colsum_scratch = torch.empty(64 * max(nc, 4), device=dev)

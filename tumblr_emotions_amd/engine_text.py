@@ -21,7 +21,7 @@ import ctypes as C
 import torch
 
 from . import ops
-from .ops import WgradPlan, gemm_plan, DS_EPI_ACCUM, DS_EPI_BIAS, DS_EPI_MASK, DS_EPI_RELU
+from .ops import WgradPlan, gemm_plan, head_gemm_plan, DS_EPI_ACCUM, DS_EPI_BIAS, DS_EPI_MASK, DS_EPI_RELU
 
 FORGET_BIAS = 1.0     # tf.contrib.rnn.BasicLSTMCell default (im_text_rnn_model.py:89)
 
@@ -199,13 +199,13 @@ class JointHeadEngine:
 
     def _plans(self, ld_im, ld_tx):
         B, im, tx, fc, nc = self.B, self.im, self.tx, self.fc, self.nc
-        self.fc_im = gemm_plan(B, im, fc, ld_im, fc, fc)
-        self.fc_tx = gemm_plan(B, tx, fc, ld_tx, fc, fc, flags=DS_EPI_ACCUM | DS_EPI_BIAS | DS_EPI_RELU)
-        self.sm = gemm_plan(B, fc, nc, fc, nc, nc, flags=DS_EPI_BIAS)
-        self.sm_dgrad = gemm_plan(B, nc, fc, nc, fc, nc, transposed_w=True, flags=DS_EPI_MASK, ldmask=fc)
+        self.fc_im = head_gemm_plan(B, im, fc, ld_im, fc, fc)
+        self.fc_tx = head_gemm_plan(B, tx, fc, ld_tx, fc, fc, flags=DS_EPI_ACCUM | DS_EPI_BIAS | DS_EPI_RELU)
+        self.sm = head_gemm_plan(B, fc, nc, fc, nc, nc, flags=DS_EPI_BIAS)
+        self.sm_dgrad = head_gemm_plan(B, nc, fc, nc, fc, nc, transposed_w=True, flags=DS_EPI_MASK, ldmask=fc)
         self.sm_wgrad = _gemm_wgrad(B, fc, nc, fc, nc)
-        self.im_dgrad = gemm_plan(B, fc, im, fc, im, fc, transposed_w=True)
-        self.tx_dgrad = gemm_plan(B, fc, tx, fc, tx, fc, transposed_w=True)
+        self.im_dgrad = head_gemm_plan(B, fc, im, fc, im, fc, transposed_w=True)
+        self.tx_dgrad = head_gemm_plan(B, fc, tx, fc, tx, fc, transposed_w=True)
         self.im_wgrad = _gemm_wgrad(B, im, fc, ld_im, fc)
         self.tx_wgrad = _gemm_wgrad(B, tx, fc, ld_tx, fc)
         self.ws_bytes = max(p.ws_bytes for p in (self.sm_wgrad, self.im_wgrad, self.tx_wgrad))
@@ -263,8 +263,8 @@ class TextHeadEngine:
         st = self.store
         self.w_sm, self.gw_sm = _vp(st.ptr("W_softmax")), _vp(st.grad_ptr("W_softmax"))
         self.b_sm, self.gb_sm = _vp(st.ptr("b_softmax")), st.grad_view("b_softmax")
-        self.sm = gemm_plan(B, H, nc, H, nc, nc, flags=DS_EPI_BIAS)
-        self.sm_dgrad = gemm_plan(B, nc, H, nc, H, nc, transposed_w=True)
+        self.sm = head_gemm_plan(B, H, nc, H, nc, nc, flags=DS_EPI_BIAS)
+        self.sm_dgrad = head_gemm_plan(B, nc, H, nc, H, nc, transposed_w=True)
         self.sm_wgrad = _gemm_wgrad(B, H, nc, H, nc)
         self.ws_bytes = self.sm_wgrad.ws_bytes
         self.ws = torch.empty(max(self.ws_bytes // 4, 4), device=dev)

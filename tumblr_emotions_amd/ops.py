@@ -5,6 +5,7 @@ libds_kernels.so.  All wrappers enqueue on the *current* torch stream (so they a
 torch.cuda.graph) and never synchronise.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -141,6 +142,15 @@ class ConvTimer:
 CONV_TIMER = None      # set to a ConvTimer to time the dominant kernel
 
 
+def head_gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=False, flags=0, ldmask=0, device="cuda"):
+    """gemm_plan for the batch x features GEMMs of the heads (Logits, W_fc, W_softmax and their dgrads): with M <= 512 rows
+    and K >= 256 a SplitGemm (split-K + fixed-order combine with the epilogue), else the plain plan.  DS_SPLIT_GEMM=0: always
+    the plain plan (A/B aid)."""
+    if M <= 512 and K >= 256 and os.environ.get("DS_SPLIT_GEMM", "1") != "0":
+        return SplitGemm(M, K, N, lda, ldc, w_ld, transposed_w, flags, ldmask, 8 if K >= 512 else 4, device)
+    return gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=transposed_w, flags=flags, ldmask=ldmask)
+
+
 def gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=False, flags=0, ldmask=0, splits=1, z_split_stride=0,
               dtype=DS_DTYPE_F32):
     """C[M,N] = A[M,K] * W (row-major W[K,N] with row stride w_ld), or * W^T when transposed_w
@@ -151,6 +161,31 @@ def gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=False, flags=0, ldmask=0, sp
                         pad_t=0, pad_l=0, OH=1, OW=1, splits=splits, z_split_stride=z_split_stride, dtype=dtype)
     return ConvPlan(M, 1, 1, K, lda, 1, 1, 1, N, ldc, 0, 1, w_ld, flags=flags, ldmask=ldmask,
                     pad_t=0, pad_l=0, OH=1, OW=1, splits=splits, z_split_stride=z_split_stride, dtype=dtype)
+
+
+class SplitGemm:
+    """A batch x features GEMM (M <= 512 rows: one or two row tiles) as split-K ds_conv_igemm + ds_slab_epilogue: the
+    single launch walks K serially in a handful of workgroups; `splits` slabs of partial sums and a fixed-order combine
+    with the epilogue (bias / accumulate / mask / relu) take a third of the time.  Same call as ConvPlan.run."""
+
+    def __init__(self, M, K, N, lda, ldc, w_ld, transposed_w, flags, ldmask, splits, device):
+        self.M, self.N, self.ldc, self.flags, self.ldmask, self.splits = M, N, ldc, flags, ldmask, splits
+        self.slabs = torch.empty(splits, M, N, device=device)
+        self.plan = gemm_plan(M, K, N, lda, N, w_ld, transposed_w=transposed_w, splits=splits, z_split_stride=M * N)
+        self.d, self.alg_flops, self.partials = self.plan.d, self.plan.alg_flops, 0
+
+    def run(self, x, w, z, bias=None, mask=None, stats=None, pivot=None):
+        assert stats is None
+        t = CONV_TIMER
+        if t is not None:
+            t.begin()
+        lib = _lib.load()
+        _lib.check(lib.ds_conv_igemm(C.byref(self.plan.d), x, w, _p(self.slabs), None, None, None, None, _stream()),
+                   "ds_conv_igemm")
+        _lib.check(lib.ds_slab_epilogue(_p(self.slabs), self.splits, self.M * self.N, self.N, self.M, self.N, z, self.ldc,
+                                        bias, mask, self.ldmask, self.flags, _stream()), "ds_slab_epilogue")
+        if t is not None:
+            t.end(self)
 
 
 class WinoPlan:
