@@ -602,17 +602,27 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float *z, 
         const float4 k2 = *reinterpret_cast<const float4 *>(coef + C + c);
         const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
         const float a1[4] = {k1.x, k1.y, k1.z, k1.w}, a2[4] = {k2.x, k2.y, k2.z, k2.w};
+        // the patch's four z values first, then the four stores: a load behind a store waits for it (one in-order memory
+        // counter), which made the patch a chain of four round trips; z is read once (dz overwrites it): non-temporal
+        float4 zv[2][2];
+        bool ok[2][2];
+        int64_t offs[2][2];
 #pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            const int ih = 2 * p - pad_t + 1 + y;
-            if ((unsigned)ih >= (unsigned)H) continue;
+        for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
-                const int iw = 2 * q - pad_l + 1 + x;
-                if ((unsigned)iw >= (unsigned)W) continue;
-                const int64_t off = (((int64_t)n * H + ih) * W + iw) * C + c;
-                const float4 zv = *reinterpret_cast<const float4 *>(z + off);
-                const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+                const int ih = 2 * p - pad_t + 1 + y, iw = 2 * q - pad_l + 1 + x;
+                ok[y][x] = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                offs[y][x] = (((int64_t)n * H + ih) * W + iw) * C + c;
+                zv[y][x] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok[y][x]) zv[y][x] = ds::ld_stream4(z + offs[y][x]);
+            }
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                if (!ok[y][x]) continue;
+                const float zz[4] = {zv[y][x].x, zv[y][x].y, zv[y][x].z, zv[y][x].w};
                 float o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -620,9 +630,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float *z, 
                     const float xhat = (zz[j] - mm[j]) * rr[j];
                     o[j] = rr[j] * (g - a1[j] - xhat * a2[j]);
                 }
-                *reinterpret_cast<float4 *>(dz + off) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4 *>(dz + offs[y][x]) = make_float4(o[0], o[1], o[2], o[3]);
             }
-        }
     }
 }
 
