@@ -4,9 +4,10 @@
 // (text_model/text_embedding.py:79-82): at T = 32 that was 31 + 32 dependent launches forward and as many
 // backward, each a 256 x 2048 x 512 GEMM that cannot fill the chip.  Here:
 //   * the recurrent weights Wh [H, 4H] never move: workgroup (cg, rg) owns hidden units [16 cg, 16 cg + 16) for
-//     batch rows [32 rg, 32 rg + 32) and keeps ITS slice of Wh in registers as MFMA B fragments for all T steps
-//     (64 columns x H for the forward gates, 16 rows x 4H for the backward product), split over the waves along K;
-//   * the cell state c (forward) / the carried gradients dc, dh (backward) of those 32 x 16 cells live in
+//     the batch rows of row group rg (RB = 32 rows, or 16 where the batch leaves CUs idle: pick_rb) and keeps ITS
+//     slice of Wh in registers as MFMA B fragments for all T steps (64 columns x H for the forward gates, 16 rows x
+//     4H for the backward product), split over the waves along K;
+//   * the cell state c (forward) / the carried gradients dc, dh (backward) of those RB x 16 cells live in
 //     registers for the whole sequence; gates, masking (t >= seq_len copies the state through) and the
 //     last-valid-step capture (h[T] is gather_nd(outputs, seq_len - 1)) are fused into the step;
 //   * per step the only exchange is h_t (forward) / dgates_t (backward) among the H/16 workgroups of ONE row
@@ -16,6 +17,11 @@
 //     atomic; consumers poll that one word relaxed from one lane, then read the payload with sc1 loads (served
 //     past the non-coherent L1, so no acquire fence is needed).  Every spin is bounded: on a timeout an error
 //     word is set and the kernel still terminates.
+//   * round 4: the payload travels through a two-slot ring in MFMA-FRAGMENT order (X[t & 1][row group][k / 4][row][4]:
+//     a wave's A load is 1 KB of consecutive bytes; out of the [B, 4H] tensor it touched sixteen half-used lines and
+//     the backward step was bound by exactly that), and where the MEASURED placement (HW_REG_XCC_ID, group_on_one_xcd)
+//     puts a whole row group on one XCD the ring is written with plain stores that stay in that XCD's L2.  h / dgates
+//     themselves are written behind the publish for the kernels that follow.
 //   * the input projection x_t Wx + b stays hoisted in one big GEMM in front (ds_conv_igemm), the two weight
 //     gradients in two big wgrad GEMMs behind (ds_conv_wgrad), as before.
 // Numerics: fp32 MFMA (v_mfma_f32_32x32x2_f32 forward, v_mfma_f32_16x16x4_f32 backward), the K reduction split
