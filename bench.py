@@ -2,7 +2,9 @@
 """Headline benchmark: Deep Sentiment training samples/s (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; started as plain
+  `python bench.py --gpus N` -- no WORLD_SIZE in the environment -- it re-executes itself under exactly that launcher,
+  `self_launch_argv`)
 
 One step = forward + backward + (RCCL gradient all-reduce) + TF-Adam of train_deep_sentiment on a
 synthetic batch resident in HBM: 224x224x3 images + 32-token posts, Inception-v1 + 300-d embedding +
@@ -87,14 +89,20 @@ def cpu_baseline(post_size, vocab, dim, rnn, warmup=3, steps=10):
             timed("joint", 16, threads)
         steps, warmup = max(3, steps // 2), 2      # the larger batch, bounded: ~64 / 45 s per step
         timed("joint", 64, min(16, phys))
+        steps, warmup = 2, 1                       # the HEADLINE batch itself: ~7 s per step
+        timed("joint", 256, phys)
     finally:
         torch.set_num_threads(prev)
     joint = [r for r in runs if r["workload"].startswith("joint")]
+    head = [r for r in joint if r["batch"] == 256][-1]      # the headline workload at its own batch is the reported sample
     best = max(joint, key=lambda r: r["samples_per_s"])
-    return dict(value=best["samples_per_s"], unit="samples/s", cores=best["threads"], kind="port",
-                sample="joint train step (fwd+bwd+TF-Adam), fp32, batch %d, %d timed steps after %d warm-up, PyTorch-CPU "
-                       "restatement of the TF1 step (reference-equivalent CPU path: TensorFlow 1.x is not installable "
-                       "here); best of the joint runs listed in `runs`" % (best["batch"], best["steps"], best["warmup"]),
+    return dict(value=head["samples_per_s"], unit="samples/s", cores=head["threads"], kind="port",
+                sample="the headline workload itself: joint train step (fwd+bwd+TF-Adam), fp32, batch %d, %d timed steps after "
+                       "%d warm-up at %d threads, PyTorch-CPU restatement of the TF1 step (reference-equivalent CPU path: "
+                       "TensorFlow 1.x is not installable here); the other thread counts / batches are listed in `runs` "
+                       "(best of them: %.1f samples/s at batch %d, %d threads)"
+                       % (head["batch"], head["steps"], head["warmup"], head["threads"], best["samples_per_s"], best["batch"],
+                          best["threads"]),
                 runs=runs, host=dict(logical_cpus=os.cpu_count(), physical_cores=phys, model=cpu_model()))
 
 
@@ -138,6 +146,40 @@ def cpu_model():
     return "unknown"
 
 
+def conv_arithmetic(net):
+    """Which multiply each conv launch of the image tower runs in, as ds_conv_plan decided (forward / dgrad launches per
+    kernel family).  For --dtype fp8 this is the honest label: fp8 only on the layers where ds_conv_fp8 beats the bf16
+    kernels (profiles/r04_fp8_layers_b128.txt), bf16 elsewhere."""
+    img = getattr(net, "image", None)
+    if img is None:
+        return None
+    from tumblr_emotions_amd import ops
+    names = {getattr(ops, k): k[7:].lower() for k in dir(ops) if k.startswith("DS_FAM_")}
+    count = {"forward": {}, "dgrad": {}}
+    for layer in img.layers:
+        for role, plan in (("forward", getattr(layer, "fwd", None)), ("dgrad", getattr(layer, "dgrad", None))):
+            fam = getattr(plan, "family", None)
+            if fam is not None:
+                key = names.get(fam, str(fam))
+                count[role][key] = count[role].get(key, 0) + 1
+    label = {"f32": "fp32 MFMA", "bf16": "bf16 MFMA", "fp8": "bf16 MFMA + fp8 MFMA where it wins (bf16+fp8-auto)"}[img.dtype]
+    return dict(label=label, launches_by_family=count)
+
+
+def self_launch_argv(gpus, argv, port=None):
+    """The command `python bench.py --gpus N ...` turns itself into when it was started WITHOUT a launcher (no WORLD_SIZE in
+    the environment): one rank per GPU under torch.distributed.run on this node, rendezvous on 127.0.0.1 (the container
+    hostname may not resolve), the caller's own arguments passed through unchanged.  Data-parallel semantics are those of
+    /root/reference/slim/deployment/model_deploy.py:221-223,301-302; rank 0 still prints the ONE JSON line."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 CONV_FAMILY = ("conv_igemm_kernel", "conv_glds_kernel", "gemm_wide_kernel", "conv_wino_kernel", "conv_wino4_kernel",
                "conv_stem_kernel", "conv_bf16_kernel", "conv_bf16d_kernel", "conv_fp8d_kernel")
 
@@ -155,13 +197,13 @@ def pmc_traffic_live(steps=3, timeout=90):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None
-    tot, calls = {}, 0
+    tot, calls = {}, {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="ds_pmc_", dir="/tmp")
             env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable,
-                   os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "0", "--no-cpu-baseline", "--no-conv-timing",
+                   os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-conv-timing",
                    "--no-gather", "--no-branch-streams", "--no-live-traffic"]
             # own process group: on a timeout the profiler AND the bench it wraps are killed, nothing lingers on the GPU
             proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
@@ -185,10 +227,13 @@ def pmc_traffic_live(steps=3, timeout=90):
             shutil.rmtree(d, ignore_errors=True)
             if n == 0:
                 return None
-            tot[counter], calls = b, n
+            tot[counter], calls[counter] = b, n
+        if calls["FETCH_SIZE"] != calls["WRITE_SIZE"]:
+            raise RuntimeError("the two counter passes saw different launch counts: %r" % (calls,))
+        calls = calls["FETCH_SIZE"]
         hbm = 2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]
         return round(hbm / calls), ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only; FETCH x 2 "
-                                    "for gfx950) over %d steps of this workload, %d bracketed launches" % (steps, calls))
+                                    "for gfx950) over 1 warm-up + %d steps of this workload, %d bracketed launches" % (steps, calls))
     except Exception as e:      # missing counters, a crashed pass, a timeout: never fail the benchmark over this
         sys.stderr.write("bench.py: live PMC traffic pass failed (%s); using the committed profile\n" % (e,))
         return None
@@ -278,6 +323,14 @@ def main():
                     help="roofline.traffic from the committed profile instead of two rocprofv3 --pmc sub-runs (about 40 s)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (how the driver starts the N = 1 bench): become the N-rank job
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # ROCr reads it at hsa_init: before any rank starts
+        cmd = self_launch_argv(args.gpus, sys.argv[1:])
+        sys.stderr.write("bench.py: no launcher in the environment, re-executing as: %s\n" % " ".join(cmd))
+        sys.stderr.flush()
+        os.execv(cmd[0], cmd)
+
     import torch
     import torch.distributed as dist
     from tumblr_emotions_amd import ops
@@ -287,26 +340,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
     # DS_BENCH_ONE_DEVICE=1 (self-test on a 1-GPU box): every rank uses cuda:0 and gloo carries the
     # all-reduce, because RCCL refuses two ranks on one device.  Never set for a real measurement.
     one_device = os.environ.get("DS_BENCH_ONE_DEVICE") == "1"
-    torch.cuda.set_device(0 if one_device else local_rank)
-    from tumblr_emotions_amd import streams
-    if os.environ.get("DS_BENCH_NO_RESERVE") != "1":
-        streams.reserve()          # the step's streams take their hardware queues BEFORE RCCL creates its own
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if one_device:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    from tumblr_emotions_amd import dp, streams
     force_dp = bool(args.rccl_world1 and world == 1)
-    if force_dp:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    if world > 1 or force_dp:
+        # dp.init_distributed: the step's streams take their hardware queues BEFORE RCCL creates its own
+        if force_dp:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dp.init_distributed("nccl", device=dev_index, rank=0, world_size=1)
+        else:
+            dp.init_distributed("gloo" if one_device else "nccl", device=dev_index)
+    elif os.environ.get("DS_BENCH_NO_RESERVE") != "1":
+        streams.reserve()
     rccl_ranks = None
     if world > 1 or force_dp:          # a real collective before anything is timed: how many ranks does the backend connect?
         probe = torch.ones(1, device="cuda")
@@ -527,6 +579,7 @@ def main():
                        "launch": "hipGraph replay" if graphed else "eager",
                        "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3)},
             "roofline": roof,
+            "conv_arithmetic": conv_arithmetic(net),
             "dp": dp_report,
             "strong_scaling": strong_block,
             "gather": gather_bandwidth() if (args.mode != "image" and not args.no_gather) else None,

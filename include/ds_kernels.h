@@ -288,6 +288,7 @@ int ds_conv_wino4(const float *x, const float *u, float *z, float *stats, const 
 #define DS_PLAN_NO_BF16_DIRECT 8u   /* A/B: the LDS-staged bf16 kernel everywhere                                       */
 #define DS_PLAN_ACT16 16u           /* the net keeps activations in 16-bit storage (only the register-direct kernels read it) */
 #define DS_PLAN_FP8_EVERYWHERE 64u  /* A/B: ds_conv_fp8 wherever it applies (default: only where it beats the bf16 kernels) */
+#define DS_PLAN_FP8_WIDE_RULE 128u  /* A/B: fp8 for every 1x1 / 3x3 layer with >= 64 reduction channels into >= 96 columns  */
 #define DS_PLAN_PACKED_RGB 32u      /* Conv2d_1a_7x7: x is the packed [N, H, W, 3] batch, filter stored [7][7][4][Cout]   */
 typedef struct ds_conv_layer_plan {
     ds_conv_desc d;          /* descriptor of the chosen launch (dgrad: channel roles swapped, flipped taps)            */

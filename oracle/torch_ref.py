@@ -240,14 +240,14 @@ class DeepSentimentRef:
         return True                                 # Text/rnn/*, W_fc, b_fc, W_softmax, b_softmax
 
     # -- towers -------------------------------------------------------------------------------
-    def _cbr(self, x, scope, stride=1, launch_cout=None):
+    def _cbr(self, x, scope, stride=1):
         w_ = self.p[scope + "/weights"]
         fp8_ok = w_.shape[0] in (1, 3) and stride == 1 and x.shape[1] % 8 == 0
         if self.conv_multiply == "fp8" and fp8_ok:
             # the layers ds_conv_fp8 takes (1x1 / 3x3, stride 1, Cin % 8 == 0); the rest -- the stem -- multiplies in bf16
             z = conv2d_same_fp8_multiply(x, self.p[scope + "/weights"], stride)
         elif self.conv_multiply == "fp8_auto":
-            # fp8 only where the build's launch rule picks it (launch_cout: the fused 1x1 launch's summed columns)
+            # fp8 only where the build's plan rule picks it (forward 3x3, >= 96 input channels, >= 14x14 maps)
             k, cin = w_.shape[0], w_.shape[2]
             z = _ConvMixedMultiply.apply(_same_pad_nchw(x, k, stride, 0.0), w_.permute(3, 2, 0, 1), stride,
                                          fp8_ok and fp8_where_it_wins(k, cin, x.shape[2], False),
@@ -299,11 +299,9 @@ class DeepSentimentRef:
             else:
                 pre = "InceptionV1/%s/" % name
                 nm = [n for (n, _, _, _) in S.mixed_conv_names(name)]
-                # (the build runs Branch_0/1/2's 1x1 convs as ONE launch: its column count decides the fp8 rule)
-                nf = sum(self.p[pre + nm[i] + "/weights"].shape[3] for i in (0, 1, 3))
-                b0 = self._cbr(net, pre + nm[0], launch_cout=nf)
-                b1 = self._cbr(self._cbr(net, pre + nm[1], launch_cout=nf), pre + nm[2])
-                b2 = self._cbr(self._cbr(net, pre + nm[3], launch_cout=nf), pre + nm[4])
+                b0 = self._cbr(net, pre + nm[0])
+                b1 = self._cbr(self._cbr(net, pre + nm[1]), pre + nm[2])
+                b2 = self._cbr(self._cbr(net, pre + nm[3]), pre + nm[4])
                 b3 = self._cbr(self._pool(net, 3, 1, name + "/Branch_3"), pre + nm[5])
                 net = torch.cat([b0, b1, b2, b3], dim=1)
         self.last_mixed_5c = net

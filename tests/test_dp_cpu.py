@@ -40,8 +40,11 @@ def _text_problem():
 
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tumblr_emotions_amd import dp
+    assert dp.init_distributed("gloo", rank=rank, world_size=world) == (rank, world)
     try:
+        with pytest.raises(RuntimeError):          # a second call would reserve the streams too late: refused
+            dp.init_distributed("gloo", rank=rank, world_size=world)
         # ---- bucketed all-reduce over a flat buffer laid out by ParamStore --------------------------
         st = ParamStore("cpu")
         st.declare("conv/weights", (3, 5), True, l2=True, bucket=1)
@@ -125,3 +128,32 @@ def test_param_store_layout_and_tf_names_roundtrip():
     np.testing.assert_allclose(fused[..., 2:5], sd["InceptionV1/Mixed_5c/Branch_1/Conv2d_0a_1x1/weights"].astype(np.float32))
     assert st.entries["InceptionV1/Mixed_5c/fused_1x1/weights"].offset == 0 and st.n_l2 == 24
     assert all(e.offset % 4 == 0 for e in st.entries.values())
+
+
+def test_bench_started_without_a_launcher_relaunches_itself_one_rank_per_gpu(tmp_path):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (how the driver starts a bench) must become the
+    N-rank torch.distributed.run job instead of failing: the re-exec argv is the contract's launcher line, rendezvous on
+    127.0.0.1, the caller's arguments unchanged; under a launcher (WORLD_SIZE set) nothing is re-executed and a rank
+    count that disagrees with --gpus is an error, not an assert."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ds_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv = bench.self_launch_argv(8, ["--gpus", "8", "--steps", "3", "--warmup", "1"], port=29999)
+    assert argv == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                    "--master-addr", "127.0.0.1", "--master-port", "29999", os.path.join(root, "bench.py"),
+                    "--gpus", "8", "--steps", "3", "--warmup", "1"]
+    port = int(bench.self_launch_argv(2, [])[9])
+    assert 1024 < port < 65536
+    # the real thing, end to end on CPU: a stand-in for `python` records what bench.py exec's
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    src = open(os.path.join(root, "bench.py")).read()
+    probe = tmp_path / "bench_probe.py"
+    probe.write_text(src.replace("os.execv(cmd[0], cmd)", "print('EXEC ' + ' '.join(cmd[1:])); sys.exit(0)"))
+    r = subprocess.run([sys.executable, str(probe), "--gpus", "4", "--steps", "2"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("EXEC -m torch.distributed.run --nnodes=1 --nproc-per-node 4 "), r.stderr
+    assert r.stdout.rstrip().endswith("--gpus 4 --steps 2")

@@ -43,8 +43,8 @@ def _free_port():
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tumblr_emotions_amd import dp
+    dp.init_distributed("gloo", device=0, rank=rank, world_size=world)
     try:
         from tumblr_emotions_amd.net import SentimentNet
         from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
@@ -102,8 +102,8 @@ def _rccl_world1_worker(port, out):
     RCCL's async work handle and the event ordering across the text-tower stream -- the code path of an 8-GPU run."""
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from tumblr_emotions_amd import dp
+    dp.init_distributed("nccl", device=0, rank=0, world_size=1)
     try:
         from tumblr_emotions_amd.net import SentimentNet
         from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
@@ -173,8 +173,8 @@ def _dp_parity_inputs():
 def _dp_parity_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tumblr_emotions_amd import dp
+    dp.init_distributed("gloo", device=0, rank=rank, world_size=world)
     try:
         import sys
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -260,8 +260,8 @@ def test_two_rank_joint_step_matches_the_clone_oracle():
 def _sync_bn_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tumblr_emotions_amd import dp
+    dp.init_distributed("gloo", device=0, rank=rank, world_size=world)
     try:
         from tumblr_emotions_amd.net import SentimentNet
         from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device

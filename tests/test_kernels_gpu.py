@@ -1683,7 +1683,7 @@ def test_split_gemm_with_slab_epilogue_matches_the_single_launch(case):
                         (ops.DS_EPI_ACCUM | ops.DS_EPI_BIAS | ops.DS_EPI_RELU, np.maximum(core + bias + prev, 0)),
                         (ops.DS_EPI_MASK, core * mask), (0, core)):
         plan = ops.head_gemm_plan(M, K, N, K + 8, N + 4, K if transposed else N, transposed_w=transposed, flags=flags,
-                                  ldmask=N + 4)
+                                  ldmask=N + 4, device="cuda")
         assert isinstance(plan, ops.SplitGemm)
         outs = []
         for rep in range(2):
@@ -1700,5 +1700,5 @@ def test_split_gemm_with_slab_epilogue_matches_the_single_launch(case):
         torch.cuda.synchronize()
         assert float((outs[0] - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
     # below the thresholds the plain plan is returned
-    assert not isinstance(ops.head_gemm_plan(4096, 512, 64, 512, 64, 64), ops.SplitGemm)
-    assert not isinstance(ops.head_gemm_plan(64, 15, 512, 15, 512, 15, transposed_w=True), ops.SplitGemm)
+    assert not isinstance(ops.head_gemm_plan(4096, 512, 64, 512, 64, 64, device="cuda"), ops.SplitGemm)
+    assert not isinstance(ops.head_gemm_plan(64, 15, 512, 15, 512, 15, transposed_w=True, device="cuda"), ops.SplitGemm)

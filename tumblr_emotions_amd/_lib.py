@@ -16,7 +16,7 @@ DS_CONV_FWD, DS_CONV_DGRAD = 0, 1
 DS_ARITH_F32, DS_ARITH_BF16, DS_ARITH_FP8, DS_ARITH_F32X3 = 0, 1, 2, 3
 DS_FAM_IGEMM, DS_FAM_WINO2, DS_FAM_WINO4, DS_FAM_STEM, DS_FAM_BF16D, DS_FAM_FP8D, DS_FAM_F32X3 = range(7)
 DS_PLAN_NO_WINO, DS_PLAN_NO_WINO4, DS_PLAN_NO_STEM_DIRECT, DS_PLAN_NO_BF16_DIRECT, DS_PLAN_ACT16, DS_PLAN_PACKED_RGB = 1, 2, 4, 8, 16, 32
-DS_PLAN_FP8_EVERYWHERE = 64
+DS_PLAN_FP8_EVERYWHERE, DS_PLAN_FP8_WIDE_RULE = 64, 128
 
 
 class ConvDesc(C.Structure):

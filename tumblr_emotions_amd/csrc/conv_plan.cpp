@@ -123,14 +123,9 @@ extern "C" int ds_conv_plan(ds_conv_layer_plan *out, int32_t role, int32_t arith
         // most shapes, 3x SLOWER on the 16 / 24 / 32-channel 3x3 layers, 5-30 % slower into 64 columns (Conv2d_2c's dgrad:
         // 375 against 283 us) -- and 1.09-1.5x FASTER on the forward 3x3 layers with >= 96 input channels on 14 x 14 and
         // larger maps.  Only those run in fp8; the rest takes the bf16 rules.  In-box, ms/step at B = 256: bf16 13.02,
-        // fp8 by this rule 13.07, by the wider rule (>= 64 channels into >= 96 columns, DS_FP8_RULE=1) 13.46, everywhere 13.8.
-        static int fp8_rule = -1;
-        if (fp8_rule < 0) {
-            const char *e = getenv("DS_FP8_RULE");        // A/B aid: 1 = the wider round-4 rule (reduction >= 64 into >= 96 columns)
-            fp8_rule = e ? atoi(e) : 0;
-        }
-        const bool wins = fp8_rule == 1 ? (cin >= 64 && cout >= 96)
-                                        : (!dgrad && k == 3 && cin >= 96 && H >= 14);      // the 1.09-1.5x layers only
+        // fp8 by this rule 13.07, by the wider rule (>= 64 channels into >= 96 columns, DS_PLAN_FP8_WIDE_RULE) 13.46, everywhere 13.8.
+        const bool wins = (options & DS_PLAN_FP8_WIDE_RULE) ? (cin >= 64 && cout >= 96)      // A/B: the wider round-4 rule
+                                                            : (!dgrad && k == 3 && cin >= 96 && H >= 14);      // the 1.09-1.5x layers only
         const bool fp8 = arith == DS_ARITH_FP8 && stride == 1 && cin % 8 == 0 && ((options & DS_PLAN_FP8_EVERYWHERE) || wins);
         if (fp8) {
             fam = DS_FAM_FP8D;

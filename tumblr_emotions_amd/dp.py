@@ -25,18 +25,33 @@ import torch.distributed as dist
 def init_distributed(backend="nccl", device=None, **kwargs):
     """`torch.distributed.init_process_group` for one rank of a data-parallel job, with the step's HIP streams bound to
     their hardware queues FIRST (streams.reserve: RCCL's own streams must not take the queue the text tower's stream
-    would have got -- 1.4 ms per step, profiles/r03_notes.md).  Call after `torch.cuda.set_device`; `device` defaults
-    to the current one.  Extra keyword arguments go to init_process_group (rank, world_size, init_method ...)."""
+    would have got -- 1.4 ms per step, profiles/r03_notes.md).  `device` (index or torch.device; default: the current
+    one) is made current here.  Extra keyword arguments go to init_process_group (rank, world_size, init_method ...).
+    Used by bench.py and tests/test_dp_gpu.py.
+
+    Two things this function cannot repair and therefore reports:
+      * HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the environment before the process first touches HIP (ROCr reads it at
+        hsa_init; this driver stack only supports dmabuf IPC).  It is set here for child processes and for a HIP runtime
+        that has not started yet; if HIP is already up without it, a RuntimeWarning says so.
+      * a process group that already exists was created BEFORE the streams were reserved: RuntimeError."""
     import os
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # this driver stack only supports dmabuf IPC
+    import warnings
+    if dist.is_initialized():
+        raise RuntimeError("init_distributed: a process group already exists; call this INSTEAD of "
+                           "init_process_group so that streams.reserve() runs before RCCL creates its streams")
+    if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+        if torch.cuda.is_available() and torch.cuda.is_initialized() and backend == "nccl":
+            warnings.warn("HSA_ENABLE_IPC_MODE_LEGACY=0 was not set before HIP initialised; RCCL across processes may "
+                          "fail with hipIpcGetMemHandle: invalid argument", RuntimeWarning)
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     if torch.cuda.is_available():
         from . import streams
+        if device is not None:
+            torch.cuda.set_device(device)
         streams.reserve(device)
         if backend == "nccl" and "device_id" not in kwargs:
-            kwargs["device_id"] = torch.device("cuda", torch.cuda.current_device() if device is None
-                                               else torch.device(device).index or 0)
-    if not dist.is_initialized():
-        dist.init_process_group(backend, **kwargs)
+            kwargs["device_id"] = torch.device("cuda", torch.cuda.current_device())
+    dist.init_process_group(backend, **kwargs)
     return world_info()
 
 

@@ -813,6 +813,7 @@ class InceptionV1Engine:
         self.branch_streams = True   # Mixed blocks: Branch_2 and Branch_3 on side streams next to Branch_0/1 (False: one stream)
         self.side = None
         self.fp8_everywhere = os.environ.get("DS_FP8_EVERYWHERE", "0") == "1"      # A/B: ds_conv_fp8 also where the bf16 kernels are faster
+        self.fp8_wide_rule = os.environ.get("DS_FP8_RULE", "0") == "1"             # A/B: the wider round-4 rule (a plan option)
         self.bf16_direct = True      # dtype bf16: ds_conv_bf16 where it wins (False: the LDS-staged bf16 kernel everywhere)
         self.winograd = True         # 3x3 layers through ds_conv_wino where it wins (False: implicit GEMM everywhere)
         self.mul3 = os.environ.get("DS_MUL3", "0") == "1"     # opt-in: forward 1x1 convs with fp32 products on the bf16 matrix cores
@@ -875,6 +876,8 @@ class InceptionV1Engine:
             o |= ops.DS_PLAN_ACT16
         if self.fp8_everywhere:
             o |= ops.DS_PLAN_FP8_EVERYWHERE
+        if self.fp8_wide_rule:
+            o |= ops.DS_PLAN_FP8_WIDE_RULE
         return o
 
     def all_reduce(self, t):
@@ -953,8 +956,8 @@ class InceptionV1Engine:
         self.dpooled = torch.empty(B, F, device=dev)
         self.mask = torch.ones(B, F, device=dev)
         self.logits = torch.empty(B, nc, device=dev)
-        self.fc = ops.head_gemm_plan(B, F, nc, F, nc, nc, flags=DS_EPI_BIAS)
-        self.fc_dgrad = ops.head_gemm_plan(B, nc, F, nc, F, nc, transposed_w=True)
+        self.fc = ops.head_gemm_plan(B, F, nc, F, nc, nc, flags=DS_EPI_BIAS, device=dev)
+        self.fc_dgrad = ops.head_gemm_plan(B, nc, F, nc, F, nc, transposed_w=True, device=dev)
         self.fc_wgrad = WgradPlan(B, 1, 1, F, F, 1, 1, 1, nc, nc, pad_t=0, pad_l=0, OH=1, OW=1)
         self.need_ws(self.fc_wgrad.ws_bytes)
         self.colsum_scratch = torch.empty(64 * max(nc, 4), device=dev)

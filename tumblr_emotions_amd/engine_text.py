@@ -199,13 +199,13 @@ class JointHeadEngine:
 
     def _plans(self, ld_im, ld_tx):
         B, im, tx, fc, nc = self.B, self.im, self.tx, self.fc, self.nc
-        self.fc_im = head_gemm_plan(B, im, fc, ld_im, fc, fc)
-        self.fc_tx = head_gemm_plan(B, tx, fc, ld_tx, fc, fc, flags=DS_EPI_ACCUM | DS_EPI_BIAS | DS_EPI_RELU)
-        self.sm = head_gemm_plan(B, fc, nc, fc, nc, nc, flags=DS_EPI_BIAS)
-        self.sm_dgrad = head_gemm_plan(B, nc, fc, nc, fc, nc, transposed_w=True, flags=DS_EPI_MASK, ldmask=fc)
+        self.fc_im = head_gemm_plan(B, im, fc, ld_im, fc, fc, device=self.device)
+        self.fc_tx = head_gemm_plan(B, tx, fc, ld_tx, fc, fc, flags=DS_EPI_ACCUM | DS_EPI_BIAS | DS_EPI_RELU, device=self.device)
+        self.sm = head_gemm_plan(B, fc, nc, fc, nc, nc, flags=DS_EPI_BIAS, device=self.device)
+        self.sm_dgrad = head_gemm_plan(B, nc, fc, nc, fc, nc, transposed_w=True, flags=DS_EPI_MASK, ldmask=fc, device=self.device)
         self.sm_wgrad = _gemm_wgrad(B, fc, nc, fc, nc)
-        self.im_dgrad = head_gemm_plan(B, fc, im, fc, im, fc, transposed_w=True)
-        self.tx_dgrad = head_gemm_plan(B, fc, tx, fc, tx, fc, transposed_w=True)
+        self.im_dgrad = head_gemm_plan(B, fc, im, fc, im, fc, transposed_w=True, device=self.device)
+        self.tx_dgrad = head_gemm_plan(B, fc, tx, fc, tx, fc, transposed_w=True, device=self.device)
         self.im_wgrad = _gemm_wgrad(B, im, fc, ld_im, fc)
         self.tx_wgrad = _gemm_wgrad(B, tx, fc, ld_tx, fc)
         self.ws_bytes = max(p.ws_bytes for p in (self.sm_wgrad, self.im_wgrad, self.tx_wgrad))
@@ -263,8 +263,8 @@ class TextHeadEngine:
         st = self.store
         self.w_sm, self.gw_sm = _vp(st.ptr("W_softmax")), _vp(st.grad_ptr("W_softmax"))
         self.b_sm, self.gb_sm = _vp(st.ptr("b_softmax")), st.grad_view("b_softmax")
-        self.sm = head_gemm_plan(B, H, nc, H, nc, nc, flags=DS_EPI_BIAS)
-        self.sm_dgrad = head_gemm_plan(B, nc, H, nc, H, nc, transposed_w=True)
+        self.sm = head_gemm_plan(B, H, nc, H, nc, nc, flags=DS_EPI_BIAS, device=self.device)
+        self.sm_dgrad = head_gemm_plan(B, nc, H, nc, H, nc, transposed_w=True, device=self.device)
         self.sm_wgrad = _gemm_wgrad(B, H, nc, H, nc)
         self.ws_bytes = self.sm_wgrad.ws_bytes
         self.ws = torch.empty(max(self.ws_bytes // 4, 4), device=dev)

@@ -15,7 +15,7 @@ from ._lib import (ConvDesc, Segments, SumSegments, DS_EPI_ACCUM, DS_EPI_BIAS, D
                    DS_DTYPE_BF16, DS_DTYPE_F32, DS_FP8_E4M3, DS_FP8_E5M2, DS_CONV_FWD, DS_CONV_DGRAD, DS_ARITH_F32, DS_ARITH_BF16,
                    DS_ARITH_FP8, DS_ARITH_F32X3, DS_FAM_IGEMM, DS_FAM_WINO2, DS_FAM_WINO4, DS_FAM_STEM, DS_FAM_BF16D, DS_FAM_FP8D,
                    DS_FAM_F32X3, DS_PLAN_NO_WINO, DS_PLAN_NO_WINO4, DS_PLAN_NO_STEM_DIRECT, DS_PLAN_NO_BF16_DIRECT, DS_PLAN_ACT16,
-                   DS_PLAN_PACKED_RGB, DS_PLAN_FP8_EVERYWHERE)
+                   DS_PLAN_PACKED_RGB, DS_PLAN_FP8_EVERYWHERE, DS_PLAN_FP8_WIDE_RULE)
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -142,10 +142,10 @@ class ConvTimer:
 CONV_TIMER = None      # set to a ConvTimer to time the dominant kernel
 
 
-def head_gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=False, flags=0, ldmask=0, device="cuda"):
+def head_gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=False, flags=0, ldmask=0, *, device):
     """gemm_plan for the batch x features GEMMs of the heads (Logits, W_fc, W_softmax and their dgrads): with M <= 512 rows
     and K >= 256 a SplitGemm (split-K + fixed-order combine with the epilogue), else the plain plan.  DS_SPLIT_GEMM=0: always
-    the plain plan (A/B aid)."""
+    the plain plan (A/B aid).  `device`: the engine's device (the slabs live beside its tensors, not on the current device)."""
     if M <= 512 and K >= 256 and os.environ.get("DS_SPLIT_GEMM", "1") != "0":
         return SplitGemm(M, K, N, lda, ldc, w_ld, transposed_w, flags, ldmask, 8 if K >= 512 else 4, device)
     return gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=transposed_w, flags=flags, ldmask=ldmask)
@@ -175,7 +175,8 @@ class SplitGemm:
         self.d, self.alg_flops, self.partials = self.plan.d, self.plan.alg_flops, 0
 
     def run(self, x, w, z, bias=None, mask=None, stats=None, pivot=None):
-        assert stats is None
+        if stats is not None or pivot is not None:
+            raise ValueError("SplitGemm has no BatchNorm-statistics epilogue (the heads' GEMMs are not followed by BatchNorm)")
         t = CONV_TIMER
         if t is not None:
             t.begin()
