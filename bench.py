@@ -89,8 +89,8 @@ def cpu_baseline(post_size, vocab, dim, rnn, warmup=3, steps=10):
             timed("joint", 16, threads)
         steps, warmup = max(3, steps // 2), 2      # the larger batch, bounded: ~64 / 45 s per step
         timed("joint", 64, min(16, phys))
-        steps, warmup = 2, 1                       # the HEADLINE batch itself: ~7 s per step
-        timed("joint", 256, phys)
+        steps, warmup = 3, 1                       # the HEADLINE batch itself: ~6 s per step
+        timed("joint", 256, min(16, phys))         # (every core: 22 s per step on 2 x EPYC 9575F -- oversubscribed; 16 threads ~6 s)
     finally:
         torch.set_num_threads(prev)
     joint = [r for r in runs if r["workload"].startswith("joint")]

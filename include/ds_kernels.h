@@ -130,6 +130,9 @@ int ds_debug_conv_set_wide(int mode);
 /* ds_conv_wino's kernel carries four ablation bits in `flags` (256 / 512 / 1024 / 2048: skip the pixel loads, the weight
  * DMAs, the output stores ... -- garbage results, timing only).  They are refused (DS_ERR_ARG) unless switched on here. */
 int ds_debug_conv_wino_allow_ablation(int on);
+/* ds_conv_wino4: pin the 32-channel blocks per workgroup (1, 2; 0 = the launch-time model, the default).  Both choices give
+ * the same z up to summation order; the statistics partial count does not depend on it.                                  */
+int ds_debug_conv_wino4_set_nb(int nb);
 /* Number of row-tile blocks (P) the launch for `d` will use = number of stats partials.   */
 int ds_conv_igemm_partials(const ds_conv_desc *d);
 /* 1 if a launch for `d` can carry DS_EPI_BNSUMS (plain 1x1 stride-1 shapes that run on the wide kernel).  */

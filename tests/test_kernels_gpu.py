@@ -227,7 +227,7 @@ def test_gemm_lstm_shape():
     close(dh, dg @ kern[40:].T)
 
 
-@pytest.mark.parametrize("f4", [False, True], ids=["F2x2", "F4x4"])
+@pytest.mark.parametrize("f4", [False, True, 1, 2], ids=["F2x2", "F4x4", "F4x4-NB1", "F4x4-NB2"])
 @pytest.mark.parametrize("case", [(2, 8, 8, 16, 32), (3, 14, 14, 24, 64), (2, 28, 28, 96, 128), (5, 7, 7, 160, 320),
                                   (2, 13, 11, 48, 176), (1, 9, 10, 8, 40), (2, 56, 56, 64, 192), (3, 14, 14, 32, 64),
                                   (1, 4, 4, 16, 16), (9, 5, 6, 16, 48)])
@@ -235,8 +235,22 @@ def test_winograd_conv_forward_and_dgrad_match_oracle(case, f4):
     """ds_conv_wino (fused Winograd F(2x2,3x3), fp32 MFMA) and ds_conv_wino4 (F(4x4,3x3)) against the fp64
     direct-convolution oracle: forward with BatchNorm statistics about a pivot, and the input gradient through the
     flipped / transposed transformed filter; map sizes that are not multiples of the tile (half-empty border tiles),
-    Cout not a multiple of 32, a ragged last tile group, one tile per image."""
+    Cout not a multiple of 32, a ragged last tile group, one tile per image.  F4x4-NB1 / -NB2 pin the channel blocks per
+    workgroup (ds_debug_conv_wino4_set_nb): at these sizes the launch-time model would pick NB = 1 almost everywhere, and
+    the NB = 2 instantiations (position 8's accumulators in architectural registers, two epilogue passes) would only run in
+    the full-size step tests."""
     ops = _ops()
+    from tumblr_emotions_amd import _lib
+    nb_pin = 0 if isinstance(f4, bool) else int(f4)
+    f4 = bool(f4)
+    assert _lib.load().ds_debug_conv_wino4_set_nb(nb_pin) == 0
+    try:
+        _winograd_case(ops, case, f4)
+    finally:
+        _lib.load().ds_debug_conv_wino4_set_nb(0)
+
+
+def _winograd_case(ops, case, f4):
     N, H, W, Ci, Co = case
     step = 16 if f4 else 8                      # channels per K step: the reduction axis must be a multiple
     if Ci % step:

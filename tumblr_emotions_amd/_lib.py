@@ -80,6 +80,7 @@ SIGNATURES = {
     "ds_debug_conv_set_path": (C.c_int, [C.c_int]),
     "ds_debug_conv_set_wide": (C.c_int, [C.c_int]),
     "ds_debug_conv_wino_allow_ablation": (C.c_int, [C.c_int]),
+    "ds_debug_conv_wino4_set_nb": (C.c_int, [C.c_int]),
     "ds_conv_igemm_partials": (C.c_int, [_CD]),
     "ds_conv_igemm_bnsums_supported": (C.c_int, [_CD]),
     "ds_conv_igemm_norm_supported": (C.c_int, [_CD]),

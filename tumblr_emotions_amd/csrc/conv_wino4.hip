@@ -61,7 +61,30 @@ struct Wino4Params {
     int groups, ncol;       // 32-tile groups, (32 NB)-channel blocks
     unsigned x_bytes, u_bytes, z_bytes;
     int flags;
+#ifdef DS_W4_PROF
+    unsigned long long *prof;      // [workgroup][16] s_memtime stamps (scripts/wino4_phase_prof.py builds this variant)
+#endif
 };
+
+// Phase profiler (only in the -DDS_W4_PROF build of scripts/wino4_phase_prof.py; the library build compiles none of it):
+// wave 0 of every workgroup stamps s_memtime at its phase boundaries (scalar registers) and lane 0 stores the stamps last.
+// DS_W4_ABL (same build) compiles pieces of the K loop out: 1 weight-fragment loads, 2 pixel loads, 4 transform VALU,
+// 8 LDS writes of V.
+#ifdef DS_W4_PROF
+#define W4_STAMP(i) do { asm volatile("s_waitcnt lgkmcnt(0)"); prof_t[i] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)"); } while (0)
+#else
+#define W4_STAMP(i) do { } while (0)
+#endif
+#ifndef DS_W4_ABL
+#define DS_W4_ABL 0
+#endif
+// tuning knobs (compile time; the values below are the measured choice, scripts/wino4_phase_prof.py --def sweeps them)
+#ifndef DS_W4_PIX
+#define DS_W4_PIX 0
+#endif
+#ifndef DS_W4_RING1
+#define DS_W4_RING1 6
+#endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t w4srd(const void *p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
@@ -114,25 +137,38 @@ __device__ __forceinline__ void in1d(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32
     t5 = pfma(4.f, d1, pfma(-5.f, d3, d5));
 }
 
-// A^T m for one line of six, on four tiles at once: A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-__device__ __forceinline__ f32x4 qfma(float k, f32x4 a, f32x4 b) { return __builtin_elementwise_fma(f32x4{k, k, k, k}, a, b); }
-__device__ __forceinline__ void out1d(f32x4 m0, f32x4 m1, f32x4 m2, f32x4 m3, f32x4 m4, f32x4 m5, f32x4 &y0, f32x4 &y1,
+// A^T m for one line of six, on four channels at once: A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].
+// Every operation is a packed fp32 one on the channel pairs.  hipcc packs additions and multiply-adds but not subtractions
+// (and it folds fma(-1, b, a) back into a subtraction): the four differences per line came out as four scalar v_sub_f32
+// each, 288 of the epilogue's ~1200 VALU instructions at NB = 2, and every VALU slot is a slot the matrix pipe idles.  So
+// a - b is written fma(m1, b, a) with m1 = -1 hidden from the optimiser in a scalar register (same value, one rounding).
+// NOT inline asm as in the input transform: these results share registers with the data of the output stores just issued,
+// and the gfx940 "VALU overwrites the data of a >64-bit store" wait states are not inserted in front of inline asm
+// (measured: one corrupted channel per store).
+__device__ __forceinline__ f32x4 qfma(f32x4 k, f32x4 a, f32x4 b) { return __builtin_elementwise_fma(k, a, b); }
+__device__ __forceinline__ f32x4 q4(float k) { return f32x4{k, k, k, k}; }
+__device__ __forceinline__ void out1d(float m1, f32x4 m0, f32x4 a1, f32x4 a2, f32x4 a3, f32x4 a4, f32x4 m5, f32x4 &y0, f32x4 &y1,
                                       f32x4 &y2, f32x4 &y3) {
-    const f32x4 s0 = qfma(1.f, m2, m1), s1 = qfma(-1.f, m2, m1), s2 = qfma(1.f, m4, m3), s3 = qfma(-1.f, m4, m3);
-    y0 = qfma(1.f, s2, qfma(1.f, s0, m0));
-    y1 = qfma(2.f, s3, s1);
-    y2 = qfma(4.f, s2, s0);
-    y3 = qfma(1.f, m5, qfma(8.f, s3, s1));
+    const f32x4 s0 = a1 + a2, s1 = qfma(q4(m1), a2, a1), s2 = a3 + a4, s3 = qfma(q4(m1), a4, a3);
+    y0 = s2 + (s0 + m0);
+    y1 = qfma(q4(2.f), s3, s1);
+    y2 = qfma(q4(4.f), s2, s0);
+    y3 = m5 + qfma(q4(8.f), s3, s1);
 }
 
 template <int NB, bool BNS, bool EDGE>      // EDGE: H or W is not a multiple of four (partial last tile row / column)
 __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p) {
     // K loop: V[2][36][32 tiles][16 ci] = 144 KB; epilogue: M[36][32 co][32 tiles] = 144 KB
     __shared__ __attribute__((aligned(128))) float smem[36 * 32 * 32];
-    __shared__ float red[4 * 32 * 2];
+    __shared__ __attribute__((aligned(16))) float red[2 * 32 * 32];      // statistics exchange: [sum | sum of squares][tile][channel]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
+#ifdef DS_W4_PROF
+    unsigned long long prof_t[12];
+    const unsigned long long prof_rt0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz, the same on every XCD
+    W4_STAMP(0);
+#endif
     // 1-D XCD-aware launch as conv_wino.hip: the channel blocks of a tile group run back to back on one XCD
     const int id = blockIdx.x;
     const int lin = (id & 7) * (int)(gridDim.x >> 3) + (id >> 3);
@@ -194,13 +230,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
         for (int e = 0; e < 16; ++e) accv[nb][e] = 0.f;
 
     f32x2 raw[36];
-    f32x4 b[6][NB];             // ring: group g (half step g / 9, position g % 9) uses slot g % 6, six groups of lead
+    // weight-fragment ring: group g (half step g / 9, position g % 9) uses slot g % RING and is requested RING groups ahead.
+    // NB = 2 has registers for six slots (3072 matrix cycles of lead); NB = 1 runs its 18 groups in half the time, so six
+    // slots would be 1536 cycles -- less than a loaded L2 round trip -- and it has the registers for a whole K step.
+    constexpr int RING = NB == 1 ? DS_W4_RING1 : 6;
+    static_assert(18 % RING == 0, "the slot of a group must not depend on the K step");
+    f32x4 b[RING][NB];
     auto load_pixel = [&](int q, int c0, const unsigned *ro) {
         const int py = q / 6, px = q - py * 6;
+        if ((DS_W4_ABL & 2) && c0 >= 32) return;
         raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(srd_x, cv[px] ? ro[py] : kOOB,
                                                                                  py * rowstep + px * pixstep + c0 * 4, 0));
     };
     auto load_b = [&](int slot, int pi, int hs) {
+        if ((DS_W4_ABL & 1) && hs > 0) return;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
             b[slot][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_u, boff[nb], (wave * 9 + pi) * upos + hs * ustep, 0));
@@ -212,21 +255,30 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     //   row chunk i:     B^T applied along row i of t -> the six positions (i, 0..5), written position-major to LDS
     f32x2 t[36];
     auto col_chunk = [&](int px) {
+        if (DS_W4_ABL & 4) return;
         in1d(raw[px], raw[6 + px], raw[12 + px], raw[18 + px], raw[24 + px], raw[30 + px], t[px], t[6 + px], t[12 + px],
              t[18 + px], t[24 + px], t[30 + px]);
     };
     auto row_chunk = [&](int i, float *Vw) {
+        if (DS_W4_ABL & 4) {
+            if (!(DS_W4_ABL & 8))
+#pragma unroll
+                for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2 *>(Vw + (i * 6 + j) * 512 + tid * 2) = t[i * 6 + j];
+            return;
+        }
         f32x2 v[6];
         in1d(t[i * 6], t[i * 6 + 1], t[i * 6 + 2], t[i * 6 + 3], t[i * 6 + 4], t[i * 6 + 5], v[0], v[1], v[2], v[3], v[4], v[5]);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2 *>(Vw + (i * 6 + j) * 512 + tid * 2) = v[j];
+        for (int j = 0; j < 6; ++j)
+            if (!(DS_W4_ABL & 8)) *reinterpret_cast<f32x2 *>(Vw + (i * 6 + j) * 512 + tid * 2) = v[j];
+            else asm volatile("" :: "v"(v[j]));
     };
 
     // prologue: pixels and transform of K step 0, pixels of K step 1, the first six weight fragments
 #pragma unroll
     for (int q = 0; q < 36; ++q) load_pixel(q, 0, rowoff);
 #pragma unroll
-    for (int g = 0; g < 6; ++g) load_b(g, g, 0);
+    for (int g = 0; g < RING; ++g) load_b(g, g % 9, g / 9);
 #pragma unroll
     for (int px = 0; px < 6; ++px) col_chunk(px);
     if (ksteps > 1) {
@@ -235,7 +287,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) row_chunk(i, smem);
+    W4_STAMP(1);
     lds_barrier();
+    W4_STAMP(2);
 
     // One K step.  LAST = false: every step but the last -- the transform of step ks + 1 and the pixel requests of step
     // ks + 2 are UNCONDITIONAL (past the last step the requests carry out-of-range offsets and return zeros nobody
@@ -277,9 +331,22 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
                 for (int g = g0; g < g0 + GP; ++g) {
                     if (g < 6) col_chunk(g);
                     else if (g < 12) row_chunk(g - 6, Vw);
-                    if (g >= 6) {               // three pixels per group over groups 6-17, column by column
+                    // the pixels of K step ks + 2, column by column into the registers the column chunks freed
+                    if (DS_W4_PIX == 0 && g >= 6) {          // three per group over groups 6-17 (lead: 6-11 groups)
 #pragma unroll
                         for (int k = 3 * (g - 6); k < 3 * (g - 6) + 3; ++k) load_pixel((k % 6) * 6 + k / 6, c2, ro);
+                    }
+                    if (DS_W4_PIX == 1 && g < 6) {           // column g right behind its column chunk (lead: 18 groups)
+#pragma unroll
+                        for (int k = 6 * g; k < 6 * g + 6; ++k) load_pixel((k % 6) * 6 + k / 6, c2, ro);
+                    }
+                    if (DS_W4_PIX == 2 && g < 9) {           // four per group over groups 0-8 (column k / 6 <= g is free)
+#pragma unroll
+                        for (int k = 4 * g; k < 4 * g + 4; ++k) load_pixel((k % 6) * 6 + k / 6, c2, ro);
+                    }
+                    if (DS_W4_PIX == 3 && g < 12) {          // three per group over groups 0-11
+#pragma unroll
+                        for (int k = 3 * g; k < 3 * g + 3; ++k) load_pixel((k % 6) * 6 + k / 6, c2, ro);
                     }
                 }
             }
@@ -291,15 +358,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         const int g = g0 + u, pi = g % 9;
-                        if (NB == 2 && pi == 8) mfma_v(accv[nb], av[u][j], b[g % 6][nb][j]);
-                        else acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][j], b[g % 6][nb][j], acc[pi][nb], 0, 0, 0);
+                        if (NB == 2 && pi == 8) mfma_v(accv[nb], av[u][j], b[g % RING][nb][j]);
+                        else acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][j], b[g % RING][nb][j], acc[pi][nb], 0, 0, 0);
                     }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < GP; ++u) {
                 const int g = g0 + u;
-                if (g + 6 < 18) load_b(g % 6, (g + 6) % 9, 2 * ks + (g + 6) / 9);
-                else if (!LAST) load_b(g % 6, g + 6 - 18, 2 * ks + 2);
+                if (g + RING < 18) load_b(g % RING, (g + RING) % 9, 2 * ks + (g + RING) / 9);
+                else if (!LAST) load_b(g % RING, (g + RING - 18) % 9, 2 * ks + 2 + (g + RING - 18) / 9);
             }
 #pragma unroll
             for (int u = 0; u < GP; ++u) av[u] = avn[u];
@@ -310,6 +377,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
         lds_barrier();          // V of step ks + 1 is complete, V of step ks is free
     }
     k_step(__builtin_amdgcn_readfirstlane(ksteps - 1), std::true_type{});      // (uniform: no waterfall loops around its loads)
+    W4_STAMP(3);
 
     // ---- output transform Y = A^T M A through LDS, one 32-channel block at a time ---------------------------------------
     // The waves park their accumulators as M[xi][tile][co] (dword writes, a wave's 32 channel lanes side by side); then
@@ -318,6 +386,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     // instructions per thread and block where a thread-per-channel layout needs 64 (the dword stores were the bulk of the
     // epilogue's time).
     const int et = tid >> 3, eq = tid & 7;
+    float neg1 = -1.f;
+    asm volatile("" : "+s"(neg1));          // opaque -1 (see out1d)
     const __amdgpu_buffer_rsrc_t srd_z = w4srd(p.z, p.z_bytes);
     const __amdgpu_buffer_rsrc_t srd_y = w4srd(BNS ? p.y : p.z, p.z_bytes);
     const int orow = p.W * p.ldz * 4, opix = p.ldz * 4;
@@ -342,6 +412,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
                 const f32x16 &c = (NB == 2 && pi == 8) ? accv[nb] : acc[pi][nb];
                 smem[(wave * 9 + pi) * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * kh) * 32 + li] = c[e];
             }
+        W4_STAMP(4 + 3 * nb);     // parked
         lds_barrier();
         const int col = co0 + 32 * nb + 4 * eq;                 // first of this thread's four channels (Cout % 4 == 0)
         const bool colok = col < p.Cout;
@@ -352,7 +423,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
         f32x4 P[4][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j)
-            out1d(*reinterpret_cast<const f32x4 *>(Mq + (0 * 6 + j) * 1024), *reinterpret_cast<const f32x4 *>(Mq + (1 * 6 + j) * 1024),
+            out1d(neg1, *reinterpret_cast<const f32x4 *>(Mq + (0 * 6 + j) * 1024), *reinterpret_cast<const f32x4 *>(Mq + (1 * 6 + j) * 1024),
                   *reinterpret_cast<const f32x4 *>(Mq + (2 * 6 + j) * 1024), *reinterpret_cast<const f32x4 *>(Mq + (3 * 6 + j) * 1024),
                   *reinterpret_cast<const f32x4 *>(Mq + (4 * 6 + j) * 1024), *reinterpret_cast<const f32x4 *>(Mq + (5 * 6 + j) * 1024),
                   P[0][j], P[1][j], P[2][j], P[3][j]);
@@ -369,54 +440,59 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
                     yv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_y, vof[k], rr * orow + k * opix, 0));
             }
             f32x4 y[4];
-            out1d(P[rr][0], P[rr][1], P[rr][2], P[rr][3], P[rr][4], P[rr][5], y[0], y[1], y[2], y[3]);
+            out1d(neg1, P[rr][0], P[rr][1], P[rr][2], P[rr][3], P[rr][4], P[rr][5], y[0], y[1], y[2], y[3]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[k]), srd_z, vof[k], rr * orow + k * opix, 2 /* nt */);
                 if constexpr (BNS) {
+                    f32x4 g;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float g = yv[k][c] > 0.f ? y[k][c] : 0.f;          // (an out-of-range offset reads y = 0)
-                        s[c] += g;
-                        q[c] += g * yv[k][c];
-                    }
+                    for (int c = 0; c < 4; ++c) g[c] = yv[k][c] > 0.f ? y[k][c] : 0.f;      // (an out-of-range offset reads y = 0)
+                    s += g;
+                    q = qfma(g, yv[k], q);
                 } else {
-                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                    const f32x4 uu = vof[k] != kOOB ? y[k] - pv : zero;
+                    // pixels outside the image (EDGE) and tiles / channels past the end do not count: on full maps the
+                    // condition is the thread's own (vo), applied once behind the loop
+                    f32x4 uu = qfma(q4(neg1), pv, y[k]);
+                    if (EDGE && vof[k] == kOOB) uu = q4(0.f);
                     s += uu;
-                    q += uu * uu;
+                    q = qfma(uu, uu, q);
                 }
             }
         }
+        if (!BNS && !EDGE && vo == kOOB) s = q = f32x4{0.f, 0.f, 0.f, 0.f};
+        W4_STAMP(5 + 3 * nb);     // gathered, transformed, stores issued
         if (BNS || (p.flags & DS_EPI_STATS)) {
-            // the 32 tiles of a channel: lanes eq, eq + 8, ... of the four waves, combined in a fixed order
-#pragma unroll
-            for (int o = 8; o < 64; o <<= 1)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    s[c] += __shfl_xor(s[c], o);
-                    q[c] += __shfl_xor(q[c], o);
-                }
-            if (lane < 8) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    red[(wave * 32 + 4 * lane + c) * 2 + 0] = s[c];
-                    red[(wave * 32 + 4 * lane + c) * 2 + 1] = q[c];
-                }
-            }
+            // the 32 tiles of a channel: every thread leaves its four channels' partial sums in LDS, then 64 threads (channel,
+            // sum | sum of squares) add the 32 tiles in index order.  (Was: three rounds of eight ds_bpermute shuffles, a
+            // four-wave combine and a barrier -- 1 us per channel block, measured by scripts/wino4_phase_prof.py.)
+            *reinterpret_cast<f32x4 *>(red + et * 32 + 4 * eq) = s;
+            *reinterpret_cast<f32x4 *>(red + 1024 + et * 32 + 4 * eq) = q;
             lds_barrier();
-            if (tid < 32 && co0 + 32 * nb + tid < p.Cout) {
-                float ss = 0.f, qq = 0.f;
+            if (tid < 64) {
+                const int ch = tid & 31, which = tid >> 5;
+                float acc2 = 0.f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    ss += red[(w * 32 + tid) * 2 + 0];
-                    qq += red[(w * 32 + tid) * 2 + 1];
-                }
-                p.stats[(int64_t)(co0 + 32 * nb + tid) * p.groups + group] = ss;
-                p.stats[((int64_t)p.Cout + co0 + 32 * nb + tid) * p.groups + group] = qq;
+                for (int tt = 0; tt < 32; ++tt) acc2 += red[which * 1024 + tt * 32 + ch];
+                if (co0 + 32 * nb + ch < p.Cout)
+                    p.stats[((int64_t)which * p.Cout + co0 + 32 * nb + ch) * p.groups + group] = acc2;
             }
         }
+        W4_STAMP(6 + 3 * nb);
     }
+#ifdef DS_W4_PROF
+    asm volatile("s_waitcnt vmcnt(0)");
+    W4_STAMP(10);                 // stores drained
+    if (tid == 0 && p.prof) {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) p.prof[(int64_t)blockIdx.x * 16 + i] = (i >= 4 + 3 * NB && i < 10) ? 0ull : prof_t[i];
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p.prof[(int64_t)blockIdx.x * 16 + 11] = xcc & 15u;
+        p.prof[(int64_t)blockIdx.x * 16 + 12] = prof_rt0;
+        p.prof[(int64_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // U = G g G^T (6 x 6) for every (ci, co) pair of the TF HWIO filter w [3][3][Cin][Cout], stored for the kernel's
@@ -475,12 +551,13 @@ struct W4Choice {
     int nb;             // 1, 2: F(4x4) with that channel-block count
     double us4, us2;    // expected launch time of F(4x4) with nb / of F(2x2)
 };
+int g_w4_forced_nb = -1;      // ds_debug_conv_wino4_set_nb (tests, tuning); -1: not set yet -> DS_WINO4_NB or automatic
 W4Choice w4_choose(int N, int H, int W, int Cin, int Cout) {
-    static int forced = -1;
-    if (forced < 0) {
+    if (g_w4_forced_nb < 0) {
         const char *e = getenv("DS_WINO4_NB");
-        forced = e ? atoi(e) : 0;
+        g_w4_forced_nb = e ? atoi(e) : 0;
     }
+    const int forced = g_w4_forced_nb;
     const double cus = 256.0;
     const int64_t mt4 = (int64_t)N * ((H + 3) / 4) * ((W + 3) / 4), g4 = (mt4 + 31) / 32;
     const int64_t mt2 = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2), g2 = (mt2 + 127) / 128;
@@ -497,6 +574,19 @@ W4Choice w4_choose(int N, int H, int W, int Cin, int Cout) {
 }
 
 }  // namespace
+
+#ifdef DS_W4_PROF
+static unsigned long long *g_w4_prof = nullptr;
+extern "C" void ds_debug_w4_set_prof(unsigned long long *buf) { g_w4_prof = buf; }
+#endif
+
+// Debug aid (process-global, never called by the product path): pin the channel blocks per workgroup of ds_conv_wino4
+// (1, 2; 0 = the launch-time model) so that tests reach both instantiations at small sizes.
+extern "C" int ds_debug_conv_wino4_set_nb(int nb) {
+    DS_REQUIRE(nb >= 0 && nb <= 2, "ds_debug_conv_wino4_set_nb: 0 = automatic, 1, 2");
+    g_w4_forced_nb = nb;
+    return DS_OK;
+}
 
 extern "C" int ds_conv_wino4_supported(int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
     return (H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0 && Cout % 4 == 0) ? 1 : 0;
@@ -548,6 +638,9 @@ extern "C" int ds_conv_wino4(const float *x, const float *u, float *z, float *st
     DS_REQUIRE(zb * 4 < (1ll << 31), "ds_conv_wino4: output larger than 2 GiB");
     p.z_bytes = (unsigned)(zb * 4);
     p.flags = flags;
+#ifdef DS_W4_PROF
+    p.prof = g_w4_prof;
+#endif
     p.groups = (int)((mt + 31) / 32);
     const int nb = w4_choose(N, H, W, Cin, Cout).nb;
     p.ncol = (Cout + 32 * nb - 1) / (32 * nb);
