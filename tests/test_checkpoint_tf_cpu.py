@@ -149,3 +149,25 @@ def test_handmade_v1_checkpoint_fixture():
     assert len(raw0) > handles[0][1]                                # the compressed block really is smaller
     only = C.read_tf_v1_checkpoint(path, names=lambda n: n.startswith("c/"))
     assert list(only) == ["c/idx"]
+
+
+def test_protobuf_runtime_serialised_checkpoint_messages():
+    """tests/golden/protobuf_v1.ckpt: a V1 checkpoint table whose VALUES are SavedTensorSlices messages serialised by the
+    official protobuf runtime (descriptors declared from TensorFlow's published .proto files in
+    tests/golden/make_protobuf_fixtures.py): meta with VersionDef and per-tensor slice lists, tensor_content, packed
+    float_val / double_val / int_val (negatives) / int64_val, a tensor saved as two row slices, a rank-0 tensor, extents
+    with and without a length.  read_tf_v1_checkpoint must return the arrays that went into the runtime, bit for bit."""
+    import json
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    fx = json.load(open(os.path.join(here, "protobuf_fixtures.json")))["checkpoint"]
+    got = C.read_tf_v1_checkpoint(os.path.join(here, "protobuf_v1.ckpt"), verify_checksums=True)
+    assert sorted(got) == sorted(fx) and len(fx) == 6
+    for name, want in fx.items():
+        arr = np.frombuffer(bytes.fromhex(want["hex"]), dtype=want["dtype"]).reshape(want["shape"])
+        assert got[name].dtype == arr.dtype and got[name].shape == arr.shape, name
+        assert got[name].tobytes() == arr.tobytes(), name
+    assert got["Text/idx"].tolist() == [7, -3, 0, 2 ** 31 - 1, -2 ** 31]
+    assert int(got["global_step"]) == 1234567890123
+    # the model-variable filter of get_init_fn (image_model/im_model.py:118-137) applied to runtime-serialised names
+    only = C.read_tf_v1_checkpoint(os.path.join(here, "protobuf_v1.ckpt"), names=lambda n: n.startswith("InceptionV1/"))
+    assert sorted(only) == sorted(n for n in fx if n.startswith("InceptionV1/"))
