@@ -1099,7 +1099,7 @@ def test_lstm_sequence_kernels_match_oracle(case):
     # rounding only where that one ran 16-row groups (small batches, H = 64 ... 512: the 16x16x4 MFMA sums the
     # reduction in another order than the 32x32x2 one).
     ref = None
-    for rows in (2, 4, 8):
+    for rows in (2, 4):
         g2, h2, c2 = dev(pre), torch.zeros_like(h), torch.zeros_like(c)
         ops.lstm_seq_fwd(g2, ops._p(whd), 4 * H, h2, c2, seqd, T, B, H, S.FORGET_BIAS, ws, rows=rows)
         dg3 = torch.empty_like(dg)

@@ -1818,10 +1818,14 @@ KernelFn bf16_kernel(int nt, Variant v) {
 }
 
 void launch_wide(int nb, bool bnmajor, bool bnb, dim3 grid, hipStream_t st, const ConvParams &p) {
+    if (bnb) {          // (wide_nb: at most two column blocks per wave with ds_conv_desc.bnb)
+        if (nb == 1) hipLaunchKernelGGL((gemm_wide_kernel<1, false, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_wide_kernel<2, false, true>), grid, dim3(256), 0, st, p);
+        return;
+    }
 #define DS_WIDE(NBV)                                                                                      \
     case NBV:                                                                                             \
         if (bnmajor) hipLaunchKernelGGL((gemm_wide_kernel<NBV, true>), grid, dim3(256), 0, st, p);        \
-        else if (bnb) hipLaunchKernelGGL((gemm_wide_kernel<NBV, false, true>), grid, dim3(256), 0, st, p); \
         else hipLaunchKernelGGL((gemm_wide_kernel<NBV, false>), grid, dim3(256), 0, st, p);               \
         break;
     switch (nb) {
@@ -1863,7 +1867,10 @@ int wide_nb(const ds_conv_desc *d, bool vec) {
         cA = e ? atoi(e) : 0;                                    // in halves of a block
     }
     const int64_t row_tiles = (M + 127) / 128;
-    for (int nb = 8; nb >= (N <= 32 ? 1 : 2); --nb) {      // one block per wave only where two would be half padding
+    // (BatchNorm backward on load is kept for narrow dgrads only -- it wins on Conv2d_2b and nowhere else,
+    // profiles/r04_bnb_layers.txt -- so its loader is instantiated for one and two column blocks per wave)
+    const int nb_max = d->bnb ? 2 : 8;
+    for (int nb = nb_max; nb >= (N <= 32 ? 1 : 2); --nb) {      // one block per wave only where two would be half padding
         const int tiles = (N + 32 * nb - 1) / (32 * nb);
         const int64_t rounds = (row_tiles * tiles + ds::kCUs - 1) / ds::kCUs;
         const int64_t cost = rounds * (2 * nb + cA);
@@ -1874,7 +1881,7 @@ int wide_nb(const ds_conv_desc *d, bool vec) {
         const char *e = getenv("DS_WIDE_NB");
         pin_nb = e ? atoi(e) : 0;
     }
-    if (pin_nb >= 1 && pin_nb <= 8) {
+    if (pin_nb >= 1 && pin_nb <= nb_max) {
         best = pin_nb;
         best_pad = (N + 32 * best - 1) / (32 * best) * 32 * best;
     }
