@@ -278,7 +278,7 @@ def main():
     ap.add_argument("--lstm-rows", type=int, default=0,
                     help="row groups per workgroup of the persistent LSTM kernels (1, 2, 4; default: the net's choice)")
     ap.add_argument("--side-mode", type=int, default=-1,
-                    help="A/B: 0 = Branch_2 and Branch_3 chains on a side stream each, 1 = both on one (default), 2 = only Branch_3")
+                    help="A/B: 0 = Branch_2 and Branch_3 chains on a side stream each, 1 = both on one, 2 = only Branch_3 (default: 0 up to 32 samples per GPU, else 1)")
     ap.add_argument("--no-pool-first", action="store_true",
                     help="Mixed backward: fused 1x1 dgrad writes the block-input gradient and the Branch_3 pool adds (default: the reverse)")
     ap.add_argument("--no-stem-direct", action="store_true",
@@ -388,7 +388,7 @@ def main():
     if args.no_branch_streams and net.image is not None:
         net.image.branch_streams = False
     if args.side_mode >= 0 and net.image is not None:
-        net.image.one_side_stream = args.side_mode
+        net.image.side_mode = args.side_mode
     if os.environ.get("DS_WGRAD_SIDE") == "0" and net.image is not None:
         net.image.wgrad_side = False
     if args.no_bwd_sums and net.image is not None:

@@ -677,7 +677,7 @@ def test_branch_streams_and_pool_order_do_not_change_a_bit(B):
         for streams, pool_first, side in variants:
             net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10)
             net.initialize(seed=3)
-            net.image.branch_streams, net.image.pool_first, net.image.one_side_stream = streams, pool_first, side
+            net.image.branch_streams, net.image.pool_first, net.image.side_mode = streams, pool_first, side
             net.image.bwd_sums = sums
             for _ in range(2):
                 net.train_step(batch, 1e-3)

@@ -358,6 +358,11 @@ class SentimentNet:
         keep = [b.clone() for b in (st.theta, st.m, st.v, st.frozen)]
         if self.image is not None and self.image.B != batch["images"].shape[0]:
             self.image.alloc(batch["images"].shape[0])
+        if self.image is not None and self.image.side_mode is None:
+            # the small-batch default (a side stream per branch chain) is for eager launches: hipStreamEndCapture of this
+            # ROCm (7.2) segfaults on the joint step captured with three chains joined per block (B = 32, real dims), and a
+            # replayed graph gains nothing from it (4.07 ms with one side stream)
+            self.image.one_side_stream = 1
         # ... and of the BatchNorm pivots (each layer's previous batch mean), so that the first replayed step rounds
         # exactly like the eager step it replaces
         pivots = [] if self.image is None else [l.mean for l in self.image.layers]
