@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libds_kernels.so")
+# DS_LIB: an alternatively built library (kernel variants measured side by side on one box; tuning aid)
+LIB_PATH = os.environ.get("DS_LIB") or os.path.join(_HERE, "libds_kernels.so")
 
 DS_EPI_BIAS, DS_EPI_RELU, DS_EPI_ACCUM, DS_EPI_STATS, DS_EPI_MASK, DS_EPI_BNSUMS = 1, 2, 4, 8, 16, 32
 DS_DTYPE_F32, DS_DTYPE_BF16 = 0, 1

@@ -1114,6 +1114,13 @@ __global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void conv_bf16_kernel(const C
 // dz = bn_bwd_dz(z, dy, ...) as it is loaded -- a second float4 (dy, from up to three channel ranges whose boundaries are
 // multiples of the 16-channel K step, so a step's range is wave-uniform) and five per-channel values from LDS per A
 // float4, ~8 VALU per element against NB MFMAs: the layer's ds_bn_bwd_apply pass (12 B per element) disappears.
+// Both A loads of the next K step are issued back to back: a row's 16 channels are ONE 64-byte sector, and with the second
+// load a column block (8 MFMAs x the resident waves) behind the first the sector had left the 32 KB L1 again -- 19.8 M
+// L1 -> L2 read requests per launch on the 28 x 28, 256 -> 288 layer against 9.6 M sectors of A (rocprofv3 TCP_TCC_READ_REQ,
+// profiles/r05_notes.md).  Fifteen 1x1 shapes: dgrad with accumulate + sums 2399 -> 2334 us, step 14.51 -> 14.39 ms.
+#ifndef DS_WIDE_A_B2B
+#define DS_WIDE_A_B2B 1
+#endif
 template <int NB, bool BNMAJOR, bool BNB = false>
 __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const ConvParams p) {
     constexpr int BN = NB * 32, WK = 16;                       // K step: 16 channels = two float4 per lane
@@ -1268,7 +1275,7 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
                     n0v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, cn * 4, 0));
                     if (BNB) d0 = load_dy(cn, 0);
                 }
-                if (b == (NB > 1 ? 1 : 0)) {
+                if (b == ((NB > 1 && !DS_WIDE_A_B2B) ? 1 : 0)) {
                     n1v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, cn * 4 + 32, 0));
                     if (BNB) d1 = load_dy(cn, 1);
                 }
