@@ -22,6 +22,7 @@
 //   * fp32 MFMA is an exact k-ordered fmaf chain (cdna_hip_programming.md section 3), so results
 //     match a scalar fp32 reference to rounding.
 #include <stdlib.h>
+#include <type_traits>
 #include "ds_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1312,20 +1313,38 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
     const int flags = d.flags;
     float *red = smem + 2 * BSZ;
     const int mrow0 = t0.row * 128 + wave * 32;
+    // (outputs of 2 GiB and more stay on the LDS-tile kernels: wide_nb)
+    const __amdgpu_buffer_rsrc_t srd_z = make_srd(p.z, (unsigned)(((int64_t)(p.M - 1) * d.ldz + d.Cout) * 4));
+    const __amdgpu_buffer_rsrc_t srd_m = make_srd((flags & DS_EPI_BNSUMS) ? p.mask : p.z,
+                                                  (flags & DS_EPI_BNSUMS) ? (unsigned)(((int64_t)(p.M - 1) * d.ldmask + d.Cout) * 4) : 0u);
+    const int rz = d.ldz * 4, rm = d.ldmask * 4;                 // bytes per row
+    const int rbase = mrow0 + 4 * kh;                            // this lane's first row; accumulator element r: + (r & 3) + 8 (r >> 2)
+    // z (and the accumulate / activation reads at the same rows and columns) through buffer descriptors: ONE 32-bit lane
+    // offset per column block plus the row's wave-uniform byte offset, added into the VECTOR offset (the scalar offset of a
+    // buffer instruction is not range-checked); rows past M and columns past Cout (offset kOOB = 2^31, which the row offsets
+    // cannot wrap) fall out of the descriptor's range: loads return 0, stores are dropped.  The 64-bit address per row and
+    // the per-row branches of the pointer form cost more than the accesses: fifteen 1x1 shapes, forward with statistics
+    // 1747 -> 1658 us, dgrad with accumulate + sums 2346 -> 2121 us, step 14.34 -> 14.10 ms (three interleaved pairs).
+    auto ld_row = [&](__amdgpu_buffer_rsrc_t srd, unsigned v, int r, int row_bytes) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, v + (unsigned)(((r & 3) + 8 * (r >> 2)) * row_bytes), 0, 0));
+    };
+    auto st_row = [&](float val, unsigned v, int r) {
+        const unsigned bits = __builtin_bit_cast(unsigned, val);          // (of a COPY: bit_cast of a vector-element lvalue reads element 0)
+        __builtin_amdgcn_raw_buffer_store_b32(bits, srd_z, v + (unsigned)(((r & 3) + 8 * (r >> 2)) * rz), 0, 2 /* nt */);
+    };
     float pss[NB], pqq[NB];                          // (threads 0..31) this workgroup's partials of column block b
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int col = n0 + 32 * b + li;
         const bool colok = item && col < d.Cout;
         const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
+        const unsigned vz = colok ? (unsigned)(rbase * d.ldz + col) * 4u : kOOB;
+        const unsigned vm = colok ? (unsigned)(rbase * d.ldmask + col) * 4u : kOOB;
         float s = 0.f, q = 0.f;
         if (flags & DS_EPI_ACCUM) {                  // the sixteen previous values, requested together
             float zv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                zv[r] = (row < p.M && colok) ? p.z[(int64_t)row * d.ldz + col] : 0.f;
-            }
+            for (int r = 0; r < 16; ++r) zv[r] = ld_row(srd_z, vz, r, rz);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] += zv[r];
         }
@@ -1334,28 +1353,26 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
             // consumer layer's forward activation (same rows / columns as dy)
             float yv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                yv[r] = (row < p.M && colok) ? p.mask[(int64_t)row * d.ldmask + col] : 0.f;
-            }
+            for (int r = 0; r < 16; ++r)
+                yv[r] = ld_row(srd_m, vm, r, rm);
             if (d.mask_rstd && colok) {      // `mask` holds z of the consumer layers: y = relu(z * rstd + shift) per column
                 const float mr = d.mask_rstd[col], ms = d.mask_shift[col];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) yv[r] = fmaxf(fmaf(yv[r], mr, ms), 0.f);
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    yv[r] = row < p.M ? fmaxf(fmaf(yv[r], mr, ms), 0.f) : 0.f;      // (rows past M read 0, which a shift > 0 would turn on)
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < p.M && colok) {
-                    const float u = yv[r] > 0.f ? acc[b][r] : 0.f;
-                    s += u;
-                    q += u * yv[r];
-                }
+                const float u = yv[r] > 0.f ? acc[b][r] : 0.f;          // (out of range: y = 0)
+                s += u;
+                q += u * yv[r];
             }
         } else if (flags & DS_EPI_STATS) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row < p.M && colok) {
                     const float u = acc[b][r] - pv;
                     s += u;
@@ -1386,11 +1403,10 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
     for (int b = 0; b < NB; ++b) {
         const int col = n0 + 32 * b + li;
         const bool colok = item && col < d.Cout;
+        const unsigned vz = colok ? (unsigned)(rbase * d.ldz + col) * 4u : kOOB;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row < p.M && colok) __builtin_nontemporal_store(acc[b][r], p.z + (int64_t)row * d.ldz + col);
-        }
+        for (int r = 0; r < 16; ++r)
+            st_row(acc[b][r], vz, r);
         if ((flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) && tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
             p.stats[(int64_t)(n0 + 32 * b + tid) * t0.stride + t0.row] = pss[b];
             p.stats[((int64_t)d.Cout + n0 + 32 * b + tid) * t0.stride + t0.row] = pqq[b];
@@ -1862,6 +1878,9 @@ int wide_nb(const ds_conv_desc *d, bool vec) {
     if (d->flags & ~(DS_EPI_STATS | DS_EPI_ACCUM | DS_EPI_BNSUMS)) return 0;
     if (d->Cin % 8 != 0 || d->Cin < 32) return 0;
     const int64_t M = conv_M(d);
+    // the epilogue addresses z (and the BatchNorm-sums activation) through 32-bit buffer offsets
+    if (((M - 1) * d->ldz + d->Cout) * 4 >= (1ll << 31)) return 0;
+    if ((d->flags & DS_EPI_BNSUMS) && ((M - 1) * d->ldmask + d->Cout) * 4 >= (1ll << 31)) return 0;
     const int N = d->Cout;
     // Every workgroup puts one wave on each SIMD of its CU and the resident waves of a SIMD share its matrix pipe, so a
     // launch takes ceil(workgroups / CUs) x (one wave's work): NB blocks of MFMAs per K step plus about half a block
