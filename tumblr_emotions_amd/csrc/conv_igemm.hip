@@ -1601,20 +1601,29 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
     const int flags = d.flags;
     float *red = reinterpret_cast<float *>(smem + 2 * BSZ);
     const int mrow0 = t0.row * 128 + wave * 32;
+    // (as gemm_wide_kernel) z / accumulate / activation accesses through buffer descriptors: 32-bit lane offset + row offset
+    // in the vector offset, hardware range check for rows past M and columns past Cout (kOOB)
+    const bool m16 = d.mask_dtype == DS_DTYPE_BF16;      // (uniform) BatchNorm-sums activation in bf16 storage
+    const __amdgpu_buffer_rsrc_t srd_z = make_srd(p.z, (unsigned)(((int64_t)(p.M - 1) * d.ldz + d.Cout) * 4));
+    const __amdgpu_buffer_rsrc_t srd_m = make_srd((flags & DS_EPI_BNSUMS) ? p.mask : p.z,
+                                                  (flags & DS_EPI_BNSUMS) ? (unsigned)(((int64_t)(p.M - 1) * d.ldmask + d.Cout) * (m16 ? 2 : 4)) : 0u);
+    const int rz = d.ldz * 4, rm = d.ldmask * (m16 ? 2 : 4);
+    const int rbase = mrow0 + 4 * kh;
+    auto roff = [](int r, int row_bytes) -> unsigned { return (unsigned)(((r & 3) + 8 * (r >> 2)) * row_bytes); };
     float pss[NB], pqq[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int col = n0 + 32 * b + li;
         const bool colok = item && col < d.Cout;
         const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
+        const unsigned vz = colok ? (unsigned)(rbase * d.ldz + col) * 4u : kOOB;
+        const unsigned vm = colok ? (unsigned)(rbase * d.ldmask + col) * (m16 ? 2u : 4u) : kOOB;
         float s = 0.f, q = 0.f;
         if (flags & DS_EPI_ACCUM) {
             float zv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                zv[r] = (row < p.M && colok) ? p.z[(int64_t)row * d.ldz + col] : 0.f;
-            }
+            for (int r = 0; r < 16; ++r)
+                zv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_z, vz + roff(r, rz), 0, 0));
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] += zv[r];
         }
@@ -1623,26 +1632,24 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
             // g = dy (y > 0) and g * y; `mask` holds y (fp32, or bf16 under 16-bit activation storage), or z with
             // mask_rstd / mask_shift
             float yv[16];
-            const bool m16 = d.mask_dtype == DS_DTYPE_BF16;      // (uniform)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int64_t at = (int64_t)row * d.ldmask + col;
-                yv[r] = !(row < p.M && colok) ? 0.f : m16 ? (float)reinterpret_cast<const __bf16 *>(p.mask)[at] : p.mask[at];
+                if (m16) yv[r] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(srd_m, vm + roff(r, rm), 0, 0) << 16);
+                else yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_m, vm + roff(r, rm), 0, 0));
             }
             if (d.mask_rstd && colok) {
                 const float mr = d.mask_rstd[col], ms = d.mask_shift[col];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) yv[r] = fmaxf(fmaf(yv[r], mr, ms), 0.f);
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    yv[r] = row < p.M ? fmaxf(fmaf(yv[r], mr, ms), 0.f) : 0.f;
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < p.M && colok) {
-                    const float u = yv[r] > 0.f ? acc[b][r] : 0.f;
-                    s += u;
-                    q += u * yv[r];
-                }
+                const float u = yv[r] > 0.f ? acc[b][r] : 0.f;          // (out of range: y = 0)
+                s += u;
+                q += u * yv[r];
             }
         } else if (flags & DS_EPI_STATS) {
 #pragma unroll
@@ -1678,10 +1685,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
     for (int b = 0; b < NB; ++b) {
         const int col = n0 + 32 * b + li;
         const bool colok = item && col < d.Cout;
+        const unsigned vz = colok ? (unsigned)(rbase * d.ldz + col) * 4u : kOOB;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row < p.M && colok) __builtin_nontemporal_store(acc[b][r], p.z + (int64_t)row * d.ldz + col);
+            const float val = acc[b][r];          // (bit_cast of a vector-element lvalue reads element 0: copy first)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_z, vz + roff(r, rz), 0, 2 /* nt */);
         }
         if ((flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) && tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
             p.stats[(int64_t)(n0 + 32 * b + tid) * t0.stride + t0.row] = pss[b];
@@ -2213,7 +2221,10 @@ int bf16d_nb(int Cout) {
 bool bf16d_ok(const ds_conv_desc *d) {
     return (d->KH == d->KW) && (d->KH == 1 || d->KH == 3) && d->fold_cin == 0 && d->Cin % 8 == 0 && d->ldx % 4 == 0 &&
            !(d->flags & ~(DS_EPI_STATS | DS_EPI_ACCUM | DS_EPI_BNSUMS)) &&
-           !((d->flags & DS_EPI_BNSUMS) && (d->flags & DS_EPI_STATS)) && d->splits <= 1;
+           !((d->flags & DS_EPI_BNSUMS) && (d->flags & DS_EPI_STATS)) && d->splits <= 1 &&
+           // the epilogue addresses z (and the BatchNorm-sums activation) through 32-bit buffer offsets
+           ((conv_M(d) - 1) * d->ldz + d->Cout) * 4 < (1ll << 31) &&
+           (!(d->flags & DS_EPI_BNSUMS) || ((conv_M(d) - 1) * d->ldmask + d->Cout) * 4 < (1ll << 31));
 }
 }  // namespace
 

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemParams p) {
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_z = __builtin_amdgcn_make_buffer_rsrc(p.z, 0, (int)(((int64_t)(p.M - 1) * p.ldz + CO) * 4), 0x00020000);
     const float pv0 = p.pivot ? p.pivot[li] : 0.f, pv1 = p.pivot ? p.pivot[32 + li] : 0.f;
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
     const int ohw = p.OH * p.OW;
@@ -133,16 +134,20 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemParams p) {
             }
         }
         // ---- store + statistics: element e of a block is output row (e&3) + 8 (e>>2) + 4 kh, column li ---------------
+        // (stores through a buffer descriptor: one 32-bit lane offset per block + the row's offset, rows past M dropped by the
+        // hardware range check -- as gemm_wide_kernel's epilogue; the second 32 columns ride in the instruction offset)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const int row0 = tile * 256 + wave * 64 + a * 32;
+            const int row0 = tile * 256 + wave * 64 + a * 32 + 4 * kh;
+            const unsigned vz = (unsigned)(row0 * p.ldz + li) * 4u;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                const int row = row0 + (e & 3) + 8 * (e >> 2);
+                const float v0 = acc[a][0][e], v1 = acc[a][1][e];
+                const unsigned vo = vz + (unsigned)(((e & 3) + 8 * (e >> 2)) * p.ldz * 4);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), srd_z, vo, 0, 2 /* nt */);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), srd_z, vo, 128, 2 /* nt */);
                 if (row < p.M) {
-                    const float v0 = acc[a][0][e], v1 = acc[a][1][e];
-                    __builtin_nontemporal_store(v0, p.z + (int64_t)row * p.ldz + li);
-                    __builtin_nontemporal_store(v1, p.z + (int64_t)row * p.ldz + 32 + li);
                     const float u0 = v0 - pv0, u1 = v1 - pv1;
                     s0 += u0; q0 += u0 * u0;
                     s1 += u1; q1 += u1 * u1;
@@ -194,7 +199,8 @@ extern "C" int ds_conv_stem(const float *x, const float *w, float *z, float *sta
     p.cin_store = cin_store; p.ldz = ldz;
     const int64_t M = (int64_t)N * p.OH * p.OW;
     const int64_t xb = (int64_t)N * H * W * 12;
-    DS_REQUIRE(M < (1ll << 31) && xb < (1ll << 31), "ds_conv_stem: input larger than 2 GiB (split the batch)");
+    DS_REQUIRE(M < (1ll << 31) && xb < (1ll << 31) && ((M - 1) * ldz + CO) * 4 < (1ll << 31),
+               "ds_conv_stem: input or output larger than 2 GiB (split the batch)");
     p.M = (int)M; p.tiles = (int)((M + 255) / 256);
     p.x_bytes = (unsigned)xb;
     hipLaunchKernelGGL(conv_stem_kernel, dim3(stem_grid(M)), dim3(256), 0, (hipStream_t)stream, p);
