@@ -419,6 +419,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
         f32x4 pv = {0.f, 0.f, 0.f, 0.f};
         if (!BNS && p.pivot && colok) pv = *reinterpret_cast<const f32x4 *>(p.pivot + col);
         const unsigned vo = (tbase >= 0 && colok) ? (unsigned)(tbase * p.ldz + col) * 4u : kOOB;
+        // DS_EPI_BNSUMS: the consumer's activations at the sixteen store offsets, ALL requested here -- in front of the
+        // gathers and of every store of this pass.  Requested row by row inside the store loop, each row's reads sat behind
+        // the previous row's stores (one in-order memory counter): a round trip per output row.
+        f32x4 yall[BNS ? 4 : 1][4];
+        if constexpr (BNS) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    yall[rr][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        srd_y, (!EDGE || (rr < hrem && k < wrem)) ? vo : kOOB, rr * orow + k * opix, 0));
+        }
         const float *Mq = smem + tid * 4;
         f32x4 P[4][6];
 #pragma unroll
@@ -433,17 +445,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
             unsigned vof[4];            // store offsets of this output row's four pixels
 #pragma unroll
             for (int k = 0; k < 4; ++k) vof[k] = (!EDGE || (rr < hrem && k < wrem)) ? vo : kOOB;
-            f32x4 yv[4];
-            if constexpr (BNS) {        // the consumer's activations at this output row's store offsets
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    yv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_y, vof[k], rr * orow + k * opix, 0));
-            }
+            const f32x4 *yv = yall[rr];
             f32x4 y[4];
             out1d(neg1, P[rr][0], P[rr][1], P[rr][2], P[rr][3], P[rr][4], P[rr][5], y[0], y[1], y[2], y[3]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[k]), srd_z, vof[k], rr * orow + k * opix, 2 /* nt */);
+                // the pixel's offset goes into the VECTOR offset, the scalar offset stays the constant 0: with an SGPR there
+                // the compiler assumes that a 16-byte buffer store has no "VALU overwrites the store data" hazard (true on
+                // gfx900) and schedules the writes of y's registers right behind the store -- on gfx950 the store then
+                // carried the NEW value in lanes 4-7 of every 8 (measured: one channel of one pixel per tile)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[k]), srd_z, vof[k] + (unsigned)(rr * orow + k * opix), 0, 2 /* nt */);
                 if constexpr (BNS) {
                     f32x4 g;
 #pragma unroll
