@@ -194,13 +194,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
         const int r = (tv ? m : 0) - n * tpi;
         const int th = r / p.TW, tw = r - th * p.TW;
         const unsigned vbase = (unsigned)(((n * p.H + 4 * th) * p.W + 4 * tw) * p.ldx + 2 * cp) * 4u;
+        const unsigned rowstep = (unsigned)(p.W * p.ldx) * 4u;
+        // the patch ROW's offset rides in the lane's vector offset (six registers that exist anyway), so the scalar offset of
+        // a request is only (patch column, channel step): six values per K step instead of thirty-six multiply-add pairs --
+        // with one wave per SIMD every scalar instruction is an issue slot too (~150 s_mul / s_add per K step before)
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            rowoff[k] = (tv && (unsigned)(4 * th - 1 + k) < (unsigned)p.H) ? vbase : kOOB;
+            rowoff[k] = (tv && (unsigned)(4 * th - 1 + k) < (unsigned)p.H) ? vbase + (unsigned)k * rowstep : kOOB;
             cv[k] = (unsigned)(4 * tw - 1 + k) < (unsigned)p.W;
         }
     }
-    const int rowstep = p.W * p.ldx * 4, pixstep = p.ldx * 4;
+    const int pixstep = p.ldx * 4;
 
     // ---- matrix role: B fragment offsets (column li of channel block nb, channels 4 kh .. of an 8-channel half step) ----
     const int ksteps = p.Cin >> 4, nhalf = 2 * ksteps;
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
         const int py = q / 6, px = q - py * 6;
         if ((DS_W4_ABL & 2) && c0 >= 32) return;
         raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(srd_x, cv[px] ? ro[py] : kOOB,
-                                                                                 py * rowstep + px * pixstep + c0 * 4, 0));
+                                                                                 px * pixstep + c0 * 4, 0));
     };
     auto load_b = [&](int slot, int pi, int hs) {
         if ((DS_W4_ABL & 1) && hs > 0) return;
