@@ -127,14 +127,17 @@ __device__ __forceinline__ void mfma_v(f32x16 &c, float a, float b) {
 // B^T d for one line of six: B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 __device__ __forceinline__ void in1d(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2 d5, f32x2 &t0, f32x2 &t1,
                                      f32x2 &t2, f32x2 &t3, f32x2 &t4, f32x2 &t5) {
+    // (six independent first-level results, then six that use them: a packed op right behind the one it depends on costs
+    // a wait state -- 39 s_nop per K step in the first version of this order)
     const f32x2 a = pfma(-4.f, d2, d4), b = pfma(-4.f, d1, d3);
     const f32x2 c = psub(d4, d2), e = psub(d3, d1);
-    t0 = pfma(4.f, d0, pfma(-5.f, d2, d4));
+    const f32x2 i0 = pfma(-5.f, d2, d4), i5 = pfma(-5.f, d3, d5);
     t1 = padd(a, b);
     t2 = psub(a, b);
     t3 = pfma(2.f, e, c);
     t4 = pfma(-2.f, e, c);
-    t5 = pfma(4.f, d1, pfma(-5.f, d3, d5));
+    t0 = pfma(4.f, d0, i0);
+    t5 = pfma(4.f, d1, i5);
 }
 
 // A^T m for one line of six, on four channels at once: A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].
@@ -243,7 +246,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     auto load_pixel = [&](int q, int c0, const unsigned *ro) {
         const int py = q / 6, px = q - py * 6;
         if ((DS_W4_ABL & 2) && c0 >= 32) return;
-        raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(srd_x, cv[px] ? ro[py] : kOOB,
+        // (patch columns 1 .. 4 are image columns 4 tw .. 4 tw + 3: inside the image unless the map has a partial last tile)
+        raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(srd_x, (cv[px] || (!EDGE && px >= 1 && px <= 4)) ? ro[py] : kOOB,
                                                                                  px * pixstep + c0 * 4, 0));
     };
     auto load_b = [&](int slot, int pi, int hs) {
