@@ -123,6 +123,10 @@ __device__ __forceinline__ f32x2 psub(f32x2 a, f32x2 b) {                // a - 
 __device__ __forceinline__ void mfma_v(f32x16 &c, float a, float b) {
     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
+// ... the first one of an accumulator: C = 0
+__device__ __forceinline__ void mfma_v0(f32x16 &c, float a, float b) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+}
 
 // B^T d for one line of six: B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 __device__ __forceinline__ void in1d(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2 d5, f32x2 &t0, f32x2 &t1,
@@ -224,18 +228,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     // and are swapped through the vector registers around their MFMAs (192 moves and two pipeline drains per K step:
     // the MFMA-only loop measured 5.5-6.4 us per step against 3.84 of matrix cycles).  Position 8's two accumulators are
     // therefore pinned to the ARCHITECTURAL vector registers (mfma_v: the gfx90a+ MFMA takes C / D in either file).
-    f32x16 acc[9][NB], accv[NB];
-#pragma unroll
-    for (int pi = 0; pi < 9; ++pi)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[pi][nb][e] = 0.f;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accv[nb][e] = 0.f;
-
+    f32x16 acc[9][NB], accv[NB];      // not initialised: the first K step's first MFMA per accumulator takes C = 0 (k_step FIRST)
     f32x2 raw[36];
     // weight-fragment ring: group g (half step g / 9, position g % 9) uses slot g % RING and is requested RING groups ahead.
     // NB = 2 has registers for six slots (3072 matrix cycles of lead); NB = 1 runs its 18 groups in half the time, so six
@@ -303,8 +296,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     // ks + 2 are UNCONDITIONAL (past the last step the requests carry out-of-range offsets and return zeros nobody
     // uses): a condition around them would keep all 72 pixel registers alive across the whole loop next to the 72
     // registers of the half-transformed patch, which the kernel does not have.  LAST = true: MFMAs only.
-    auto k_step = [&](int ks, auto last_tag) {
+    auto k_step = [&](int ks, auto last_tag, auto first_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;      // the accumulators are not initialised: C = 0 in their first MFMA
         const float *Vr = smem + (ks & 1) * (36 * 512);
         float *Vw = smem + ((ks + 1) & 1) * (36 * 512);
         const int c2 = (ks + 2) * 16;
@@ -366,7 +360,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         const int g = g0 + u, pi = g % 9;
-                        if (NB == 2 && pi == 8) mfma_v(accv[nb], av[u][j], b[g % RING][nb][j]);
+                        if (FIRST && g < 9 && j == 0) {
+                            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            if (NB == 2 && pi == 8) mfma_v0(accv[nb], av[u][j], b[g % RING][nb][j]);
+                            else acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][j], b[g % RING][nb][j], zero16, 0, 0, 0);
+                        } else if (NB == 2 && pi == 8) mfma_v(accv[nb], av[u][j], b[g % RING][nb][j]);
                         else acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][j], b[g % RING][nb][j], acc[pi][nb], 0, 0, 0);
                     }
             __builtin_amdgcn_sched_barrier(0);
@@ -380,11 +378,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
             for (int u = 0; u < GP; ++u) av[u] = avn[u];
         }
     };
-    for (int ks = 0; ks + 1 < ksteps; ++ks) {
-        k_step(ks, std::false_type{});
+    if (ksteps > 1) {
+        k_step(0, std::false_type{}, std::true_type{});
         lds_barrier();          // V of step ks + 1 is complete, V of step ks is free
+        for (int ks = 1; ks + 1 < ksteps; ++ks) {
+            k_step(ks, std::false_type{}, std::false_type{});
+            lds_barrier();
+        }
+        k_step(__builtin_amdgcn_readfirstlane(ksteps - 1), std::true_type{}, std::false_type{});      // (uniform: no waterfall loops around its loads)
+    } else {
+        k_step(0, std::true_type{}, std::true_type{});
     }
-    k_step(__builtin_amdgcn_readfirstlane(ksteps - 1), std::true_type{});      // (uniform: no waterfall loops around its loads)
     W4_STAMP(3);
 
     // ---- output transform Y = A^T M A through LDS, one 32-channel block at a time ---------------------------------------
