@@ -567,9 +567,17 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float *w, floa
 
 // Which kernel for a shape?  Launch-time model fitted to profiles/r03_wino4_layers.txt (B = 256 and B = 32): a launch
 // takes ceil(workgroups / CUs) rounds of one workgroup's duration,
-//     F(4x4), NB = 2: 13.5 us + 5.4 us per 16-channel K step      NB = 1: 8.5 us + 3.2 us per K step
+//     F(4x4), NB = 2: 10 us + 5.3 us per 16-channel K step      NB = 1: 6 us + 3.1 us per K step
 //     F(2x2) (conv_wino.hip): 8.7 us + 2.35 us per 8-channel K step, 128 tiles of 2x2 x 32 channels per workgroup
 // so the 14 x 14 and 7 x 7 maps (128 / 32 tile groups only) go to whichever fills the rounds best.
+// (round 5, after the C = 0 first step and the issue-slot diet: 10 + 5.3 / step at NB = 2, 6 + 3.1 / step at NB = 1; with the
+// round-3 constants 13.5 + 5.4 and 8.5 + 3.2 the step was 0.08 ms slower, three interleaved pairs)
+#ifndef W4_FIX2
+#define W4_FIX2 10.0
+#define W4_STEP2 5.3
+#define W4_FIX1 6.0
+#define W4_STEP1 3.1
+#endif
 struct W4Choice {
     int nb;             // 1, 2: F(4x4) with that channel-block count
     double us4, us2;    // expected launch time of F(4x4) with nb / of F(2x2)
@@ -588,7 +596,7 @@ W4Choice w4_choose(int N, int H, int W, int Cin, int Cout) {
     double t[3];
     for (int nb = 1; nb <= 2; ++nb) {
         const int64_t wgs = g4 * ((Cout + 32 * nb - 1) / (32 * nb));
-        t[nb] = ceil(wgs / cus) * ((Cin / 16) * (nb == 2 ? 5.4 : 3.2) + (nb == 2 ? 13.5 : 8.5));
+        t[nb] = ceil(wgs / cus) * ((Cin / 16) * (nb == 2 ? W4_STEP2 : W4_STEP1) + (nb == 2 ? W4_FIX2 : W4_FIX1));
     }
     c.us2 = ceil(g2 * ((Cout + 31) / 32) / cus) * (8.7 + 2.35 * (Cin / 8));
     c.nb = (forced == 1 || forced == 2) ? forced : (t[2] <= t[1] ? 2 : 1);
