@@ -162,7 +162,8 @@ def conv_arithmetic(net):
             if fam is not None:
                 key = names.get(fam, str(fam))
                 count[role][key] = count[role].get(key, 0) + 1
-    label = {"f32": "fp32 MFMA", "bf16": "bf16 MFMA", "fp8": "bf16 MFMA + fp8 MFMA where it wins (bf16+fp8-auto)"}[img.dtype]
+    label = {"f32": "fp32 MFMA", "bf16": "bf16 MFMA (3x3 input gradients: F(4x4) of the bf16-rounded operands, two bf16 pieces per Winograd-domain value)",
+             "fp8": "bf16 MFMA + fp8 MFMA where it wins (bf16+fp8-auto)"}[img.dtype]
     return dict(label=label, launches_by_family=count)
 
 

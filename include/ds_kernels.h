@@ -133,6 +133,8 @@ int ds_debug_conv_wino_allow_ablation(int on);
 /* ds_conv_wino4: pin the 32-channel blocks per workgroup (1, 2; 0 = the launch-time model, the default).  Both choices give
  * the same z up to summation order; the statistics partial count does not depend on it.                                  */
 int ds_debug_conv_wino4_set_nb(int nb);
+/* tuning: the most column blocks (of 32) a wave of ds_conv_bf16 may own (1 .. 8; default 8) */
+int ds_debug_conv_bf16_set_max_nb(int nb);
 /* Number of row-tile blocks (P) the launch for `d` will use = number of stats partials.   */
 int ds_conv_igemm_partials(const ds_conv_desc *d);
 /* 1 if a launch for `d` can carry DS_EPI_BNSUMS (plain 1x1 stride-1 shapes that run on the wide kernel).  */
@@ -249,6 +251,16 @@ int ds_conv_wino4_partials(int32_t N, int32_t H, int32_t W);
 int ds_conv_wino4(const float *x, const float *u, float *z, float *stats, const float *pivot, const float *ymask,
                   int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz, int32_t flags,
                   void *stream);
+/* ds_conv_wino4 for the 16-bit configurations (bf16 / fp8 labels): the convolution of the bf16-ROUNDED operands (x is rounded
+ * as it is loaded, the filter before G g G^T) evaluated through F(4x4, 3x3) on the bf16 matrix cores, every Winograd-domain
+ * value carried as two bf16 pieces (three v_mfma_f32_32x32x16_bf16 per product: ~2^-16 relative in the transform domain).
+ * Same geometry, epilogues, partial count and NB pin as ds_conv_wino4; u2 (36 * Cin * Cout * 4 bytes, 16-byte aligned) from
+ * ds_wino4_transform_weights_bf16x2 (reduction channels % 16 == 0).  Replaces the reference's tf.nn.conv2d 3x3 / its input
+ * gradient (slim/nets inception_v1.py:74-75, :86-247) under the cfg5 label. */
+int ds_wino4_transform_weights_bf16x2(const float *w, void *u2, int32_t Cin, int32_t Cout, int32_t dgrad, void *stream);
+int ds_conv_wino4_bf16x2(const float *x, const void *u2, float *z, float *stats, const float *pivot, const void *ymask,
+                         int32_t y_dtype /* of ymask: DS_DTYPE_F32 / DS_DTYPE_BF16 (16-bit activation storage) */, int32_t N,
+                         int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz, int32_t flags, void *stream);
 
 /* ---- ONE conv-layer interface over the kernel families above (the product path's conv entry points) ---------------
  * slim.conv2d (image_model/inception_v1.py:63-250) and its Conv2DBackpropInput, described in TensorFlow's terms; the
@@ -285,6 +297,7 @@ int ds_conv_wino4(const float *x, const float *u, float *z, float *stats, const 
 #define DS_FAM_BF16D 4
 #define DS_FAM_FP8D 5
 #define DS_FAM_F32X3 6
+#define DS_FAM_WINO4H 7        /* ds_conv_wino4_bf16x2: F(4x4, 3x3) of the bf16-rounded operands on the bf16 matrix cores */
 #define DS_PLAN_NO_WINO 1u          /* A/B: implicit GEMM for every 3x3 layer                                           */
 #define DS_PLAN_NO_WINO4 2u         /* A/B: F(2x2) wherever Winograd applies                                            */
 #define DS_PLAN_NO_STEM_DIRECT 4u   /* A/B: the stem through the generic kernel on a 4-channel copy of the batch        */
@@ -292,6 +305,7 @@ int ds_conv_wino4(const float *x, const float *u, float *z, float *stats, const 
 #define DS_PLAN_ACT16 16u           /* the net keeps activations in 16-bit storage (only the register-direct kernels read it) */
 #define DS_PLAN_FP8_EVERYWHERE 64u  /* A/B: ds_conv_fp8 wherever it applies (default: only where it beats the bf16 kernels) */
 #define DS_PLAN_FP8_WIDE_RULE 128u  /* A/B: fp8 for every 1x1 / 3x3 layer with >= 64 reduction channels into >= 96 columns  */
+#define DS_PLAN_NO_WINO4H 256u      /* A/B: the 16-bit configurations' 3x3 input gradients on the direct bf16 kernels only  */
 #define DS_PLAN_PACKED_RGB 32u      /* Conv2d_1a_7x7: x is the packed [N, H, W, 3] batch, filter stored [7][7][4][Cout]   */
 typedef struct ds_conv_layer_plan {
     ds_conv_desc d;          /* descriptor of the chosen launch (dgrad: channel roles swapped, flipped taps)            */

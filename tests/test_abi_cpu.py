@@ -158,7 +158,15 @@ def test_conv_plan_picks_the_kernel_family_without_a_device(lib):
     assert p.family in (L.DS_FAM_WINO2, L.DS_FAM_WINO4) and l.ds_conv_plan_enable_bnsums(C.byref(p), 96) > 0
     rc, p = plan(L.DS_CONV_DGRAD, L.DS_ARITH_BF16, 0, B, 28, 28, 192, 176, 1, 1, 0, ldx=176, ldz=192)
     assert p.family == L.DS_FAM_BF16D and l.ds_conv_plan_enable_bnsums(C.byref(p), 192) > 0 and p.w_bytes > 0
-    rc, p = plan(L.DS_CONV_DGRAD, L.DS_ARITH_BF16, 0, B, 28, 28, 96, 128, 3, 1, 0, ldx=128, ldz=96)      # LDS-staged bf16 kernel
+    # the 16-bit configurations' 3x3 input gradients: F(4x4) of the bf16-rounded operands on the bf16 matrix cores, with the
+    # BatchNorm-sums epilogue; the two 14 x 14 layers with >= 288 reduction channels stay on the register-direct kernel;
+    # DS_PLAN_NO_WINO4H restores the round-4 choice (LDS-staged bf16 kernel below 160 columns: no sums epilogue)
+    rc, p = plan(L.DS_CONV_DGRAD, L.DS_ARITH_BF16, 0, B, 28, 28, 96, 128, 3, 1, 0, ldx=128, ldz=96)
+    assert p.family == L.DS_FAM_WINO4H and p.w_bytes == 4 * 36 * 96 * 128 and l.ds_conv_plan_enable_bnsums(C.byref(p), 96) > 0
+    assert plan(L.DS_CONV_DGRAD, L.DS_ARITH_FP8, 0, B, 56, 56, 64, 192, 3, 1, 0, ldx=192, ldz=64)[1].family == L.DS_FAM_WINO4H
+    assert plan(L.DS_CONV_DGRAD, L.DS_ARITH_BF16, 0, B, 14, 14, 144, 288, 3, 1, 0, ldx=288, ldz=144)[1].family == L.DS_FAM_BF16D
+    assert plan(L.DS_CONV_FWD, L.DS_ARITH_BF16, 0, B, 28, 28, 96, 128, 3, 1)[1].family == L.DS_FAM_BF16D      # forward: unchanged
+    rc, p = plan(L.DS_CONV_DGRAD, L.DS_ARITH_BF16, L.DS_PLAN_NO_WINO4H, B, 28, 28, 96, 128, 3, 1, 0, ldx=128, ldz=96)      # LDS-staged bf16 kernel
     assert p.family == L.DS_FAM_IGEMM and l.ds_conv_plan_enable_bnsums(C.byref(p), 96) == 0
     # stem: the packed-RGB kernel, or the generic kernel with KW folded into the channel axis
     rc, p = plan(L.DS_CONV_FWD, L.DS_ARITH_F32, L.DS_PLAN_PACKED_RGB, B, 224, 224, 4, 64, 7, 2, L.DS_EPI_STATS)
@@ -185,7 +193,7 @@ def test_conv_plan_picks_the_kernel_family_without_a_device(lib):
     assert plan(L.DS_CONV_FWD, L.DS_ARITH_FP8, 0, B, 28, 28, 256, 288, 1, 1)[1].family == L.DS_FAM_BF16D
     assert plan(L.DS_CONV_FWD, L.DS_ARITH_FP8, L.DS_PLAN_ACT16, B, 14, 14, 16, 48, 3, 1)[1].family == L.DS_FAM_BF16D
     assert plan(L.DS_CONV_FWD, L.DS_ARITH_FP8, L.DS_PLAN_FP8_EVERYWHERE, B, 14, 14, 16, 48, 3, 1)[1].family == L.DS_FAM_FP8D
-    assert plan(L.DS_CONV_DGRAD, L.DS_ARITH_FP8, 0, B, 56, 56, 64, 192, 3, 1, ldx=192, ldz=64)[1].family == L.DS_FAM_IGEMM
+    assert plan(L.DS_CONV_DGRAD, L.DS_ARITH_FP8, L.DS_PLAN_NO_WINO4H, B, 56, 56, 64, 192, 3, 1, ldx=192, ldz=64)[1].family == L.DS_FAM_IGEMM
     # zcat probe: BatchNorm + ReLU on load is the wide 1x1 kernel's (and the f32x3 kernel's)
     rc, p = plan(L.DS_CONV_FWD, L.DS_ARITH_F32, 0, B, 28, 28, 256, 288, 1, 1, L.DS_EPI_STATS)
     assert l.ds_conv_plan_norm_supported(C.byref(p)) == 1

@@ -947,6 +947,73 @@ BF16D_CASES = [
 ]
 
 
+@pytest.mark.parametrize("nb", [1, 2])
+@pytest.mark.parametrize("case", [(2, 8, 8, 16, 32), (2, 28, 28, 96, 128), (5, 7, 7, 160, 320), (2, 13, 11, 48, 176), (1, 9, 10, 16, 40),
+                                  (1, 56, 56, 64, 192), (3, 14, 14, 32, 64), (9, 5, 6, 16, 48)])
+def test_winograd_f4_on_bf16_matrix_cores_matches_bf16_rounding_oracle(case, nb):
+    """ds_conv_wino4_bf16x2 (the 16-bit configurations' 3x3 kernel: F(4x4, 3x3) of the bf16-ROUNDED operands, every
+    Winograd-domain value as two bf16 pieces, three v_mfma_f32_32x32x16_bf16 per product) against the fp64 direct convolution of
+    the bf16-rounded operands: forward with statistics about a pivot, dgrad plain and with the BatchNorm-sums epilogue from
+    fp32 and from bf16 activation storage; both channel-block counts, border tiles, ragged groups.  Bound 5e-4 of max|ref|
+    (measured 1e-4: two pieces carry 16 mantissa bits through transforms with constants up to 100), and 1e-2 against the
+    exact convolution as for the other bf16 kernels."""
+    ops = _ops()
+    from tumblr_emotions_amd import _lib
+    lib = _lib.load()
+    N, H, W, Ci, Co = case
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.RandomState(11)
+    x = rng.normal(size=(N, H, W, Ci))
+    w = rng.normal(size=(3, 3, Ci, Co)) * 0.1
+    ref = S.conv2d_same(_bf16_round(x), _bf16_round(w), 1)
+    M = N * H * W
+    xd, wd = dev(x), dev(w)
+    P = lib.ds_conv_wino4_partials(N, H, W)
+    assert lib.ds_debug_conv_wino4_set_nb(nb) == 0
+    try:
+        u2 = torch.empty(36 * Ci * Co, device="cuda")
+        assert lib.ds_wino4_transform_weights_bf16x2(ops._p(wd), ops._p(u2), Ci, Co, 0, st) == 0
+        z = torch.full((M, Co), float("nan"), device="cuda")
+        stats = torch.zeros(2, Co, P, device="cuda")
+        pivot = dev(rng.normal(size=Co) * 0.1)
+        assert lib.ds_conv_wino4_bf16x2(ops._p(xd), ops._p(u2), ops._p(z), ops._p(stats), ops._p(pivot), None, ops.DS_DTYPE_F32,
+                                        N, H, W, Ci, Ci, Co, Co, ops.DS_EPI_STATS, st) == 0
+        torch.cuda.synchronize()
+        zz = ref.reshape(M, Co)
+        close(z, zz, 5e-4)
+        close(z, S.conv2d_same(x, w, 1).reshape(M, Co), 1e-2)
+        pv = pivot.cpu().numpy().astype(np.float64)
+        close(stats[0].sum(1), (zz - pv).sum(0), 2e-3)
+        close(stats[1].sum(1), ((zz - pv) ** 2).sum(0), 2e-3)
+        if Co % 16 == 0:
+            dy = rng.normal(size=ref.shape)
+            dyd = dev(dy)
+            ud = torch.empty(36 * Ci * Co, device="cuda")
+            assert lib.ds_wino4_transform_weights_bf16x2(ops._p(wd), ops._p(ud), Ci, Co, 1, st) == 0
+            dx = torch.zeros(M, Ci + 4, device="cuda")          # strided output rows
+            assert lib.ds_conv_wino4_bf16x2(ops._p(dyd), ops._p(ud), ops._p(dx), None, None, None, ops.DS_DTYPE_F32,
+                                            N, H, W, Co, Co, Ci, Ci + 4, 0, st) == 0
+            torch.cuda.synchronize()
+            dx_ref = S.conv2d_same_bwd_input(_bf16_round(dy), _bf16_round(w), (N, H, W, Ci), 1).reshape(-1, Ci)
+            close(dx[:, :Ci], dx_ref, 5e-4)
+            assert float(dx[:, Ci:].abs().max()) == 0.0
+            yv = np.maximum(rng.normal(size=(M, Ci)), 0.0) * (rng.uniform(size=(M, Ci)) < 0.7)
+            ypad = np.pad(yv, ((0, 0), (0, 4)), constant_values=5.0)
+            for dt, yd in ((ops.DS_DTYPE_F32, dev(ypad)), (ops.DS_DTYPE_BF16, dev(ypad, torch.bfloat16))):
+                y_seen = yd.float().cpu().numpy().astype(np.float64)[:, :Ci]
+                sums = torch.full((2, Ci, P), float("nan"), device="cuda")
+                dx2 = torch.zeros(M, Ci + 4, device="cuda")
+                assert lib.ds_conv_wino4_bf16x2(ops._p(dyd), ops._p(ud), ops._p(dx2), ops._p(sums), None, ops._p(yd), dt,
+                                                N, H, W, Co, Co, Ci, Ci + 4, ops.DS_EPI_BNSUMS, st) == 0
+                torch.cuda.synchronize()
+                assert torch.equal(dx2, dx)
+                gm = dx[:, :Ci].cpu().numpy().astype(np.float64) * (y_seen > 0)          # sums of what the kernel stored
+                close(sums[0].sum(1), gm.sum(0), 2e-3)
+                close(sums[1].sum(1), (gm * y_seen).sum(0), 2e-3)
+    finally:
+        lib.ds_debug_conv_wino4_set_nb(0)
+
+
 @pytest.mark.parametrize("case", BF16D_CASES)
 def test_conv_bf16_register_direct_forward_dgrad_match_oracle(case):
     """ds_conv_bf16 (register-direct A, pre-converted weights): forward with BatchNorm statistics about a pivot and

@@ -15,9 +15,9 @@ DS_DTYPE_F32, DS_DTYPE_BF16 = 0, 1
 DS_FP8_E4M3, DS_FP8_E5M2 = 0, 1
 DS_CONV_FWD, DS_CONV_DGRAD = 0, 1
 DS_ARITH_F32, DS_ARITH_BF16, DS_ARITH_FP8, DS_ARITH_F32X3 = 0, 1, 2, 3
-DS_FAM_IGEMM, DS_FAM_WINO2, DS_FAM_WINO4, DS_FAM_STEM, DS_FAM_BF16D, DS_FAM_FP8D, DS_FAM_F32X3 = range(7)
+DS_FAM_IGEMM, DS_FAM_WINO2, DS_FAM_WINO4, DS_FAM_STEM, DS_FAM_BF16D, DS_FAM_FP8D, DS_FAM_F32X3, DS_FAM_WINO4H = range(8)
 DS_PLAN_NO_WINO, DS_PLAN_NO_WINO4, DS_PLAN_NO_STEM_DIRECT, DS_PLAN_NO_BF16_DIRECT, DS_PLAN_ACT16, DS_PLAN_PACKED_RGB = 1, 2, 4, 8, 16, 32
-DS_PLAN_FP8_EVERYWHERE, DS_PLAN_FP8_WIDE_RULE = 64, 128
+DS_PLAN_FP8_EVERYWHERE, DS_PLAN_FP8_WIDE_RULE, DS_PLAN_NO_WINO4H = 64, 128, 256
 
 
 class ConvDesc(C.Structure):
@@ -82,6 +82,7 @@ SIGNATURES = {
     "ds_debug_conv_set_wide": (C.c_int, [C.c_int]),
     "ds_debug_conv_wino_allow_ablation": (C.c_int, [C.c_int]),
     "ds_debug_conv_wino4_set_nb": (C.c_int, [C.c_int]),
+    "ds_debug_conv_bf16_set_max_nb": (C.c_int, [C.c_int]),
     "ds_conv_igemm_partials": (C.c_int, [_CD]),
     "ds_conv_igemm_bnsums_supported": (C.c_int, [_CD]),
     "ds_conv_igemm_norm_supported": (C.c_int, [_CD]),
@@ -113,6 +114,8 @@ SIGNATURES = {
     "ds_wino4_transform_weights": (C.c_int, [_P, _P, _i32, _i32, _i32, _P]),
     "ds_conv_wino4_partials": (C.c_int, [_i32, _i32, _i32]),
     "ds_conv_wino4": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
+    "ds_conv_wino4_bf16x2": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
+    "ds_wino4_transform_weights_bf16x2": (C.c_int, [_P, _P, _i32, _i32, _i32, _P]),
     "ds_conv_plan": (C.c_int, [_LP, _i32, _i32, C.c_uint32] + [_i32] * 10),
     "ds_conv_plan_set_flags": (C.c_int, [_LP, _i32]),
     "ds_conv_plan_enable_bnsums": (C.c_int, [_LP, _i32]),

@@ -2208,10 +2208,11 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
 
 // ---- bf16 register-direct path -------------------------------------------------------------------------------------
 namespace {
+int g_bf16d_max_nb = 8;       // ds_debug_conv_bf16_set_max_nb (tuning)
 int bf16d_nb(int Cout) {
     // a workgroup's cost per K step ~ (A fetch + NB MFMAs); minimise column tiles x (c + NB), c ~ 4, ties to wider
-    int best = 8, best_cost = 1 << 30;
-    for (int nb = 8; nb >= 1; --nb) {
+    int best = g_bf16d_max_nb, best_cost = 1 << 30;
+    for (int nb = g_bf16d_max_nb; nb >= 1; --nb) {
         const int tiles = (Cout + 32 * nb - 1) / (32 * nb);
         const int cost = tiles * (4 + nb);
         if (cost < best_cost) { best_cost = cost; best = nb; }
@@ -2243,6 +2244,12 @@ extern "C" int ds_weights_to_bf16(const float *w, void *wb, int32_t Cin, int32_t
 }
 
 extern "C" int ds_conv_bf16_supported(const ds_conv_desc *d) { return d && bf16d_ok(d) ? 1 : 0; }
+
+extern "C" int ds_debug_conv_bf16_set_max_nb(int nb) {
+    DS_REQUIRE(nb >= 1 && nb <= 8, "ds_debug_conv_bf16_set_max_nb: 1 .. 8 column blocks per wave");
+    g_bf16d_max_nb = nb;
+    return 0;
+}
 
 extern "C" int ds_conv_bf16_partials(const ds_conv_desc *d) { return (int)((conv_M(d) + 127) / 128); }
 

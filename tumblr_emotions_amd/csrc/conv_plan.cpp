@@ -34,7 +34,7 @@ inline void same_pad(int n, int k, int s, int *out, int *before) {
     *before = total / 2;
 }
 
-inline bool is_wino(const ds_conv_layer_plan *p) { return p->family == DS_FAM_WINO2 || p->family == DS_FAM_WINO4; }
+inline bool is_wino(const ds_conv_layer_plan *p) { return p->family == DS_FAM_WINO2 || p->family == DS_FAM_WINO4 || p->family == DS_FAM_WINO4H; }
 
 // partial count of the statistics epilogue of the chosen launch
 int plan_partials(const ds_conv_layer_plan *p) {
@@ -42,7 +42,8 @@ int plan_partials(const ds_conv_layer_plan *p) {
     if (!(d.flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) && p->family != DS_FAM_STEM) return 0;
     switch (p->family) {
     case DS_FAM_WINO2: return ds_conv_wino_partials(d.N, d.H, d.W);
-    case DS_FAM_WINO4: return ds_conv_wino4_partials(d.N, d.H, d.W);
+    case DS_FAM_WINO4:
+    case DS_FAM_WINO4H: return ds_conv_wino4_partials(d.N, d.H, d.W);
     case DS_FAM_STEM: return ds_conv_stem_partials(d.N, d.OH, d.OW);
     case DS_FAM_BF16D: return ds_conv_bf16_partials(&d);
     case DS_FAM_FP8D: return ds_conv_fp8_partials(&d);
@@ -136,6 +137,15 @@ extern "C" int ds_conv_plan(ds_conv_layer_plan *out, int32_t role, int32_t arith
             if (!dgrad && cin % 8 == 0 && (cout >= 48 || (options & DS_PLAN_ACT16))) fam = DS_FAM_BF16D;
             if (dgrad && cin % 8 == 0 && (k == 1 || cout >= 160)) fam = DS_FAM_BF16D;
         }
+        // the 3x3 input gradients (dz is fp32 in every configuration): F(4x4, 3x3) of the bf16-rounded operands on the bf16
+        // matrix cores (ds_conv_wino4_bf16x2) against the LDS-staged and the register-direct bf16 kernels, us per launch at
+        // B = 256 with the BatchNorm-sums epilogue (scripts/wino4h_dgrad_bench.py, profiles/r05_notes.md): all nineteen layers
+        // 1756 against 2516 (direct), Conv2d_2c's 496 against 854; the two exceptions are the 14 x 14 layers with >= 288
+        // reduction channels (direct: 130 / 141 against 144 / 155)
+        if (!fp8 && dgrad && k == 3 && stride == 1 && !(options & DS_PLAN_NO_WINO4H) && ds_conv_wino4_supported(H, W, cin, cout)) {
+            if (!(H == 14 && cin >= 288)) fam = DS_FAM_WINO4H;
+            else if (!(options & DS_PLAN_NO_BF16_DIRECT) && cin % 8 == 0) fam = DS_FAM_BF16D;      // (the staged kernel: 141 / 155, no sums epilogue)
+        }
         if (fam == DS_FAM_BF16D && !ds_conv_bf16_supported(&d)) fam = DS_FAM_IGEMM;
         if (fam == DS_FAM_FP8D && !ds_conv_fp8_supported(&d)) fam = DS_FAM_IGEMM;
     }
@@ -145,7 +155,8 @@ extern "C" int ds_conv_plan(ds_conv_layer_plan *out, int32_t role, int32_t arith
     const int taps = k * k;
     switch (fam) {
     case DS_FAM_WINO2: out->w_bytes = 4LL * 16 * cin * cout; break;
-    case DS_FAM_WINO4: out->w_bytes = 4LL * 36 * cin * cout; break;
+    case DS_FAM_WINO4:
+    case DS_FAM_WINO4H: out->w_bytes = 4LL * 36 * cin * cout; break;
     case DS_FAM_BF16D: out->w_bytes = (int64_t)ds_weights_bf16_bytes(w_cin, w_cout, taps, dgrad); break;
     case DS_FAM_FP8D:
         out->w_bytes = (int64_t)ds_weights_fp8_bytes(w_cin, w_cout, taps, dgrad);
@@ -217,6 +228,7 @@ extern "C" int ds_conv_prepare_weights(const ds_conv_layer_plan *p, const float 
     switch (p->family) {
     case DS_FAM_WINO2: return ds_wino_transform_weights(w_hwio, (float *)w_prepared, p->w_cin, p->w_cout, dgrad, stream);
     case DS_FAM_WINO4: return ds_wino4_transform_weights(w_hwio, (float *)w_prepared, p->w_cin, p->w_cout, dgrad, stream);
+    case DS_FAM_WINO4H: return ds_wino4_transform_weights_bf16x2(w_hwio, w_prepared, p->w_cin, p->w_cout, dgrad, stream);
     case DS_FAM_BF16D: return ds_weights_to_bf16(w_hwio, w_prepared, p->w_cin, p->w_cout, taps, dgrad, stream);
     case DS_FAM_F32X3: return ds_weights_to_f32x3(w_hwio, w_prepared, p->w_cin, p->w_cout, taps, dgrad, stream);
     case DS_FAM_FP8D:
@@ -242,6 +254,10 @@ extern "C" int ds_conv_run(const ds_conv_layer_plan *p, const void *x, const voi
     case DS_FAM_WINO4:
         return ds_conv_wino4((const float *)x, (const float *)w, z, io->stats, io->pivot, io->mask, d.N, d.H, d.W, d.Cin,
                              d.ldx, d.Cout, d.ldz, d.flags, stream);
+    case DS_FAM_WINO4H:
+        return ds_conv_wino4_bf16x2((const float *)x, w, z, io->stats, io->pivot, io->mask,
+                                    (d.flags & DS_EPI_BNSUMS) ? d.mask_dtype : DS_DTYPE_F32, d.N, d.H, d.W, d.Cin, d.ldx, d.Cout, d.ldz,
+                                    d.flags, stream);
     case DS_FAM_STEM:
         return ds_conv_stem((const float *)x, (const float *)w, z, (d.flags & DS_EPI_STATS) ? io->stats : nullptr,
                             io->pivot, d.N, d.H, d.W, p->w_cin, d.Cout, d.ldz, stream);

@@ -85,12 +85,29 @@ struct Wino4Params {
 #ifndef DS_W4_RING1
 #define DS_W4_RING1 6
 #endif
+#ifndef DS_W4H_FIRST
+#define DS_W4H_FIRST 1        // AR: C = 0 in the first MFMA of every accumulator (0: zero the accumulators up front)
+#endif
+#ifndef DS_W4H_UNILOOP
+#define DS_W4H_UNILOOP (NB == 2)      // AR: no separate last K step (see the K loop); measured: NB = 2 -7 .. -15 %, NB = 1 +2 .. 4 us
+#endif
+#ifndef DS_W4H_RP2
+#define DS_W4H_RP2 3          // AR, NB = 2: positions of weight fragments in flight
+#endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t w4srd(const void *p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// AR = 1 (ds_conv_wino4_bf16x2): a channel pair rounded to bf16 (RNE, one v_cvt_pk_bf16_f32) and the pair back in fp32
+__device__ __forceinline__ unsigned pk_bf16(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+__device__ __forceinline__ f32x2 unpk_bf16(unsigned h) {
+    return f32x2{__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+}
 
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() is a release fence + s_barrier and therefore waits for
 // vmcnt(0) as well: in the epilogue that is the drain of the 64 output stores every thread has just issued (measured:
@@ -128,6 +145,14 @@ __device__ __forceinline__ void mfma_v0(f32x16 &c, float a, float b) {
     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
 }
 
+// v_mfma_f32_32x32x16_bf16 with the accumulator in architectural vector registers (operands: eight bf16 = four registers)
+__device__ __forceinline__ void mfma_hv(f32x16 &c, f32x4 a, f32x4 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_hv0(f32x16 &c, f32x4 a, f32x4 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+}
+
 // B^T d for one line of six: B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 __device__ __forceinline__ void in1d(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2 d5, f32x2 &t0, f32x2 &t1,
                                      f32x2 &t2, f32x2 &t3, f32x2 &t4, f32x2 &t5) {
@@ -163,7 +188,15 @@ __device__ __forceinline__ void out1d(float m1, f32x4 m0, f32x4 a1, f32x4 a2, f3
     y3 = m5 + qfma(q4(8.f), s3, s1);
 }
 
-template <int NB, bool BNS, bool EDGE>      // EDGE: H or W is not a multiple of four (partial last tile row / column)
+// AR = 1 (ds_conv_wino4_bf16x2, the 16-bit configurations): the thirty-six GEMMs on the bf16 matrix cores.  The operands of
+// the CONVOLUTION are the bf16-rounded ones the configuration defines (x rounded as it is loaded, the filter rounded before
+// G g G^T), but the Winograd-domain values V and U have constants up to 100 in front of cancelling sums, so each is carried
+// as TWO bf16 pieces (hi + lo: 16 mantissa bits) and a product is Vlo Uhi + Vhi Ulo + Vhi Uhi: three v_mfma_f32_32x32x16_bf16
+// (8 passes each) per 16 channels where the fp32 kernel runs eight v_mfma_f32_32x32x2_f32 (16 passes each) -- 5.3x fewer
+// matrix cycles at ~2^-16 relative accuracy in the transform domain.  V in LDS: [xi][piece][tile][16 ci] bf16 (the same 2 KB per
+// position), U: [xi][K step][piece][Cout][16 ci] bf16 (ds_wino4_transform_weights_bf16x2; the same bytes as the fp32 form).
+// Everything else -- tiles, roles, software pipeline, epilogue -- is the fp32 kernel's.
+template <int NB, bool BNS, bool EDGE, int AR = 0, bool Y16 = false>      // EDGE: H or W is not a multiple of four (partial last tile row / column); Y16: the BatchNorm-sums activation is stored as bf16
 __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p) {
     // K loop: V[2][36][32 tiles][16 ci] = 144 KB; epilogue: M[36][32 co][32 tiles] = 144 KB
     __shared__ __attribute__((aligned(128))) float smem[36 * 32 * 32];
@@ -219,9 +252,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int col = co0 + 32 * nb + li;
-        boff[nb] = col < p.Cout ? (unsigned)(col * 8 + 4 * kh) * 4u : kOOB;
+        boff[nb] = col < p.Cout ? (AR ? (unsigned)(col * 32 + 16 * kh) : (unsigned)(col * 8 + 4 * kh) * 4u) : kOOB;
     }
-    const int ustep = p.Cout * 32;                                 // bytes between half steps of one position
+    const int ustep = p.Cout * 32;                                 // bytes between half steps (AR: pieces) of one position
     const int upos = nhalf * ustep;                                // bytes between positions
 
     // NB = 2: 18 accumulators but 256 accumulation registers -- left to the compiler, two accumulators share 16 of them
@@ -229,6 +262,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     // the MFMA-only loop measured 5.5-6.4 us per step against 3.84 of matrix cycles).  Position 8's two accumulators are
     // therefore pinned to the ARCHITECTURAL vector registers (mfma_v: the gfx90a+ MFMA takes C / D in either file).
     f32x16 acc[9][NB], accv[NB];      // not initialised: the first K step's first MFMA per accumulator takes C = 0 (k_step FIRST)
+    if constexpr (AR != 0 && !DS_W4H_FIRST) {
+#pragma unroll
+        for (int pi = 0; pi < 9; ++pi)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[pi][nb][e] = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accv[nb][e] = 0.f;
+    }
     f32x2 raw[36];
     // weight-fragment ring: group g (half step g / 9, position g % 9) uses slot g % RING and is requested RING groups ahead.
     // NB = 2 has registers for six slots (3072 matrix cycles of lead); NB = 1 runs its 18 groups in half the time, so six
@@ -242,6 +287,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
         // (patch columns 1 .. 4 are image columns 4 tw .. 4 tw + 3: inside the image unless the map has a partial last tile)
         raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(srd_x, (cv[px] || (!EDGE && px >= 1 && px <= 4)) ? ro[py] : kOOB,
                                                                                  px * pixstep + c0 * 4, 0));
+    };
+    // AR: a slot holds one POSITION of a K step (hi and lo piece per channel block), requested RP positions ahead
+    constexpr int RP = NB == 1 ? 9 : DS_W4H_RP2;
+    f32x4 bh[AR ? RP : 1][NB], bl[AR ? RP : 1][NB];
+    auto load_b_h = [&](int slot, int pi, int ks) {
+        const int so = ((wave * 9 + pi) * ksteps + ks) * 2 * ustep;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            bh[slot][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_u, boff[nb], so, 0));
+            bl[slot][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_u, boff[nb], so + ustep, 0));
+        }
     };
     auto load_b = [&](int slot, int pi, int hs) {
         if ((DS_W4_ABL & 1) && hs > 0) return;
@@ -257,6 +313,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     f32x2 t[36];
     auto col_chunk = [&](int px) {
         if (DS_W4_ABL & 4) return;
+        if constexpr (AR == 1) {          // the convolution's operand is bf16(x)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) raw[6 * k + px] = unpk_bf16(pk_bf16(raw[6 * k + px]));
+        }
         in1d(raw[px], raw[6 + px], raw[12 + px], raw[18 + px], raw[24 + px], raw[30 + px], t[px], t[6 + px], t[12 + px],
              t[18 + px], t[24 + px], t[30 + px]);
     };
@@ -269,6 +329,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
         }
         f32x2 v[6];
         in1d(t[i * 6], t[i * 6 + 1], t[i * 6 + 2], t[i * 6 + 3], t[i * 6 + 4], t[i * 6 + 5], v[0], v[1], v[2], v[3], v[4], v[5]);
+        if constexpr (AR) {               // two bf16 pieces per value: [position][piece][tile][16 ci]
+            unsigned *Vu = reinterpret_cast<unsigned *>(Vw);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const unsigned h = pk_bf16(v[j]);
+                Vu[(i * 6 + j) * 512 + tid] = h;
+                Vu[(i * 6 + j) * 512 + 256 + tid] = pk_bf16(psub(v[j], unpk_bf16(h)));
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 6; ++j)
             if (!(DS_W4_ABL & 8)) *reinterpret_cast<f32x2 *>(Vw + (i * 6 + j) * 512 + tid * 2) = v[j];
@@ -278,8 +348,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     // prologue: pixels and transform of K step 0, pixels of K step 1, the first six weight fragments
 #pragma unroll
     for (int q = 0; q < 36; ++q) load_pixel(q, 0, rowoff);
+    if constexpr (AR) {
 #pragma unroll
-    for (int g = 0; g < RING; ++g) load_b(g, g % 9, g / 9);
+        for (int g = 0; g < RP; ++g) load_b_h(g, g, 0);
+    } else {
+#pragma unroll
+        for (int g = 0; g < RING; ++g) load_b(g, g % 9, g / 9);
+    }
 #pragma unroll
     for (int px = 0; px < 6; ++px) col_chunk(px);
     if (ksteps > 1) {
@@ -378,16 +453,89 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
             for (int u = 0; u < GP; ++u) av[u] = avn[u];
         }
     };
-    if (ksteps > 1) {
-        k_step(0, std::false_type{}, std::true_type{});
+    // AR: one K step = nine groups (a position each: both pieces of V, 3 NB MFMAs); the work between the groups is the fp32
+    // step's, two of its eighteen slices per group.
+    auto k_step_h = [&](int ks, auto last_tag, auto first_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value && DS_W4H_FIRST;
+        const float *Vr = smem + (ks & 1) * (36 * 512);
+        float *Vw = smem + ((ks + 1) & 1) * (36 * 512);
+        const int c2 = (ks + 2) * 16;
+        unsigned ro[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            ro[k] = (ks + 2 < ksteps) ? rowoff[k] : kOOB;
+            asm volatile("" : "+v"(ro[k]));
+        }
+        const float *Va = Vr + (wave * 9) * 512 + li * 8 + kh * 4;          // tile li, channels 8 kh .. 8 kh + 7 (16 bytes)
+        f32x4 avh = *reinterpret_cast<const f32x4 *>(Va), avl = *reinterpret_cast<const f32x4 *>(Va + 256), nvh = avh, nvl = avl;
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+            if (g + 1 < 9) {
+                nvh = *reinterpret_cast<const f32x4 *>(Va + (g + 1) * 512);
+                nvl = *reinterpret_cast<const f32x4 *>(Va + (g + 1) * 512 + 256);
+            }
+            if constexpr (!LAST) {
+#pragma unroll
+                for (int G = 2 * g; G < 2 * g + 2; ++G) {
+                    if (G < 6) col_chunk(G);
+                    else if (G < 12) row_chunk(G - 6, Vw);
+                    if (G >= 6) {
+#pragma unroll
+                        for (int k = 3 * (G - 6); k < 3 * (G - 6) + 3; ++k) load_pixel((k % 6) * 6 + k / 6, c2, ro);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3)          // small terms first: Vlo Uhi, Vhi Ulo, Vhi Uhi
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const f32x4 va = s3 == 0 ? avl : avh, vb = s3 == 1 ? bl[g % RP][nb] : bh[g % RP][nb];
+                    if (NB == 2 && g == 8) {
+                        if (FIRST && s3 == 0) mfma_hv0(accv[nb], va, vb);
+                        else mfma_hv(accv[nb], va, vb);
+                    } else if (FIRST && s3 == 0) {
+                        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, vb), zero16, 0, 0, 0);
+                    } else {
+                        acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, vb), acc[g][nb], 0, 0, 0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + RP < 9) load_b_h(g % RP, g + RP, ks);
+            else if (!LAST) load_b_h(g % RP, g + RP - 9, (DS_W4H_UNILOOP && ks + 1 >= ksteps) ? ks : ks + 1);      // (the scalar offset is not range-checked)
+            avh = nvh;
+            avl = nvl;
+        }
+    };
+    auto step = [&](int ks, auto last_tag, auto first_tag) {
+        if constexpr (AR) k_step_h(ks, last_tag, first_tag);
+        else k_step(ks, last_tag, first_tag);
+    };
+    if (AR != 0 && DS_W4H_UNILOOP && ksteps > 1) {
+        // AR, NB = 2: every step after the first runs the loop body, the last one too (its transform and requests work on zeros:
+        // the offsets past the reduction are out of range).  With a separate last step behind a loop that may run zero times the
+        // register allocator parked all 256 accumulation registers in scratch on the edge around the loop (1 KB per lane,
+        // 300 KB of scratch writes per workgroup): Conv2d_2c's input gradient 474 -> 406 us without it.  NB = 1 has the
+        // registers and keeps the cheaper last step.
+        step(0, std::false_type{}, std::true_type{});
+        lds_barrier();
+        int ks = 1;
+        do {
+            step(ks, std::false_type{}, std::false_type{});
+            lds_barrier();
+        } while (++ks < ksteps);
+    } else if (ksteps > 1) {
+        step(0, std::false_type{}, std::true_type{});
         lds_barrier();          // V of step ks + 1 is complete, V of step ks is free
         for (int ks = 1; ks + 1 < ksteps; ++ks) {
-            k_step(ks, std::false_type{}, std::false_type{});
+            step(ks, std::false_type{}, std::false_type{});
             lds_barrier();
         }
-        k_step(__builtin_amdgcn_readfirstlane(ksteps - 1), std::true_type{}, std::false_type{});      // (uniform: no waterfall loops around its loads)
+        step(__builtin_amdgcn_readfirstlane(ksteps - 1), std::true_type{}, std::false_type{});      // (uniform: no waterfall loops around its loads)
     } else {
-        k_step(0, std::true_type{}, std::true_type{});
+        step(0, std::true_type{}, std::true_type{});
     }
     W4_STAMP(3);
 
@@ -401,7 +549,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     float neg1 = -1.f;
     asm volatile("" : "+s"(neg1));          // opaque -1 (see out1d)
     const __amdgpu_buffer_rsrc_t srd_z = w4srd(p.z, p.z_bytes);
-    const __amdgpu_buffer_rsrc_t srd_y = w4srd(BNS ? p.y : p.z, p.z_bytes);
+    const __amdgpu_buffer_rsrc_t srd_y = w4srd(BNS ? p.y : p.z, Y16 ? p.z_bytes / 2 : p.z_bytes);
     const int orow = p.W * p.ldz * 4, opix = p.ldz * 4;
     int tbase, hrem, wrem;      // pixel index of the tile's top-left output (or -1); EDGE: rows / columns inside the image
     {
@@ -440,8 +588,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
             for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    yall[rr][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                        srd_y, (!EDGE || (rr < hrem && k < wrem)) ? vo : kOOB, rr * orow + k * opix, 0));
+                    if constexpr (Y16) {          // four bf16 = 8 bytes at half the fp32 offsets
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                            srd_y, (!EDGE || (rr < hrem && k < wrem)) ? (vo == kOOB ? kOOB : vo >> 1) : kOOB, (rr * orow + k * opix) >> 1, 0));
+                        yall[rr][k] = f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
+                                            __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
+                    } else {
+                        yall[rr][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            srd_y, (!EDGE || (rr < hrem && k < wrem)) ? vo : kOOB, rr * orow + k * opix, 0));
+                    }
         }
         const float *Mq = smem + tid * 4;
         f32x4 P[4][6];
@@ -522,6 +678,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
 // B loads as U[xi][r / 8][o][r % 8] with (r, o) = (reduction channel, output channel):
 //   dgrad == 0: g = w[:, :, ci, co], (r, o) = (ci, co)                               (forward)
 //   dgrad == 1: g = w[2 - kh, 2 - kw, ci, co], (r, o) = (co, ci)                     (Conv2DBackpropInput)
+//   HB (ds_wino4_transform_weights_bf16x2): g is rounded to bf16 first (the 16-bit configurations' operand), U is stored as
+//   two bf16 pieces (hi + lo) in the K-loop order of the AR kernel: [xi][r / 16][piece][o][r % 16].
+template <bool HB>
 __global__ __launch_bounds__(256) void wino4_weights_kernel(const float *w, float *u, int Cin, int Cout, int dgrad) {
     const int64_t total = (int64_t)Cin * Cout;
     const int R = dgrad ? Cout : Cin, O = dgrad ? Cin : Cout;
@@ -532,7 +691,10 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float *w, floa
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b)
+            {
                 g[a][b] = w[((int64_t)((dgrad ? 2 - a : a) * 3 + (dgrad ? 2 - b : b)) * Cin + ci) * Cout + co];
+                if (HB) g[a][b] = (float)(__bf16)g[a][b];
+            }
         // G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
         auto g1d = [](float g0, float g1, float g2, float *t) {
             const float e = (g0 + g2) * (-1.f / 6.f), o = g1 * (1.f / 6.f);
@@ -560,7 +722,17 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float *w, floa
             float c[6];
             g1d(t[a][0], t[a][1], t[a][2], c);
 #pragma unroll
-            for (int bb = 0; bb < 6; ++bb) u[(a * 6 + bb) * plane + base] = c[bb];
+            for (int bb = 0; bb < 6; ++bb) {
+                if (HB) {
+                    __bf16 *uh = reinterpret_cast<__bf16 *>(u);
+                    const int64_t at = ((((int64_t)(a * 6 + bb) * (R >> 4) + (r >> 4)) * 2) * O + o) * 16 + (r & 15);
+                    const __bf16 hi = (__bf16)c[bb];
+                    uh[at] = hi;
+                    uh[at + (int64_t)O * 16] = (__bf16)(c[bb] - (float)hi);
+                } else {
+                    u[(a * 6 + bb) * plane + base] = c[bb];
+                }
+            }
         }
     }
 }
@@ -578,12 +750,17 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float *w, floa
 #define W4_FIX1 6.0
 #define W4_STEP1 3.1
 #endif
+// (bf16x2 arithmetic: the K step is the transform's, not the matrix pipe's)
+#ifndef W4H_STEP2
+#define W4H_STEP2 2.6
+#define W4H_STEP1 1.8
+#endif
 struct W4Choice {
     int nb;             // 1, 2: F(4x4) with that channel-block count
     double us4, us2;    // expected launch time of F(4x4) with nb / of F(2x2)
 };
 int g_w4_forced_nb = -1;      // ds_debug_conv_wino4_set_nb (tests, tuning); -1: not set yet -> DS_WINO4_NB or automatic
-W4Choice w4_choose(int N, int H, int W, int Cin, int Cout) {
+W4Choice w4_choose(int N, int H, int W, int Cin, int Cout, int ar = 0) {
     if (g_w4_forced_nb < 0) {
         const char *e = getenv("DS_WINO4_NB");
         g_w4_forced_nb = e ? atoi(e) : 0;
@@ -596,7 +773,8 @@ W4Choice w4_choose(int N, int H, int W, int Cin, int Cout) {
     double t[3];
     for (int nb = 1; nb <= 2; ++nb) {
         const int64_t wgs = g4 * ((Cout + 32 * nb - 1) / (32 * nb));
-        t[nb] = ceil(wgs / cus) * ((Cin / 16) * (nb == 2 ? W4_STEP2 : W4_STEP1) + (nb == 2 ? W4_FIX2 : W4_FIX1));
+        const double stp = ar ? (nb == 2 ? W4H_STEP2 : W4H_STEP1) : (nb == 2 ? W4_STEP2 : W4_STEP1);
+        t[nb] = ceil(wgs / cus) * ((Cin / 16) * stp + (nb == 2 ? W4_FIX2 : W4_FIX1));
     }
     c.us2 = ceil(g2 * ((Cout + 31) / 32) / cus) * (8.7 + 2.35 * (Cin / 8));
     c.nb = (forced == 1 || forced == 2) ? forced : (t[2] <= t[1] ? 2 : 1);
@@ -632,9 +810,17 @@ extern "C" int ds_conv_wino4_prefer(int32_t N, int32_t H, int32_t W, int32_t Cin
 extern "C" int ds_wino4_transform_weights(const float *w, float *u, int32_t Cin, int32_t Cout, int32_t dgrad, void *stream) {
     DS_REQUIRE(w && u && Cin > 0 && Cout > 0, "ds_wino4_transform_weights: bad argument");
     DS_REQUIRE((dgrad ? Cout : Cin) % 8 == 0, "ds_wino4_transform_weights: the reduction channels must be a multiple of 8");
-    hipLaunchKernelGGL(wino4_weights_kernel, dim3(ds::stream_grid((int64_t)Cin * Cout, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(wino4_weights_kernel<false>, dim3(ds::stream_grid((int64_t)Cin * Cout, 256)), dim3(256), 0,
                        (hipStream_t)stream, w, u, Cin, Cout, dgrad);
     return ds::check_launch("ds_wino4_transform_weights");
+}
+
+extern "C" int ds_wino4_transform_weights_bf16x2(const float *w, void *u2, int32_t Cin, int32_t Cout, int32_t dgrad, void *stream) {
+    DS_REQUIRE(w && u2 && Cin > 0 && Cout > 0, "ds_wino4_transform_weights_bf16x2: bad argument");
+    DS_REQUIRE((dgrad ? Cout : Cin) % 16 == 0, "ds_wino4_transform_weights_bf16x2: the reduction channels must be a multiple of 16");
+    hipLaunchKernelGGL(wino4_weights_kernel<true>, dim3(ds::stream_grid((int64_t)Cin * Cout, 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, (float *)u2, Cin, Cout, dgrad);
+    return ds::check_launch("ds_wino4_transform_weights_bf16x2");
 }
 
 extern "C" int ds_conv_wino4_partials(int32_t N, int32_t H, int32_t W) {
@@ -642,9 +828,9 @@ extern "C" int ds_conv_wino4_partials(int32_t N, int32_t H, int32_t W) {
     return (int)((mt + 31) / 32);
 }
 
-extern "C" int ds_conv_wino4(const float *x, const float *u, float *z, float *stats, const float *pivot, const float *ymask,
-                             int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz,
-                             int32_t flags, void *stream) {
+namespace {
+int w4_launch(int ar, bool y16, const float *x, const float *u, float *z, float *stats, const float *pivot, const float *ymask,
+              int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz, int32_t flags, void *stream) {
     DS_REQUIRE(x && u && z && N > 0, "ds_conv_wino4: bad argument");
     DS_REQUIRE(ds_conv_wino4_supported(H, W, Cin, Cout) && ldx >= Cin && ldx % 2 == 0 && ldz >= Cout && ldz % 4 == 0 && ((((uintptr_t)u) | ((uintptr_t)z)) & 15) == 0 &&
                    (((uintptr_t)x) & 7) == 0 && (!(flags & DS_EPI_BNSUMS) || (((uintptr_t)ymask) & 15) == 0) &&
@@ -673,13 +859,18 @@ extern "C" int ds_conv_wino4(const float *x, const float *u, float *z, float *st
     p.prof = g_w4_prof;
 #endif
     p.groups = (int)((mt + 31) / 32);
-    const int nb = w4_choose(N, H, W, Cin, Cout).nb;
+    const int nb = w4_choose(N, H, W, Cin, Cout, ar).nb;
     p.ncol = (Cout + 32 * nb - 1) / (32 * nb);
     const dim3 grid((unsigned)(((int64_t)p.groups * p.ncol + 7) / 8 * 8));
     const bool bns = (flags & DS_EPI_BNSUMS) != 0;
     hipStream_t st = (hipStream_t)stream;
     const bool edge = (H % 4) != 0 || (W % 4) != 0;
-#define DS_W4_LAUNCH(NBV, BNSV, EDGEV) hipLaunchKernelGGL((conv_wino4_kernel<NBV, BNSV, EDGEV>), grid, dim3(256), 0, st, p)
+#define DS_W4_LAUNCH(NBV, BNSV, EDGEV)                                                                          \
+    do {                                                                                                        \
+        if (ar && BNSV && y16) hipLaunchKernelGGL((conv_wino4_kernel<NBV, BNSV, EDGEV, 1, BNSV>), grid, dim3(256), 0, st, p); \
+        else if (ar) hipLaunchKernelGGL((conv_wino4_kernel<NBV, BNSV, EDGEV, 1>), grid, dim3(256), 0, st, p);   \
+        else hipLaunchKernelGGL((conv_wino4_kernel<NBV, BNSV, EDGEV, 0>), grid, dim3(256), 0, st, p);           \
+    } while (0)
     if (nb == 2) {
         if (bns) { if (edge) DS_W4_LAUNCH(2, true, true); else DS_W4_LAUNCH(2, true, false); }
         else { if (edge) DS_W4_LAUNCH(2, false, true); else DS_W4_LAUNCH(2, false, false); }
@@ -688,5 +879,22 @@ extern "C" int ds_conv_wino4(const float *x, const float *u, float *z, float *st
         else { if (edge) DS_W4_LAUNCH(1, false, true); else DS_W4_LAUNCH(1, false, false); }
     }
 #undef DS_W4_LAUNCH
-    return ds::check_launch("ds_conv_wino4");
+    return ds::check_launch(ar ? "ds_conv_wino4_bf16x2" : "ds_conv_wino4");
+}
+}  // namespace
+
+extern "C" int ds_conv_wino4(const float *x, const float *u, float *z, float *stats, const float *pivot, const float *ymask,
+                             int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz,
+                             int32_t flags, void *stream) {
+    return w4_launch(0, false, x, u, z, stats, pivot, ymask, N, H, W, Cin, ldx, Cout, ldz, flags, stream);
+}
+
+// The same convolution for the 16-bit configurations: bf16-rounded operands, the Winograd-domain products from two bf16
+// pieces per operand on the bf16 matrix cores (conv_wino4_kernel<.., AR = 1>); u2 from ds_wino4_transform_weights_bf16x2.
+extern "C" int ds_conv_wino4_bf16x2(const float *x, const void *u2, float *z, float *stats, const float *pivot, const void *ymask,
+                                    int32_t y_dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout,
+                                    int32_t ldz, int32_t flags, void *stream) {
+    DS_REQUIRE(y_dtype == DS_DTYPE_F32 || y_dtype == DS_DTYPE_BF16, "ds_conv_wino4_bf16x2: y_dtype must be DS_DTYPE_F32 or DS_DTYPE_BF16");
+    return w4_launch(1, y_dtype == DS_DTYPE_BF16, x, (const float *)u2, z, stats, pivot, (const float *)ymask, N, H, W, Cin, ldx, Cout, ldz,
+                     flags, stream);
 }

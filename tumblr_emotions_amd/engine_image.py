@@ -819,6 +819,8 @@ class InceptionV1Engine:
         self.fp8_everywhere = os.environ.get("DS_FP8_EVERYWHERE", "0") == "1"      # A/B: ds_conv_fp8 also where the bf16 kernels are faster
         self.fp8_wide_rule = os.environ.get("DS_FP8_RULE", "0") == "1"             # A/B: the wider round-4 rule (a plan option)
         self.bf16_direct = True      # dtype bf16: ds_conv_bf16 where it wins (False: the LDS-staged bf16 kernel everywhere)
+        # bf16 / fp8: the 3x3 input gradients through ds_conv_wino4_bf16x2 where ds_conv_plan's table prefers it (DS_WINO16=0: A/B)
+        self.wino16 = os.environ.get("DS_WINO16", "1") != "0"
         self.winograd = True         # 3x3 layers through ds_conv_wino where it wins (False: implicit GEMM everywhere)
         self.mul3 = os.environ.get("DS_MUL3", "0") == "1"     # opt-in: forward 1x1 convs with fp32 products on the bf16 matrix cores
         self.bnb_on_load = int(os.environ.get("DS_BNB", "1"))      # BatchNorm backward formed by the 1x1 dgrad's loader: see ConvBN.make_dgrad
@@ -882,6 +884,8 @@ class InceptionV1Engine:
             o |= ops.DS_PLAN_FP8_EVERYWHERE
         if self.fp8_wide_rule:
             o |= ops.DS_PLAN_FP8_WIDE_RULE
+        if not self.wino16:
+            o |= ops.DS_PLAN_NO_WINO4H
         return o
 
     def all_reduce(self, t):
