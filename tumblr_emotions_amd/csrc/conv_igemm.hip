@@ -2209,10 +2209,14 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
 // ---- bf16 register-direct path -------------------------------------------------------------------------------------
 namespace {
 int g_bf16d_max_nb = 8;       // ds_debug_conv_bf16_set_max_nb (tuning)
-int bf16d_nb(int Cout) {
-    // a workgroup's cost per K step ~ (A fetch + NB MFMAs); minimise column tiles x (c + NB), c ~ 4, ties to wider
-    int best = g_bf16d_max_nb, best_cost = 1 << 30;
-    for (int nb = g_bf16d_max_nb; nb >= 1; --nb) {
+int bf16d_nb(int Cout, bool x16_1x1) {
+    // a workgroup's cost per K step ~ (A fetch + NB MFMAs); minimise column tiles x (c + NB), c ~ 4, ties to wider.
+    // 1x1 launches from 16-bit activation storage are pure streaming (8 passes per 16 channels): at most four column blocks
+    // per wave, i.e. 3-4 waves per SIMD instead of 2 -- twelve 1x1 shapes of the tower, forward with statistics:
+    // 479 -> 434 us (scripts/bf16_wide_sweep.py); the input gradients (fp32 dz) keep eight (492 against 521)
+    const int top = x16_1x1 && g_bf16d_max_nb > 4 ? 4 : g_bf16d_max_nb;
+    int best = top, best_cost = 1 << 30;
+    for (int nb = top; nb >= 1; --nb) {
         const int tiles = (Cout + 32 * nb - 1) / (32 * nb);
         const int cost = tiles * (4 + nb);
         if (cost < best_cost) { best_cost = cost; best = nb; }
@@ -2279,7 +2283,7 @@ extern "C" int ds_conv_bf16(const ds_conv_desc *d, const void *x, const void *wb
     p.x_bytes = (unsigned)(x_elems * (xb ? 2 : 4));
     p.w_bytes = (unsigned)wb_bytes;
     p.col_total = (d->Cout + 31) / 32 * 32;
-    const int nb = bf16d_nb(d->Cout);
+    const int nb = bf16d_nb(d->Cout, xb && d->KH == 1);
     p.row_tiles = (int)((conv_M(d) + 127) / 128);
     p.col_tiles = (d->Cout + 32 * nb - 1) / (32 * nb);
     const dim3 grid((unsigned)(((int64_t)p.row_tiles * p.col_tiles + 7) / 8 * 8));
