@@ -216,6 +216,12 @@ int ds_conv_fp8(const ds_conv_desc *d, const void *x, const float *x_amax, int32
 int ds_conv_stem_partials(int32_t N, int32_t OH, int32_t OW);
 int ds_conv_stem(const float *x, const float *w, float *z, float *stats, const float *pivot, int32_t N, int32_t H,
                  int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream);
+/* ds_conv_stem for the 16-bit configurations: x and w rounded to bf16 (RNE) as they are packed, v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation (two kernel rows per three MFMAs: 11 instead of 84 per accumulator); same arguments and layout; stats as
+ * float[2][64][ds_conv_stem_bf16_partials(N, OH, OW)]. */
+int ds_conv_stem_bf16_partials(int32_t N, int32_t OH, int32_t OW);      /* its own partial count (one per workgroup) */
+int ds_conv_stem_bf16(const float *x, const float *w, float *z, float *stats, const float *pivot, int32_t N, int32_t H, int32_t W,
+                      int32_t cin_store, int32_t Cout, int32_t ldz, void *stream);
 
 /* 3x3 stride-1 SAME convolution as fused Winograd F(2x2, 3x3) on fp32 MFMA: 2.25x fewer matrix passes than the
  * implicit GEMM for Conv2d_2c_3x3 and the Branch_1 / Branch_2 Conv2d_0b_3x3 of every Mixed block

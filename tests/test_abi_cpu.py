@@ -174,7 +174,10 @@ def test_conv_plan_picks_the_kernel_family_without_a_device(lib):
     assert p.alg_flops == 2.0 * B * 112 * 112 * 64 * 147
     rc, p = plan(L.DS_CONV_FWD, L.DS_ARITH_F32, L.DS_PLAN_PACKED_RGB | L.DS_PLAN_NO_STEM_DIRECT, B, 224, 224, 4, 64, 7, 2)
     assert p.family == L.DS_FAM_IGEMM and (p.d.fold_cin, p.d.Cin, p.d.KW) == (4, 28, 1)
-    assert plan(L.DS_CONV_FWD, L.DS_ARITH_BF16, L.DS_PLAN_PACKED_RGB, B, 224, 224, 4, 64, 7, 2)[1].family == L.DS_FAM_IGEMM
+    # the 16-bit configurations: the same packed-RGB kernel on the bf16 matrix cores (ds_conv_stem_bf16)
+    rc, p = plan(L.DS_CONV_FWD, L.DS_ARITH_BF16, L.DS_PLAN_PACKED_RGB, B, 224, 224, 4, 64, 7, 2, L.DS_EPI_STATS)
+    assert p.family == L.DS_FAM_STEM and p.d.dtype == L.DS_DTYPE_BF16 and p.partials > 0
+    assert plan(L.DS_CONV_FWD, L.DS_ARITH_FP8, L.DS_PLAN_PACKED_RGB | L.DS_PLAN_NO_STEM_DIRECT, B, 224, 224, 4, 64, 7, 2)[1].family == L.DS_FAM_IGEMM
     # arithmetic configurations
     assert plan(L.DS_CONV_FWD, L.DS_ARITH_F32X3, 0, B, 28, 28, 192, 176, 1, 1)[1].family == L.DS_FAM_F32X3
     assert plan(L.DS_CONV_DGRAD, L.DS_ARITH_F32X3, 0, B, 28, 28, 192, 176, 1, 1, ldx=176, ldz=192)[1].family == L.DS_FAM_IGEMM

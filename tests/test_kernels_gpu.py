@@ -110,6 +110,34 @@ def test_conv_stem_packed_rgb(case):
     close(stats[1].sum(1), (u ** 2).sum(0), 1e-3)
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 4), (3, 37, 29, 3), (5, 64, 64, 4), (1, 224, 224, 4)])
+def test_conv_stem_packed_rgb_on_bf16_matrix_cores(case):
+    """ds_conv_stem_bf16 (the 16-bit configurations' stem: two kernel rows per three v_mfma_f32_32x32x16_bf16, operands rounded
+    to bf16 as they are packed): against the fp64 convolution of the bf16-ROUNDED operands the result is fp32-accumulation
+    exact (2e-4 of max|ref|: K order, zero slots, padding sides, ragged last tile all right), against the exact convolution
+    the bf16 tolerance (1e-2); statistics about a pivot as ds_conv_stem."""
+    ops = _ops()
+    N, H, W, cs = case
+    rng = np.random.RandomState(13)
+    x = rng.uniform(-1, 1, size=(N, H, W, 3))
+    w = rng.normal(size=(7, 7, 3, 64)) * 0.1
+    ref = S.conv2d_same(_bf16_round(x), _bf16_round(w), 2)
+    ws = np.zeros((7, 7, cs, 64))
+    ws[:, :, :3] = w
+    plan = ops.StemPlan(N, H, W, cs, 64, 64, bf16=True)
+    z = torch.full((plan.M, 64), float("nan"), device="cuda")
+    stats = torch.zeros(2, 64, plan.partials, device="cuda")
+    pivot = dev(rng.normal(size=64))
+    xd, wd = dev(x), dev(ws)
+    plan.run(ops._p(xd), ops._p(wd), ops._p(z), stats=ops._p(stats), pivot=ops._p(pivot))
+    torch.cuda.synchronize()
+    close(z, ref.reshape(plan.M, 64), 2e-4)
+    close(z, S.conv2d_same(x, w, 2).reshape(plan.M, 64), 1e-2)
+    u = ref.reshape(plan.M, 64) - pivot.double().cpu().numpy()
+    close(stats[0].sum(1), u.sum(0), 1e-3)
+    close(stats[1].sum(1), (u ** 2).sum(0), 1e-3)
+
+
 @pytest.mark.parametrize("case", [(2, 14, 14, 24, 64, 3), (2, 7, 7, 192, 384, 3), (3, 9, 9, 32, 176, 1)])
 def test_conv_dgrad_reads_hwio_weights_in_place(case):
     ops = _ops()

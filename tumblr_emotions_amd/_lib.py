@@ -105,7 +105,9 @@ SIGNATURES = {
     "ds_conv_fp8_partials": (C.c_int, [_CD]),
     "ds_conv_fp8": (C.c_int, [_CD, _P, _P, _i32, _P, _P, _P, _P, _P, _P, _P]),
     "ds_conv_stem_partials": (C.c_int, [_i32, _i32, _i32]),
+    "ds_conv_stem_bf16_partials": (C.c_int, [_i32, _i32, _i32]),
     "ds_conv_stem": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
+    "ds_conv_stem_bf16": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "ds_wino_transform_weights": (C.c_int, [_P, _P, _i32, _i32, _i32, _P]),
     "ds_conv_wino_partials": (C.c_int, [_i32, _i32, _i32]),
     "ds_conv_wino": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),

@@ -44,7 +44,7 @@ int plan_partials(const ds_conv_layer_plan *p) {
     case DS_FAM_WINO2: return ds_conv_wino_partials(d.N, d.H, d.W);
     case DS_FAM_WINO4:
     case DS_FAM_WINO4H: return ds_conv_wino4_partials(d.N, d.H, d.W);
-    case DS_FAM_STEM: return ds_conv_stem_partials(d.N, d.OH, d.OW);
+    case DS_FAM_STEM: return d.dtype == DS_DTYPE_BF16 ? ds_conv_stem_bf16_partials(d.N, d.OH, d.OW) : ds_conv_stem_partials(d.N, d.OH, d.OW);
     case DS_FAM_BF16D: return ds_conv_bf16_partials(&d);
     case DS_FAM_FP8D: return ds_conv_fp8_partials(&d);
     case DS_FAM_F32X3: return ds_conv_f32x3_partials(&d);
@@ -109,7 +109,8 @@ extern "C" int ds_conv_plan(ds_conv_layer_plan *out, int32_t role, int32_t arith
     const bool f32 = arith == DS_ARITH_F32 || arith == DS_ARITH_F32X3;
     int fam = DS_FAM_IGEMM;
     if (stem) {
-        if (f32 && cout == 64 && !(options & DS_PLAN_NO_STEM_DIRECT)) fam = DS_FAM_STEM;
+        // (the 16-bit configurations run the same kernel on the bf16 matrix cores: ds_conv_stem_bf16)
+        if (cout == 64 && !(options & DS_PLAN_NO_STEM_DIRECT)) fam = DS_FAM_STEM;
     } else if (f32) {
         // 3x3 stride-1 layers: fused Winograd where it beats the implicit GEMM (profiles/r02_wino_layers.txt: every
         // 56x56 / 28x28 / 14x14 layer; on the 7x7 maps only the wide ones), F(4x4) where the launch-time model says so
@@ -259,8 +260,9 @@ extern "C" int ds_conv_run(const ds_conv_layer_plan *p, const void *x, const voi
                                     (d.flags & DS_EPI_BNSUMS) ? d.mask_dtype : DS_DTYPE_F32, d.N, d.H, d.W, d.Cin, d.ldx, d.Cout, d.ldz,
                                     d.flags, stream);
     case DS_FAM_STEM:
-        return ds_conv_stem((const float *)x, (const float *)w, z, (d.flags & DS_EPI_STATS) ? io->stats : nullptr,
-                            io->pivot, d.N, d.H, d.W, p->w_cin, d.Cout, d.ldz, stream);
+        return (d.dtype == DS_DTYPE_BF16 ? ds_conv_stem_bf16 : ds_conv_stem)(
+            (const float *)x, (const float *)w, z, (d.flags & DS_EPI_STATS) ? io->stats : nullptr, io->pivot, d.N, d.H, d.W, p->w_cin,
+            d.Cout, d.ldz, stream);
     case DS_FAM_BF16D: return ds_conv_bf16(&d, x, w, z, io->mask, io->stats, io->pivot, stream);
     case DS_FAM_F32X3: return ds_conv_f32x3(&d, (const float *)x, w, z, io->mask, io->stats, io->pivot, stream);
     case DS_FAM_FP8D:

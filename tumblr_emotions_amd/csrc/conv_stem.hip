@@ -17,10 +17,22 @@
 //   * workgroups are persistent (grid = 2 per CU) and keep the BatchNorm column sums about the pivot in registers
 //     across their tiles: one partial per workgroup.
 // SAME padding (pad 2 top/left for 224 -> 112) and rows past the end come back as zeros from an out-of-range offset.
+//
+// BF (ds_conv_stem_bf16, the 16-bit configurations): the same kernel on v_mfma_f32_32x32x16_bf16.  A lane's twelve values of
+// a kernel row (four pixels x three channels) do not fill whole 8-value fragments, so TWO kernel rows (24 values) feed three
+// MFMAs: K = 4 row pairs x 24 = 96 slots (147 real; the eighth row and the eighth pixel are zero weights), 11 MFMAs per
+// accumulator instead of 84 -- 15x fewer matrix cycles, which leaves the image reads and the 64 output columns' stores.  x and
+// w are rounded to bf16 (RNE) as they are packed; the filter lives in LDS as [mfma][kh][co][8 k] bf16 (22.5 KB), a B fragment
+// is one ds_read_b128.  The generic path it replaces in those configurations was a zero-padded 4-channel copy of the batch
+// (96 us) + the LDS-staged bf16 kernel (578 us).
 #include "ds_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 
 namespace {
@@ -39,16 +51,31 @@ struct StemParams {
     unsigned x_bytes;
 };
 
-__global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemParams p) {
-    __shared__ float wl[7 * 4 * 3 * 2 * CO];          // [dh][j][c][kh][co]
+template <bool BF>
+__global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemParams p) {
+    // row blocks of 32 output pixels per wave: two on the fp32 matrix cores (every B fragment feeds two MFMAs); ONE for BF,
+    // which is bound by the image reads and the stores: three waves per SIMD, no spills
+    constexpr int NA = BF ? 1 : 2, TP = 128 * NA;
+    __shared__ __attribute__((aligned(16))) float wl[BF ? 11 * 2 * CO * 8 / 2 : 7 * 4 * 3 * 2 * CO];          // [dh][j][c][kh][co]; BF: [mfma][kh][co][8] bf16
     __shared__ float red[4 * CO * 2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
-    for (int i = tid; i < 7 * 4 * 3 * 2 * CO; i += 256) {
-        const int co = i & 63, k2 = (i >> 6) & 1, c = (i >> 7) % 3, j = ((i >> 7) / 3) & 3, dh = (i >> 7) / 12;
-        const int px = 2 * j + k2;
-        wl[i] = px < 7 ? p.w[((dh * 7 + px) * p.cin_store + c) * CO + co] : 0.f;
+    if constexpr (BF) {
+        __bf16 *wb = reinterpret_cast<__bf16 *>(wl);
+        for (int i = tid; i < 11 * 2 * CO * 8; i += 256) {
+            const int slot = i & 7, co = (i >> 3) & 63, k2 = (i >> 9) & 1, m = i >> 10;
+            const int t = m / 3, q = (m - 3 * t) * 8 + slot;          // row pair, position among its 24 values
+            const int r = q / 12, jj = (q - 12 * r) / 3, c = q % 3;
+            const int dh = 2 * t + r, px = 2 * jj + k2;
+            wb[i] = (__bf16)((dh < 7 && px < 7) ? p.w[((dh * 7 + px) * p.cin_store + c) * CO + co] : 0.f);
+        }
+    } else {
+        for (int i = tid; i < 7 * 4 * 3 * 2 * CO; i += 256) {
+            const int co = i & 63, k2 = (i >> 6) & 1, c = (i >> 7) % 3, j = ((i >> 7) / 3) & 3, dh = (i >> 7) / 12;
+            const int px = 2 * j + k2;
+            wl[i] = px < 7 ? p.w[((dh * 7 + px) * p.cin_store + c) * CO + co] : 0.f;
+        }
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
@@ -57,88 +84,42 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemParams p) {
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
     const int ohw = p.OH * p.OW;
 
-    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
-        // ---- the lane's two output pixels (row blocks a = 0, 1) ------------------------------------------------
-        int ih0[2], iw0[2], nb[2];
-        bool rv[2];
+    // the lane's two output pixels (row blocks a = 0, 1) of a tile, and the byte offsets of a kernel row's four pixels
+    struct Pix { int ih0[NA], iw0[NA], nb[NA]; bool rv[NA]; };
+    auto coords = [&](int tile, Pix &c) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int m = tile * 256 + wave * 64 + a * 32 + li;
-            rv[a] = m < p.M;
-            const int mm = rv[a] ? m : 0;
+        for (int a = 0; a < NA; ++a) {
+            const int m = tile * TP + wave * (32 * NA) + a * 32 + li;
+            c.rv[a] = m < p.M;
+            const int mm = c.rv[a] ? m : 0;
             const int n = mm / ohw, r = mm - n * ohw;
             const int oh = r / p.OW, ow = r - oh * p.OW;
-            ih0[a] = 2 * oh - p.pad_t;
-            iw0[a] = 2 * ow - p.pad_l + kh;             // pixel 2 j + kh of the kernel row
-            nb[a] = n * p.H;
+            c.ih0[a] = 2 * oh - p.pad_t;
+            c.iw0[a] = 2 * ow - p.pad_l + kh;             // pixel 2 j + kh of the kernel row
+            c.nb[a] = n * p.H;
         }
-        auto row_offsets = [&](int dh, unsigned (&vo)[2][4]) {
+    };
+    auto row_offsets_of = [&](const Pix &c, int dh, unsigned (&vo)[NA][4]) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int ih = ih0[a] + dh;
-                const bool rok = rv[a] && (unsigned)ih < (unsigned)p.H;
-                const int base = (nb[a] + ih) * p.W;
+        for (int a = 0; a < NA; ++a) {
+            const int ih = c.ih0[a] + dh;
+            const bool rok = c.rv[a] && (unsigned)ih < (unsigned)p.H;
+            const int base = (c.nb[a] + ih) * p.W;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int iw = iw0[a] + 2 * j;
-                    const bool ok = rok && (unsigned)iw < (unsigned)p.W && (2 * j + kh) < 7;
-                    vo[a][j] = ok ? (unsigned)(base + iw) * 12u : kOOB;
-                }
-            }
-        };
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-        f32x3 cur[2][4], nxt[2][4];
-        {
-            unsigned vo[2][4];
-            row_offsets(0, vo);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    cur[a][j] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(srd, vo[a][j], 0, 0));
-        }
-#pragma unroll 1
-        for (int dh = 0; dh < 7; ++dh) {
-            if (dh < 6) {
-                unsigned vo[2][4];
-                row_offsets(dh + 1, vo);
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        nxt[a][j] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(srd, vo[a][j], 0, 0));
-            }
-            const float *wr = wl + dh * (4 * 3 * 2 * CO) + kh * CO + li;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float b0 = wr[(j * 3 + c) * 2 * CO], b1 = wr[(j * 3 + c) * 2 * CO + 32];
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][j][c], b0, acc[0][0], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[1][j][c], b0, acc[1][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][j][c], b1, acc[0][1], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[1][j][c], b1, acc[1][1], 0, 0, 0);
-                }
-            if (dh < 6) {
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) cur[a][j] = nxt[a][j];
+            for (int j = 0; j < 4; ++j) {
+                const int iw = c.iw0[a] + 2 * j;
+                const bool ok = rok && (unsigned)iw < (unsigned)p.W && (2 * j + kh) < 7;
+                vo[a][j] = ok ? (unsigned)(base + iw) * 12u : kOOB;
             }
         }
-        // ---- store + statistics: element e of a block is output row (e&3) + 8 (e>>2) + 4 kh, column li ---------------
-        // (stores through a buffer descriptor: one 32-bit lane offset per block + the row's offset, rows past M dropped by the
-        // hardware range check -- as gemm_wide_kernel's epilogue; the second 32 columns ride in the instruction offset)
+    };
+    // store + statistics: element e of a block is output row (e&3) + 8 (e>>2) + 4 kh, column li
+    // (stores through a buffer descriptor: one 32-bit lane offset per block + the row's offset, rows past M dropped by the
+    // hardware range check -- as gemm_wide_kernel's epilogue; the second 32 columns ride in the instruction offset)
+    auto epilogue = [&](int tile, const f32x16 (&acc)[NA][2]) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int row0 = tile * 256 + wave * 64 + a * 32 + 4 * kh;
+        for (int a = 0; a < NA; ++a) {
+            const int row0 = tile * TP + wave * (32 * NA) + a * 32 + 4 * kh;
             const unsigned vz = (unsigned)(row0 * p.ldz + li) * 4u;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -154,6 +135,145 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemParams p) {
                 }
             }
         }
+    };
+
+    if constexpr (BF) {
+        // Row pair t = kernel rows 2 t, 2 t + 1 (row 7 does not exist: zeros against zero weights).  Two pairs of requests are
+        // always in flight -- across tiles too: the first two pairs of the NEXT tile are requested before this tile's last
+        // MFMAs and stores -- and a pair is packed to bf16 fragments (24 registers) as soon as it has arrived.
+        f32x3 rawA[2][NA][4], rawB[2][NA][4];          // [row of the pair][row block a][pixel j]
+        auto issue = [&](const Pix &c, int t, f32x3 (&dst)[2][NA][4]) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (2 * t + r >= 7) continue;
+                unsigned vo[NA][4];
+                row_offsets_of(c, 2 * t + r, vo);
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        dst[r][a][j] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(srd, vo[a][j], 0, 0));
+            }
+        };
+        bf16x8 pk[NA][3];
+        auto pack = [&](int t, const f32x3 (&src)[2][NA][4]) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int ml = 0; ml < 3; ++ml) {
+                    float v[8];
+#pragma unroll
+                    for (int sl = 0; sl < 8; ++sl) {
+                        const int q = ml * 8 + sl, r = q / 12, jj = (q - 12 * r) / 3, c = q % 3;
+                        v[sl] = (2 * t + r < 7) ? src[r][a][jj][c] : 0.f;
+                    }
+                    const bf16x2 p0 = __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2), p1 = __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2);
+                    const bf16x2 p2 = __builtin_convertvector(f32x2{v[4], v[5]}, bf16x2), p3 = __builtin_convertvector(f32x2{v[6], v[7]}, bf16x2);
+                    pk[a][ml] = bf16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+                }
+        };
+        const __bf16 *wb = reinterpret_cast<const __bf16 *>(wl) + (kh * CO + li) * 8;
+        f32x16 acc[NA][2];
+        auto mfmas = [&](int t, bool first) {
+#pragma unroll
+            for (int ml = 0; ml < (t < 3 ? 3 : 2); ++ml) {
+                const int m = 3 * t + ml;
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(wb + (m * 2 * CO) * 8);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(wb + (m * 2 * CO + 32) * 8);
+                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pk[a][ml], b0, (first && ml == 0) ? zero16 : acc[a][0], 0, 0, 0);
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pk[a][ml], b1, (first && ml == 0) ? zero16 : acc[a][1], 0, 0, 0);
+                }
+            }
+        };
+        Pix cu, nx;
+        int tile = blockIdx.x;
+        if (tile < p.tiles) {
+            coords(tile, cu);
+            issue(cu, 0, rawA);
+            issue(cu, 1, rawB);
+        }
+        for (; tile < p.tiles; tile += gridDim.x) {
+            const int ntile = tile + gridDim.x;
+            const bool more = ntile < p.tiles;          // (uniform)
+            if (more) coords(ntile, nx);
+            pack(0, rawA);
+            issue(cu, 2, rawA);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(0, true);
+            pack(1, rawB);
+            issue(cu, 3, rawB);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(1, false);
+            pack(2, rawA);
+            if (more) issue(nx, 0, rawA);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(2, false);
+            pack(3, rawB);
+            if (more) issue(nx, 1, rawB);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(3, false);
+            epilogue(tile, acc);
+            cu = nx;
+        }
+    } else {
+    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+        Pix cu;
+        coords(tile, cu);
+        auto row_offsets = [&](int dh, unsigned (&vo)[2][4]) { row_offsets_of(cu, dh, vo); };
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+        {
+            f32x3 cur[2][4], nxt[2][4];
+            {
+                unsigned vo[2][4];
+                row_offsets(0, vo);
+    #pragma unroll
+                for (int a = 0; a < 2; ++a)
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        cur[a][j] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(srd, vo[a][j], 0, 0));
+            }
+    #pragma unroll 1
+            for (int dh = 0; dh < 7; ++dh) {
+                if (dh < 6) {
+                    unsigned vo[2][4];
+                    row_offsets(dh + 1, vo);
+    #pragma unroll
+                    for (int a = 0; a < 2; ++a)
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            nxt[a][j] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(srd, vo[a][j], 0, 0));
+                }
+                const float *wr = wl + dh * (4 * 3 * 2 * CO) + kh * CO + li;
+    #pragma unroll
+                for (int j = 0; j < 4; ++j)
+    #pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float b0 = wr[(j * 3 + c) * 2 * CO], b1 = wr[(j * 3 + c) * 2 * CO + 32];
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][j][c], b0, acc[0][0], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[1][j][c], b0, acc[1][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][j][c], b1, acc[0][1], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[1][j][c], b1, acc[1][1], 0, 0, 0);
+                    }
+                if (dh < 6) {
+    #pragma unroll
+                    for (int a = 0; a < 2; ++a)
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) cur[a][j] = nxt[a][j];
+                }
+            }
+        }
+        epilogue(tile, acc);
+    }
     }
     if (p.stats) {
         s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32);
@@ -176,18 +296,20 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemParams p) {
     }
 }
 
-int stem_grid(int64_t M) {
-    const int64_t tiles = (M + 255) / 256;
-    const int64_t g = 2 * ds::kCUs;
+int stem_grid(int64_t M, bool bf = false) {
+    const int64_t tiles = bf ? (M + 127) / 128 : (M + 255) / 256;
+    const int64_t g = (bf ? 3 : 2) * ds::kCUs;
     return (int)(tiles < g ? tiles : g);
 }
 
 }  // namespace
 
 extern "C" int ds_conv_stem_partials(int32_t N, int32_t OH, int32_t OW) { return stem_grid((int64_t)N * OH * OW); }
+extern "C" int ds_conv_stem_bf16_partials(int32_t N, int32_t OH, int32_t OW) { return stem_grid((int64_t)N * OH * OW, true); }
 
-extern "C" int ds_conv_stem(const float *x, const float *w, float *z, float *stats, const float *pivot, int32_t N, int32_t H,
-                            int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream) {
+namespace {
+int stem_launch(bool bf, const float *x, const float *w, float *z, float *stats, const float *pivot, int32_t N, int32_t H,
+                int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream) {
     DS_REQUIRE(x && w && z, "ds_conv_stem: null argument");
     DS_REQUIRE(Cout == CO && (cin_store == 3 || cin_store == 4) && ldz >= CO, "ds_conv_stem: the 7x7/2 stem has 3 input and 64 output channels");
     StemParams p = {};
@@ -201,8 +323,21 @@ extern "C" int ds_conv_stem(const float *x, const float *w, float *z, float *sta
     const int64_t xb = (int64_t)N * H * W * 12;
     DS_REQUIRE(M < (1ll << 31) && xb < (1ll << 31) && ((M - 1) * ldz + CO) * 4 < (1ll << 31),
                "ds_conv_stem: input or output larger than 2 GiB (split the batch)");
-    p.M = (int)M; p.tiles = (int)((M + 255) / 256);
+    p.M = (int)M; p.tiles = (int)(bf ? (M + 127) / 128 : (M + 255) / 256);
     p.x_bytes = (unsigned)xb;
-    hipLaunchKernelGGL(conv_stem_kernel, dim3(stem_grid(M)), dim3(256), 0, (hipStream_t)stream, p);
-    return ds::check_launch("ds_conv_stem");
+    if (bf) hipLaunchKernelGGL(conv_stem_kernel<true>, dim3(stem_grid(M, true)), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv_stem_kernel<false>, dim3(stem_grid(M)), dim3(256), 0, (hipStream_t)stream, p);
+    return ds::check_launch(bf ? "ds_conv_stem_bf16" : "ds_conv_stem");
+}
+}  // namespace
+
+extern "C" int ds_conv_stem(const float *x, const float *w, float *z, float *stats, const float *pivot, int32_t N, int32_t H,
+                            int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream) {
+    return stem_launch(false, x, w, z, stats, pivot, N, H, W, cin_store, Cout, ldz, stream);
+}
+
+// The same layer for the 16-bit configurations: x and w rounded to bf16 (RNE), v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+extern "C" int ds_conv_stem_bf16(const float *x, const float *w, float *z, float *stats, const float *pivot, int32_t N, int32_t H,
+                                 int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream) {
+    return stem_launch(true, x, w, z, stats, pivot, N, H, W, cin_store, Cout, ldz, stream);
 }

@@ -334,12 +334,13 @@ def wino_transform_weights(w_ptr, u, Cin, Cout, dgrad, f4=False):
 class StemPlan:
     """Conv2d_1a_7x7 through ds_conv_stem: packed RGB input [N, H, W, 3], HWIO weights with `cin_store` input rows."""
 
-    def __init__(self, N, H, W, cin_store, Cout, ldz):
+    def __init__(self, N, H, W, cin_store, Cout, ldz, bf16=False):
         self.args = (N, H, W, cin_store, Cout, ldz)
+        self.bf16 = bf16               # ds_conv_stem_bf16: operands rounded to bf16, bf16 MFMA (the 16-bit configurations)
         self.flags = DS_EPI_STATS      # kept for the common plan interface: statistics are on iff `stats` is passed
         OH, OW = (H + 1) // 2, (W + 1) // 2
         self.M = N * OH * OW
-        self.partials = _lib.load().ds_conv_stem_partials(N, OH, OW)
+        self.partials = (_lib.load().ds_conv_stem_bf16_partials if bf16 else _lib.load().ds_conv_stem_partials)(N, OH, OW)
         self.alg_flops = 2.0 * self.M * Cout * 147
 
     def run(self, x, w, z, stats=None, pivot=None):
@@ -347,7 +348,8 @@ class StemPlan:
         if t is not None:
             t.begin()
         N, H, W, cs, Cout, ldz = self.args
-        _lib.check(_lib.load().ds_conv_stem(x, w, z, stats, pivot, N, H, W, cs, Cout, ldz, _stream()), "ds_conv_stem")
+        f = _lib.load().ds_conv_stem_bf16 if self.bf16 else _lib.load().ds_conv_stem
+        _lib.check(f(x, w, z, stats, pivot, N, H, W, cs, Cout, ldz, _stream()), "ds_conv_stem")
         if t is not None:
             t.end(self)
 
