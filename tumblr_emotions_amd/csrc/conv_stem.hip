@@ -71,11 +71,19 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
             wb[i] = (__bf16)((dh < 7 && px < 7) ? p.w[((dh * 7 + px) * p.cin_store + c) * CO + co] : 0.f);
         }
     } else {
-        for (int i = tid; i < 7 * 4 * 3 * 2 * CO; i += 256) {
+        // (all 42 reads of a thread requested before the first LDS write: one memory round trip instead of 42 in a row --
+        // ~60 us at the head of every persistent workgroup)
+        constexpr int WN = 7 * 4 * 3 * 2 * CO / 256;
+        float wv[WN];
+#pragma unroll
+        for (int t = 0; t < WN; ++t) {
+            const int i = t * 256 + tid;
             const int co = i & 63, k2 = (i >> 6) & 1, c = (i >> 7) % 3, j = ((i >> 7) / 3) & 3, dh = (i >> 7) / 12;
             const int px = 2 * j + k2;
-            wl[i] = px < 7 ? p.w[((dh * 7 + px) * p.cin_store + c) * CO + co] : 0.f;
+            wv[t] = px < 7 ? p.w[((dh * 7 + px) * p.cin_store + c) * CO + co] : 0.f;
         }
+#pragma unroll
+        for (int t = 0; t < WN; ++t) wl[t * 256 + tid] = wv[t];
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
@@ -219,61 +227,105 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
             cu = nx;
         }
     } else {
-    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
-        Pix cu;
-        coords(tile, cu);
-        auto row_offsets = [&](int dh, unsigned (&vo)[2][4]) { row_offsets_of(cu, dh, vo); };
-        f32x16 acc[2][2];
+        // fp32: with two waves per SIMD the vector instructions between the MFMAs add to the matrix time (ablation builds,
+        // profiles/r05_notes.md: the launch without any memory access still took 596 us against 392 us of matrix cycles), so
+        // the per-tile index math is kept small: column offsets / validity once per tile, the kernel-row loop unrolled with
+        // ping-pong registers (no copies), the first MFMA of every accumulator with C = 0, and for tiles that lie wholly
+        // inside M the store row offsets in the instruction's scalar offset.
+        struct Cols { unsigned o[2][4]; };          // byte offset of pixel 2 j + kh inside its image row, or out of range
+        auto setup = [&](int tile, Pix &c, Cols &co) {
+            coords(tile, c);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+                for (int j = 0; j < 4; ++j) {
+                    const int iw = c.iw0[a] + 2 * j;
+                    co.o[a][j] = (c.rv[a] && (unsigned)iw < (unsigned)p.W && (2 * j + kh) < 7) ? (unsigned)iw * 12u : kOOB;
+                }
+        };
+        f32x3 buf[2][2][4];
+        auto issue = [&](const Pix &c, const Cols &co, int dh, f32x3 (&dst)[2][4]) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-        {
-            f32x3 cur[2][4], nxt[2][4];
-            {
-                unsigned vo[2][4];
-                row_offsets(0, vo);
-    #pragma unroll
-                for (int a = 0; a < 2; ++a)
-    #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        cur[a][j] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(srd, vo[a][j], 0, 0));
+            for (int a = 0; a < 2; ++a) {
+                const int ih = c.ih0[a] + dh;
+                // (an out-of-range column offset stays out of range with the row offset added: both < 2^31)
+                const unsigned rowo = (unsigned)ih < (unsigned)p.H ? (unsigned)((c.nb[a] + ih) * p.W) * 12u : kOOB;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dst[a][j] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(srd, (rowo | co.o[a][j]) & kOOB ? kOOB : rowo + co.o[a][j], 0, 0));
             }
-    #pragma unroll 1
+        };
+        // the B fragments of a kernel row (12 K steps x 2 column blocks) are read one row AHEAD: read just in time, every
+        // group of four MFMAs waited for its own ds_read (one MFMA of cover for ~100 cycles of LDS latency)
+        float bw[2][12][2];
+        auto read_b = [&](int dh, float (&dst)[12][2]) {
+            const float *wr = wl + dh * (4 * 3 * 2 * CO) + kh * CO + li;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                dst[k][0] = wr[k * 2 * CO];
+                dst[k][1] = wr[k * 2 * CO + 32];
+            }
+        };
+        // One tile (kernel row dh in buf[dh & 1]).  Requesting the NEXT tile's first row behind this tile's last one -- in front of
+        // the 128 stores -- was built (two copies of this body, the parity alternates with seven rows) and bought nothing: 677 us.
+        auto run_tile = [&](int tile, const Pix &c, const Cols &co) {
+            constexpr int P = 0;
+            f32x16 acc[2][2];
+            read_b(0, bw[0]);
+#pragma unroll
             for (int dh = 0; dh < 7; ++dh) {
                 if (dh < 6) {
-                    unsigned vo[2][4];
-                    row_offsets(dh + 1, vo);
-    #pragma unroll
-                    for (int a = 0; a < 2; ++a)
-    #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            nxt[a][j] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(srd, vo[a][j], 0, 0));
+                    issue(c, co, dh + 1, buf[(dh + 1 + P) & 1]);
+                    read_b(dh + 1, bw[(dh + 1) & 1]);
                 }
-                const float *wr = wl + dh * (4 * 3 * 2 * CO) + kh * CO + li;
-    #pragma unroll
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x3 (&cur)[2][4] = buf[(dh + P) & 1];
+#pragma unroll
                 for (int j = 0; j < 4; ++j)
-    #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float b0 = wr[(j * 3 + c) * 2 * CO], b1 = wr[(j * 3 + c) * 2 * CO + 32];
-                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][j][c], b0, acc[0][0], 0, 0, 0);
-                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[1][j][c], b0, acc[1][0], 0, 0, 0);
-                        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][j][c], b1, acc[0][1], 0, 0, 0);
-                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[1][j][c], b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        const float b0 = bw[dh & 1][j * 3 + cc][0], b1 = bw[dh & 1][j * 3 + cc][1];
+                        if (dh == 0 && j == 0 && cc == 0) {
+                            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][j][cc], b0, zero16, 0, 0, 0);
+                            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[1][j][cc], b0, zero16, 0, 0, 0);
+                            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][j][cc], b1, zero16, 0, 0, 0);
+                            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[1][j][cc], b1, zero16, 0, 0, 0);
+                        } else {
+                            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][j][cc], b0, acc[0][0], 0, 0, 0);
+                            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[1][j][cc], b0, acc[1][0], 0, 0, 0);
+                            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][j][cc], b1, acc[0][1], 0, 0, 0);
+                            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[1][j][cc], b1, acc[1][1], 0, 0, 0);
+                        }
                     }
-                if (dh < 6) {
-    #pragma unroll
-                    for (int a = 0; a < 2; ++a)
-    #pragma unroll
-                        for (int j = 0; j < 4; ++j) cur[a][j] = nxt[a][j];
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if ((tile + 1) * TP <= p.M) {          // (uniform) every row of the tile exists
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const unsigned vz = (unsigned)((tile * TP + wave * 64 + a * 32 + 4 * kh) * p.ldz + li) * 4u;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float v0 = acc[a][0][e], v1 = acc[a][1][e];
+                        const int so = ((e & 3) + 8 * (e >> 2)) * p.ldz * 4;          // (rows inside M: the unchecked scalar offset is safe)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), srd_z, vz, so, 2 /* nt */);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), srd_z, vz + 128u, so, 2 /* nt */);
+                        const float u0 = v0 - pv0, u1 = v1 - pv1;          // (the arithmetic of `epilogue`, to the bit)
+                        s0 += u0; q0 += u0 * u0;
+                        s1 += u1; q1 += u1 * u1;
+                    }
+                }
+            } else {
+                epilogue(tile, acc);
+            }
+        };
+        for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+            Pix cA;
+            Cols oA;
+            setup(tile, cA, oA);
+            issue(cA, oA, 0, buf[0]);
+            run_tile(tile, cA, oA);
         }
-        epilogue(tile, acc);
-    }
     }
     if (p.stats) {
         s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32);
