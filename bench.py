@@ -301,6 +301,9 @@ def main():
     ap.add_argument("--no-zcat", action="store_true",
                     help="A/B aid: every conv followed by its BatchNorm-apply pass (default: the 3x3 / Branch_3 convs of "
                          "Mixed_3b..4f write z into the concat and the consumers normalise on load)")
+    ap.add_argument("--no-fuse-b3", action="store_true",
+                    help="A/B aid: Branch_3's 3x3/1 max pool as its own pass in front of the 1x1 conv (default: formed on load "
+                         "by the conv, ds_conv_desc.pool_argmax)")
     ap.add_argument("--no-wino4", action="store_true",
                     help="A/B aid: F(2x2,3x3) also on the 56 x 56 / 28 x 28 maps instead of the F(4x4,3x3) kernel")
     ap.add_argument("--graph", action="store_true",
@@ -384,6 +387,8 @@ def main():
         net.image.winograd4 = False
     if args.no_zcat and net.image is not None:
         net.image.zcat = False
+    if args.no_fuse_b3 and net.image is not None:
+        net.image.fuse_branch3 = False
     if args.mul3 and net.image is not None:
         net.image.mul3 = True
     if args.no_branch_streams and net.image is not None:

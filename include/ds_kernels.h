@@ -97,6 +97,15 @@ typedef struct ds_conv_desc {
     const struct ds_bn_bwd_on_load *bnb;   /* HOST pointer, nullable: BatchNorm + ReLU backward applied ON LOAD (below)  */
     int32_t mask_dtype;       /* DS_EPI_BNSUMS in ds_conv_bf16 / ds_conv_fp8: storage type of `mask` (DS_DTYPE_F32 or, under     */
                               /* 16-bit activation storage, DS_DTYPE_BF16: ldmask then counts bf16 elements)                    */
+    /* MaxPool 3x3 / 1 SAME applied ON LOAD (wide 1x1 kernel only, ds_conv_igemm_pool3_supported; nullable): an Inception   */
+    /* block's Branch_3 = slim.max_pool2d(net, [3, 3], stride 1) -> slim.conv2d(., [1, 1]) (image_model/inception_v1.py:94-95  */
+    /* ... :246-247) as ONE launch.  The reduction operand of pixel (h, w) is the maximum of x over its 3x3 neighbourhood     */
+    /* (padded cells never win), formed as the loader reads the three rows; with norm_rstd / norm_shift the maximum is taken  */
+    /* over the pre-BatchNorm values and normalised afterwards (rstd > 0: the same value).  pool_argmax [N*H*W][Cin] bytes    */
+    /* receives the row-major-first winner of every window (kh * 3 + kw, what ds_maxpool_fwd records and ds_maxpool_bwd       */
+    /* reads); the pooled tensor itself never reaches memory.  z is bit-identical to ds_maxpool_fwd + the plain launch; the   */
+    /* statistics partials group other rows (32-pixel blocks of whole image rows), so their sums differ in rounding.          */
+    uint8_t *pool_argmax;
 } ds_conv_desc;
 
 /* Conv2DBackpropInput of a 1x1 conv + BatchNorm + ReLU layer WITHOUT the separate ds_bn_bwd_apply pass (wide 1x1 kernel
@@ -143,6 +152,10 @@ int ds_conv_igemm_bnsums_supported(const ds_conv_desc *d);
 int ds_conv_igemm_norm_supported(const ds_conv_desc *d);
 /* ... and whether it takes ds_conv_desc.bnb (k-contiguous weights, i.e. a dgrad, on the wide kernel; Cin <= 1024).     */
 int ds_conv_igemm_bnb_supported(const ds_conv_desc *d);
+/* ... and whether it would form the 3x3 / 1 max pool of x on load for this shape (ds_conv_desc.pool_argmax: forward 1x1,
+ * n-contiguous weights, W <= 32, Cin % 16 == 0, Cout <= 128 -- one column tile, so the pooling is done once).  Judged on
+ * the shape alone: d->pool_argmax may still be null.                                                                  */
+int ds_conv_igemm_pool3_supported(const ds_conv_desc *d);
 /* stats (DS_EPI_STATS): float[2][Cout][P] partial column sums of (z - pivot) and (z - pivot)^2.
  * pivot (nullable = 0): float[Cout], any value near the column mean -- the build passes the previous step's
  * batch mean (the moving mean after a restore) -- so that the fp32 partial sums carry the spread of z rather
@@ -284,6 +297,10 @@ int ds_conv_wino4_bf16x2(const float *x, const void *u2, float *z, float *stats,
  *                            cannot carry it (the caller then keeps the separate ds_bn_bwd_reduce pass)
  *   ds_conv_plan_norm_supported   would the launch apply d.norm_rstd / d.norm_shift (BatchNorm + ReLU on load)?
  *   ds_conv_plan_bnb_supported    dgrad: would it apply the layer's BatchNorm backward on load (d.bnb)?
+ *   ds_conv_plan_enable_pool3     forward 1x1 conv behind a 3x3 / 1 SAME max pool (an Inception block's Branch_3): the pool is
+ *                            formed on load (d.pool_argmax = the winners' bytes, what ds_maxpool_fwd would record) and
+ *                            plan.partials is recomputed; returns 1, or 0 when the chosen kernel cannot (the plan is unchanged
+ *                            and the caller keeps the separate pool pass)
  *   ds_conv_prepare_weights  plan.w_bytes > 0: converts the HWIO filter into the form the family reads (G g G^T, bf16 /
  *                            fp8 / three-piece K-loop order); redo whenever the filter changes.  fp8: wscale =
  *                            float[plan.wscale_floats]
@@ -339,6 +356,7 @@ int ds_conv_plan_set_flags(ds_conv_layer_plan *plan, int32_t flags);
 int ds_conv_plan_enable_bnsums(ds_conv_layer_plan *plan, int32_t ldy);
 int ds_conv_plan_norm_supported(const ds_conv_layer_plan *plan);
 int ds_conv_plan_bnb_supported(const ds_conv_layer_plan *plan);      /* would ds_conv_run take plan.d.bnb?                 */
+int ds_conv_plan_enable_pool3(ds_conv_layer_plan *plan, uint8_t *argmax);
 int ds_conv_prepare_weights(const ds_conv_layer_plan *plan, const float *w_hwio, void *w_prepared, float *wscale,
                             void *stream);
 int ds_conv_run(const ds_conv_layer_plan *plan, const void *x, const void *w, float *z, const ds_conv_io *io, void *stream);

@@ -344,3 +344,34 @@ def test_sync_bn_reproduces_the_single_process_step():
         assert np.array_equal(got[r]["theta_same"], net2.store.theta.detach().cpu().numpy())
         assert np.array_equal(got[r]["frozen_same"], net2.store.frozen.detach().cpu().numpy())      # (moving statistics)
     print("sync_bn: max|dlogits| %.2e, median gradient rel L2 %.2e, worst %.2e" % (np.abs(both - logits).max(), np.median(rels), max(rels)))
+
+
+def test_bench_self_launched_two_rank_run_prints_one_json_line():
+    """The N-rank bench path end to end, the way the driver starts it: plain `python bench.py --gpus 2` (no launcher in the
+    environment) must re-execute itself under torch.distributed.run, bring up two ranks, time the weak-scaling headline and
+    the strong-scaling point of BASELINE configs[3], and have rank 0 print exactly ONE JSON line.  On this 1-GPU box both
+    ranks share cuda:0 and gloo carries the all-reduce (DS_BENCH_ONE_DEVICE=1: RCCL refuses two ranks on one device) -- the
+    host code path, sharding, bucket schedule and report are the ones an 8-GPU run over RCCL takes
+    (slim/deployment/model_deploy.py:414-444 is what the all-reduce replaces)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DS_BENCH_ONE_DEVICE"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "32", "--no-cpu-baseline", "--no-live-traffic", "--no-gather"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "re-executing as" in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.lstrip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-4000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["dp"]["rccl_ranks"] == 2 and rec["dp"]["world_size"] == 2
+    assert rec["config"]["global_batch"] == 64 and rec["config"]["per_gpu_batch"] == 32
+    assert rec["value"] > 0 and abs(rec["value"] - 64 / (rec["ms_per_step"] * 1e-3)) <= 1e-2 * rec["value"]
+    ss = rec["strong_scaling"]
+    assert ss["scaling"] == "strong" and ss["n_gpus"] == 2 and ss["per_gpu_batch"] * 2 == ss["global_batch"] and ss["value"] > 0
+    assert np.isfinite(rec["config"]["final_loss"])

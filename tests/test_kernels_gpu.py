@@ -1447,6 +1447,71 @@ def test_max_pool_with_deferred_batch_norm_relu(case):
     assert np.abs(got - want).max() <= 1e-6
 
 
+@pytest.mark.parametrize("case", [(24, 28, 28, 192, 32, False, True), (24, 28, 28, 256, 64, True, True), (96, 14, 14, 480, 64, True, True),
+                                  (96, 14, 14, 528, 128, True, True), (384, 7, 7, 832, 128, False, True), (3, 9, 11, 48, 96, True, False),
+                                  (2, 5, 32, 64, 40, False, False), (1, 1, 1, 32, 32, True, False)])
+def test_branch3_max_pool_formed_on_load_equals_pool_then_conv(case):
+    """ds_conv_desc.pool_argmax (an Inception block's Branch_3, image_model/inception_v1.py:94-95: max_pool2d 3x3 / 1 SAME ->
+    conv2d 1x1, as ONE launch of the wide kernel): z bit-identical to ds_maxpool_fwd / ds_maxpool_bn_relu_fwd followed by the
+    plain launch wherever that also runs on the wide kernel (same MFMA sequence per output element), the recorded winners
+    identical byte for byte -- on inputs with many exact ties (values on a coarse grid, half of them ReLU zeros), so the
+    row-major-first rule is exercised -- the statistics equal up to the grouping of the partial sums, and everything within
+    2e-4 of the fp64 oracle."""
+    ops = _ops()
+    N, H, W, K, Nc, norm, bit = case
+    rng = np.random.RandomState(7 + H + K)
+    x = np.round(rng.normal(size=(N, H, W, K)) * 3) / 3              # coarse grid: exact ties inside most windows
+    r = (np.abs(rng.normal(size=K)) + 0.5).astype(np.float32)
+    sh = (rng.normal(size=K) * 0.3).astype(np.float32)
+    if norm:
+        r[:K // 4], sh[:K // 4] = 1.0, 0.0                           # a Branch_0 slice: activations already
+        x[..., :K // 4] = np.maximum(x[..., :K // 4], 0)
+    else:
+        x = np.maximum(x, 0)                                          # a materialised concat / stage pool output
+    xt, rt, st = dev(x), dev(r), dev(sh)
+    w = dev(rng.normal(size=(K, Nc)) * 0.1)
+    pivot = dev(rng.normal(size=Nc) * 0.1)
+    M = N * H * W
+    # the two-launch form
+    pooled = torch.empty(N, H, W, K, device="cuda")
+    am_ref = torch.empty(N, H, W, K, dtype=torch.uint8, device="cuda")
+    if norm:
+        ops.maxpool_bn_relu_fwd(xt, rt, st, pooled, am_ref, N, H, W, K, 3, 1)
+    else:
+        ops.maxpool_fwd(xt, pooled, am_ref, N, H, W, K, 3, 1, "SAME")
+    beta = torch.zeros(Nc, device="cuda")
+
+    def run(fused):
+        plan = ops.LayerPlan(ops.DS_CONV_FWD, ops.DS_ARITH_F32, 0, N, H, W, K, Nc, 1, 1, K, Nc, ops.DS_EPI_STATS)
+        am = torch.full((N, H, W, K), 77, dtype=torch.uint8, device="cuda")
+        if fused:
+            assert plan.enable_pool3(am)
+            if norm:
+                plan.d.norm_rstd, plan.d.norm_shift = rt.data_ptr(), st.data_ptr()
+        z = torch.full((M + 3, Nc), 5.0, device="cuda")             # (three guard rows behind the output)
+        stats = torch.zeros(2 * Nc * plan.partials, device="cuda")
+        plan.run(ops._p(xt if fused else pooled), ops._p(w), ops._p(z), stats=ops._p(stats), pivot=ops._p(pivot))
+        mean, rstd, shift = (torch.empty(Nc, device="cuda") for _ in range(3))
+        ops.bn_finalize(stats, plan.partials, M, Nc, beta, 1e-3, 0.9997, mean, rstd, shift, None, None, pivot=pivot)
+        torch.cuda.synchronize()
+        assert float((z[M:] - 5.0).abs().max()) == 0.0
+        return z[:M], am, mean, rstd
+
+    z0, _, mean0, rstd0 = run(False)
+    z1, am1, mean1, rstd1 = run(True)
+    assert torch.equal(am1, am_ref), "winners differ at %d of %d positions" % (int((am1 != am_ref).sum()), am_ref.numel())
+    if bit:
+        assert torch.equal(z0, z1)
+    y = np.maximum(x * r + sh, 0) if norm else x
+    ref = S.max_pool(y, 3, 1, "SAME").reshape(M, K) @ w.cpu().numpy().astype(np.float64)
+    close(z1, ref)
+    close(z0, ref)
+    assert float((mean0 - mean1).abs().max()) <= 1e-5 * max(1.0, float(mean0.abs().max()))
+    if M >= 64:          # (a single pixel has variance 0: rstd = eps^-1/2 amplifies the last bit of the two groupings)
+        assert float((rstd0 - rstd1).abs().max()) <= 1e-5 * float(rstd0.abs().max())
+    close(mean1, ref.mean(0), 1e-4)
+
+
 @pytest.mark.parametrize("case", [(2, 17, 24), (3, 12, 64), (1, 30, 192)])
 def test_batch_norm_backward_from_the_pooled_gradient(case):
     """ds_bn_pool_bwd_reduce/_apply (BN+ReLU backward of a conv behind a 3x3/2 SAME pool, straight from the pool's

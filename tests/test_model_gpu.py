@@ -524,6 +524,48 @@ def test_zcat_step_is_bit_identical():
         assert torch.equal(a, b) if torch.is_tensor(a) else a == b
 
 
+def test_branch3_pool_on_load_step_follows_the_two_pass_form():
+    """InceptionV1Engine.fuse_branch3 (default): Branch_3 of Mixed_3b .. 5b (inception_v1.py:94-95 ... :227) runs as ONE
+    launch -- the 1x1 conv's loader takes the 3x3 / 1 maximum of the block input as it reads it and records the winners
+    (ds_conv_desc.pool_argmax); Mixed_5c keeps the pool pass (its weight gradient reads the pooled activation).  In the first
+    block, whose input has the same bits either way, the conv output z and the winners are BIT-identical to the two-pass
+    form; the BatchNorm statistics group their partial sums by image rows instead of 128-pixel tiles, so from there on the
+    two steps differ by fp32 summation order: logits within 1e-4, loss 1e-5, every gradient 3e-2 in relative L2 (a 1e-7
+    change of a statistic flips a ReLU / arg-max decision here and there, and the gradients below carry it as sqrt(fraction
+    flipped): measured 1.1e-2 on the stem's beta, the deepest variable -- the fp64 oracle run in fp32 differs from itself by
+    the same amount, profiles/r02_oracle_fp32_spread.txt; the oracle tests hold the fused form itself to 1e-3 along its
+    own decisions)."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    batch = to_device(synthetic_batch_numpy(32, 10, 50, seed=5))
+    res, fused = [], []
+    for on in (True, False):
+        net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10)
+        net.image.fuse_branch3 = on
+        net.image.zcat = False                      # (the concat keeps activations: z of a block's Branch_3 conv stays readable)
+        net.initialize(seed=7)
+        net.predict(batch, is_training=True)
+        torch.cuda.synchronize()
+        b3 = next(st for st in net.image.stages if st.name == "Mixed_3b")
+        z3, am3 = b3.c3.z.clone(), b3.argmax.clone()
+        net.image.B = None
+        net.image.zcat = True
+        net.train_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        fused.append([st.name for st in net.image.stages if getattr(st, "fuse_b3", False)])
+        res.append((z3, am3, net.logits.clone(), net.total_loss_value(), net.grads_state_dict()))
+    assert fused[0] == ["Mixed_3b", "Mixed_3c", "Mixed_4b", "Mixed_4c", "Mixed_4d", "Mixed_4e", "Mixed_4f", "Mixed_5b"] and fused[1] == [], fused
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert float((res[0][2] - res[1][2]).detach().abs().max()) <= 1e-4
+    assert abs(res[0][3] - res[1][3]) <= 1e-5
+    worst = 0.0
+    for name, g in res[1][4].items():
+        rel = np.linalg.norm(res[0][4][name] - g) / max(np.linalg.norm(g), 1e-30)
+        worst = max(worst, rel)
+        assert rel <= 3e-2, (name, rel)
+    print("fuse_branch3 vs two-pass: max|dlogits| %.2e, worst gradient rel L2 %.2e" % (float((res[0][2] - res[1][2]).abs().max()), worst))
+
+
 def test_bn_backward_on_load_step_is_bit_identical():
     """InceptionV1Engine.bnb_on_load = 2: the frozen 1x1 layers -- every block's fused Branch_0/1/2 conv, Branch_3's conv,
     Conv2d_2b -- run no ds_bn_bwd_apply pass; their wide dgrad forms dz = rstd (g - mean g - xhat mean(g xhat)) from z and

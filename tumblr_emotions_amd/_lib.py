@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
         ("tile_nt", C.c_int32), ("grid_x", C.c_int32), ("dtype", C.c_int32), ("x_dtype", C.c_int32),
         ("partials", C.c_int32),
         ("norm_rstd", C.c_void_p), ("norm_shift", C.c_void_p), ("mask_rstd", C.c_void_p), ("mask_shift", C.c_void_p),
-        ("bnb", C.c_void_p), ("mask_dtype", C.c_int32),
+        ("bnb", C.c_void_p), ("mask_dtype", C.c_int32), ("pool_argmax", C.c_void_p),
     ]
 
 
@@ -87,6 +87,7 @@ SIGNATURES = {
     "ds_conv_igemm_bnsums_supported": (C.c_int, [_CD]),
     "ds_conv_igemm_norm_supported": (C.c_int, [_CD]),
     "ds_conv_igemm_bnb_supported": (C.c_int, [_CD]),
+    "ds_conv_igemm_pool3_supported": (C.c_int, [_CD]),
     "ds_conv_igemm": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ds_weights_bf16_bytes": (C.c_size_t, [_i32, _i32, _i32, _i32]),
     "ds_weights_to_bf16": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _P]),
@@ -123,6 +124,7 @@ SIGNATURES = {
     "ds_conv_plan_enable_bnsums": (C.c_int, [_LP, _i32]),
     "ds_conv_plan_norm_supported": (C.c_int, [_LP]),
     "ds_conv_plan_bnb_supported": (C.c_int, [_LP]),
+    "ds_conv_plan_enable_pool3": (C.c_int, [_LP, C.c_void_p]),
     "ds_conv_prepare_weights": (C.c_int, [_LP, _P, _P, _P, _P]),
     "ds_conv_run": (C.c_int, [_LP, _P, _P, _P, _IO, _P]),
     "ds_conv_wgrad_workspace": (C.c_size_t, [_CD]),

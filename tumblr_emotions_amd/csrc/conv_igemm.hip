@@ -54,6 +54,7 @@ struct ConvParams {
     int col_tiles;               // > 0: 1-D XCD-aware launch (see TileId); 0: (row, column) = (blockIdx.x, blockIdx.y)
     int col_total;               // conv_bf16d_kernel: columns of the converted weight tensor (Cout rounded up to 32)
     ds_bn_bwd_on_load bnb;       // gemm_wide_kernel<.., BNB = true>: copy of *d.bnb (the descriptor's pointer is a host pointer)
+    int pool_rpb, pool_bpi;      // gemm_wide_kernel<.., POOL = true>: image rows per 32-pixel block, blocks per image
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *p, unsigned bytes) {
@@ -1122,7 +1123,16 @@ __global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void conv_bf16_kernel(const C
 #ifndef DS_WIDE_A_B2B
 #define DS_WIDE_A_B2B 1
 #endif
-template <int NB, bool BNMAJOR, bool BNB = false>
+// POOL (ds_conv_desc.pool_argmax: an Inception block's Branch_3, MaxPool 3x3/1 SAME -> Conv2d_0b_1x1, as ONE launch): the A
+// fragment of pixel (h, w) becomes the maximum of x over its 3x3 neighbourhood as it is loaded.  A wave's 32-row block holds
+// WHOLE image rows (28 of 32 lanes on the 28 / 14 / 7-wide maps), so that a pixel's left and right neighbours are the
+// neighbouring lanes: lane (pixel, kh) loads its own column -- rows h-1, h, h+1, the same 2 x 4 channels -- takes the column
+// maximum and the first row that holds it, gets its neighbours' column maxima by two DPP wave shifts and keeps the
+// row-major-first winner (kh * 3 + kw: what maxpool3_fwd_rolling records), 3 loads per output instead of 9 and no LDS.
+// With norm_rstd / norm_shift the maximum is taken over the raw z and relu(max * rstd + shift) applied once (rstd > 0), as
+// ds_maxpool_bn_relu_fwd does.  The winners' bytes are the only thing besides z that is written: the pooled tensor
+// (4 B per element out of the pool kernel and 4 B back into this one) never exists.
+template <int NB, bool BNMAJOR, bool BNB = false, bool POOL = false>
 __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const ConvParams p) {
     constexpr int BN = NB * 32, WK = 16;                       // K step: 16 channels = two float4 per lane
     constexpr int DJ = (WK * BN / 4 + 255) / 256;              // 16-byte DMA slots per thread per K step: ceil(NB / 2)
@@ -1138,11 +1148,31 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
     const TileId t0 = tile_id(p);
     const int n0 = t0.col * BN;
     const bool item = t0.row < p.row_tiles;
-    const int m = t0.row * 128 + wave * 32 + li;
     const __amdgpu_buffer_rsrc_t srd_x = make_srd(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t srd_w = make_srd(p.w, p.w_bytes);
     const int K = d.Cin;
-    const unsigned voff = (item && m < p.M) ? ((unsigned)m * (unsigned)d.ldx + 4u * kh) * 4u : kOOB;
+    // this wave's 32-row block: rows mrow0 ... of the output, the first Mw - mrow0 of them real
+    int mrow0 = t0.row * 128 + wave * 32, Mw = p.M;
+    bool hasU = false, hasD = false, hasL = false, hasR = false;      // POOL: which neighbours of the lane's pixel exist
+    int prow = 0;                                                     // POOL: bytes between image rows of x
+    if constexpr (POOL) {
+        const int blk = t0.row * 4 + wave;                           // (uniform)
+        const int n = blk / p.pool_bpi, rb = blk - n * p.pool_bpi;
+        const int r0 = rb * p.pool_rpb;
+        const int rows = (d.H - r0) < p.pool_rpb ? (d.H - r0) : p.pool_rpb;
+        const int cnt = (item && n < d.N) ? rows * d.W : 0;
+        mrow0 = (n * d.H + r0) * d.W;
+        Mw = mrow0 + cnt;
+        const int dr = li / d.W, ow = li - dr * d.W, oh = r0 + dr;
+        const bool ok = li < cnt;
+        hasU = ok && oh > 0;
+        hasD = ok && oh + 1 < d.H;
+        hasL = ok && ow > 0;
+        hasR = ok && ow + 1 < d.W;
+        prow = d.W * d.ldx * 4;
+    }
+    const int m = mrow0 + li;
+    const unsigned voff = (item && m < Mw) ? ((unsigned)m * (unsigned)d.ldx + 4u * kh) * 4u : kOOB;
 
     // B DMA slots.  n-contiguous weights (forward): buffer layout [k][n], slot -> (k = idx / (BN/4), n4 = idx % (BN/4)).
     // k-contiguous weights (dgrad): buffer layout [n][16 k] with the four 16-byte chunks of a row XOR-swizzled by
@@ -1179,8 +1209,51 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
 
+    // POOL: the rows above and below (out-of-range where they do not exist), the winners' bytes, the neighbour exchange
+    const unsigned vup = (POOL && hasU) ? voff - (unsigned)prow : kOOB, vdn = (POOL && hasD) ? voff + (unsigned)prow : kOOB;
+    const __amdgpu_buffer_rsrc_t srd_am = make_srd(POOL ? (const void *)d.pool_argmax : (const void *)p.x,
+                                                   POOL ? (unsigned)((int64_t)p.M * K) : 0u);
+    const unsigned vam = (POOL && item && m < Mw && t0.col == 0) ? (unsigned)m * (unsigned)K + 4u * kh : kOOB;
+    f32x4 ru0, ru1, rd0, rd1;                      // POOL: the same channels of the pixel above / below
+    auto load_ud = [&](int c0) {
+        ru0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vup, c0 * 4, 0));
+        ru1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vup, c0 * 4 + 32, 0));
+        rd0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vdn, c0 * 4, 0));
+        rd1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, vdn, c0 * 4 + 32, 0));
+    };
+    // lane i <- lane i - 1 / lane i + 1 of the wave (DPP wave shifts: one VALU move each, no LDS).  The block starts and ends
+    // at image-row boundaries, so the lanes the shift wraps into (0, 31 | 32, 63) never use what they get.
+    auto from_left = [](float v) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+    };
+    auto from_right = [](float v) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+    };
+    // c <- max over the 3x3 neighbourhood (c = the centre row's values), returns the four winners kh * 3 + kw as bytes:
+    // column maximum and its FIRST row, then among the (up to) three columns that reach the overall maximum the smallest
+    // kh * 3 + kw -- the first maximum in row-major order, maxpool3_fwd_rolling's rule
+    auto pool4 = [&](f32x4 &c, const f32x4 &u, const f32x4 &dn) -> unsigned {
+        unsigned bytes = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float uu = hasU ? u[j] : -INFINITY, dd = hasD ? dn[j] : -INFINITY;
+            const float cm = fmaxf(fmaxf(uu, c[j]), dd);
+            const int t = uu == cm ? 0 : (c[j] == cm ? 3 : 6);
+            const float lraw = from_left(cm), rraw = from_right(cm);
+            const int tl = __builtin_amdgcn_update_dpp(0, t, 0x138, 0xf, 0xf, false);
+            const int tr = __builtin_amdgcn_update_dpp(0, t, 0x130, 0xf, 0xf, false);
+            const float lv = hasL ? lraw : -INFINITY, rv = hasR ? rraw : -INFINITY;
+            const float best = fmaxf(fmaxf(lv, cm), rv);
+            const int il = lv == best ? tl : 99, ic = cm == best ? t + 1 : 99, ir = rv == best ? tr + 2 : 99;
+            const int arg = min(min(il, ic), ir);
+            c[j] = best;
+            bytes |= (unsigned)arg << (8 * j);
+        }
+        return bytes;
+    };
     f32x4 a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, 0, 0));
     f32x4 a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, 32, 0));
+    if constexpr (POOL) load_ud(0);
     // BNB: the gradient dy of the layer's activation, per channel range its own descriptor and row offset
     const ds_bn_bwd_on_load &bb = p.bnb;
     __amdgpu_buffer_rsrc_t srd_dy[3];
@@ -1241,6 +1314,12 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
         for (int j = 0; j < 4; ++j) a[j] = ds::bn_bwd_dz(a[j], dy[j], r[j], sh[j], mu[j], k1[j], k2[j]);
     };
     __syncthreads();
+    auto pool_step = [&](int c0) {          // a0 / a1 hold the centre row of channels c0 ...: pool them, record the winners
+        const unsigned w0 = pool4(a0, ru0, rd0), w1 = pool4(a1, ru1, rd1);
+        __builtin_amdgcn_raw_buffer_store_b32(w0, srd_am, vam, c0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(w1, srd_am, vam, c0 + 8, 0);
+    };
+    if constexpr (POOL) pool_step(0);
     if (norm) {
         apply_norm(a0, 4 * kh);
         apply_norm(a1, 8 + 4 * kh);
@@ -1279,6 +1358,7 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
                 if (b == ((NB > 1 && !DS_WIDE_A_B2B) ? 1 : 0)) {
                     n1v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, cn * 4 + 32, 0));
                     if (BNB) d1 = load_dy(cn, 1);
+                    if constexpr (POOL) load_ud(cn);      // (the previous step's rows were consumed before this K step began)
                 }
                 if (b < DJ) dma_b((ks + 1) & 1, cn, b);
             }
@@ -1295,6 +1375,9 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
         }
         a0 = n0v;
         a1 = n1v;
+        if constexpr (POOL) {
+            if (more) pool_step(cn);
+        }
         if (norm && more) {
             apply_norm(a0, cn + 4 * kh);
             apply_norm(a1, cn + 8 + 4 * kh);
@@ -1312,11 +1395,13 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
     // block cost a memory round trip (a load behind a store waits for it: one in-order counter).
     const int flags = d.flags;
     float *red = smem + 2 * BSZ;
-    const int mrow0 = t0.row * 128 + wave * 32;
     // (outputs of 2 GiB and more stay on the LDS-tile kernels: wide_nb)
-    const __amdgpu_buffer_rsrc_t srd_z = make_srd(p.z, (unsigned)(((int64_t)(p.M - 1) * d.ldz + d.Cout) * 4));
+    // POOL: the descriptors end with this wave's last real row (Mw, wave-uniform), so the rows a 28-pixel block leaves
+    // unused -- they would alias the NEXT block's pixels -- are dropped by the same range check as the rows past M
+    const bool any_row = Mw > mrow0;          // (uniform; POOL: a surplus wave past the last image has none)
+    const __amdgpu_buffer_rsrc_t srd_z = make_srd(p.z, any_row ? (unsigned)(((int64_t)(Mw - 1) * d.ldz + d.Cout) * 4) : 0u);
     const __amdgpu_buffer_rsrc_t srd_m = make_srd((flags & DS_EPI_BNSUMS) ? p.mask : p.z,
-                                                  (flags & DS_EPI_BNSUMS) ? (unsigned)(((int64_t)(p.M - 1) * d.ldmask + d.Cout) * 4) : 0u);
+                                                  ((flags & DS_EPI_BNSUMS) && any_row) ? (unsigned)(((int64_t)(Mw - 1) * d.ldmask + d.Cout) * 4) : 0u);
     const int rz = d.ldz * 4, rm = d.ldmask * 4;                 // bytes per row
     const int rbase = mrow0 + 4 * kh;                            // this lane's first row; accumulator element r: + (r & 3) + 8 (r >> 2)
     // z (and the accumulate / activation reads at the same rows and columns) through buffer descriptors: ONE 32-bit lane
@@ -1360,7 +1445,7 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    yv[r] = row < p.M ? fmaxf(fmaf(yv[r], mr, ms), 0.f) : 0.f;      // (rows past M read 0, which a shift > 0 would turn on)
+                    yv[r] = row < Mw ? fmaxf(fmaf(yv[r], mr, ms), 0.f) : 0.f;      // (rows past M read 0, which a shift > 0 would turn on)
                 }
             }
 #pragma unroll
@@ -1373,7 +1458,7 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < p.M && colok) {
+                if (row < Mw && colok) {
                     const float u = acc[b][r] - pv;
                     s += u;
                     q += u * u;
@@ -1849,6 +1934,15 @@ KernelFn bf16_kernel(int nt, Variant v) {
 }
 
 void launch_wide(int nb, bool bnmajor, bool bnb, dim3 grid, hipStream_t st, const ConvParams &p) {
+    if (p.d.pool_argmax) {          // (pool3_nb: forward, one column tile of at most four blocks)
+        switch (nb) {
+            case 1: hipLaunchKernelGGL((gemm_wide_kernel<1, true, false, true>), grid, dim3(256), 0, st, p); break;
+            case 2: hipLaunchKernelGGL((gemm_wide_kernel<2, true, false, true>), grid, dim3(256), 0, st, p); break;
+            case 3: hipLaunchKernelGGL((gemm_wide_kernel<3, true, false, true>), grid, dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL((gemm_wide_kernel<4, true, false, true>), grid, dim3(256), 0, st, p); break;
+        }
+        return;
+    }
     if (bnb) {          // (wide_nb: at most two column blocks per wave with ds_conv_desc.bnb)
         if (nb == 1) hipLaunchKernelGGL((gemm_wide_kernel<1, false, true>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemm_wide_kernel<2, false, true>), grid, dim3(256), 0, st, p);
@@ -1876,7 +1970,29 @@ void launch_wide(int nb, bool bnmajor, bool bnb, dim3 grid, hipStream_t st, cons
 // Column blocks per wave of the wide 1x1 kernel for `d`, or 0 when the layer stays on the LDS-tile kernels:
 // plain 1x1 stride-1 GEMM shape, flags within {STATS}, vector-aligned, no split-K, enough workgroups to fill the chip.
 int force_wide = -1;
-int wide_nb(const ds_conv_desc *d, bool vec) {
+
+// MaxPool 3x3/1 on load (ds_conv_desc.pool_argmax): forward 1x1 conv with n-contiguous weights on a map at most 32 wide
+// (a wave's 32-row block holds whole image rows), whole 16-channel K steps, ONE column tile of at most four blocks (the
+// pooling is the loader's work and would be redone per column tile).  Returns the column blocks per wave, 0 = unsupported.
+int pool3_nb(const ds_conv_desc *d, bool vec) {
+    if (!vec || d->dtype != DS_DTYPE_F32) return 0;
+    if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->fold_cin || d->splits > 1 || d->bnb) return 0;
+    if (d->flags & ~DS_EPI_STATS) return 0;
+    if (!(d->w_n_stride == 1 && d->w_k_stride != 1)) return 0;
+    if (d->W > 32 || d->Cin % 16 != 0 || d->Cin < 32 || d->Cin > 1024 || d->Cout > 128) return 0;
+    const int64_t M = conv_M(d);
+    if (((M - 1) * d->ldz + d->Cout) * 4 >= (1ll << 31) || M * d->Cin >= (1ll << 31)) return 0;
+    return (d->Cout + 31) / 32;
+}
+
+// POOL: image rows per 32-pixel block and blocks per image
+void pool3_blocks(const ds_conv_desc *d, int *rpb, int *bpi) {
+    *rpb = 32 / d->W;
+    *bpi = (d->H + *rpb - 1) / *rpb;
+}
+
+int wide_nb(const ds_conv_desc *d, bool vec, bool bnb_cap = false) {
+    if (d->pool_argmax) return pool3_nb(d, vec);
     if (force_wide < 0) {
         const char *e = getenv("DS_CONV_WIDE");          // A/B aid: 0 = never
         force_wide = e ? atoi(e) : 1;
@@ -1903,7 +2019,7 @@ int wide_nb(const ds_conv_desc *d, bool vec) {
     const int64_t row_tiles = (M + 127) / 128;
     // (BatchNorm backward on load is kept for narrow dgrads only -- it wins on Conv2d_2b and nowhere else,
     // profiles/r04_bnb_layers.txt -- so its loader is instantiated for one and two column blocks per wave)
-    const int nb_max = d->bnb ? 2 : 8;
+    const int nb_max = (d->bnb || bnb_cap) ? 2 : 8;      // (bnb_cap: ds_conv_igemm_bnb_supported asks before bnb is attached)
     for (int nb = nb_max; nb >= (N <= 32 ? 1 : 2); --nb) {      // one block per wave only where two would be half padding
         const int tiles = (N + 32 * nb - 1) / (32 * nb);
         const int64_t rounds = (row_tiles * tiles + ds::kCUs - 1) / ds::kCUs;
@@ -2035,6 +2151,11 @@ void grid_for(const ds_conv_desc *d, TileCfg c, Variant v, int *gx, int *gy, int
     const int64_t M = conv_M(d);
     const int bm = (c.direct ? 32 : 128) * (c.glds ? 1 : c.mt), bn = 32 * c.nt;
     *row_tiles = (int)((M + bm - 1) / bm);
+    if (c.wide && d->pool_argmax) {          // 32-row blocks of whole image rows, four per workgroup
+        int rpb, bpi;
+        pool3_blocks(d, &rpb, &bpi);
+        *row_tiles = (int)(((int64_t)d->N * bpi + 3) / 4);
+    }
     *gy = (d->Cout + bn - 1) / bn;
     const int wg_tiles = c.direct ? (*row_tiles + 3) / 4 : *row_tiles;     // row tiles in units of workgroups
     int x;
@@ -2108,10 +2229,16 @@ extern "C" int ds_conv_igemm_norm_supported(const ds_conv_desc *d) {
     return wide_nb(d, dims_vec(d)) > 0 ? 1 : 0;
 }
 
+extern "C" int ds_conv_igemm_pool3_supported(const ds_conv_desc *d) {
+    // the 3x3 / 1 max pool on load lives in the wide 1x1 kernel's loader (forward instantiation)
+    if (!d) return 0;
+    return pool3_nb(d, dims_vec(d)) > 0 ? 1 : 0;
+}
+
 extern "C" int ds_conv_igemm_bnb_supported(const ds_conv_desc *d) {
     // BatchNorm backward on load lives in the wide 1x1 kernel's loader, k-contiguous-weights (dgrad) instantiation
     if (!d || d->Cin > 1024 || (d->w_n_stride == 1 && d->w_k_stride != 1) || d->norm_rstd) return 0;
-    return wide_nb(d, dims_vec(d)) > 0 ? 1 : 0;
+    return wide_nb(d, dims_vec(d), true) > 0 ? 1 : 0;      // with the launch's own cap of two column blocks per wave
 }
 
 extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float *w, float *z, const float *bias,
@@ -2200,6 +2327,13 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
                        "ds_conv_igemm: bnb channel range %d (16-byte aligned dy, ld %% 4 == 0, boundaries %% 16 == 0)", i);
         }
         p.bnb = b;
+    }
+    p.pool_rpb = p.pool_bpi = 0;
+    if (d->pool_argmax) {
+        DS_REQUIRE(c.wide && v.bnmajor && pool3_nb(d, v.vec) == c.wide && !d->bnb,
+                   "ds_conv_igemm: ds_conv_desc.pool_argmax is implemented by the wide 1x1 kernel's forward instantiation only "
+                   "(ds_conv_igemm_pool3_supported)");
+        pool3_blocks(d, &p.pool_rpb, &p.pool_bpi);
     }
     if (c.wide) launch_wide(c.wide, v.bnmajor, d->bnb != nullptr, grid, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(kernel_for(c, v), grid, dim3(256), 0, (hipStream_t)stream, p);

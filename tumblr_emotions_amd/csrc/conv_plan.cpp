@@ -220,6 +220,18 @@ extern "C" int ds_conv_plan_bnb_supported(const ds_conv_layer_plan *p) {
     return ds_conv_igemm_bnb_supported(&t);
 }
 
+extern "C" int ds_conv_plan_enable_pool3(ds_conv_layer_plan *p, uint8_t *argmax) {
+    if (p == nullptr || argmax == nullptr || p->role != DS_CONV_FWD || p->family != DS_FAM_IGEMM || p->k != 1) return 0;
+    ds_conv_desc t = p->d;
+    t.partials = 0;
+    if (!ds_conv_igemm_pool3_supported(&t)) return 0;
+    p->d.pool_argmax = argmax;
+    p->d.partials = 0;
+    p->partials = plan_partials(p);
+    p->d.partials = p->partials;
+    return 1;
+}
+
 extern "C" int ds_conv_prepare_weights(const ds_conv_layer_plan *p, const float *w_hwio, void *w_prepared, float *wscale,
                                        void *stream) {
     PLAN_REQUIRE(p != nullptr, "ds_conv_prepare_weights: null plan");

@@ -25,6 +25,20 @@
 // w are rounded to bf16 (RNE) as they are packed; the filter lives in LDS as [mfma][kh][co][8 k] bf16 (22.5 KB), a B fragment
 // is one ds_read_b128.  The generic path it replaces in those configurations was a zero-padded 4-channel copy of the batch
 // (96 us) + the LDS-staged bf16 kernel (578 us).
+//
+// POOL (ds_conv_stem_pool, round 6): Conv2d_1a_7x7 -> [BatchNorm -> ReLU ->] MaxPool_2a_3x3 (inception_v1.py:63-67) with the
+// 3x3 / 2 max pool INSIDE the conv kernel.  The pool commutes with relu(rstd * . + shift) (rstd > 0), and the frozen stem's
+// backward pass needs only pooled tensors (ConvBN._bn_bwd_sums), so the full-resolution conv output -- 822 MB at B = 256,
+// written here and read back by the pool pass -- never has to exist: the kernel writes max(z) over every window (a quarter
+// of the elements) and the statistics of the FULL map.  A workgroup owns a contiguous range of conv ROW PAIRS (rows 2 i,
+// 2 i + 1 = pooled row i minus its third row) of the batch, walks it in 256-pixel tiles as before, and folds every
+// accumulator into a ring of pooled rows in LDS with ds_max_f32 (a conv pixel lies in up to 2 x 2 windows); a pooled row
+// is complete once conv row 2 i + 2 has passed -- written out with 16-byte stores and reset -- so three ring slots cover a
+// 256-pixel tile of the 112-wide map.  The one conv row behind the range that the last pooled row still needs (it belongs
+// to the next workgroup's first pair) is computed here too (1 row in 57: +1.8 % of the matrix work, no exchange between
+// workgroups) and left out of the statistics.  LDS: the filter without its zero rows (37.6 KB) + the ring (43 KB) = 80.6 KB,
+// two workgroups per CU as before.
+#include <math.h>
 #include "ds_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -49,15 +63,27 @@ struct StemParams {
     int N, H, W, OH, OW, pad_t, pad_l, cin_store, ldz;
     int M, tiles;        // output pixels, 256-pixel tiles
     unsigned x_bytes;
+    int PH, PW, rp_total, nslots;      // POOL: pooled map, row pairs of the batch (N * PH), ring slots (pooled rows) in LDS
 };
 
-template <bool BF>
+constexpr int kRingFloats = 3 * 56 * CO;      // POOL: three pooled rows of the 112-wide map (more rows of narrower ones)
+
+// *p = max(*p, v) in LDS (ds_max_f32, no return value)
+__device__ __forceinline__ void ds_fmax(float *p, float v) {
+    __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <bool BF, bool POOL = false>
 __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemParams p) {
     // row blocks of 32 output pixels per wave: two on the fp32 matrix cores (every B fragment feeds two MFMAs); ONE for BF,
     // which is bound by the image reads and the stores: three waves per SIMD, no spills
     constexpr int NA = BF ? 1 : 2, TP = 128 * NA;
-    __shared__ __attribute__((aligned(16))) float wl[BF ? 11 * 2 * CO * 8 / 2 : 7 * 4 * 3 * 2 * CO];          // [dh][j][c][kh][co]; BF: [mfma][kh][co][8] bf16
-    __shared__ float red[4 * CO * 2];
+    static_assert(!(BF && POOL), "the pooled stem is built for the fp32 kernel");
+    // [dh][j][c][kh][co]; POOL: without the zero rows of pixel 7 ([dh][21 (j, c, kh)][co]); BF: [mfma][kh][co][8] bf16
+    constexpr int WROW = POOL ? 21 * CO : 4 * 3 * 2 * CO;
+    __shared__ __attribute__((aligned(16))) float wl[BF ? 11 * 2 * CO * 8 / 2 : 7 * WROW];
+    __shared__ __attribute__((aligned(16))) float ring_s[POOL ? kRingFloats : 4 * CO * 2];
+    float *const red = ring_s;                 // (POOL: the statistics combine reuses the ring after its last row has left)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
@@ -83,7 +109,19 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
             wv[t] = px < 7 ? p.w[((dh * 7 + px) * p.cin_store + c) * CO + co] : 0.f;
         }
 #pragma unroll
-        for (int t = 0; t < WN; ++t) wl[t * 256 + tid] = wv[t];
+        for (int t = 0; t < WN; ++t) {
+            if constexpr (POOL) {      // the (j = 3, kh = 1) rows are not kept: their A operand is an out-of-range load = 0
+                const int i = t * 256 + tid;
+                const int co = i & 63, k2 = (i >> 6) & 1, c = (i >> 7) % 3, j = ((i >> 7) / 3) & 3, dh = (i >> 7) / 12;
+                if (j < 3) wl[dh * WROW + ((j * 3 + c) * 2 + k2) * CO + co] = wv[t];
+                else if (k2 == 0) wl[dh * WROW + (18 + c) * CO + co] = wv[t];
+            } else {
+                wl[t * 256 + tid] = wv[t];
+            }
+        }
+    }
+    if constexpr (POOL) {
+        for (int i = tid; i < kRingFloats; i += 256) ring_s[i] = -INFINITY;
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
@@ -94,11 +132,13 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
 
     // the lane's two output pixels (row blocks a = 0, 1) of a tile, and the byte offsets of a kernel row's four pixels
     struct Pix { int ih0[NA], iw0[NA], nb[NA]; bool rv[NA]; };
+    int mlim = p.M;                    // POOL: the end of this workgroup's pixel range (set below)
+    int mbase = 0;                     // POOL: its first pixel; tile t starts at mbase + t * TP
     auto coords = [&](int tile, Pix &c) {
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            const int m = tile * TP + wave * (32 * NA) + a * 32 + li;
-            c.rv[a] = m < p.M;
+            const int m = mbase + tile * TP + wave * (32 * NA) + a * 32 + li;
+            c.rv[a] = m < mlim;
             const int mm = c.rv[a] ? m : 0;
             const int n = mm / ohw, r = mm - n * ohw;
             const int oh = r / p.OW, ow = r - oh * p.OW;
@@ -140,6 +180,76 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
                     const float u0 = v0 - pv0, u1 = v1 - pv1;
                     s0 += u0; q0 += u0 * u0;
                     s1 += u1; q1 += u1 * u1;
+                }
+            }
+        }
+    };
+
+    // ---- POOL: this workgroup's row pairs, the ring, the pooled epilogue ------------------------------------------------
+    int rp0 = 0, rp1 = 0, qf = 0, ntiles = 0, stat_end = 0;
+    if constexpr (POOL) {
+        rp0 = (int)((int64_t)blockIdx.x * p.rp_total / gridDim.x);
+        rp1 = (int)((int64_t)(blockIdx.x + 1) * p.rp_total / gridDim.x);
+        mbase = rp0 * 2 * p.OW;
+        stat_end = rp1 * 2 * p.OW;
+        mlim = stat_end + ((rp1 % p.PH) != 0 ? p.OW : 0);          // + conv row 2 rp1, the last pooled row's third row
+        ntiles = (mlim - mbase + TP - 1) / TP;
+        qf = rp0;
+    }
+    // pooled row q (row pair index over the batch) lives in ring slot q % nslots; out: [N * PH][PW][64] = max of z
+    auto flush_row = [&](int q) {
+        float *slot = ring_s + (q % p.nslots) * (p.PW * CO);
+        float *dst = p.z + (int64_t)q * p.PW * p.ldz;
+        const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int i = tid; i < p.PW * (CO / 4); i += 256) {
+            const int j = i >> 4, c4 = (i & 15) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(slot + j * CO + c4);
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst + (int64_t)j * p.ldz + c4));
+            *reinterpret_cast<f32x4 *>(slot + j * CO + c4) = ninf;
+        }
+    };
+    // accumulators -> statistics (pixels of the own row pairs only) and the ring: conv pixel (row R of the batch, column c)
+    // lies in the windows of pooled rows R / 2 and -- R even, not the first row of its image -- R / 2 - 1, pooled columns
+    // c / 2 and -- c even, c > 0 -- c / 2 - 1
+    auto pool_epilogue = [&](int tile, const f32x16 (&acc)[NA][2]) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int mb = mbase + tile * TP + wave * (32 * NA) + a * 32 + 4 * kh;      // this lane's first pixel of the block
+            const int Rb = mb / p.OW, cb = mb - Rb * p.OW;
+            const int qb = Rb >> 1;
+            // (the lane's sixteen pixels span at most three conv rows = pooled rows qb, qb + 1: OW >= 16)
+            const int sl0 = qb % p.nslots, sl1 = (sl0 + 1 == p.nslots) ? 0 : sl0 + 1, slm = (sl0 == 0) ? p.nslots - 1 : sl0 - 1;
+            const bool top0 = (qb % p.PH) == 0, top1 = ((qb + 1) % p.PH) == 0;          // first row pair of an image
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int dl = (e & 3) + 8 * (e >> 2);
+                const int m = mb + dl;
+                int c = cb + dl, R = Rb;
+                if (c >= p.OW) { c -= p.OW; ++R; }
+                if (c >= p.OW) { c -= p.OW; ++R; }
+                const float v0 = acc[a][0][e], v1 = acc[a][1][e];
+                if (m < stat_end) {
+                    const float u0 = v0 - pv0, u1 = v1 - pv1;          // (the arithmetic of `epilogue`, to the bit)
+                    s0 += u0; q0 += u0 * u0;
+                    s1 += u1; q1 += u1 * u1;
+                }
+                if (m < mlim) {
+                    const int q = R >> 1;
+                    const bool second = q != qb;                         // pooled row qb + 1
+                    const int sq = second ? sl1 : sl0, sp = second ? sl0 : slm;      // slots of rows q and q - 1
+                    const bool own = q < rp1;                            // (the extension row only feeds row q - 1)
+                    const bool up = !(R & 1) && !(second ? top1 : top0) && q > rp0;
+                    const int j = c >> 1;
+                    const bool left = !(c & 1) && c > 0;
+                    float *r0 = ring_s + (sq * p.PW + j) * CO + li, *r1 = ring_s + (sp * p.PW + j) * CO + li;
+                    if (own) {
+                        ds_fmax(r0, v0); ds_fmax(r0 + 32, v1);
+                        if (left) { ds_fmax(r0 - CO, v0); ds_fmax(r0 - CO + 32, v1); }
+                    }
+                    if (up) {
+                        ds_fmax(r1, v0); ds_fmax(r1 + 32, v1);
+                        if (left) { ds_fmax(r1 - CO, v0); ds_fmax(r1 - CO + 32, v1); }
+                    }
                 }
             }
         }
@@ -259,11 +369,17 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
         // group of four MFMAs waited for its own ds_read (one MFMA of cover for ~100 cycles of LDS latency)
         float bw[2][12][2];
         auto read_b = [&](int dh, float (&dst)[12][2]) {
-            const float *wr = wl + dh * (4 * 3 * 2 * CO) + kh * CO + li;
+            const float *wr = wl + dh * WROW + kh * CO + li;
+            const float *w3 = wl + dh * WROW + li;          // POOL, j = 3: the kh = 0 rows for both halves (kh = 1: A = 0)
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
-                dst[k][0] = wr[k * 2 * CO];
-                dst[k][1] = wr[k * 2 * CO + 32];
+                if (POOL && k >= 9) {
+                    dst[k][0] = w3[(9 + k) * CO];
+                    dst[k][1] = w3[(9 + k) * CO + 32];
+                } else {
+                    dst[k][0] = wr[k * 2 * CO];
+                    dst[k][1] = wr[k * 2 * CO + 32];
+                }
             }
         };
         // One tile (kernel row dh in buf[dh & 1]).  Requesting the NEXT tile's first row behind this tile's last one -- in front of
@@ -300,7 +416,9 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if ((tile + 1) * TP <= p.M) {          // (uniform) every row of the tile exists
+            if constexpr (POOL) {
+                pool_epilogue(tile, acc);
+            } else if ((tile + 1) * TP <= p.M) {          // (uniform) every row of the tile exists
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const unsigned vz = (unsigned)((tile * TP + wave * 64 + a * 32 + 4 * kh) * p.ldz + li) * 4u;
@@ -319,12 +437,31 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
                 epilogue(tile, acc);
             }
         };
-        for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
-            Pix cA;
-            Cols oA;
-            setup(tile, cA, oA);
-            issue(cA, oA, 0, buf[0]);
-            run_tile(tile, cA, oA);
+        if constexpr (POOL) {
+            for (int tile = 0; tile < ntiles; ++tile) {
+                Pix cA;
+                Cols oA;
+                setup(tile, cA, oA);
+                issue(cA, oA, 0, buf[0]);
+                run_tile(tile, cA, oA);
+                __syncthreads();                              // the tile's maxima are in the ring
+                const int done = min(mbase + (tile + 1) * TP, mlim);
+                while (qf < rp1) {                            // (uniform) pooled rows whose last conv row has passed
+                    const int last = (qf % p.PH == p.PH - 1) ? 2 : 3;
+                    if ((2 * qf + last) * p.OW > done) break;
+                    flush_row(qf);
+                    ++qf;
+                }
+                __syncthreads();
+            }
+        } else {
+            for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+                Pix cA;
+                Cols oA;
+                setup(tile, cA, oA);
+                issue(cA, oA, 0, buf[0]);
+                run_tile(tile, cA, oA);
+            }
         }
     }
     if (p.stats) {

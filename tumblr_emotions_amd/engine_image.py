@@ -564,9 +564,17 @@ class MixedStage(Stage):
         self.r2 = torch.empty(M, b2a, device=dev, dtype=a16(r16))
         self.dr1 = torch.empty(M, b1a, device=dev)
         self.dr2 = torch.empty(M, b2a, device=dev)
-        self.pooled = torch.empty(M, cin, device=dev, dtype=self.prev.out.dtype)       # a pool copies values
         self.dpooled = torch.empty(M, cin, device=dev)
         self.argmax = torch.empty(M, cin, dtype=torch.uint8, device=dev)
+        # Branch_3 = MaxPool_0a_3x3 -> Conv2d_0b_1x1 (inception_v1.py:94-95 ... :246-247) as ONE launch: the 1x1 conv's loader
+        # takes the 3x3 maximum of the block input as it reads it (ds_conv_desc.pool_argmax) and records the winners; the
+        # pooled tensor is never written.  Frozen fp32 layers only (a weight gradient reads the pooled activation: Mixed_5c
+        # keeps the pool pass)
+        self.fuse_b3 = bool(eng.fuse_branch3 and not self.c3.trainable and eng.dtype == "f32" and not eng.act16
+                            and self.c3.fwd.enable_pool3(self.argmax))
+        if self.fuse_b3:
+            eng.need_stats(self.c3.fwd.partials * 2 * b3)          # (the fused launch groups its partial sums by image rows)
+        self.pooled = None if self.fuse_b3 else torch.empty(M, cin, device=dev, dtype=self.prev.out.dtype)       # a pool copies values
         o, do = self.out.data_ptr(), self.dout.data_ptr()
         off1, off2, off3 = b0, b0 + b1b, b0 + b1b + b2b
         nf = b0 + b1a + b2a
@@ -601,6 +609,9 @@ class MixedStage(Stage):
         if getattr(self.prev, "zcat", False):    # this block reads a zcat concat
             self.fused.fwd.d.norm_rstd = self.prev.rs_cat[0].data_ptr()
             self.fused.fwd.d.norm_shift = self.prev.rs_cat[1].data_ptr()
+            if self.fuse_b3:                     # ... and so does the pooling loader of its Branch_3 conv
+                self.c3.fwd.d.norm_rstd = self.prev.rs_cat[0].data_ptr()
+                self.c3.fwd.d.norm_shift = self.prev.rs_cat[1].data_ptr()
         self.fused.make_dgrad(cin)
         self.c1.make_dgrad(b1a)
         self.c2.make_dgrad(b2a)
@@ -663,6 +674,8 @@ class MixedStage(Stage):
     def _pool_fwd(self):
         """Branch_3's 3x3/1 max pool of the block input (normalising on load when that is a zcat concat)."""
         p = self.prev
+        if self.fuse_b3:                 # formed on load by the Branch_3 conv (alloc)
+            return
         if getattr(p, "zcat", False):
             ops.maxpool_bn_relu_fwd(p.out, p.rs_cat[0], p.rs_cat[1], self.pooled, self.argmax, self.B, p.H, p.W, p.C, 3, 1)
         else:
@@ -680,7 +693,7 @@ class MixedStage(Stage):
             self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_, a1_)
             self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_, a2_)
             self._pool_fwd()
-            self.c3.forward(ops._p(self.pooled), p.C, self.seg_3, dx_, ax_)
+            self.c3.forward(x if self.fuse_b3 else ops._p(self.pooled), p.C, self.seg_3, dx_, ax_)
             return
         main = torch.cuda.current_stream()
         s1, s2 = eng.side
@@ -691,7 +704,7 @@ class MixedStage(Stage):
         with torch.cuda.stream(s2):
             s2.wait_event(e_in)
             self._pool_fwd()
-            self.c3.forward(ops._p(self.pooled), p.C, self.seg_3, dx_, ax_)
+            self.c3.forward(x if self.fuse_b3 else ops._p(self.pooled), p.C, self.seg_3, dx_, ax_)
             if not eng.one_side_stream:
                 e_3.record(s2)
         self.fused.forward(x, p.C, self.seg_f, dx_, ax_)
@@ -725,7 +738,7 @@ class MixedStage(Stage):
         self.fused.dgrad.d.flags = (ops.DS_EPI_ACCUM if pool_first else 0) | keep
 
         def branch3():
-            self.c3.backward(ops._p(self.pooled), p.C, ops._p(self.dpooled), need_dx)
+            self.c3.backward(None if self.fuse_b3 else ops._p(self.pooled), p.C, ops._p(self.dpooled), need_dx)      # (x: weight gradient only)
             if pool_first:
                 ops.maxpool_bwd(self.dpooled, self.argmax, p.dout, False, self.B, p.H, p.W, p.C, 3, 1, "SAME")
 
@@ -825,6 +838,7 @@ class InceptionV1Engine:
         self.mul3 = os.environ.get("DS_MUL3", "0") == "1"     # opt-in: forward 1x1 convs with fp32 products on the bf16 matrix cores
         self.bnb_on_load = int(os.environ.get("DS_BNB", "1"))      # BatchNorm backward formed by the 1x1 dgrad's loader: see ConvBN.make_dgrad
         self.zcat = os.environ.get("DS_ZCAT", "1") != "0"     # 3x3 / Branch_3 convs write z into the concat, consumers normalise on load
+        self.fuse_branch3 = os.environ.get("DS_FUSE_B3", "1") != "0"      # Branch_3's 3x3/1 max pool formed on load by its 1x1 conv (MixedStage.alloc)
         self.winograd4 = os.environ.get("DS_WINO4", "1") != "0"      # ... and ds_conv_wino4 (F(4x4,3x3)) where it is faster
         self.weights_version = 0     # bumped by SentimentNet.after_load(): frozen layers redo their G g G^T
         self._stats_n = self._bwdp_n = self._ws_bytes = 0

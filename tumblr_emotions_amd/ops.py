@@ -279,6 +279,15 @@ class LayerPlan:
     def norm_supported(self):
         return bool(_lib.load().ds_conv_plan_norm_supported(self._ref))
 
+    def enable_pool3(self, argmax):
+        """Forward 1x1 conv behind a 3x3 / 1 SAME max pool (an Inception block's Branch_3): the pool is formed ON LOAD
+        (ds_conv_desc.pool_argmax) -- `argmax` [N*H*W, Cin] uint8 receives the winners ds_maxpool_fwd would record and x is
+        the pool's INPUT.  Returns False when the chosen kernel cannot (the caller keeps the separate pool pass)."""
+        if not _lib.load().ds_conv_plan_enable_pool3(self._ref, _p(argmax)):
+            return False
+        self.pool_argmax = argmax            # (kept alive: the descriptor holds its address)
+        return True
+
     def enable_bn_backward_on_load(self, mean, rstd, shift, coef, parts):
         """Conv2DBackpropInput of a 1x1 conv + BatchNorm + ReLU layer straight from z and the activation gradient: the
         layer's ds_bn_bwd_apply pass is formed on load (ds_conv_desc.bnb).  parts: [(c0, c1, address, ld)] of dy.
