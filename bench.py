@@ -304,6 +304,9 @@ def main():
     ap.add_argument("--no-fuse-b3", action="store_true",
                     help="A/B aid: Branch_3's 3x3/1 max pool as its own pass in front of the 1x1 conv (default: formed on load "
                          "by the conv, ds_conv_desc.pool_argmax)")
+    ap.add_argument("--no-stem-pool", action="store_true",
+                    help="A/B aid: Conv2d_1a_7x7 writes its full-resolution output and MaxPool_2a runs as its own pass (default: "
+                         "the pool inside the stem kernel, ds_conv_stem_pool)")
     ap.add_argument("--no-wino4", action="store_true",
                     help="A/B aid: F(2x2,3x3) also on the 56 x 56 / 28 x 28 maps instead of the F(4x4,3x3) kernel")
     ap.add_argument("--graph", action="store_true",
@@ -389,6 +392,8 @@ def main():
         net.image.zcat = False
     if args.no_fuse_b3 and net.image is not None:
         net.image.fuse_branch3 = False
+    if args.no_stem_pool and net.image is not None:
+        net.image.stem_pool = False
     if args.mul3 and net.image is not None:
         net.image.mul3 = True
     if args.no_branch_streams and net.image is not None:

@@ -229,6 +229,17 @@ int ds_conv_fp8(const ds_conv_desc *d, const void *x, const float *x_amax, int32
 int ds_conv_stem_partials(int32_t N, int32_t OH, int32_t OW);
 int ds_conv_stem(const float *x, const float *w, float *z, float *stats, const float *pivot, int32_t N, int32_t H,
                  int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream);
+/* Conv2d_1a_7x7 -> [BatchNorm -> ReLU ->] MaxPool_2a_3x3 (inception_v1.py:63-67) in ONE launch: the 3x3 / 2 SAME max pool is
+ * taken inside the conv kernel (it commutes with relu(rstd * . + shift), rstd > 0), so the full-resolution conv output is
+ * never written: zmax [N, OH/2, OW/2, 64] (pixel stride ldz, 16-byte aligned) = the window maxima of z; stats = the column
+ * sums of the FULL conv map about `pivot`, float[2][64][ds_conv_stem_pool_partials(N, OH, OW)].  The pooled activation is
+ * relu(rstd * zmax + shift); BatchNorm's backward sums of a frozen stem follow from zmax and the pooled gradient alone.
+ * zmax holds exactly the maxima of ds_conv_stem's z (same MFMA sequence); the statistics group other pixels per partial.
+ * Conv maps with even sizes and 16 .. 112 columns (ds_conv_stem_pool_supported(H, W) of the INPUT size).               */
+int ds_conv_stem_pool_supported(int32_t H, int32_t W);
+int ds_conv_stem_pool_partials(int32_t N, int32_t OH, int32_t OW);
+int ds_conv_stem_pool(const float *x, const float *w, float *zmax, float *stats, const float *pivot, int32_t N, int32_t H,
+                      int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream);
 /* ds_conv_stem for the 16-bit configurations: x and w rounded to bf16 (RNE) as they are packed, v_mfma_f32_32x32x16_bf16 with fp32
  * accumulation (two kernel rows per three MFMAs: 11 instead of 84 per accumulator); same arguments and layout; stats as
  * float[2][64][ds_conv_stem_bf16_partials(N, OH, OW)]. */
@@ -321,6 +332,7 @@ int ds_conv_wino4_bf16x2(const float *x, const void *u2, float *z, float *stats,
 #define DS_FAM_FP8D 5
 #define DS_FAM_F32X3 6
 #define DS_FAM_WINO4H 7        /* ds_conv_wino4_bf16x2: F(4x4, 3x3) of the bf16-rounded operands on the bf16 matrix cores */
+#define DS_FAM_STEM_POOL 8     /* ds_conv_stem_pool: the stem with MaxPool_2a inside (z of ds_conv_run = the pooled maxima)  */
 #define DS_PLAN_NO_WINO 1u          /* A/B: implicit GEMM for every 3x3 layer                                           */
 #define DS_PLAN_NO_WINO4 2u         /* A/B: F(2x2) wherever Winograd applies                                            */
 #define DS_PLAN_NO_STEM_DIRECT 4u   /* A/B: the stem through the generic kernel on a 4-channel copy of the batch        */
@@ -329,6 +341,7 @@ int ds_conv_wino4_bf16x2(const float *x, const void *u2, float *z, float *stats,
 #define DS_PLAN_FP8_EVERYWHERE 64u  /* A/B: ds_conv_fp8 wherever it applies (default: only where it beats the bf16 kernels) */
 #define DS_PLAN_FP8_WIDE_RULE 128u  /* A/B: fp8 for every 1x1 / 3x3 layer with >= 64 reduction channels into >= 96 columns  */
 #define DS_PLAN_NO_WINO4H 256u      /* A/B: the 16-bit configurations' 3x3 input gradients on the direct bf16 kernels only  */
+#define DS_PLAN_STEM_POOL 512u      /* with DS_PLAN_PACKED_RGB: MaxPool_2a_3x3 inside the stem kernel where the map allows  */
 #define DS_PLAN_PACKED_RGB 32u      /* Conv2d_1a_7x7: x is the packed [N, H, W, 3] batch, filter stored [7][7][4][Cout]   */
 typedef struct ds_conv_layer_plan {
     ds_conv_desc d;          /* descriptor of the chosen launch (dgrad: channel roles swapped, flipped taps)            */

@@ -41,3 +41,22 @@ z = torch.empty(plan.M, 64, device="cuda")
 stats = torch.zeros(2, 64, plan.partials, device="cuda")
 t = timeit(lambda: plan.run(ops._p(x4), ops._p(w), ops._p(z), stats=ops._p(stats)))
 print("%-20s %7.1f us (+ %.1f us for the 4-channel copy)" % ("staged bf16, folded", t, t_pad))
+
+# round 6: the stem with MaxPool_2a inside (ds_conv_stem_pool) against the two launches it replaces
+from tumblr_emotions_amd import _lib
+lib = _lib.load()
+plan = ops.StemPlan(B, 224, 224, 4, 64, 64)
+z = torch.empty(plan.M, 64, device="cuda")
+stats = torch.zeros(2, 64, plan.partials, device="cuda")
+pivot = torch.zeros(64, device="cuda")
+rstd, shift = torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")
+y = torch.empty(B, 56, 56, 64, device="cuda")
+am = torch.empty(B, 56, 56, 64, dtype=torch.uint8, device="cuda")
+t0 = timeit(lambda: plan.run(ops._p(x), ops._p(w), ops._p(z), stats=ops._p(stats), pivot=ops._p(pivot)))
+t1 = timeit(lambda: ops.maxpool_bn_relu_fwd(z, rstd, shift, y, am, B, 112, 112, 64, 3, 2))
+P = lib.ds_conv_stem_pool_partials(B, 112, 112)
+s1 = torch.zeros(2, 64, P, device="cuda")
+zmax = torch.empty(B, 56, 56, 64, device="cuda")
+t2 = timeit(lambda: _lib.check(lib.ds_conv_stem_pool(ops._p(x), ops._p(w), ops._p(zmax), ops._p(s1), ops._p(pivot), B, 224, 224, 4, 64,
+                                                     64, ops._stream()), "stem_pool"))
+print("ds_conv_stem %7.1f us + ds_maxpool_bn_relu_fwd %7.1f us = %7.1f us;  ds_conv_stem_pool %7.1f us" % (t0, t1, t0 + t1, t2))

@@ -33,7 +33,26 @@ def hip_decisions(net):
             else:
                 inj["relu/" + scope] = (st.out > 0).cpu().numpy()
         elif isinstance(st, PoolStage):
-            if getattr(st.prev, "fused_into_pool", False):
+            if getattr(st, "zmax", None) is not None:
+                # MaxPool_2a ran INSIDE the stem kernel (ds_conv_stem_pool): neither the full-resolution z nor the winners
+                # exist.  Rebuild both with the two-launch form from the same images, weights and batch statistics -- z has the
+                # same bits (same MFMA sequence; test_stem_with_the_pool_inside_...), which the pooled maxima confirm here
+                import torch
+                from tumblr_emotions_amd import ops
+                lay = st.prev.layer
+                plan = ops.LayerPlan(ops.DS_CONV_FWD, eng.arith, eng.plan_options() | ops.DS_PLAN_PACKED_RGB, lay.B, lay.H, lay.W,
+                                     4, lay.cout, 7, 2, 4, lay.cout, 0)
+                z_full = torch.empty(lay.M, lay.cout, device=eng.device)
+                plan.run(ops._p(eng.images), lay.w_ptr, ops._p(z_full))
+                y = torch.empty(lay.B, st.H, st.W, st.C, device=eng.device)
+                am = torch.empty(lay.B, st.H, st.W, st.C, dtype=torch.uint8, device=eng.device)
+                ops.maxpool_bn_relu_fwd(z_full, lay.rstd, lay.shift, y, am, lay.B, lay.OH, lay.OW, st.C, 3, 2)
+                torch.cuda.synchronize()
+                want = torch.clamp_min(torch.addcmul(lay.shift, st.zmax, lay.rstd), 0)
+                assert float((y - want).abs().max()) <= 1e-6 * max(1.0, float(y.abs().max()))
+                inj["pool/" + st.name] = am.cpu().numpy()
+                inj["poolrelu/" + st.name] = (y > 0).cpu().numpy()
+            elif getattr(st.prev, "fused_into_pool", False):
                 inj["pool/" + st.name] = st.argmax.cpu().numpy()
                 inj["poolrelu/" + st.name] = (st.out > 0).cpu().numpy()
             else:

@@ -566,6 +566,42 @@ def test_branch3_pool_on_load_step_follows_the_two_pass_form():
     print("fuse_branch3 vs two-pass: max|dlogits| %.2e, worst gradient rel L2 %.2e" % (float((res[0][2] - res[1][2]).abs().max()), worst))
 
 
+@pytest.mark.parametrize("B", [2, 8])
+def test_stem_with_the_pool_inside_step_follows_the_two_launch_form(B):
+    """InceptionV1Engine.stem_pool (default): Conv2d_1a_7x7 -> MaxPool_2a_3x3 as one kernel (ds_conv_stem_pool), the stem's
+    full-resolution output never written; the pooled maxima stay raw and Conv2d_2b normalises on load (B = 8) or, where its
+    wide kernel is not the one chosen, a BatchNorm-apply pass over the pooled map follows (B = 2); the stem's beta gradient
+    comes from the pooled tensors.  The window maxima have the same bits as the two-launch form; the statistics group their
+    partial sums differently, so the two steps differ by fp32 summation order (tolerances as in
+    test_branch3_pool_on_load_step_follows_the_two_pass_form)."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    batch = to_device(synthetic_batch_numpy(B, 10, 50, seed=5))
+    res, inside = [], []
+    for on in (True, False):
+        net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10)
+        net.image.stem_pool = on
+        net.initialize(seed=7)
+        net.train_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        stem, pool = net.image.stages[0], net.image.stages[1]
+        inside.append((stem.layer.pool_inside, pool.raw))
+        y = pool.out if not pool.raw else torch.clamp_min(torch.addcmul(stem.layer.shift, pool.out, stem.layer.rstd), 0)
+        res.append((y.clone(), net.logits.detach().clone(), net.total_loss_value(), net.grads_state_dict()))
+    assert inside == [(True, B >= 6), (False, False)], inside
+    dy, dl, dloss = float((res[0][0] - res[1][0]).abs().max()), float((res[0][1] - res[1][1]).abs().max()), abs(res[0][2] - res[1][2])
+    assert dy <= 1e-5 * float(res[1][0].abs().max()), dy
+    # (a handful of samples per BatchNorm group: the 57-layer stack amplifies a last-bit change of the stem's statistics ~100x)
+    assert dl <= (1e-4 if B >= 8 else 1e-3) and dloss <= (1e-5 if B >= 8 else 1e-4), (dl, dloss)
+    worst = 0.0
+    for name, g in res[1][3].items():
+        rel = np.linalg.norm(res[0][3][name] - g) / max(np.linalg.norm(g), 1e-30)
+        worst = max(worst, rel)
+        assert rel <= 3e-2, (name, rel)
+    print("stem_pool vs two launches (B = %d): max|dlogits| %.2e, worst gradient rel L2 %.2e"
+          % (B, float((res[0][1] - res[1][1]).abs().max()), worst))
+
+
 def test_bn_backward_on_load_step_is_bit_identical():
     """InceptionV1Engine.bnb_on_load = 2: the frozen 1x1 layers -- every block's fused Branch_0/1/2 conv, Branch_3's conv,
     Conv2d_2b -- run no ds_bn_bwd_apply pass; their wide dgrad forms dz = rstd (g - mean g - xhat mean(g xhat)) from z and

@@ -15,9 +15,9 @@ DS_DTYPE_F32, DS_DTYPE_BF16 = 0, 1
 DS_FP8_E4M3, DS_FP8_E5M2 = 0, 1
 DS_CONV_FWD, DS_CONV_DGRAD = 0, 1
 DS_ARITH_F32, DS_ARITH_BF16, DS_ARITH_FP8, DS_ARITH_F32X3 = 0, 1, 2, 3
-DS_FAM_IGEMM, DS_FAM_WINO2, DS_FAM_WINO4, DS_FAM_STEM, DS_FAM_BF16D, DS_FAM_FP8D, DS_FAM_F32X3, DS_FAM_WINO4H = range(8)
+DS_FAM_IGEMM, DS_FAM_WINO2, DS_FAM_WINO4, DS_FAM_STEM, DS_FAM_BF16D, DS_FAM_FP8D, DS_FAM_F32X3, DS_FAM_WINO4H, DS_FAM_STEM_POOL = range(9)
 DS_PLAN_NO_WINO, DS_PLAN_NO_WINO4, DS_PLAN_NO_STEM_DIRECT, DS_PLAN_NO_BF16_DIRECT, DS_PLAN_ACT16, DS_PLAN_PACKED_RGB = 1, 2, 4, 8, 16, 32
-DS_PLAN_FP8_EVERYWHERE, DS_PLAN_FP8_WIDE_RULE, DS_PLAN_NO_WINO4H = 64, 128, 256
+DS_PLAN_FP8_EVERYWHERE, DS_PLAN_FP8_WIDE_RULE, DS_PLAN_NO_WINO4H, DS_PLAN_STEM_POOL = 64, 128, 256, 512
 
 
 class ConvDesc(C.Structure):
@@ -109,6 +109,9 @@ SIGNATURES = {
     "ds_conv_stem_bf16_partials": (C.c_int, [_i32, _i32, _i32]),
     "ds_conv_stem": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "ds_conv_stem_bf16": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
+    "ds_conv_stem_pool_supported": (C.c_int, [_i32, _i32]),
+    "ds_conv_stem_pool_partials": (C.c_int, [_i32, _i32, _i32]),
+    "ds_conv_stem_pool": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "ds_wino_transform_weights": (C.c_int, [_P, _P, _i32, _i32, _i32, _P]),
     "ds_conv_wino_partials": (C.c_int, [_i32, _i32, _i32]),
     "ds_conv_wino": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),

@@ -39,12 +39,13 @@ inline bool is_wino(const ds_conv_layer_plan *p) { return p->family == DS_FAM_WI
 // partial count of the statistics epilogue of the chosen launch
 int plan_partials(const ds_conv_layer_plan *p) {
     const ds_conv_desc &d = p->d;
-    if (!(d.flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) && p->family != DS_FAM_STEM) return 0;
+    if (!(d.flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) && p->family != DS_FAM_STEM && p->family != DS_FAM_STEM_POOL) return 0;
     switch (p->family) {
     case DS_FAM_WINO2: return ds_conv_wino_partials(d.N, d.H, d.W);
     case DS_FAM_WINO4:
     case DS_FAM_WINO4H: return ds_conv_wino4_partials(d.N, d.H, d.W);
     case DS_FAM_STEM: return d.dtype == DS_DTYPE_BF16 ? ds_conv_stem_bf16_partials(d.N, d.OH, d.OW) : ds_conv_stem_partials(d.N, d.OH, d.OW);
+    case DS_FAM_STEM_POOL: return ds_conv_stem_pool_partials(d.N, d.OH, d.OW);
     case DS_FAM_BF16D: return ds_conv_bf16_partials(&d);
     case DS_FAM_FP8D: return ds_conv_fp8_partials(&d);
     case DS_FAM_F32X3: return ds_conv_f32x3_partials(&d);
@@ -111,6 +112,10 @@ extern "C" int ds_conv_plan(ds_conv_layer_plan *out, int32_t role, int32_t arith
     if (stem) {
         // (the 16-bit configurations run the same kernel on the bf16 matrix cores: ds_conv_stem_bf16)
         if (cout == 64 && !(options & DS_PLAN_NO_STEM_DIRECT)) fam = DS_FAM_STEM;
+        // ... with MaxPool_2a inside the kernel when the caller asks for it (a frozen stem whose only consumer is the pool)
+        if (fam == DS_FAM_STEM && (options & DS_PLAN_STEM_POOL) && arith == DS_ARITH_F32 && stride == 2 &&
+            ds_conv_stem_pool_supported(H, W))
+            fam = DS_FAM_STEM_POOL;
     } else if (f32) {
         // 3x3 stride-1 layers: fused Winograd where it beats the implicit GEMM (profiles/r02_wino_layers.txt: every
         // 56x56 / 28x28 / 14x14 layer; on the 7x7 maps only the wide ones), F(4x4) where the launch-time model says so
@@ -275,6 +280,9 @@ extern "C" int ds_conv_run(const ds_conv_layer_plan *p, const void *x, const voi
         return (d.dtype == DS_DTYPE_BF16 ? ds_conv_stem_bf16 : ds_conv_stem)(
             (const float *)x, (const float *)w, z, (d.flags & DS_EPI_STATS) ? io->stats : nullptr, io->pivot, d.N, d.H, d.W, p->w_cin,
             d.Cout, d.ldz, stream);
+    case DS_FAM_STEM_POOL:
+        return ds_conv_stem_pool((const float *)x, (const float *)w, z, (d.flags & DS_EPI_STATS) ? io->stats : nullptr, io->pivot,
+                                 d.N, d.H, d.W, p->w_cin, d.Cout, d.ldz, stream);
     case DS_FAM_BF16D: return ds_conv_bf16(&d, x, w, z, io->mask, io->stats, io->pivot, stream);
     case DS_FAM_F32X3: return ds_conv_f32x3(&d, (const float *)x, w, z, io->mask, io->stats, io->pivot, stream);
     case DS_FAM_FP8D:

@@ -99,26 +99,32 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
     } else {
         // (all 42 reads of a thread requested before the first LDS write: one memory round trip instead of 42 in a row --
         // ~60 us at the head of every persistent workgroup)
-        constexpr int WN = 7 * 4 * 3 * 2 * CO / 256;
+        // POOL: the (j = 3, kh = 1) rows are not kept (their A operand is an out-of-range load = 0): 21 rows per kernel row,
+        // walked in DESTINATION order -- rows 0 .. 17 = (j, c, kh) for j < 3, rows 18 .. 20 = (3, c, 0)
+        constexpr int WN = (7 * WROW + 255) / 256;
         float wv[WN];
 #pragma unroll
         for (int t = 0; t < WN; ++t) {
             const int i = t * 256 + tid;
-            const int co = i & 63, k2 = (i >> 6) & 1, c = (i >> 7) % 3, j = ((i >> 7) / 3) & 3, dh = (i >> 7) / 12;
+            const int co = i & 63;
+            int k2, c, j, dh;
+            if constexpr (POOL) {
+                const int e = (i >> 6) % 21;
+                dh = (i >> 6) / 21;
+                j = e < 18 ? e / 6 : 3;
+                c = e < 18 ? (e % 6) >> 1 : e - 18;
+                k2 = e < 18 ? e & 1 : 0;
+            } else {
+                k2 = (i >> 6) & 1; c = (i >> 7) % 3; j = ((i >> 7) / 3) & 3; dh = (i >> 7) / 12;
+            }
             const int px = 2 * j + k2;
-            wv[t] = px < 7 ? p.w[((dh * 7 + px) * p.cin_store + c) * CO + co] : 0.f;
+            const bool ok = px < 7 && dh < 7;
+            const float wq = p.w[ok ? ((dh * 7 + px) * p.cin_store + c) * CO + co : 0];          // (unconditional load: no branch)
+            wv[t] = ok ? wq : 0.f;
         }
 #pragma unroll
-        for (int t = 0; t < WN; ++t) {
-            if constexpr (POOL) {      // the (j = 3, kh = 1) rows are not kept: their A operand is an out-of-range load = 0
-                const int i = t * 256 + tid;
-                const int co = i & 63, k2 = (i >> 6) & 1, c = (i >> 7) % 3, j = ((i >> 7) / 3) & 3, dh = (i >> 7) / 12;
-                if (j < 3) wl[dh * WROW + ((j * 3 + c) * 2 + k2) * CO + co] = wv[t];
-                else if (k2 == 0) wl[dh * WROW + (18 + c) * CO + co] = wv[t];
-            } else {
-                wl[t * 256 + tid] = wv[t];
-            }
-        }
+        for (int t = 0; t < WN; ++t)
+            if (!POOL || t * 256 + tid < 7 * WROW) wl[t * 256 + tid] = wv[t];
     }
     if constexpr (POOL) {
         for (int i = tid; i < kRingFloats; i += 256) ring_s[i] = -INFINITY;
@@ -197,8 +203,10 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
         qf = rp0;
     }
     // pooled row q (row pair index over the batch) lives in ring slot q % nslots; out: [N * PH][PW][64] = max of z
+    int qf_slot = POOL ? qf % p.nslots : 0;
     auto flush_row = [&](int q) {
-        float *slot = ring_s + (q % p.nslots) * (p.PW * CO);
+        float *slot = ring_s + qf_slot * (p.PW * CO);
+        if (++qf_slot == p.nslots) qf_slot = 0;
         float *dst = p.z + (int64_t)q * p.PW * p.ldz;
         const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         for (int i = tid; i < p.PW * (CO / 4); i += 256) {
@@ -210,48 +218,83 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
     };
     // accumulators -> statistics (pixels of the own row pairs only) and the ring: conv pixel (row R of the batch, column c)
     // lies in the windows of pooled rows R / 2 and -- R even, not the first row of its image -- R / 2 - 1, pooled columns
-    // c / 2 and -- c even, c > 0 -- c / 2 - 1
+    // c / 2 and -- c even, c > 0 -- c / 2 - 1.  Branch-free: a window that does not apply is replaced by one that does (the
+    // maximum is idempotent), a pixel past the range by -inf; no division in here (the lane's position advances by a fixed
+    // step per tile).
+    struct Pos { int R, c, slot, i; };          // first pixel of the lane's block: conv row of the batch, column; slot of its
+    Pos pos[NA];                                // pooled row R / 2 and that row's index inside its image
+    int cstep = 0, rstep = 0;
+    if constexpr (POOL) {
+        cstep = TP % p.OW;
+        rstep = TP / p.OW;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int mb = mbase + wave * (32 * NA) + a * 32 + 4 * kh;
+            pos[a].R = mb / p.OW;
+            pos[a].c = mb - pos[a].R * p.OW;
+            pos[a].slot = (pos[a].R >> 1) % p.nslots;
+            pos[a].i = (pos[a].R >> 1) % p.PH;
+        }
+    }
     auto pool_epilogue = [&](int tile, const f32x16 (&acc)[NA][2]) {
+        // Per QUAD of consecutive pixels (accumulator elements 4 g .. 4 g + 3: columns c .. c + 3 of one conv row -- OW and
+        // every block start are multiples of 4, so c is too): pooled column c / 2 takes max(v0, v1, v2), column c / 2 + 1
+        // max(v2, v3), column c / 2 - 1 takes v0 -- three LDS maxima per pooled row instead of six, one position per quad.
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             const int mb = mbase + tile * TP + wave * (32 * NA) + a * 32 + 4 * kh;      // this lane's first pixel of the block
-            const int Rb = mb / p.OW, cb = mb - Rb * p.OW;
+            const int Rb = pos[a].R, cb = pos[a].c;
             const int qb = Rb >> 1;
             // (the lane's sixteen pixels span at most three conv rows = pooled rows qb, qb + 1: OW >= 16)
-            const int sl0 = qb % p.nslots, sl1 = (sl0 + 1 == p.nslots) ? 0 : sl0 + 1, slm = (sl0 == 0) ? p.nslots - 1 : sl0 - 1;
-            const bool top0 = (qb % p.PH) == 0, top1 = ((qb + 1) % p.PH) == 0;          // first row pair of an image
+            const int sl0 = pos[a].slot, sl1 = (sl0 + 1 == p.nslots) ? 0 : sl0 + 1, slm = (sl0 == 0) ? p.nslots - 1 : sl0 - 1;
+            const bool top0 = pos[a].i == 0, top1 = pos[a].i + 1 == p.PH;               // first row pair of an image
+            float *const rb0 = ring_s + sl0 * (p.PW * CO) + li, *const rb1 = ring_s + sl1 * (p.PW * CO) + li;
+            float *const rbm = ring_s + slm * (p.PW * CO) + li;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int dl = (e & 3) + 8 * (e >> 2);
-                const int m = mb + dl;
-                int c = cb + dl, R = Rb;
-                if (c >= p.OW) { c -= p.OW; ++R; }
-                if (c >= p.OW) { c -= p.OW; ++R; }
-                const float v0 = acc[a][0][e], v1 = acc[a][1][e];
-                if (m < stat_end) {
-                    const float u0 = v0 - pv0, u1 = v1 - pv1;          // (the arithmetic of `epilogue`, to the bit)
-                    s0 += u0; q0 += u0 * u0;
-                    s1 += u1; q1 += u1 * u1;
-                }
-                if (m < mlim) {
-                    const int q = R >> 1;
-                    const bool second = q != qb;                         // pooled row qb + 1
-                    const int sq = second ? sl1 : sl0, sp = second ? sl0 : slm;      // slots of rows q and q - 1
-                    const bool own = q < rp1;                            // (the extension row only feeds row q - 1)
-                    const bool up = !(R & 1) && !(second ? top1 : top0) && q > rp0;
-                    const int j = c >> 1;
-                    const bool left = !(c & 1) && c > 0;
-                    float *r0 = ring_s + (sq * p.PW + j) * CO + li, *r1 = ring_s + (sp * p.PW + j) * CO + li;
-                    if (own) {
-                        ds_fmax(r0, v0); ds_fmax(r0 + 32, v1);
-                        if (left) { ds_fmax(r0 - CO, v0); ds_fmax(r0 - CO + 32, v1); }
-                    }
-                    if (up) {
-                        ds_fmax(r1, v0); ds_fmax(r1 + 32, v1);
-                        if (left) { ds_fmax(r1 - CO, v0); ds_fmax(r1 - CO + 32, v1); }
-                    }
+            for (int g = 0; g < 4; ++g) {
+                const int m = mb + 8 * g;
+                int c = cb + 8 * g, R = Rb;
+                const bool w1 = c >= p.OW;
+                c -= w1 ? p.OW : 0; R += w1 ? 1 : 0;
+                const bool w2 = c >= p.OW;
+                c -= w2 ? p.OW : 0; R += w2 ? 1 : 0;
+                const bool valid = m < mlim, instat = m < stat_end;       // (both limits are multiples of 4: whole quads)
+                const int q = R >> 1;
+                const bool second = q != qb;                              // pooled row qb + 1
+                const bool own = q < rp1;                                 // (the row behind the range only feeds row q - 1)
+                const bool up = !(R & 1) && !(second ? top1 : top0) && q > rp0;
+                const int jo = (c >> 1) * CO;
+                float *const t_own = (second ? rb1 : rb0) + jo, *const t_up = (second ? rb0 : rbm) + jo;
+                float *A = own ? t_own : t_up;
+                float *Bq = up ? t_up : A;
+                A = valid ? A : ring_s + li;
+                Bq = valid ? Bq : ring_s + li;
+                const int lo = (valid && c > 0) ? -CO : 0;               // pooled column c / 2 - 1, or c / 2 again (idempotent)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const float v0 = acc[a][nb][4 * g], v1 = acc[a][nb][4 * g + 1], v2 = acc[a][nb][4 * g + 2], v3 = acc[a][nb][4 * g + 3];
+                    const float pv = nb ? pv1 : pv0;
+                    const float u0 = v0 - pv, u1 = v1 - pv, u2 = v2 - pv, u3 = v3 - pv;
+                    const float su = (u0 + u1) + (u2 + u3), qu = (u0 * u0 + u1 * u1) + (u2 * u2 + u3 * u3);
+                    if (nb) { s1 += instat ? su : 0.f; q1 += instat ? qu : 0.f; }
+                    else { s0 += instat ? su : 0.f; q0 += instat ? qu : 0.f; }
+                    const float h0 = valid ? fmaxf(fmaxf(v0, v1), v2) : -INFINITY, h1 = valid ? fmaxf(v2, v3) : -INFINITY;
+                    const float h2 = valid ? v0 : -INFINITY;
+                    ds_fmax(A + 32 * nb, h0); ds_fmax(A + CO + 32 * nb, h1); ds_fmax(A + lo + 32 * nb, h2);
+                    ds_fmax(Bq + 32 * nb, h0); ds_fmax(Bq + CO + 32 * nb, h1); ds_fmax(Bq + lo + 32 * nb, h2);
                 }
             }
+            // the block's position in the next tile (conditional subtractions: stem_pool_ok bounds the steps)
+            int c2 = cb + cstep, R2 = Rb + rstep;
+            const bool w = c2 >= p.OW;
+            c2 -= w ? p.OW : 0; R2 += w ? 1 : 0;
+            const int dq = (R2 >> 1) - qb;
+            int sl = sl0 + dq, ii = pos[a].i + dq;
+            sl -= sl >= p.nslots ? p.nslots : 0;
+            sl -= sl >= p.nslots ? p.nslots : 0;
+            ii -= ii >= p.PH ? p.PH : 0;
+            ii -= ii >= p.PH ? p.PH : 0;
+            pos[a].R = R2; pos[a].c = c2; pos[a].slot = sl; pos[a].i = ii;
         }
     };
 
@@ -384,6 +427,9 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
         };
         // One tile (kernel row dh in buf[dh & 1]).  Requesting the NEXT tile's first row behind this tile's last one -- in front of
         // the 128 stores -- was built (two copies of this body, the parity alternates with seven rows) and bought nothing: 677 us.
+        Pix cN;                 // POOL: the next tile's coordinates (set inside run_tile, ahead of the epilogue)
+        Cols oN;
+        int qf_i = POOL ? qf % p.PH : 0;      // POOL: row qf's index inside its image
         auto run_tile = [&](int tile, const Pix &c, const Cols &co) {
             constexpr int P = 0;
             f32x16 acc[2][2];
@@ -417,6 +463,12 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (POOL) {
+                // the next tile's first kernel row is requested BEFORE the epilogue: its latency passes under the ring work
+                if (tile + 1 < ntiles) {
+                    setup(tile + 1, cN, oN);
+                    issue(cN, oN, 0, buf[0]);
+                }
+                if (tile > 0) __syncthreads();                // every wave is through the previous tile's row flush
                 pool_epilogue(tile, acc);
             } else if ((tile + 1) * TP <= p.M) {          // (uniform) every row of the tile exists
 #pragma unroll
@@ -438,22 +490,29 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
             }
         };
         if constexpr (POOL) {
-            for (int tile = 0; tile < ntiles; ++tile) {
-                Pix cA;
-                Cols oA;
-                setup(tile, cA, oA);
+            Pix cA;
+            Cols oA;
+            if (ntiles > 0) {
+                setup(0, cA, oA);
                 issue(cA, oA, 0, buf[0]);
+            }
+            for (int tile = 0; tile < ntiles; ++tile) {
                 run_tile(tile, cA, oA);
                 __syncthreads();                              // the tile's maxima are in the ring
                 const int done = min(mbase + (tile + 1) * TP, mlim);
                 while (qf < rp1) {                            // (uniform) pooled rows whose last conv row has passed
-                    const int last = (qf % p.PH == p.PH - 1) ? 2 : 3;
+                    const int last = (qf_i == p.PH - 1) ? 2 : 3;
                     if ((2 * qf + last) * p.OW > done) break;
                     flush_row(qf);
                     ++qf;
+                    if (++qf_i == p.PH) qf_i = 0;
                 }
-                __syncthreads();
+                // (the barrier that keeps the next tile's maxima off the rows being reset sits in front of its epilogue, a whole
+                // K loop away: nobody waits there)
+                cA = cN;
+                oA = oN;
             }
+            __syncthreads();                                  // `red` below lies over the ring
         } else {
             for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
                 Pix cA;
@@ -491,7 +550,28 @@ int stem_grid(int64_t M, bool bf = false) {
     return (int)(tiles < g ? tiles : g);
 }
 
+// POOL: one workgroup per contiguous range of conv row pairs, two per CU (never more workgroups than row pairs)
+int stem_pool_grid(int64_t row_pairs) {
+    const int64_t g = 2 * ds::kCUs;
+    return (int)(row_pairs < g ? row_pairs : g);
+}
+
+// the pooled stem needs: an even conv map (the 3x3 / 2 SAME pool then pads bottom / right only), rows of 16 .. 112 pixels, a
+// multiple of 4 (a lane's sixteen pixels span at most three rows, its quads one; a pooled row fits a ring slot), and enough
+// ring slots for a tile
+bool stem_pool_ok(int OH, int OW) {
+    // (OW % 4: a lane's four consecutive pixels share a conv row; OH >= 10: the per-tile position update, pool_epilogue)
+    if (OH < 10 || OW < 16 || (OH & 1) || (OW & 3) || OW > 112) return false;
+    // a 256-pixel tile spans at most R = 254 / OW + 2 conv rows, which lie in at most (R - 1) / 2 + 2 pooled rows -- the rows
+    // that are live in the ring while the tile is folded in (complete rows leave at the end of every tile)
+    const int PW = OW / 2, nslots = kRingFloats / (PW * CO), R = 254 / OW + 2;
+    return nslots >= (R - 1) / 2 + 2;
+}
+
 }  // namespace
+
+extern "C" int ds_conv_stem_pool_supported(int32_t H, int32_t W) { return stem_pool_ok((H + 1) / 2, (W + 1) / 2) ? 1 : 0; }
+extern "C" int ds_conv_stem_pool_partials(int32_t N, int32_t OH, int32_t OW) { return stem_pool_grid((int64_t)N * (OH / 2)); }
 
 extern "C" int ds_conv_stem_partials(int32_t N, int32_t OH, int32_t OW) { return stem_grid((int64_t)N * OH * OW); }
 extern "C" int ds_conv_stem_bf16_partials(int32_t N, int32_t OH, int32_t OW) { return stem_grid((int64_t)N * OH * OW, true); }
@@ -523,6 +603,34 @@ int stem_launch(bool bf, const float *x, const float *w, float *z, float *stats,
 extern "C" int ds_conv_stem(const float *x, const float *w, float *z, float *stats, const float *pivot, int32_t N, int32_t H,
                             int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream) {
     return stem_launch(false, x, w, z, stats, pivot, N, H, W, cin_store, Cout, ldz, stream);
+}
+
+// Conv2d_1a_7x7 + MaxPool_2a_3x3 (inception_v1.py:63-67) in one launch: zmax [N, OH/2, OW/2, 64] (pixel stride ldz) = the 3x3 / 2
+// SAME maximum of the conv output z, which is not written; stats = the column sums of the FULL map about the pivot,
+// float[2][64][ds_conv_stem_pool_partials(N, OH, OW)].  relu(rstd * zmax + shift) is the pooled activation (rstd > 0).
+extern "C" int ds_conv_stem_pool(const float *x, const float *w, float *zmax, float *stats, const float *pivot, int32_t N,
+                                 int32_t H, int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream) {
+    DS_REQUIRE(x && w && zmax, "ds_conv_stem_pool: null argument");
+    DS_REQUIRE(Cout == CO && (cin_store == 3 || cin_store == 4) && ldz >= CO && ldz % 4 == 0 && (((uintptr_t)zmax) & 15) == 0,
+               "ds_conv_stem_pool: the 7x7/2 stem has 3 input and 64 output channels (16-byte aligned output rows)");
+    StemParams p = {};
+    p.x = x; p.w = w; p.z = zmax; p.stats = stats; p.pivot = stats ? pivot : nullptr;
+    p.N = N; p.H = H; p.W = W;
+    p.OH = (H + 1) / 2; p.OW = (W + 1) / 2;
+    DS_REQUIRE(stem_pool_ok(p.OH, p.OW), "ds_conv_stem_pool: conv map %d x %d (even sizes, 16 .. 112 columns: ds_conv_stem_pool_supported)", p.OH, p.OW);
+    const int ph = (p.OH - 1) * 2 + 7 - H, pw = (p.OW - 1) * 2 + 7 - W;     // TF SAME: the smaller half in front
+    p.pad_t = (ph > 0 ? ph : 0) / 2; p.pad_l = (pw > 0 ? pw : 0) / 2;
+    p.cin_store = cin_store; p.ldz = ldz;
+    const int64_t M = (int64_t)N * p.OH * p.OW;
+    const int64_t xb = (int64_t)N * H * W * 12;
+    DS_REQUIRE(M + p.OW < (1ll << 31) && xb < (1ll << 31), "ds_conv_stem_pool: input or output larger than 2 GiB (split the batch)");
+    p.M = (int)M; p.tiles = 0;
+    p.x_bytes = (unsigned)xb;
+    p.PH = p.OH / 2; p.PW = p.OW / 2;
+    p.rp_total = N * p.PH;
+    p.nslots = kRingFloats / (p.PW * CO);
+    hipLaunchKernelGGL((conv_stem_kernel<false, true>), dim3(stem_pool_grid(p.rp_total)), dim3(256), 0, (hipStream_t)stream, p);
+    return ds::check_launch("ds_conv_stem_pool");
 }
 
 // The same layer for the 16-bit configurations: x and w rounded to bf16 (RNE), v_mfma_f32_32x32x16_bf16, fp32 accumulation.

@@ -61,6 +61,7 @@ class ConvBN:
         self.eng, self.scopes, self.k, self.stride = eng, scopes, k, stride
         self.cin, self.cout, self.H, self.W = cin, cout, H, W
         self.trainable, self.fold = trainable, fold
+        self.pool_inside = False   # Conv2d_1a_7x7 only: MaxPool_2a inside the conv kernel (z = the window maxima)
         self.slot = 0          # which of the engine's scratch sets (one per branch stream) this layer uses
         self.OH, _ = same_pad(H, k, stride)
         self.OW, _ = same_pad(W, k, stride)
@@ -81,7 +82,6 @@ class ConvBN:
         k, cin, cout = self.k, self.cin, self.cout
         self.B = B
         self.M = B * self.OH * self.OW
-        self.z = torch.empty(self.M, cout, device=dev)
         self.ldz = cout               # row stride of z (use_concat_slice: the conv writes into the block's concat buffer)
         self.skip_apply = False       # ... and its consumers apply BatchNorm + ReLU on load
         self.mean = torch.empty(cout, device=dev)
@@ -94,13 +94,19 @@ class ConvBN:
         # layer is (one conv entry point; the selection rules live next to the kernels).
         opts = eng.plan_options()
         if self.fold:      # Conv2d_1a_7x7 reads the packed RGB batch (or, generic kernel, its zero-padded 4-channel copy)
+            if self.pool_inside:          # ... and takes MaxPool_2a inside the kernel (ConvStage.alloc decides)
+                opts |= ops.DS_PLAN_STEM_POOL
             self.fwd = ops.LayerPlan(ops.DS_CONV_FWD, eng.arith, opts | ops.DS_PLAN_PACKED_RGB, B, self.H, self.W, 4, cout,
                                      k, self.stride, 4, cout, DS_EPI_STATS)
+            self.pool_inside = self.fwd.family == ops.DS_FAM_STEM_POOL
         else:
             self.fwd = ops.LayerPlan(ops.DS_CONV_FWD, eng.arith, opts, B, self.H, self.W, cin, cout, k, self.stride, 0, cout,
                                      DS_EPI_STATS)
         self.fwd.alloc_weights(dev)
-        self.stem_direct = self.fwd.family == ops.DS_FAM_STEM
+        # z: the pre-BatchNorm conv output, kept for the backward pass.  pool_inside: the 3x3 / 2 window maxima of it
+        # [B, OH/2, OW/2, cout] -- the only thing the fused stem writes
+        self.z = torch.empty(B * (self.OH // 2) * (self.OW // 2) if self.pool_inside else self.M, cout, device=dev)
+        self.stem_direct = self.fwd.family in (ops.DS_FAM_STEM, ops.DS_FAM_STEM_POOL)
         # fp8: device records with max|x| of the forward input / of dz for the layers ds_conv_fp8 can take
         fp8 = eng.dtype == "fp8" and not self.fold and k in (1, 3) and self.stride == 1
         if fp8:
@@ -210,9 +216,14 @@ class ConvBN:
                     o0 = (scratch - self.bwdp_buf.data_ptr()) // 4
                     self._sync_views.append(self.bwdp_buf[o0:o0 + 2 * n * Pp])
                     seg = make_segments([(0, n, pool.dout.data_ptr() + 4 * off, pool.C)])
+                    if getattr(pool, "raw", False):
+                        # the pool's output holds the window maxima of z itself (pool_inside): the plain reduce on
+                        # (zmax, mean, rstd, shift) -- the same predicate rstd * zmax + shift > 0, the same sum of g
+                        stat = (_vp(self.mean.data_ptr() + 4 * c0), _vp(self.rstd.data_ptr() + 4 * c0), _vp(self.shift.data_ptr() + 4 * c0))
+                    else:
+                        stat = (_vp(self.beta.data_ptr() + 4 * c0), ops._p(eng.ones), ops._p(eng.zeros))
                     self._reduce_jobs.append(("pool", seg, Mp, n, _vp(pool.out.data_ptr() + pool.out.element_size() * off),
-                                              pool.C, _vp(self.beta.data_ptr() + 4 * c0), _vp(scratch),
-                                              ops.act_dtype(pool.out)))
+                                              pool.C, stat, _vp(scratch), ops.act_dtype(pool.out)))
                     scratch += 4 * 2 * n * Pp
                 else:
                     n = c1 - c0
@@ -225,8 +236,8 @@ class ConvBN:
             self._sum_segs = sg
         for job in self._reduce_jobs:
             if job[0] == "pool":
-                _, seg, Mp, n, yp, ldy, beta_p, dst, ydt = job
-                ops.bn_bwd_reduce(yp, seg, Mp, n, beta_p, ops._p(eng.ones), ops._p(eng.zeros), dst, ldz=ldy, z_dtype=ydt)
+                _, seg, Mp, n, yp, ldy, stat, dst, ydt = job
+                ops.bn_bwd_reduce(yp, seg, Mp, n, stat[0], stat[1], stat[2], dst, ldz=ldy, z_dtype=ydt)
                 continue
             _, i, c0, n, dst = job
             off = 4 * c0
@@ -335,12 +346,15 @@ class ConvBN:
         B, H, W = self.B, self.OH, self.OW
         if self.part_pool[0] is not None:        # both sums from the pooled tensors: z is not read (see _bn_bwd_sums)
             self._bn_bwd_sums()
+        elif self.pool_inside:
+            raise RuntimeError("%s: the pooled stem needs BatchNorm's backward sums from the pooled tensors (bwd_sums)" % self.key)
         else:
             ops.bn_pool_bwd_reduce(self.z, pool.dout, pool.argmax, B, H, W, Cc, self.mean, self.rstd, self.shift,
                                    self.bwdp_buf)
             self._finalize_plain(self.pool_P)
         if not (need_dx or self.trainable):
             return
+        assert not self.pool_inside          # (a frozen stem: nothing below it)
         ops.bn_pool_bwd_apply(self.z, pool.dout, pool.argmax, B, H, W, Cc, self.mean, self.rstd, self.shift, self.coef,
                               self.z)
         self._dz_amax_live = False
@@ -427,6 +441,13 @@ class ConvStage(Stage):
 
     def alloc(self, B):
         dev = self.eng.device
+        eng = self.eng
+        nxt = getattr(self, "next", None)
+        # Conv2d_1a_7x7 -> MaxPool_2a_3x3 in one kernel (ds_conv_stem_pool): a frozen fp32 stem whose BatchNorm + ReLU run
+        # behind the pool anyway (fuse_bn_pool) and whose backward sums come from the pooled tensors (bwd_sums)
+        self.layer.pool_inside = bool(self.layer.fold and eng.stem_pool and eng.stem_direct and eng.fuse_bn_pool and eng.bwd_sums
+                                      and eng.dtype == "f32" and not eng.act16 and not self.layer.trainable
+                                      and isinstance(nxt, PoolStage) and nxt.k == 3 and nxt.stride == 2)
         self.layer.alloc(B)
         self.out16 = self.eng.act16 and not self.layer.fold       # Conv2d_2b / 2c (the stem's output is read by hip tests only)
         self.out = torch.empty(B, self.H, self.W, self.C, device=dev, dtype=torch.bfloat16 if self.out16 else torch.float32)
@@ -435,6 +456,12 @@ class ConvStage(Stage):
         self.segs = make_segments([(0, self.C, self.out.data_ptr(), self.C, ops.act_dtype(self.out),
                                     ops._p(self.out_amax))])
         self.layer.set_dy_parts([(0, self.C, self.dout.data_ptr(), self.C)])
+        # the layer behind a pool that holds raw window maxima (the pooled stem) applies BatchNorm + ReLU as it loads
+        self.norm_in = None
+        if getattr(self.prev, "raw", False):
+            assert self.layer.fwd.norm_supported()           # (PoolStage.alloc checked it with the same plan arguments)
+            self.norm_in = self.prev.rs
+            self.layer.fwd.d.norm_rstd, self.layer.fwd.d.norm_shift = self.norm_in[0].data_ptr(), self.norm_in[1].data_ptr()
         if not self.layer.fold:
             self.layer.make_dgrad(self.prev.C)
             # Conv2d_2c's dgrad writes the gradient of Conv2d_2b's activation: it can emit 2b's BatchNorm sums
@@ -472,7 +499,25 @@ class PoolStage(Stage):
         # storage follows the input's (a pool copies values); behind a conv fused into it (reads z) the engine's choice
         p = self.prev
         o16 = p.out.dtype == torch.bfloat16 or (self.eng.act16 and isinstance(p, ConvStage) and self.k == 3)
-        self.out = torch.empty(B, self.H, self.W, self.C, device=dev, dtype=torch.bfloat16 if o16 else torch.float32)
+        # Behind the pooled stem (ConvBN.pool_inside) this stage has no kernel: its output IS the stem's z buffer, the window
+        # maxima.  raw: the consumer (Conv2d_2b: wide 1x1 kernel) applies relu(rstd * . + shift) as it loads; where that kernel
+        # is not the one chosen (a handful of samples) a BatchNorm-apply pass over the pooled map produces the activation
+        inside = isinstance(p, ConvStage) and p.layer.pool_inside
+        self.raw, self.rs, self.zmax = False, None, None
+        if inside:
+            self.zmax = p.layer.z.view(B, self.H, self.W, self.C)
+            nxt = getattr(self, "next", None)
+            if isinstance(nxt, ConvStage) and nxt.layer.k == 1 and not nxt.layer.trainable:
+                probe = ops.LayerPlan(ops.DS_CONV_FWD, self.eng.arith, self.eng.plan_options(), B, self.H, self.W, self.C,
+                                      nxt.layer.cout, 1, 1, self.C, nxt.layer.cout, DS_EPI_STATS)
+                self.raw = probe.norm_supported()
+            self.rs = (p.layer.rstd, p.layer.shift)
+        if self.raw:
+            self.out = self.zmax
+        else:
+            self.out = torch.empty(B, self.H, self.W, self.C, device=dev, dtype=torch.bfloat16 if o16 else torch.float32)
+        if inside and not self.raw:
+            self.apply_segs = make_segments([(0, self.C, self.out.data_ptr(), self.C)])
         self.dout = torch.empty(B, self.H, self.W, self.C, device=dev)
         self.argmax = torch.empty(B, self.H, self.W, self.C, dtype=torch.uint8, device=dev)
         self._own_amax = self.eng.new_amax()
@@ -500,6 +545,10 @@ class PoolStage(Stage):
 
     def forward(self):
         p = self.prev
+        if self.zmax is not None:        # the stem kernel pooled already
+            if not self.raw:
+                ops.bn_apply_relu(p.layer.z, self.B * self.H * self.W, self.C, self.rs[0], self.rs[1], self.apply_segs)
+            return
         if getattr(p, "fused_into_pool", False):
             ops.maxpool_bn_relu_fwd(p.layer.z, p.layer.rstd, p.layer.shift, self.out, self.argmax, self.B, p.H, p.W, p.C,
                                     self.k, self.stride, amax=self._own_amax if getattr(self, "track_amax", True) else None)
@@ -827,6 +876,7 @@ class InceptionV1Engine:
         self.wgrad_stream = None
         self.bwd_sums = True         # BatchNorm backward sums from the producing dgrad's epilogue (DS_EPI_BNSUMS) where it can
         self.stem_direct = True      # Conv2d_1a_7x7 from the packed RGB batch (ds_conv_stem; False: generic kernel on a 4-channel copy)
+        self.stem_pool = os.environ.get("DS_STEM_POOL", "1") != "0"      # ... with MaxPool_2a inside that kernel (ds_conv_stem_pool; ConvStage.alloc)
         self.branch_streams = True   # Mixed blocks: Branch_2 and Branch_3 on side streams next to Branch_0/1 (False: one stream)
         self.side = None
         self.fp8_everywhere = os.environ.get("DS_FP8_EVERYWHERE", "0") == "1"      # A/B: ds_conv_fp8 also where the bf16 kernels are faster

@@ -14,7 +14,7 @@ from ._lib import (ConvDesc, Segments, SumSegments, DS_EPI_ACCUM, DS_EPI_BIAS, D
                    DS_EPI_STATS,
                    DS_DTYPE_BF16, DS_DTYPE_F32, DS_FP8_E4M3, DS_FP8_E5M2, DS_CONV_FWD, DS_CONV_DGRAD, DS_ARITH_F32, DS_ARITH_BF16,
                    DS_ARITH_FP8, DS_ARITH_F32X3, DS_FAM_IGEMM, DS_FAM_WINO2, DS_FAM_WINO4, DS_FAM_STEM, DS_FAM_BF16D, DS_FAM_FP8D,
-                   DS_FAM_F32X3, DS_FAM_WINO4H, DS_PLAN_NO_WINO4H, DS_PLAN_NO_WINO, DS_PLAN_NO_WINO4, DS_PLAN_NO_STEM_DIRECT, DS_PLAN_NO_BF16_DIRECT, DS_PLAN_ACT16,
+                   DS_FAM_F32X3, DS_FAM_WINO4H, DS_FAM_STEM_POOL, DS_PLAN_STEM_POOL, DS_PLAN_NO_WINO4H, DS_PLAN_NO_WINO, DS_PLAN_NO_WINO4, DS_PLAN_NO_STEM_DIRECT, DS_PLAN_NO_BF16_DIRECT, DS_PLAN_ACT16,
                    DS_PLAN_PACKED_RGB, DS_PLAN_FP8_EVERYWHERE, DS_PLAN_FP8_WIDE_RULE)
 
 
