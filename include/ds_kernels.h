@@ -240,6 +240,9 @@ int ds_conv_stem_pool_supported(int32_t H, int32_t W);
 int ds_conv_stem_pool_partials(int32_t N, int32_t OH, int32_t OW);
 int ds_conv_stem_pool(const float *x, const float *w, float *zmax, float *stats, const float *pivot, int32_t N, int32_t H,
                       int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream);
+/* ... of ds_conv_stem_bf16 (the 16-bit configurations: operands rounded to bf16, bf16 MFMA; zmax and the sums stay fp32) */
+int ds_conv_stem_pool_bf16(const float *x, const float *w, float *zmax, float *stats, const float *pivot, int32_t N, int32_t H,
+                           int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream);
 /* ds_conv_stem for the 16-bit configurations: x and w rounded to bf16 (RNE) as they are packed, v_mfma_f32_32x32x16_bf16 with fp32
  * accumulation (two kernel rows per three MFMAs: 11 instead of 84 per accumulator); same arguments and layout; stats as
  * float[2][64][ds_conv_stem_bf16_partials(N, OH, OW)]. */

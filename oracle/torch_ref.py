@@ -347,8 +347,10 @@ class DeepSentimentRef:
         im = self.image_tower(g("images").to(self.dtype), dropout_mask)
         concat = torch.cat([im, tx], dim=1)
         self.features = concat
-        dense = torch.relu(concat @ self.p["W_fc"] + self.p["b_fc"])
-        return dense @ self.p["W_softmax"] + self.p["b_softmax"]
+        # (kept for tests/golden/make_golden_dense_flips.py: the dense layer's ReLU decisions, im_text_rnn_model.py:98-101)
+        self.dense_pre = concat @ self.p["W_fc"] + self.p["b_fc"]
+        self.dense_out = torch.relu(self.dense_pre)
+        return self.dense_out @ self.p["W_softmax"] + self.p["b_softmax"]
 
     # -- loss / step ---------------------------------------------------------------------------
     def loss(self, logits, labels):

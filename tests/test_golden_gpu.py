@@ -124,15 +124,37 @@ def test_full_size_step_matches_committed_golden_vector(which):
     grads = net.grads_state_dict()
     names = [k[5:] for k in g.files if k.startswith("grad/")]
     assert len(names) == (13 if which == "joint" else 7)
+    # The dense layer's ReLU (relu(concat W_fc + b_fc): 256 x 512 decisions) sits between the logits and every gated gradient
+    # except W_softmax / b_softmax.  Nineteen of its units have pre-activations within 1e-4 of zero for this batch -- the HIP
+    # path's forward noise there is 4e-5 -- and ONE flipped unit moves those gradients by 2-5e-3 (profiles/r06_notes.md: a
+    # different grouping of the stem's statistics partials flipped the unit at +4.4e-6).  The fixture therefore carries the
+    # oracle's decisions and, per undecidable unit, the (exactly linear) change of each gradient when it flips
+    # (tests/golden/make_golden_dense_flips.py): the oracle is evaluated ALONG the HIP path's dense decisions, as
+    # tests/hip_decisions.py does for the tower, and a decision may differ only at a unit the oracle itself cannot resolve.
+    flipped = []
+    if which == "joint":
+        want = np.unpackbits(g["dense_mask"])[:cfg["B"] * 512].reshape(cfg["B"], 512).astype(bool)
+        got_mask = (net.head.dense.detach() > 0).cpu().numpy()
+        units = [tuple(u) for u in g["flip/units"].tolist()]
+        for b, j in zip(*np.nonzero(want != got_mask)):
+            assert (int(b), int(j)) in units, "dense unit (%d, %d): ReLU decision differs from the oracle's, whose pre-activation " \
+                "is not within 1e-4 of zero" % (b, j)
+            flipped.append(units.index((int(b), int(j))))
     report = []
     for n in names:
         ref = g["grad/" + n].astype(np.float64)
+        for i in flipped:
+            if "flip/%d/%s" % (i, n) in g.files:
+                ref = ref + g["flip/%d/%s" % (i, n)].astype(np.float64)
         got = grads[n].reshape(-1)
         got = got[::cfg["stride"]] if got.size > cfg["big"] else got
         rel = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
         gate = max(1e-3, 3 * float(g["spread/" + n]))
         report.append((rel, gate, n))
         assert rel <= gate, "gradient of %s: relative L2 %.3e above %.3e" % (n, rel, gate)
+    if flipped:
+        print("dense units decided the other way (oracle pre-activations %s): the oracle follows them"
+              % ", ".join("%+.1e" % float(g["flip/pre"][i]) for i in flipped))
     print("%s B=%d: max|dlogits| %.2e, |dloss| %.2e; %s" % (which, cfg["B"], dl, dloss,
           "; ".join("%s %.1e/%.1e" % (n.split("/")[-3] if n.count("/") > 2 else n, r, gt) for r, gt, n in report)))
 

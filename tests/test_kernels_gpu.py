@@ -112,16 +112,20 @@ def test_conv_stem_packed_rgb(case):
 
 @pytest.mark.parametrize("case", [(2, 32, 32, 4), (5, 64, 64, 4), (3, 96, 64, 3), (7, 160, 192, 4), (3, 224, 224, 4), (1, 31, 224, 4),
                                   (2, 20, 40, 4), (1, 64, 36, 3)])
-def test_stem_with_the_pool_inside_writes_the_window_maxima_of_the_same_z(case):
+@pytest.mark.parametrize("bf", [False, True], ids=["f32", "bf16"])
+def test_stem_with_the_pool_inside_writes_the_window_maxima_of_the_same_z(case, bf):
     """ds_conv_stem_pool (Conv2d_1a_7x7 -> MaxPool_2a_3x3, inception_v1.py:63-67, in one launch): the pooled maxima are BIT
     identical to ds_conv_stem's z pooled by ds_maxpool_fwd (3x3 / 2 SAME: the same MFMA sequence per output pixel; LDS float
     maxima are exact), whatever the split of the batch's row pairs over the workgroups -- image boundaries, the recomputed row
     behind a workgroup's range, the last row pair of an image (two conv rows) -- and the statistics of the FULL map agree with
-    the unfused launch up to the grouping of the partial sums, and with the fp64 oracle."""
+    the unfused launch up to the grouping of the partial sums, and with the fp64 oracle.  bf16: the same for ds_conv_stem_pool_bf16
+    against ds_conv_stem_bf16 (the oracle then convolves the bf16-rounded operands)."""
     ops = _ops()
     from tumblr_emotions_amd import _lib
     lib = _lib.load()
     N, H, W, cs = case
+    f_plain, f_pool = (lib.ds_conv_stem_bf16, lib.ds_conv_stem_pool_bf16) if bf else (lib.ds_conv_stem, lib.ds_conv_stem_pool)
+    f_parts = lib.ds_conv_stem_bf16_partials if bf else lib.ds_conv_stem_partials
     rng = np.random.RandomState(41 + H)
     x = rng.uniform(-1, 1, size=(N, H, W, 3))
     w = np.zeros((7, 7, cs, 64))
@@ -130,22 +134,21 @@ def test_stem_with_the_pool_inside_writes_the_window_maxima_of_the_same_z(case):
     assert bool(lib.ds_conv_stem_pool_supported(H, W)) == (OH % 2 == 0 and OH >= 10 and OW % 4 == 0 and 16 <= OW <= 112)
     if not lib.ds_conv_stem_pool_supported(H, W):
         z = torch.empty(N, OH // 2, OW // 2, 64, device="cuda")
-        assert lib.ds_conv_stem_pool(ops._p(dev(x)), ops._p(dev(w)), ops._p(z), None, None, N, H, W, cs, 64, 64, None) != 0
+        assert f_pool(ops._p(dev(x)), ops._p(dev(w)), ops._p(z), None, None, N, H, W, cs, 64, 64, None) != 0
         return
     xt, wt = dev(x), dev(w)
     pivot = dev(rng.normal(size=64) * 0.05)
     M = N * OH * OW
-    P0, P1 = lib.ds_conv_stem_partials(N, OH, OW), lib.ds_conv_stem_pool_partials(N, OH, OW)
+    P0, P1 = f_parts(N, OH, OW), lib.ds_conv_stem_pool_partials(N, OH, OW)
     z = torch.empty(M, 64, device="cuda")
     s0 = torch.zeros(2 * 64 * P0, device="cuda")
-    _lib.check(lib.ds_conv_stem(ops._p(xt), ops._p(wt), ops._p(z), ops._p(s0), ops._p(pivot), N, H, W, cs, 64, 64, ops._stream()), "stem")
+    _lib.check(f_plain(ops._p(xt), ops._p(wt), ops._p(z), ops._p(s0), ops._p(pivot), N, H, W, cs, 64, 64, ops._stream()), "stem")
     pooled = torch.empty(N, OH // 2, OW // 2, 64, device="cuda")
     am = torch.empty(N, OH // 2, OW // 2, 64, dtype=torch.uint8, device="cuda")
     ops.maxpool_fwd(z.view(N, OH, OW, 64), pooled, am, N, OH, OW, 64, 3, 2, "SAME")
     zmax = torch.full((N * (OH // 2) * (OW // 2) + 2, 64), 3.0, device="cuda")
     s1 = torch.zeros(2 * 64 * P1, device="cuda")
-    _lib.check(lib.ds_conv_stem_pool(ops._p(xt), ops._p(wt), ops._p(zmax), ops._p(s1), ops._p(pivot), N, H, W, cs, 64, 64, ops._stream()),
-               "stem_pool")
+    _lib.check(f_pool(ops._p(xt), ops._p(wt), ops._p(zmax), ops._p(s1), ops._p(pivot), N, H, W, cs, 64, 64, ops._stream()), "stem_pool")
     beta = torch.zeros(64, device="cuda")
     outs = []
     for st, P in ((s0, P0), (s1, P1)):
@@ -157,7 +160,7 @@ def test_stem_with_the_pool_inside_writes_the_window_maxima_of_the_same_z(case):
     assert torch.equal(zmax[:-2].view(N, OH // 2, OW // 2, 64), pooled)
     assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-6 * max(1.0, float(outs[0][0].abs().max()))
     assert float((outs[0][1] - outs[1][1]).abs().max()) <= 1e-5 * float(outs[0][1].abs().max())
-    zr = S.conv2d_same(x, w[:, :, :3], 2).reshape(M, 64)
+    zr = (S.conv2d_same(_bf16_round(x), _bf16_round(w[:, :, :3]), 2) if bf else S.conv2d_same(x, w[:, :, :3], 2)).reshape(M, 64)
     close(outs[1][0], zr.mean(0), 1e-4)
     close(outs[1][1], 1.0 / np.sqrt(zr.var(0) + 1e-3), 1e-4)
     close(zmax[:-2], S.max_pool(zr.reshape(N, OH, OW, 64), 3, 2, "SAME").reshape(-1, 64))

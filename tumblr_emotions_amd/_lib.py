@@ -112,6 +112,7 @@ SIGNATURES = {
     "ds_conv_stem_pool_supported": (C.c_int, [_i32, _i32]),
     "ds_conv_stem_pool_partials": (C.c_int, [_i32, _i32, _i32]),
     "ds_conv_stem_pool": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
+    "ds_conv_stem_pool_bf16": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "ds_wino_transform_weights": (C.c_int, [_P, _P, _i32, _i32, _i32, _P]),
     "ds_conv_wino_partials": (C.c_int, [_i32, _i32, _i32]),
     "ds_conv_wino": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
@@ -181,6 +182,9 @@ def load():
         raise RuntimeError(
             "tumblr_emotions_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C tumblr_emotions_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    if os.environ.get("DS_LIB"):          # a tuning build replaces the product library: say so once
+        import sys
+        sys.stderr.write("tumblr_emotions_amd: DS_LIB overrides the kernel library: %s\n" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)           # AttributeError if the .so lacks a declared symbol

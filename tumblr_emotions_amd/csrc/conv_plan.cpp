@@ -113,7 +113,7 @@ extern "C" int ds_conv_plan(ds_conv_layer_plan *out, int32_t role, int32_t arith
         // (the 16-bit configurations run the same kernel on the bf16 matrix cores: ds_conv_stem_bf16)
         if (cout == 64 && !(options & DS_PLAN_NO_STEM_DIRECT)) fam = DS_FAM_STEM;
         // ... with MaxPool_2a inside the kernel when the caller asks for it (a frozen stem whose only consumer is the pool)
-        if (fam == DS_FAM_STEM && (options & DS_PLAN_STEM_POOL) && arith == DS_ARITH_F32 && stride == 2 &&
+        if (fam == DS_FAM_STEM && (options & DS_PLAN_STEM_POOL) && arith != DS_ARITH_F32X3 && stride == 2 &&
             ds_conv_stem_pool_supported(H, W))
             fam = DS_FAM_STEM_POOL;
     } else if (f32) {
@@ -281,8 +281,9 @@ extern "C" int ds_conv_run(const ds_conv_layer_plan *p, const void *x, const voi
             (const float *)x, (const float *)w, z, (d.flags & DS_EPI_STATS) ? io->stats : nullptr, io->pivot, d.N, d.H, d.W, p->w_cin,
             d.Cout, d.ldz, stream);
     case DS_FAM_STEM_POOL:
-        return ds_conv_stem_pool((const float *)x, (const float *)w, z, (d.flags & DS_EPI_STATS) ? io->stats : nullptr, io->pivot,
-                                 d.N, d.H, d.W, p->w_cin, d.Cout, d.ldz, stream);
+        return (d.dtype == DS_DTYPE_BF16 ? ds_conv_stem_pool_bf16 : ds_conv_stem_pool)(
+            (const float *)x, (const float *)w, z, (d.flags & DS_EPI_STATS) ? io->stats : nullptr, io->pivot, d.N, d.H, d.W, p->w_cin,
+            d.Cout, d.ldz, stream);
     case DS_FAM_BF16D: return ds_conv_bf16(&d, x, w, z, io->mask, io->stats, io->pivot, stream);
     case DS_FAM_F32X3: return ds_conv_f32x3(&d, (const float *)x, w, z, io->mask, io->stats, io->pivot, stream);
     case DS_FAM_FP8D:

@@ -74,11 +74,10 @@ __device__ __forceinline__ void ds_fmax(float *p, float v) {
 }
 
 template <bool BF, bool POOL = false>
-__global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemParams p) {
+__global__ __launch_bounds__(256, (BF && !POOL) ? 3 : 2) void conv_stem_kernel(const StemParams p) {
     // row blocks of 32 output pixels per wave: two on the fp32 matrix cores (every B fragment feeds two MFMAs); ONE for BF,
     // which is bound by the image reads and the stores: three waves per SIMD, no spills
     constexpr int NA = BF ? 1 : 2, TP = 128 * NA;
-    static_assert(!(BF && POOL), "the pooled stem is built for the fp32 kernel");
     // [dh][j][c][kh][co]; POOL: without the zero rows of pixel 7 ([dh][21 (j, c, kh)][co]); BF: [mfma][kh][co][8] bf16
     constexpr int WROW = POOL ? 21 * CO : 4 * 3 * 2 * CO;
     __shared__ __attribute__((aligned(16))) float wl[BF ? 11 * 2 * CO * 8 / 2 : 7 * WROW];
@@ -204,6 +203,7 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
     }
     // pooled row q (row pair index over the batch) lives in ring slot q % nslots; out: [N * PH][PW][64] = max of z
     int qf_slot = POOL ? qf % p.nslots : 0;
+    int qf_i = POOL ? qf % p.PH : 0;      // row qf's index inside its image
     auto flush_row = [&](int q) {
         float *slot = ring_s + qf_slot * (p.PW * CO);
         if (++qf_slot == p.nslots) qf_slot = 0;
@@ -298,6 +298,18 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
         }
     };
 
+    // after the barrier behind a tile's epilogue: the pooled rows whose last conv row has passed leave the ring
+    auto flush_done_rows = [&](int tile) {
+        const int done = min(mbase + (tile + 1) * TP, mlim);
+        while (qf < rp1) {                            // (uniform)
+            const int last = (qf_i == p.PH - 1) ? 2 : 3;
+            if ((2 * qf + last) * p.OW > done) break;
+            flush_row(qf);
+            ++qf;
+            if (++qf_i == p.PH) qf_i = 0;
+        }
+    };
+
     if constexpr (BF) {
         // Row pair t = kernel rows 2 t, 2 t + 1 (row 7 does not exist: zeros against zero weights).  Two pairs of requests are
         // always in flight -- across tiles too: the first two pairs of the NEXT tile are requested before this tile's last
@@ -350,15 +362,17 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
             }
         };
         Pix cu, nx;
-        int tile = blockIdx.x;
-        if (tile < p.tiles) {
+        // (POOL: this workgroup's own tiles 0 .. ntiles - 1 of its row-pair range instead of a stride over the batch)
+        const int tend = POOL ? ntiles : p.tiles, tstep = POOL ? 1 : (int)gridDim.x;
+        int tile = POOL ? 0 : (int)blockIdx.x;
+        if (tile < tend) {
             coords(tile, cu);
             issue(cu, 0, rawA);
             issue(cu, 1, rawB);
         }
-        for (; tile < p.tiles; tile += gridDim.x) {
-            const int ntile = tile + gridDim.x;
-            const bool more = ntile < p.tiles;          // (uniform)
+        for (; tile < tend; tile += tstep) {
+            const int ntile = tile + tstep;
+            const bool more = ntile < tend;          // (uniform)
             if (more) coords(ntile, nx);
             pack(0, rawA);
             issue(cu, 2, rawA);
@@ -376,9 +390,17 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
             if (more) issue(nx, 1, rawB);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(3, false);
-            epilogue(tile, acc);
+            if constexpr (POOL) {
+                if (tile > 0) __syncthreads();                // every wave is through the previous tile's row flush
+                pool_epilogue(tile, acc);
+                __syncthreads();                              // the tile's maxima are in the ring
+                flush_done_rows(tile);
+            } else {
+                epilogue(tile, acc);
+            }
             cu = nx;
         }
+        if constexpr (POOL) __syncthreads();                  // `red` below lies over the ring
     } else {
         // fp32: with two waves per SIMD the vector instructions between the MFMAs add to the matrix time (ablation builds,
         // profiles/r05_notes.md: the launch without any memory access still took 596 us against 392 us of matrix cycles), so
@@ -429,7 +451,6 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
         // the 128 stores -- was built (two copies of this body, the parity alternates with seven rows) and bought nothing: 677 us.
         Pix cN;                 // POOL: the next tile's coordinates (set inside run_tile, ahead of the epilogue)
         Cols oN;
-        int qf_i = POOL ? qf % p.PH : 0;      // POOL: row qf's index inside its image
         auto run_tile = [&](int tile, const Pix &c, const Cols &co) {
             constexpr int P = 0;
             f32x16 acc[2][2];
@@ -499,14 +520,7 @@ __global__ __launch_bounds__(256, BF ? 3 : 2) void conv_stem_kernel(const StemPa
             for (int tile = 0; tile < ntiles; ++tile) {
                 run_tile(tile, cA, oA);
                 __syncthreads();                              // the tile's maxima are in the ring
-                const int done = min(mbase + (tile + 1) * TP, mlim);
-                while (qf < rp1) {                            // (uniform) pooled rows whose last conv row has passed
-                    const int last = (qf_i == p.PH - 1) ? 2 : 3;
-                    if ((2 * qf + last) * p.OW > done) break;
-                    flush_row(qf);
-                    ++qf;
-                    if (++qf_i == p.PH) qf_i = 0;
-                }
+                flush_done_rows(tile);
                 // (the barrier that keeps the next tile's maxima off the rows being reset sits in front of its epilogue, a whole
                 // K loop away: nobody waits there)
                 cA = cN;
@@ -608,8 +622,9 @@ extern "C" int ds_conv_stem(const float *x, const float *w, float *z, float *sta
 // Conv2d_1a_7x7 + MaxPool_2a_3x3 (inception_v1.py:63-67) in one launch: zmax [N, OH/2, OW/2, 64] (pixel stride ldz) = the 3x3 / 2
 // SAME maximum of the conv output z, which is not written; stats = the column sums of the FULL map about the pivot,
 // float[2][64][ds_conv_stem_pool_partials(N, OH, OW)].  relu(rstd * zmax + shift) is the pooled activation (rstd > 0).
-extern "C" int ds_conv_stem_pool(const float *x, const float *w, float *zmax, float *stats, const float *pivot, int32_t N,
-                                 int32_t H, int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream) {
+namespace {
+int stem_pool_launch(bool bf, const float *x, const float *w, float *zmax, float *stats, const float *pivot, int32_t N,
+                     int32_t H, int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream) {
     DS_REQUIRE(x && w && zmax, "ds_conv_stem_pool: null argument");
     DS_REQUIRE(Cout == CO && (cin_store == 3 || cin_store == 4) && ldz >= CO && ldz % 4 == 0 && (((uintptr_t)zmax) & 15) == 0,
                "ds_conv_stem_pool: the 7x7/2 stem has 3 input and 64 output channels (16-byte aligned output rows)");
@@ -629,8 +644,21 @@ extern "C" int ds_conv_stem_pool(const float *x, const float *w, float *zmax, fl
     p.PH = p.OH / 2; p.PW = p.OW / 2;
     p.rp_total = N * p.PH;
     p.nslots = kRingFloats / (p.PW * CO);
-    hipLaunchKernelGGL((conv_stem_kernel<false, true>), dim3(stem_pool_grid(p.rp_total)), dim3(256), 0, (hipStream_t)stream, p);
-    return ds::check_launch("ds_conv_stem_pool");
+    if (bf) hipLaunchKernelGGL((conv_stem_kernel<true, true>), dim3(stem_pool_grid(p.rp_total)), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv_stem_kernel<false, true>), dim3(stem_pool_grid(p.rp_total)), dim3(256), 0, (hipStream_t)stream, p);
+    return ds::check_launch(bf ? "ds_conv_stem_pool_bf16" : "ds_conv_stem_pool");
+}
+}  // namespace
+
+extern "C" int ds_conv_stem_pool(const float *x, const float *w, float *zmax, float *stats, const float *pivot, int32_t N,
+                                 int32_t H, int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream) {
+    return stem_pool_launch(false, x, w, zmax, stats, pivot, N, H, W, cin_store, Cout, ldz, stream);
+}
+
+// ... and of ds_conv_stem_bf16 (the 16-bit configurations): operands rounded to bf16, bf16 MFMA, fp32 maxima
+extern "C" int ds_conv_stem_pool_bf16(const float *x, const float *w, float *zmax, float *stats, const float *pivot, int32_t N,
+                                      int32_t H, int32_t W, int32_t cin_store, int32_t Cout, int32_t ldz, void *stream) {
+    return stem_pool_launch(true, x, w, zmax, stats, pivot, N, H, W, cin_store, Cout, ldz, stream);
 }
 
 // The same layer for the 16-bit configurations: x and w rounded to bf16 (RNE), v_mfma_f32_32x32x16_bf16, fp32 accumulation.

@@ -47,6 +47,9 @@ def init_distributed(backend="nccl", device=None, **kwargs):
     if torch.cuda.is_available():
         from . import streams
         if device is not None:
+            # (a torch.device("cuda") without an index means the current device)
+            dev = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+            device = dev.index if dev.index is not None else torch.cuda.current_device()
             torch.cuda.set_device(device)
         streams.reserve(device)
         if backend == "nccl" and "device_id" not in kwargs:

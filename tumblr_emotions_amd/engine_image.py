@@ -443,10 +443,10 @@ class ConvStage(Stage):
         dev = self.eng.device
         eng = self.eng
         nxt = getattr(self, "next", None)
-        # Conv2d_1a_7x7 -> MaxPool_2a_3x3 in one kernel (ds_conv_stem_pool): a frozen fp32 stem whose BatchNorm + ReLU run
-        # behind the pool anyway (fuse_bn_pool) and whose backward sums come from the pooled tensors (bwd_sums)
-        self.layer.pool_inside = bool(self.layer.fold and eng.stem_pool and eng.stem_direct and eng.fuse_bn_pool and eng.bwd_sums
-                                      and eng.dtype == "f32" and not eng.act16 and not self.layer.trainable
+        # Conv2d_1a_7x7 -> MaxPool_2a_3x3 in one kernel (ds_conv_stem_pool / _bf16): a frozen stem whose BatchNorm + ReLU run
+        # behind the pool anyway (fuse_bn_pool); its backward sums come from the pooled tensors (PoolStage.alloc)
+        self.layer.pool_inside = bool(self.layer.fold and eng.stem_pool and eng.stem_direct and eng.fuse_bn_pool
+                                      and not eng.mul3 and not self.layer.trainable
                                       and isinstance(nxt, PoolStage) and nxt.k == 3 and nxt.stride == 2)
         self.layer.alloc(B)
         self.out16 = self.eng.act16 and not self.layer.fold       # Conv2d_2b / 2c (the stem's output is read by hip tests only)
@@ -507,7 +507,7 @@ class PoolStage(Stage):
         if inside:
             self.zmax = p.layer.z.view(B, self.H, self.W, self.C)
             nxt = getattr(self, "next", None)
-            if isinstance(nxt, ConvStage) and nxt.layer.k == 1 and not nxt.layer.trainable:
+            if isinstance(nxt, ConvStage) and nxt.layer.k == 1 and not nxt.layer.trainable and not o16:
                 probe = ops.LayerPlan(ops.DS_CONV_FWD, self.eng.arith, self.eng.plan_options(), B, self.H, self.W, self.C,
                                       nxt.layer.cout, 1, 1, self.C, nxt.layer.cout, DS_EPI_STATS)
                 self.raw = probe.norm_supported()
@@ -516,16 +516,17 @@ class PoolStage(Stage):
             self.out = self.zmax
         else:
             self.out = torch.empty(B, self.H, self.W, self.C, device=dev, dtype=torch.bfloat16 if o16 else torch.float32)
-        if inside and not self.raw:
-            self.apply_segs = make_segments([(0, self.C, self.out.data_ptr(), self.C)])
+        self.apply_segs = None           # (built at the first forward pass: the fp8 configuration prunes the max|.| records after alloc)
         self.dout = torch.empty(B, self.H, self.W, self.C, device=dev)
         self.argmax = torch.empty(B, self.H, self.W, self.C, dtype=torch.uint8, device=dev)
         self._own_amax = self.eng.new_amax()
         # the layers whose activation feeds nothing but this pool take their BatchNorm backward sums from the pooled
         # tensors (ConvBN._bn_bwd_sums)
-        if self.eng.bwd_sums:
+        if self.eng.bwd_sums or inside:          # (the pooled stem has nothing else to take them from, whatever the switch says)
             if isinstance(p, ConvStage) and self.k == 3 and self.stride == 2:
                 targets = [(p.layer, 0)]
+            elif not self.eng.bwd_sums:
+                targets = []
             elif isinstance(p, MixedStage):
                 pb0, _, pb1b, _, pb2b, _ = p.b
                 targets = [(p.fused, 0), (p.c1, pb0), (p.c2, pb0 + pb1b), (p.c3, pb0 + pb1b + pb2b)]
@@ -547,6 +548,9 @@ class PoolStage(Stage):
         p = self.prev
         if self.zmax is not None:        # the stem kernel pooled already
             if not self.raw:
+                if self.apply_segs is None:
+                    am = self._own_amax if getattr(self, "track_amax", True) else None
+                    self.apply_segs = make_segments([(0, self.C, self.out.data_ptr(), self.C, ops.act_dtype(self.out), ops._p(am))])
                 ops.bn_apply_relu(p.layer.z, self.B * self.H * self.W, self.C, self.rs[0], self.rs[1], self.apply_segs)
             return
         if getattr(p, "fused_into_pool", False):

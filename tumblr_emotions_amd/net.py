@@ -92,6 +92,7 @@ class SentimentNet:
         self.logits = None
         self._graph = None           # captured training step (capture_step)
         self._graph_key = None
+        self._eager_side_streams = None      # the image engine's one_side_stream before a capture narrowed it (release_graph)
 
     # ---- variables --------------------------------------------------------------------------------
     def initialize(self, seed=1):
@@ -358,11 +359,15 @@ class SentimentNet:
         keep = [b.clone() for b in (st.theta, st.m, st.v, st.frozen)]
         if self.image is not None and self.image.B != batch["images"].shape[0]:
             self.image.alloc(batch["images"].shape[0])
-        if self.image is not None and self.image.side_mode is None:
-            # the small-batch default (a side stream per branch chain) is for eager launches: hipStreamEndCapture of this
-            # ROCm (7.2) segfaults on the joint step captured with three chains joined per block (B = 32, real dims), and a
-            # replayed graph gains nothing from it (4.07 ms with one side stream)
-            self.image.one_side_stream = 1
+        if self.image is not None:
+            # the small-batch default (a side stream per branch chain, side_mode 0) is for eager launches: hipStreamEndCapture
+            # of this ROCm (7.2) segfaults on the joint step captured with three chains joined per block (B = 32, real dims),
+            # and a replayed graph gains nothing from it (4.07 ms with one side stream) -- whatever side_mode says, a captured
+            # step keeps ONE side stream; release_graph() restores the eager setting
+            if self._eager_side_streams is None:
+                self._eager_side_streams = self.image.one_side_stream
+            if self.image.one_side_stream == 0:
+                self.image.one_side_stream = 1
         # ... and of the BatchNorm pivots (each layer's previous batch mean), so that the first replayed step rounds
         # exactly like the eager step it replaces
         pivots = [] if self.image is None else [l.mean for l in self.image.layers]
@@ -389,3 +394,6 @@ class SentimentNet:
         self._graph = self._graph_key = None
         if self.image is not None:
             self.image.seed_dev = None       # eager steps and predict() take the host seed again
+            if self._eager_side_streams is not None:      # (capture_step may have narrowed it to one side stream)
+                self.image.one_side_stream = self._eager_side_streams
+                self._eager_side_streams = None
