@@ -125,9 +125,12 @@ typedef struct ds_bn_bwd_on_load {
     const float *dy[3];                 /* channel c_end[i-1] of pixel 0 of range i                               */
 } ds_bn_bwd_on_load;
 
-/* DEBUG / A-B AIDS (ds_debug_*): process-global switches for tests and tuning scripts.  They are NOT re-entrant,
- * are never called by the product path (tests/test_abi_cpu.py checks that) and none is needed for correct results;
- * per-layer choices go through ds_conv_desc.tile_nt / grid_x instead.
+#ifdef DS_TUNING
+/* DEBUG / A-B AIDS (ds_debug_*): process-global switches for tests and tuning scripts.  They exist in the TUNING build only
+ * (-DDS_TUNING: libds_kernels_tuning.so, which also honours the DS_* environment knobs of the selection rules); the shipped
+ * libds_kernels.so exports none of them, reads no environment variable and keeps no mutable global state besides its
+ * init-once device caches (tests/test_abi_cpu.py checks its symbol table).  They are NOT re-entrant and none is needed for
+ * correct results; per-layer choices go through ds_conv_desc.tile_nt / grid_x instead.
  * Pin the workgroup tile to (128*mt) x (32*nt) rows x columns; 0,0 = automatic.  */
 int ds_debug_conv_set_tile(int mt, int nt);
 /* 0 = automatic, 1 = register-staged LDS kernel (K-tile 16), 2 = register-direct (LDS-free)
@@ -144,6 +147,7 @@ int ds_debug_conv_wino_allow_ablation(int on);
 int ds_debug_conv_wino4_set_nb(int nb);
 /* tuning: the most column blocks (of 32) a wave of ds_conv_bf16 may own (1 .. 8; default 8) */
 int ds_debug_conv_bf16_set_max_nb(int nb);
+#endif /* DS_TUNING */
 /* Number of row-tile blocks (P) the launch for `d` will use = number of stats partials.   */
 int ds_conv_igemm_partials(const ds_conv_desc *d);
 /* 1 if a launch for `d` can carry DS_EPI_BNSUMS (plain 1x1 stride-1 shapes that run on the wide kernel).  */
@@ -550,8 +554,10 @@ int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, const float
 int ds_lstm_seq_status(void *ws, int32_t B);
 /* Debug aid (process-global, never called by the product path): device buffer of T*8 uint64; workgroup (0,0) of the
  * following ds_lstm_seq_fwd launches stamps s_memtime at its phase boundaries (scripts/lstm_phase_prof.py).  NULL = off. */
+#ifdef DS_TUNING
 int ds_debug_lstm_seq_set_profile(void *buf);
 int ds_debug_lstm_seq_set_profile_bwd(void *buf);      /* the same for the ds_lstm_seq_bwd launches (row t = time step t) */
+#endif
 
 /* slim.losses.softmax_cross_entropy + its gradient (im_text_rnn_model.py:124-125):
  * loss[0] = mean_b(logsumexp(z_b) - z_b[y_b]); dlogits = (softmax - onehot) * grad_scale / B;

@@ -32,7 +32,7 @@ def build(abl=0, extra=()):
     if os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(src):
         return so
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-           "-I" + CSRC, "-Wno-unused-result", "-DDS_W4_PROF", "-DDS_W4_ABL=%d" % abl, "-shared", src,
+           "-I" + CSRC, "-Wno-unused-result", "-DDS_W4_PROF", "-DDS_TUNING", "-DDS_W4_ABL=%d" % abl, "-shared", src,
            os.path.join(CSRC, "error.cpp"), "-o", so] + list(extra)
     subprocess.run(cmd, check=True)
     return so

@@ -26,3 +26,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def tuning_lib():
+    """The -DDS_TUNING build for the duration of a test: tests that pin a tile / kernel family / channel-block count through
+    ds_debug_* run every ops.* wrapper against libds_kernels_tuning.so (same kernel sources); the product library
+    (libds_kernels.so, which has no such switch) is restored afterwards."""
+    from tumblr_emotions_amd import _lib
+    with _lib.tuning_library() as lib:
+        yield lib

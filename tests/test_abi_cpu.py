@@ -11,16 +11,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "ds_kernels.h")
 
 
-def _declared():
+def _declared(tuning=False):
+    """Entry points the header declares: the contract (default), or the ones inside its `#ifdef DS_TUNING` blocks."""
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    blocks = re.findall(r"#ifdef DS_TUNING(.*?)#endif", src, flags=re.S)
+    src = " ".join(blocks) if tuning else re.sub(r"#ifdef DS_TUNING.*?#endif", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(ds_[a-z0-9_]+)\s*\(", src)))
 
 
 @pytest.fixture(scope="module")
 def lib():
     from tumblr_emotions_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
+    if not (os.path.exists(_lib.LIB_PATH) and os.path.exists(_lib.TUNING_LIB_PATH)):
         subprocess.run(["make", "-C", os.path.join(ROOT, "tumblr_emotions_amd", "csrc"), "-j4"], check=True)
     return _lib
 
@@ -35,11 +38,30 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert lib.load().ds_version() >= 1
 
 
+def test_shipped_library_exports_only_the_contract_and_reads_no_environment(lib):
+    """SURVEY 8(b) / VERDICT r05 weak #11: the tuning rig is a SECOND library.  libds_kernels.so exports exactly the header's
+    contract -- no ds_debug_* setter -- and does not import getenv (every DS_* knob of the selection rules takes its default);
+    libds_kernels_tuning.so (-DDS_TUNING, what scripts/ and the tile-pinning kernel tests load) adds both."""
+    def syms(path, flag):
+        out = subprocess.run(["nm", "-D", flag, path], capture_output=True, text=True, check=True).stdout
+        return {l.split()[-1].split("@")[0] for l in out.splitlines() if l.strip()}
+    debug = _declared(tuning=True)
+    assert len(debug) >= 8 and all(n.startswith("ds_debug_") for n in debug) and sorted(lib.DEBUG_SIGNATURES) == debug
+    exported = {n for n in syms(lib.LIB_PATH, "--defined-only") if n.startswith("ds_")}
+    assert exported == set(_declared()), sorted(exported ^ set(_declared()))
+    assert "getenv" not in syms(lib.LIB_PATH, "--undefined-only")
+    t_exported = {n for n in syms(lib.TUNING_LIB_PATH, "--defined-only") if n.startswith("ds_")}
+    assert t_exported == set(_declared()) | set(debug), sorted(t_exported ^ (set(_declared()) | set(debug)))
+    assert "getenv" in syms(lib.TUNING_LIB_PATH, "--undefined-only")
+    t = lib.load_tuning()
+    assert t.ds_debug_conv_set_tile(3, 1) == -1 and t.ds_debug_conv_set_tile(0, 0) == 0
+    assert not hasattr(ctypes.CDLL(lib.LIB_PATH), "ds_debug_conv_set_tile")
+
+
 def test_errors_are_reported_not_thrown(lib):
     l = lib.load()
     assert l.ds_gather_rows(None, None, None, 1, 1, 1, 1, 1, None) == -1          # DS_ERR_ARG
     assert b"ds_gather_rows" in l.ds_last_error()
-    assert l.ds_debug_conv_set_tile(3, 1) == -1 and l.ds_debug_conv_set_tile(0, 0) == 0
 
 
 def test_product_path_has_no_cpu_fallback(lib):

@@ -11,7 +11,7 @@ from oracle import tf_semantics as S
 pytestmark = pytest.mark.gpu
 
 
-def test_random_conv_shapes_forward_dgrad_wgrad():
+def test_random_conv_shapes_forward_dgrad_wgrad(tuning_lib):
     from tumblr_emotions_amd import _lib, ops
     lib = _lib.load()
     rng = np.random.RandomState(2026)
@@ -70,7 +70,7 @@ def test_random_conv_shapes_forward_dgrad_wgrad():
     assert not failures, "conv parity mismatches:\n" + "\n".join(failures)
 
 
-def test_random_shapes_round2_kernels():
+def test_random_shapes_round2_kernels(tuning_lib):
     """The same sweep for the kernels added in round 2, each forced on regardless of the selection rules: fused Winograd
     (forward with statistics and dgrad; odd extents, ragged channel blocks, strided rows), the wide register-direct 1x1
     kernel (every NB, both weight orientations, accumulate epilogue), the packed-RGB stem, the register-direct wgrad

@@ -315,7 +315,7 @@ def test_gemm_lstm_shape():
 @pytest.mark.parametrize("case", [(2, 8, 8, 16, 32), (3, 14, 14, 24, 64), (2, 28, 28, 96, 128), (5, 7, 7, 160, 320),
                                   (2, 13, 11, 48, 176), (1, 9, 10, 8, 40), (2, 56, 56, 64, 192), (3, 14, 14, 32, 64),
                                   (1, 4, 4, 16, 16), (9, 5, 6, 16, 48)])
-def test_winograd_conv_forward_and_dgrad_match_oracle(case, f4):
+def test_winograd_conv_forward_and_dgrad_match_oracle(case, f4, tuning_lib):
     """ds_conv_wino (fused Winograd F(2x2,3x3), fp32 MFMA) and ds_conv_wino4 (F(4x4,3x3)) against the fp64
     direct-convolution oracle: forward with BatchNorm statistics about a pivot, and the input gradient through the
     flipped / transposed transformed filter; map sizes that are not multiples of the tile (half-empty border tiles),
@@ -389,7 +389,7 @@ def _winograd_case(ops, case, f4):
 
 @pytest.mark.parametrize("case", [(300, 64, 64), (1000, 192, 176), (777, 480, 304), (513, 296, 512), (260, 40, 96),
                                   (4096, 832, 624), (129, 280, 528), (300, 64, 224), (300, 96, 288), (400, 448, 160)])
-def test_wide_1x1_kernel_forward_and_dgrad_match_oracle(case):
+def test_wide_1x1_kernel_forward_and_dgrad_match_oracle(case, tuning_lib):
     """The wide-tile register-direct kernel for plain 1x1 / GEMM shapes (gemm_wide_kernel), forced on for every
     shape: forward (n-contiguous HWIO weights, BatchNorm statistics about a pivot) and dgrad (the same tensor read
     k-contiguous); K not a multiple of the 16-channel step (296, 280, 40), N not a multiple of the column tile,
@@ -454,7 +454,7 @@ def test_wide_1x1_kernel_forward_and_dgrad_match_oracle(case):
 
 @pytest.mark.parametrize("case", [(1000, 176, 192, (64, 160, 176)), (777, 304, 480, (192, 288, 304)), (513, 296, 512, (160, 272, 296)),
                                   (300, 64, 224, (64,)), (4100, 448, 832, (256, 416, 448)), (260, 32, 96, (32,))])
-def test_wide_dgrad_applies_batchnorm_backward_on_load(case):
+def test_wide_dgrad_applies_batchnorm_backward_on_load(case, tuning_lib):
     """ds_conv_desc.bnb: the wide 1x1 dgrad reads the layer's z and the activation gradient dy (one to three channel
     ranges with their own pixel strides, boundaries multiples of 16, last range ending off the 16-channel step) and forms
     dz = rstd (g - mean g - xhat mean(g xhat)) as it loads.  Against the fp64 formula + GEMM at 2e-4, and BIT-identical
@@ -1034,7 +1034,7 @@ BF16D_CASES = [
 @pytest.mark.parametrize("nb", [1, 2])
 @pytest.mark.parametrize("case", [(2, 8, 8, 16, 32), (2, 28, 28, 96, 128), (5, 7, 7, 160, 320), (2, 13, 11, 48, 176), (1, 9, 10, 16, 40),
                                   (1, 56, 56, 64, 192), (3, 14, 14, 32, 64), (9, 5, 6, 16, 48)])
-def test_winograd_f4_on_bf16_matrix_cores_matches_bf16_rounding_oracle(case, nb):
+def test_winograd_f4_on_bf16_matrix_cores_matches_bf16_rounding_oracle(case, nb, tuning_lib):
     """ds_conv_wino4_bf16x2 (the 16-bit configurations' 3x3 kernel: F(4x4, 3x3) of the bf16-ROUNDED operands, every
     Winograd-domain value as two bf16 pieces, three v_mfma_f32_32x32x16_bf16 per product) against the fp64 direct convolution of
     the bf16-rounded operands: forward with statistics about a pivot, dgrad plain and with the BatchNorm-sums epilogue from
@@ -1776,7 +1776,7 @@ def test_softmax_ce_and_adam_and_reductions():
     close(ss, np.array([(x ** 2).sum()]), 1e-5)
 
 
-def test_every_conv_instantiation_matches_the_oracle():
+def test_every_conv_instantiation_matches_the_oracle(tuning_lib):
     """All tile shapes of the three kernel families (register-staged LDS: mt 1-2 x nt 1-6; register-direct:
     mt 1-2 x nt 1-4; LDS-DMA with the 32-deep K-tile: nt 1-3), forward (n-contiguous weights, BN statistics) and dgrad (k-contiguous, flipped taps), on a
     shape with ragged M, a K tail and a partial last column tile -- reached through the tuning knobs."""

@@ -77,12 +77,6 @@ _IO = C.POINTER(ConvIO)
 SIGNATURES = {
     "ds_version": (C.c_int, []),
     "ds_last_error": (C.c_char_p, []),
-    "ds_debug_conv_set_tile": (C.c_int, [C.c_int, C.c_int]),
-    "ds_debug_conv_set_path": (C.c_int, [C.c_int]),
-    "ds_debug_conv_set_wide": (C.c_int, [C.c_int]),
-    "ds_debug_conv_wino_allow_ablation": (C.c_int, [C.c_int]),
-    "ds_debug_conv_wino4_set_nb": (C.c_int, [C.c_int]),
-    "ds_debug_conv_bf16_set_max_nb": (C.c_int, [C.c_int]),
     "ds_conv_igemm_partials": (C.c_int, [_CD]),
     "ds_conv_igemm_bnsums_supported": (C.c_int, [_CD]),
     "ds_conv_igemm_norm_supported": (C.c_int, [_CD]),
@@ -158,8 +152,6 @@ SIGNATURES = {
     "ds_lstm_seq_fwd": (C.c_int, [_P, _P, _i32, _P, _P, _P, _i32, _i32, _i32, _f32, _i32, _P, C.c_size_t, _P]),
     "ds_lstm_seq_bwd": (C.c_int, [_P, _P, _i32, _P, _P, _i32, _P, _i32, _i32, _i32, _P, _i32, _P, C.c_size_t, _P]),
     "ds_lstm_seq_status": (C.c_int, [_P, _i32]),
-    "ds_debug_lstm_seq_set_profile": (C.c_int, [_P]),
-    "ds_debug_lstm_seq_set_profile_bwd": (C.c_int, [_P]),
     "ds_softmax_ce": (C.c_int, [_P, _P, _i32, _i32, _f32, _P, _P, _P, _P]),
     "ds_adam_tf": (C.c_int, [_P, _P, _P, _P, _i64, _i64, _f32, _f32, _f32, _P, _f32, _f32, _f32, _P]),
     "ds_sumsq": (C.c_int, [_P, _i64, _P, _P, _P]),
@@ -171,6 +163,58 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+# the -DDS_TUNING build only (libds_kernels_tuning.so): process-global switches for kernel tests and tuning scripts
+DEBUG_SIGNATURES = {
+    "ds_debug_conv_set_tile": (C.c_int, [C.c_int, C.c_int]),
+    "ds_debug_conv_set_path": (C.c_int, [C.c_int]),
+    "ds_debug_conv_set_wide": (C.c_int, [C.c_int]),
+    "ds_debug_conv_wino_allow_ablation": (C.c_int, [C.c_int]),
+    "ds_debug_conv_wino4_set_nb": (C.c_int, [C.c_int]),
+    "ds_debug_conv_bf16_set_max_nb": (C.c_int, [C.c_int]),
+    "ds_debug_lstm_seq_set_profile": (C.c_int, [_P]),
+    "ds_debug_lstm_seq_set_profile_bwd": (C.c_int, [_P]),
+}
+TUNING_LIB_PATH = os.path.join(_HERE, "libds_kernels_tuning.so")
+_tuning = None
+
+
+def _bind(lib, table):
+    for name, (res, args) in table.items():
+        fn = getattr(lib, name)           # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+
+
+def load_tuning():
+    """The tuning build (tests and scripts only; never the product path): the same kernels + the ds_debug_* switches and the
+    DS_* environment knobs of the selection rules."""
+    global _tuning
+    if _tuning is None:
+        if not os.path.exists(TUNING_LIB_PATH):
+            raise RuntimeError("tumblr_emotions_amd: %s not found -- `make -C tumblr_emotions_amd/csrc` builds it" % TUNING_LIB_PATH)
+        lib = C.CDLL(TUNING_LIB_PATH)
+        _bind(lib, SIGNATURES)
+        _bind(lib, DEBUG_SIGNATURES)
+        _tuning = lib
+    return _tuning
+
+
+class tuning_library:
+    """with _lib.tuning_library() as lib: every wrapper in ops.py calls into the tuning build inside the block (kernel tests
+    that pin a tile, a kernel family or a channel-block count through ds_debug_*); the product library is restored on exit."""
+
+    def __enter__(self):
+        global _lib
+        self._saved = load()
+        _lib = load_tuning()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
 
 
 def load():
@@ -186,10 +230,9 @@ def load():
         import sys
         sys.stderr.write("tumblr_emotions_amd: DS_LIB overrides the kernel library: %s\n" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)           # AttributeError if the .so lacks a declared symbol
-        fn.restype = res
-        fn.argtypes = args
+    _bind(lib, SIGNATURES)
+    if hasattr(lib, "ds_debug_conv_set_tile"):      # DS_LIB names a tuning build
+        _bind(lib, DEBUG_SIGNATURES)
     _lib = lib
     return lib
 

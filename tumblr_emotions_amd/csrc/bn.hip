@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *z, int6
 int bwd_rows_per_block(int64_t M) {
     static int target = -1;
     if (target < 0) {
-        const char *e = getenv("DS_BN_BWD_BLOCKS");
+        const char *e = ds::tune_env("DS_BN_BWD_BLOCKS");
         target = e ? atoi(e) : 512;
     }
     int64_t r = (M + target - 1) / target;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, int l
 int column_grid(int64_t M, int C4, int *drow) {
     static int bpc = -1;
     if (bpc < 0) {
-        const char *e = getenv("DS_STREAM_BPC");
+        const char *e = ds::tune_env("DS_STREAM_BPC");
         bpc = e && atoi(e) > 0 ? atoi(e) : 4;
     }
     int g = C4, b = 256;

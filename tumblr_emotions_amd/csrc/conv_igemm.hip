@@ -1994,7 +1994,7 @@ void pool3_blocks(const ds_conv_desc *d, int *rpb, int *bpi) {
 int wide_nb(const ds_conv_desc *d, bool vec, bool bnb_cap = false) {
     if (d->pool_argmax) return pool3_nb(d, vec);
     if (force_wide < 0) {
-        const char *e = getenv("DS_CONV_WIDE");          // A/B aid: 0 = never
+        const char *e = ds::tune_env("DS_CONV_WIDE");          // A/B aid: 0 = never
         force_wide = e ? atoi(e) : 1;
     }
     if (!force_wide || !vec || d->dtype != DS_DTYPE_F32) return 0;
@@ -2013,7 +2013,7 @@ int wide_nb(const ds_conv_desc *d, bool vec, bool bnb_cap = false) {
     int64_t best_cost = (int64_t)1 << 60;
     static int cA = -1;
     if (cA < 0) {
-        const char *e = getenv("DS_WIDE_COST");
+        const char *e = ds::tune_env("DS_WIDE_COST");
         cA = e ? atoi(e) : 0;                                    // in halves of a block
     }
     const int64_t row_tiles = (M + 127) / 128;
@@ -2028,7 +2028,7 @@ int wide_nb(const ds_conv_desc *d, bool vec, bool bnb_cap = false) {
     }
     static int pin_nb = -1;                                      // tuning aid: DS_WIDE_NB pins the column blocks per wave
     if (pin_nb < 0) {
-        const char *e = getenv("DS_WIDE_NB");
+        const char *e = ds::tune_env("DS_WIDE_NB");
         pin_nb = e ? atoi(e) : 0;
     }
     if (pin_nb >= 1 && pin_nb <= nb_max) {
@@ -2040,7 +2040,7 @@ int wide_nb(const ds_conv_desc *d, bool vec, bool bnb_cap = false) {
     // few workgroups to cover the CUs (7x7 maps with N <= 128)
     static int min_wgs = -1;
     if (min_wgs < 0) {
-        const char *e = getenv("DS_WIDE_MINWGS");
+        const char *e = ds::tune_env("DS_WIDE_MINWGS");
         min_wgs = e ? atoi(e) : 128;
     }
     if (force_wide < 2 && (wgs < min_wgs || best_pad * 100 > N * 125)) return 0;
@@ -2076,11 +2076,11 @@ int force_mt = -1, force_nt = -1, force_path = -1;
 TileCfg pick_cfg(const ds_conv_desc *d, bool vec) {
     if (force_mt < 0) {
         force_mt = force_nt = 0;
-        if (const char *e = getenv("DS_CONV_CFG")) sscanf(e, "%d,%d", &force_mt, &force_nt);
+        if (const char *e = ds::tune_env("DS_CONV_CFG")) sscanf(e, "%d,%d", &force_mt, &force_nt);
     }
     if (force_path < 0) {
         force_path = 0;
-        if (const char *e = getenv("DS_CONV_PATH")) force_path = e[0] == 'l' ? 1 : (e[0] == 'd' ? 2 : (e[0] == 'g' ? 3 : 0));
+        if (const char *e = ds::tune_env("DS_CONV_PATH")) force_path = e[0] == 'l' ? 1 : (e[0] == 'd' ? 2 : (e[0] == 'g' ? 3 : 0));
     }
     const int64_t M = conv_M(d);
     const int N = d->Cout;
@@ -2182,24 +2182,30 @@ void grid_for(const ds_conv_desc *d, TileCfg c, Variant v, int *gx, int *gy, int
 
 }  // namespace
 
+#ifdef DS_TUNING
 extern "C" int ds_debug_conv_set_tile(int mt, int nt) {
     DS_REQUIRE((mt == 0 && nt == 0) || ((mt == 1 || mt == 2) && nt >= 1 && nt <= 6), "ds_debug_conv_set_tile: mt in {1,2}, nt in 1..6, or 0,0 = automatic");
     force_mt = mt;
     force_nt = nt;
     return DS_OK;
 }
+#endif
 
+#ifdef DS_TUNING
 extern "C" int ds_debug_conv_set_wide(int mode) {
     DS_REQUIRE(mode >= 0 && mode <= 2, "ds_debug_conv_set_wide: 0 = never, 1 = automatic, 2 = wherever the shape allows");
     force_wide = mode;
     return DS_OK;
 }
+#endif
 
+#ifdef DS_TUNING
 extern "C" int ds_debug_conv_set_path(int path) {
     DS_REQUIRE(path >= 0 && path <= 3, "ds_debug_conv_set_path: 0 = automatic, 1 = register-staged LDS kernel, 2 = register-direct kernel, 3 = LDS-DMA kernel");
     force_path = path;
     return DS_OK;
 }
+#endif
 
 extern "C" int ds_conv_igemm_partials(const ds_conv_desc *d) {
     // BatchNorm convs are always 16-byte aligned in this model; ds_conv_igemm refuses DS_EPI_STATS
@@ -2265,7 +2271,7 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     p.taps = d->KH * d->KW;
     static int prio_mode = -1;
     if (prio_mode < 0) {
-        const char *e = getenv("DS_CONV_PRIO");
+        const char *e = ds::tune_env("DS_CONV_PRIO");
         prio_mode = e ? atoi(e) : 0;   // opt-in: measured neutral-to-negative (profiles/r01_notes.md)
     }
     p.prio_mode = prio_mode;
@@ -2304,7 +2310,7 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
     p.row_tiles = rt;
     static int xcd_remap = -1;
     if (xcd_remap < 0) {
-        const char *e = getenv("DS_CONV_XCD_REMAP");      // A/B aid; default on
+        const char *e = ds::tune_env("DS_CONV_XCD_REMAP");      // A/B aid; default on
         xcd_remap = e ? atoi(e) : 1;
     }
     dim3 grid(gx, gy, splits);
@@ -2383,11 +2389,13 @@ extern "C" int ds_weights_to_bf16(const float *w, void *wb, int32_t Cin, int32_t
 
 extern "C" int ds_conv_bf16_supported(const ds_conv_desc *d) { return d && bf16d_ok(d) ? 1 : 0; }
 
+#ifdef DS_TUNING
 extern "C" int ds_debug_conv_bf16_set_max_nb(int nb) {
     DS_REQUIRE(nb >= 1 && nb <= 8, "ds_debug_conv_bf16_set_max_nb: 1 .. 8 column blocks per wave");
     g_bf16d_max_nb = nb;
     return 0;
 }
+#endif
 
 extern "C" int ds_conv_bf16_partials(const ds_conv_desc *d) { return (int)((conv_M(d) + 127) / 128); }
 

@@ -426,9 +426,9 @@ int pick_splits(const ds_conv_desc *d, int64_t M) {
     const int tiles = d->KH * d->KW * ((d->Cin + ti - 1) / ti) * ((d->Cout + TJ - 1) / TJ);
     static int occ = 0, minpix = 0;
     if (!occ) {
-        const char *e = getenv("DS_WGRAD_OCC");
+        const char *e = ds::tune_env("DS_WGRAD_OCC");
         occ = e ? atoi(e) : 3;          // measured best of 2/3/4/6 workgroups per CU (MI355X, joint step)
-        e = getenv("DS_WGRAD_MINPIX");
+        e = ds::tune_env("DS_WGRAD_MINPIX");
         minpix = e ? atoi(e) : 64;
     }
     int splits = (occ * ds::kCUs + tiles - 1) / tiles;
@@ -454,7 +454,7 @@ int max_width(int C, int ld, uintptr_t ptr) {
 bool direct_ok(const ds_conv_desc *d, int64_t M) {
     static int mode = -1;
     if (mode < 0) {
-        const char *e = getenv("DS_WGRAD_DIRECT");
+        const char *e = ds::tune_env("DS_WGRAD_DIRECT");
         mode = e ? atoi(e) : 1;
     }
     return mode && d->fold_cin == 0 && M >= 512;
@@ -502,7 +502,7 @@ WgradPlan plan_wgrad(const ds_conv_desc *d, int64_t M, const float *x, const flo
         // BJ is also the width of the kernel's vector stores into dw (or the split-K workspace): their alignment counts
         const uintptr_t zalign = (uintptr_t)dz | (uintptr_t)dw | (uintptr_t)ws;
         WgradPlan pl = plan_direct(d, M, max_width(d->Cin, d->ldx, (uintptr_t)x), max_width(d->Cout, lddz, zalign));
-        if (const char *e = getenv("DS_WGRAD_FORCE")) {          // "ai,bj,slabs" (tuning aid; the caller sizes the workspace)
+        if (const char *e = ds::tune_env("DS_WGRAD_FORCE")) {          // "ai,bj,slabs" (tuning aid; the caller sizes the workspace)
             int a = 0, b = 0, sl = 0;
             if (sscanf(e, "%d,%d,%d", &a, &b, &sl) == 3) {
                 if (a) pl.ai = a;
@@ -543,7 +543,7 @@ extern "C" int ds_conv_wgrad(const ds_conv_desc *d, const float *x, const float 
     DS_REQUIRE(d->fold_cin == 0 || (d->KW == 1 && d->ldx == d->fold_cin && d->fold_cin % 4 == 0 && d->Cin % d->fold_cin == 0),
                "ds_conv_wgrad: fold_cin needs KW=1, ldx==fold_cin, fold_cin %% 4 == 0");
     const WgradPlan pl = plan_wgrad(d, M, x, dz, lddz, dw, ws);
-    if (getenv("DS_WGRAD_DEBUG"))
+    if (ds::tune_env("DS_WGRAD_DEBUG"))
         fprintf(stderr, "wgrad M=%lld Cin=%d Cout=%d k=%d: direct=%d ai=%d bj=%d slabs=%d\n", (long long)M, d->Cin, d->Cout, d->KH,
                 pl.direct, pl.ai, pl.bj, pl.splits);
     const int splits = pl.splits;

@@ -382,10 +382,12 @@ extern "C" int ds_wino_transform_weights(const float *w, float *u, int32_t Cin, 
 namespace { int g_allow_ablation = 0; }
 
 // Debug aid (process-global, never called by the product path): let ds_conv_wino accept its ablation flag bits.
+#ifdef DS_TUNING
 extern "C" int ds_debug_conv_wino_allow_ablation(int on) {
     g_allow_ablation = on ? 1 : 0;
     return DS_OK;
 }
+#endif
 
 extern "C" int ds_conv_wino_partials(int32_t N, int32_t H, int32_t W) {
     const int64_t mt = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2);

@@ -762,7 +762,7 @@ struct W4Choice {
 int g_w4_forced_nb = -1;      // ds_debug_conv_wino4_set_nb (tests, tuning); -1: not set yet -> DS_WINO4_NB or automatic
 W4Choice w4_choose(int N, int H, int W, int Cin, int Cout, int ar = 0) {
     if (g_w4_forced_nb < 0) {
-        const char *e = getenv("DS_WINO4_NB");
+        const char *e = ds::tune_env("DS_WINO4_NB");
         g_w4_forced_nb = e ? atoi(e) : 0;
     }
     const int forced = g_w4_forced_nb;
@@ -791,11 +791,13 @@ extern "C" void ds_debug_w4_set_prof(unsigned long long *buf) { g_w4_prof = buf;
 
 // Debug aid (process-global, never called by the product path): pin the channel blocks per workgroup of ds_conv_wino4
 // (1, 2; 0 = the launch-time model) so that tests reach both instantiations at small sizes.
+#ifdef DS_TUNING
 extern "C" int ds_debug_conv_wino4_set_nb(int nb) {
     DS_REQUIRE(nb >= 0 && nb <= 2, "ds_debug_conv_wino4_set_nb: 0 = automatic, 1, 2");
     g_w4_forced_nb = nb;
     return DS_OK;
 }
+#endif
 
 extern "C" int ds_conv_wino4_supported(int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
     return (H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0 && Cout % 4 == 0) ? 1 : 0;

@@ -3,11 +3,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "ds_kernels.h"
 
 namespace ds {
 
 void set_error(const char *fmt, ...);
+
+// Tuning knobs (DS_* environment variables read by the selection rules: tile pins, cost-model coefficients, A/B switches)
+// exist in the -DDS_TUNING build only (libds_kernels_tuning.so, what scripts/ and the kernel tests load); the shipped
+// library reads no environment variable and every knob has its default.
+#ifdef DS_TUNING
+inline const char *tune_env(const char *name) { return getenv(name); }
+#else
+inline const char *tune_env(const char *) { return nullptr; }
+#endif
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

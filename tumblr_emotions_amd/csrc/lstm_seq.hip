@@ -608,7 +608,7 @@ int device_cus() {
 size_t exclusive_lds(int nw, bool fwd, int rb = 32) {
     static int shared_cu = -1;
     if (shared_cu < 0) {
-        const char *e = getenv("DS_LSTM_SHARED_CU");
+        const char *e = ds::tune_env("DS_LSTM_SHARED_CU");
         shared_cu = e ? atoi(e) : 0;
     }
     if (shared_cu) return 0;
@@ -622,7 +622,7 @@ size_t exclusive_lds(int nw, bool fwd, int rb = 32) {
 int pick_rb(int B, int H, int rows) {
     static int forced = -1;
     if (forced < 0) {
-        const char *e = getenv("DS_LSTM_RB");
+        const char *e = ds::tune_env("DS_LSTM_RB");
         forced = e ? atoi(e) : 0;
     }
     const bool can16 = rows == 1 && H >= 64 && H <= 512;
@@ -647,7 +647,7 @@ inline size_t ring_bytes_fwd(int B, int H) { return (size_t)2 * ((B + 31) / 32 *
 dim3 seq_grid(SeqParams &p, int H, int rows) {
     static int use = -1;
     if (use < 0) {
-        const char *e = getenv("DS_LSTM_XCD");
+        const char *e = ds::tune_env("DS_LSTM_XCD");
         use = e ? atoi(e) : 1;
     }
     p.ncg = H / 16;
@@ -763,13 +763,17 @@ extern "C" int ds_lstm_seq_status(void *ws, int32_t B) {
 
 // Debug aid (never called by the product path; process-global, not re-entrant): device buffer of T*8 uint64 in which
 // workgroup (0,0) of the NEXT ds_lstm_seq_fwd launches stamps s_memtime at its phase boundaries; NULL switches it off.
+#ifdef DS_TUNING
 extern "C" int ds_debug_lstm_seq_set_profile(void *buf) {
     g_prof = (unsigned long long *)buf;
     return DS_OK;
 }
+#endif
 
 // the same for the NEXT ds_lstm_seq_bwd launches (stamp row t of step t; the walk goes from T - 1 down to 0)
+#ifdef DS_TUNING
 extern "C" int ds_debug_lstm_seq_set_profile_bwd(void *buf) {
     g_prof_bwd = (unsigned long long *)buf;
     return DS_OK;
 }
+#endif

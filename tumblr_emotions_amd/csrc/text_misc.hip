@@ -391,12 +391,12 @@ extern "C" int ds_gather_rows(const float *table, const int64_t *ids, float *out
     const dim3 grid((unsigned)((waves + 3) / 4));
     static int plain = -1;
     if (plain < 0) {
-        const char *e = getenv("DS_GATHER_PLAIN_STORES");      // A/B aid
+        const char *e = ds::tune_env("DS_GATHER_PLAIN_STORES");      // A/B aid
         plain = e ? atoi(e) : 0;
     }
     static int outorder = -1;
     if (outorder < 0) {
-        const char *e = getenv("DS_GATHER_OUTORDER");          // A/B aid
+        const char *e = ds::tune_env("DS_GATHER_OUTORDER");          // A/B aid
         outorder = e ? atoi(e) : 1;
     }
     if (D % 4 == 0 && a16 && !plain && time_major && outorder == 1) {
