@@ -106,7 +106,26 @@ typedef struct ds_conv_desc {
     /* reads); the pooled tensor itself never reaches memory.  z is bit-identical to ds_maxpool_fwd + the plain launch; the   */
     /* statistics partials group other rows (32-pixel blocks of whole image rows), so their sums differ in rounding.          */
     uint8_t *pool_argmax;
+    /* ds_bn_finalize INSIDE the conv launch (HOST pointer, nullable; DS_EPI_STATS launches of the wide 1x1 kernel with at most  */
+    /* 256 partials per channel, ds_conv_igemm_finalize_supported): see ds_bn_finalize_in_launch below.                       */
+    const struct ds_bn_finalize_in_launch *fin;
 } ds_conv_desc;
+
+/* slim.batch_norm's statistics epilogue without its own launch.  With small per-GPU batches a conv launch is one partial round
+ * of workgroups and the ds_bn_finalize launch behind it costs a dependent-launch boundary (~3 us) for ~1 us of work, 39 times
+ * per forward pass (BASELINE configs[3]: 32 samples per GPU).  With `fin` set, every workgroup publishes its partial
+ * write-through and takes a ticket of its COLUMN TILE (one relaxed agent-scope increment, no fence); the last arriver of a
+ * column tile reads that tile's P partials back and writes mean / rstd / shift (+ the moving averages) of its columns with
+ * ds_bn_finalize's own summation tree: bit-identical to the separate launch.  ticket: one zero-initialised uint32 per column
+ * tile (ds_conv_igemm_finalize_tickets), reset by the last arriver, NOT shared by launches that can run concurrently.     */
+typedef struct ds_bn_finalize_in_launch {
+    const float *beta;              /* Cout floats                                                                          */
+    float *mean, *rstd, *shift;     /* out, Cout floats each; `mean` may be the launch's pivot                                */
+    float *moving_mean, *moving_var; /* nullable: assign_moving_average with `decay`                                          */
+    uint32_t *ticket;
+    int64_t count;                  /* elements per channel (N * OH * OW; sync_bn callers finalize themselves)               */
+    float eps, decay;
+} ds_bn_finalize_in_launch;
 
 /* Conv2DBackpropInput of a 1x1 conv + BatchNorm + ReLU layer WITHOUT the separate ds_bn_bwd_apply pass (wide 1x1 kernel
  * only, ds_conv_igemm_bnb_supported): x holds the layer's pre-BatchNorm output z (pixel stride ldx, Cin = the layer's
@@ -160,6 +179,9 @@ int ds_conv_igemm_bnb_supported(const ds_conv_desc *d);
  * n-contiguous weights, W <= 32, Cin % 16 == 0, Cout <= 128 -- one column tile, so the pooling is done once).  Judged on
  * the shape alone: d->pool_argmax may still be null.                                                                  */
 int ds_conv_igemm_pool3_supported(const ds_conv_desc *d);
+/* ... and whether a DS_EPI_STATS launch for `d` would honour ds_conv_desc.fin (wide kernel, at most 256 partials); returns the
+ * number of ticket words the launch needs (its column tiles), 0 = not supported (the caller keeps ds_bn_finalize).        */
+int ds_conv_igemm_finalize_tickets(const ds_conv_desc *d);
 /* stats (DS_EPI_STATS): float[2][Cout][P] partial column sums of (z - pivot) and (z - pivot)^2.
  * pivot (nullable = 0): float[Cout], any value near the column mean -- the build passes the previous step's
  * batch mean (the moving mean after a restore) -- so that the fp32 partial sums carry the spread of z rather
@@ -369,6 +391,7 @@ typedef struct ds_conv_io {
     const float *pivot;      /* DS_EPI_STATS pivot                                                                       */
     const float *x_amax;     /* fp8: max|x| record of the activation operand                                             */
     const float *wscale;     /* fp8: the filter's scale record (ds_conv_prepare_weights)                                 */
+    const ds_bn_finalize_in_launch *fin;   /* nullable: ds_bn_finalize inside the launch (ds_conv_plan_finalize_tickets > 0)   */
 } ds_conv_io;
 int ds_conv_plan(ds_conv_layer_plan *plan, int32_t role, int32_t arith, uint32_t options, int32_t N, int32_t H, int32_t W,
                  int32_t w_cin, int32_t w_cout, int32_t k, int32_t stride, int32_t ldx, int32_t ldz, int32_t flags);
@@ -377,6 +400,7 @@ int ds_conv_plan_enable_bnsums(ds_conv_layer_plan *plan, int32_t ldy);
 int ds_conv_plan_norm_supported(const ds_conv_layer_plan *plan);
 int ds_conv_plan_bnb_supported(const ds_conv_layer_plan *plan);      /* would ds_conv_run take plan.d.bnb?                 */
 int ds_conv_plan_enable_pool3(ds_conv_layer_plan *plan, uint8_t *argmax);
+int ds_conv_plan_finalize_tickets(const ds_conv_layer_plan *plan);      /* > 0: ds_conv_run honours io.fin (that many ticket words) */
 int ds_conv_prepare_weights(const ds_conv_layer_plan *plan, const float *w_hwio, void *w_prepared, float *wscale,
                             void *stream);
 int ds_conv_run(const ds_conv_layer_plan *plan, const void *x, const void *w, float *z, const ds_conv_io *io, void *stream);

@@ -1568,6 +1568,54 @@ def test_branch3_max_pool_formed_on_load_equals_pool_then_conv(case):
     close(mean1, ref.mean(0), 1e-4)
 
 
+@pytest.mark.parametrize("case", [(20000, 1, 1, 192, 176, False), (24, 28, 28, 192, 32, True), (64, 14, 14, 480, 192, False),
+                                  (96, 14, 14, 528, 128, True), (130, 14, 14, 64, 64, False)])
+def test_batch_norm_finalize_inside_the_conv_launch_is_bit_identical(case):
+    """ds_conv_desc.fin / ds_conv_io.fin (ds_bn_finalize_in_launch): the last workgroup of a column tile to publish its
+    statistics partials finalizes that tile's columns inside the launch -- same summation tree as ds_bn_finalize, so mean /
+    rstd / shift and the moving averages have the bits of the separate launch; the tickets are left at zero (three launches
+    in a row, the pivot aliasing `mean` as in the engine); also through the pooling loader (Branch_3)."""
+    ops = _ops()
+    from tumblr_emotions_amd import _lib
+    N, H, W, K, Nc, pool = case
+    rng = np.random.RandomState(3 + K)
+    M = N * H * W
+    xt = dev(np.maximum(rng.normal(size=(N, H, W, K)), 0))
+    w = dev(rng.normal(size=(K, Nc)) * 0.1)
+    beta = dev(rng.normal(size=Nc) * 0.1)
+    res = []
+    for fused in (False, True):
+        plan = ops.LayerPlan(ops.DS_CONV_FWD, ops.DS_ARITH_F32, 0, N, H, W, K, Nc, 1, 1, K, Nc, ops.DS_EPI_STATS)
+        am = torch.empty(M, K, dtype=torch.uint8, device="cuda")
+        if pool:
+            assert plan.enable_pool3(am)
+        nt = plan.finalize_tickets()
+        assert nt > 0 and plan.partials <= 256
+        z = torch.empty(M, Nc, device="cuda")
+        stats = torch.zeros(2 * Nc * plan.partials, device="cuda")
+        mean = dev(rng.normal(size=Nc) * 0.0 + 0.05)                  # (the pivot of the first launch)
+        rstd, shift = torch.empty(Nc, device="cuda"), torch.empty(Nc, device="cuda")
+        mm, mv = torch.zeros(Nc, device="cuda"), torch.ones(Nc, device="cuda")
+        tickets = torch.zeros(nt, dtype=torch.int32, device="cuda")
+        f = _lib.BnFinalizeInLaunch()
+        f.beta, f.mean, f.rstd, f.shift = beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), shift.data_ptr()
+        f.moving_mean, f.moving_var, f.ticket, f.count, f.eps, f.decay = mm.data_ptr(), mv.data_ptr(), tickets.data_ptr(), M, 1e-3, 0.9997
+        for _ in range(3):
+            if fused:
+                plan.run(ops._p(xt), ops._p(w), ops._p(z), stats=ops._p(stats), pivot=ops._p(mean), fin=C.addressof(f))
+            else:
+                plan.run(ops._p(xt), ops._p(w), ops._p(z), stats=ops._p(stats), pivot=ops._p(mean))
+                ops.bn_finalize(stats, plan.partials, M, Nc, beta, 1e-3, 0.9997, mean, rstd, shift, mm, mv, pivot=mean)
+        torch.cuda.synchronize()
+        assert int(tickets.abs().sum()) == 0
+        res.append((z, mean, rstd, shift, mm, mv))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    zr = res[1][0].double().cpu().numpy()
+    close(res[1][1], zr.mean(0), 1e-5)
+    close(res[1][2], 1.0 / np.sqrt(zr.var(0) + 1e-3), 1e-5)
+
+
 @pytest.mark.parametrize("case", [(2, 17, 24), (3, 12, 64), (1, 30, 192)])
 def test_batch_norm_backward_from_the_pooled_gradient(case):
     """ds_bn_pool_bwd_reduce/_apply (BN+ReLU backward of a conv behind a 3x3/2 SAME pool, straight from the pool's

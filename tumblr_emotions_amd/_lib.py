@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
         ("tile_nt", C.c_int32), ("grid_x", C.c_int32), ("dtype", C.c_int32), ("x_dtype", C.c_int32),
         ("partials", C.c_int32),
         ("norm_rstd", C.c_void_p), ("norm_shift", C.c_void_p), ("mask_rstd", C.c_void_p), ("mask_shift", C.c_void_p),
-        ("bnb", C.c_void_p), ("mask_dtype", C.c_int32), ("pool_argmax", C.c_void_p),
+        ("bnb", C.c_void_p), ("mask_dtype", C.c_int32), ("pool_argmax", C.c_void_p), ("fin", C.c_void_p),
     ]
 
 
@@ -39,6 +39,13 @@ class BnBwdOnLoad(C.Structure):
     """ds_bn_bwd_on_load"""
     _fields_ = [("mean", C.c_void_p), ("rstd", C.c_void_p), ("shift", C.c_void_p), ("coef", C.c_void_p),
                 ("nseg", C.c_int32), ("c_end", C.c_int32 * 3), ("ld", C.c_int32 * 3), ("dy", C.c_void_p * 3)]
+
+
+class BnFinalizeInLaunch(C.Structure):
+    """ds_bn_finalize_in_launch"""
+    _fields_ = [("beta", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("shift", C.c_void_p),
+                ("moving_mean", C.c_void_p), ("moving_var", C.c_void_p), ("ticket", C.c_void_p), ("count", C.c_int64),
+                ("eps", C.c_float), ("decay", C.c_float)]
 
 
 class LayerPlanStruct(C.Structure):
@@ -51,7 +58,7 @@ class LayerPlanStruct(C.Structure):
 class ConvIO(C.Structure):
     """ds_conv_io"""
     _fields_ = [("bias", C.c_void_p), ("mask", C.c_void_p), ("stats", C.c_void_p), ("pivot", C.c_void_p),
-                ("x_amax", C.c_void_p), ("wscale", C.c_void_p)]
+                ("x_amax", C.c_void_p), ("wscale", C.c_void_p), ("fin", C.c_void_p)]
 
 
 class Segments(C.Structure):
@@ -82,6 +89,7 @@ SIGNATURES = {
     "ds_conv_igemm_norm_supported": (C.c_int, [_CD]),
     "ds_conv_igemm_bnb_supported": (C.c_int, [_CD]),
     "ds_conv_igemm_pool3_supported": (C.c_int, [_CD]),
+    "ds_conv_igemm_finalize_tickets": (C.c_int, [_CD]),
     "ds_conv_igemm": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ds_weights_bf16_bytes": (C.c_size_t, [_i32, _i32, _i32, _i32]),
     "ds_weights_to_bf16": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _P]),
@@ -123,6 +131,7 @@ SIGNATURES = {
     "ds_conv_plan_norm_supported": (C.c_int, [_LP]),
     "ds_conv_plan_bnb_supported": (C.c_int, [_LP]),
     "ds_conv_plan_enable_pool3": (C.c_int, [_LP, C.c_void_p]),
+    "ds_conv_plan_finalize_tickets": (C.c_int, [_LP]),
     "ds_conv_prepare_weights": (C.c_int, [_LP, _P, _P, _P, _P]),
     "ds_conv_run": (C.c_int, [_LP, _P, _P, _P, _IO, _P]),
     "ds_conv_wgrad_workspace": (C.c_size_t, [_CD]),

@@ -56,11 +56,7 @@ __device__ __forceinline__ float4 ldz4<__bf16>(const __bf16 *p) {
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+using ds::wave_sum_f64;
 
 // ---- forward ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *stats, int P, double inv_count, int C,

@@ -55,6 +55,8 @@ struct ConvParams {
     int col_total;               // conv_bf16d_kernel: columns of the converted weight tensor (Cout rounded up to 32)
     ds_bn_bwd_on_load bnb;       // gemm_wide_kernel<.., BNB = true>: copy of *d.bnb (the descriptor's pointer is a host pointer)
     int pool_rpb, pool_bpi;      // gemm_wide_kernel<.., POOL = true>: image rows per 32-pixel block, blocks per image
+    ds_bn_finalize_in_launch fin;      // gemm_wide_kernel: copy of *d.fin (fin.ticket == nullptr: the caller finalizes)
+    double fin_inv_count;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *p, unsigned bytes) {
@@ -1493,8 +1495,34 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
         for (int r = 0; r < 16; ++r)
             st_row(acc[b][r], vz, r);
         if ((flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) && tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
-            p.stats[(int64_t)(n0 + 32 * b + tid) * t0.stride + t0.row] = pss[b];
-            p.stats[((int64_t)d.Cout + n0 + 32 * b + tid) * t0.stride + t0.row] = pqq[b];
+            float *const sp = p.stats + (int64_t)(n0 + 32 * b + tid) * t0.stride + t0.row;
+            float *const qp = p.stats + ((int64_t)d.Cout + n0 + 32 * b + tid) * t0.stride + t0.row;
+            if (p.fin.ticket) {          // (uniform) read back by another workgroup of THIS launch: write-through
+                __hip_atomic_store(reinterpret_cast<unsigned *>(sp), __float_as_uint(pss[b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(reinterpret_cast<unsigned *>(qp), __float_as_uint(pqq[b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                *sp = pss[b];
+                *qp = pqq[b];
+            }
+        }
+    }
+    // ds_bn_finalize inside the launch (ds_conv_desc.fin): the last workgroup of a column tile to publish its partials
+    // finalizes the tile's columns -- one wave per column, bn_finalize_kernel's summation tree (ds_common.h) -- so the
+    // dependent ds_bn_finalize launch disappears.  Hand-off as in lstm_seq.hip: write-through payload, every storing wave
+    // drained, ONE relaxed agent-scope increment; no fence (a fence would write back the XCD's whole L2, z included).
+    if (p.fin.ticket && item && (flags & DS_EPI_STATS)) {
+        __builtin_amdgcn_s_waitcnt(0);          // this wave's partial stores are acknowledged
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.fin.ticket + t0.col, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            red[0] = old + 1 == (unsigned)p.row_tiles ? 1.f : 0.f;
+        }
+        __syncthreads();
+        if (red[0] != 0.f) {                     // (uniform)
+            const int cend = min(n0 + BN, d.Cout);
+            for (int c = n0 + wave; c < cend; c += 4)
+                ds::bn_finalize_channel_by_wave(p.stats, t0.stride, d.Cout, c, p.fin_inv_count, p.fin, p.pivot);
+            if (tid == 0) __hip_atomic_store(p.fin.ticket + t0.col, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -2241,6 +2269,21 @@ extern "C" int ds_conv_igemm_pool3_supported(const ds_conv_desc *d) {
     return pool3_nb(d, dims_vec(d)) > 0 ? 1 : 0;
 }
 
+extern "C" int ds_conv_igemm_finalize_tickets(const ds_conv_desc *d) {
+    // ds_bn_finalize inside the launch lives in the wide 1x1 kernel's epilogue: DS_EPI_STATS launches with at most 256
+    // partials per channel (one wave re-reads a column's partials with four loads per lane)
+    if (!d || !(d->flags & DS_EPI_STATS)) return 0;
+    ds_conv_desc t = *d;
+    t.partials = 0;
+    t.fin = nullptr;
+    const Variant v = {t.w_n_stride == 1 && t.w_k_stride != 1, t.fold_cin > 0, dims_vec(&t)};
+    const TileCfg c = pick_cfg(&t, v.vec);
+    if (!c.wide) return 0;
+    int gx, gy, rt;
+    grid_for(&t, c, v, &gx, &gy, &rt);
+    return rt <= 256 ? gy : 0;
+}
+
 extern "C" int ds_conv_igemm_bnb_supported(const ds_conv_desc *d) {
     // BatchNorm backward on load lives in the wide 1x1 kernel's loader, k-contiguous-weights (dgrad) instantiation
     if (!d || d->Cin > 1024 || (d->w_n_stride == 1 && d->w_k_stride != 1) || d->norm_rstd) return 0;
@@ -2333,6 +2376,16 @@ extern "C" int ds_conv_igemm(const ds_conv_desc *d, const float *x, const float 
                        "ds_conv_igemm: bnb channel range %d (16-byte aligned dy, ld %% 4 == 0, boundaries %% 16 == 0)", i);
         }
         p.bnb = b;
+    }
+    p.fin = ds_bn_finalize_in_launch{};
+    p.fin_inv_count = 0.0;
+    if (d->fin) {
+        DS_REQUIRE(c.wide && (d->flags & DS_EPI_STATS) && rt <= 256 && d->fin->ticket && d->fin->beta && d->fin->mean &&
+                       d->fin->rstd && d->fin->shift && d->fin->count > 0,
+                   "ds_conv_igemm: ds_conv_desc.fin needs a DS_EPI_STATS launch of the wide 1x1 kernel with at most 256 partials "
+                   "(ds_conv_igemm_finalize_tickets) and beta / mean / rstd / shift / ticket / count");
+        p.fin = *d->fin;
+        p.fin_inv_count = 1.0 / (double)d->fin->count;
     }
     p.pool_rpb = p.pool_bpi = 0;
     if (d->pool_argmax) {

@@ -237,6 +237,13 @@ extern "C" int ds_conv_plan_enable_pool3(ds_conv_layer_plan *p, uint8_t *argmax)
     return 1;
 }
 
+extern "C" int ds_conv_plan_finalize_tickets(const ds_conv_layer_plan *p) {
+    if (p == nullptr || p->role != DS_CONV_FWD || p->family != DS_FAM_IGEMM) return 0;
+    ds_conv_desc t = p->d;
+    t.flags |= DS_EPI_STATS;
+    return ds_conv_igemm_finalize_tickets(&t);
+}
+
 extern "C" int ds_conv_prepare_weights(const ds_conv_layer_plan *p, const float *w_hwio, void *w_prepared, float *wscale,
                                        void *stream) {
     PLAN_REQUIRE(p != nullptr, "ds_conv_prepare_weights: null plan");
@@ -265,6 +272,11 @@ extern "C" int ds_conv_run(const ds_conv_layer_plan *p, const void *x, const voi
     const ds_conv_desc &d = p->d;
     switch (p->family) {
     case DS_FAM_IGEMM:
+        if (io->fin && (d.flags & DS_EPI_STATS)) {      // ds_bn_finalize inside the launch
+            ds_conv_desc t = d;
+            t.fin = io->fin;
+            return ds_conv_igemm(&t, (const float *)x, (const float *)w, z, io->bias, io->mask, io->stats, io->pivot, stream);
+        }
         return ds_conv_igemm(&d, (const float *)x, (const float *)w, z, io->bias, io->mask, io->stats, io->pivot, stream);
     case DS_FAM_WINO2:
         return ds_conv_wino((const float *)x, (const float *)w, z, io->stats, io->pivot, io->mask, d.N, d.H, d.W, d.Cin,

@@ -77,6 +77,49 @@ __device__ __forceinline__ float amax_read(const float *record) {
     return m;
 }
 
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ds_bn_finalize of ONE channel by ONE wave, for P <= 256 partials: bn_finalize_kernel's summation tree (thread t of 256 takes
+// partial t, a butterfly per wave, then ((w0 + w1) + w2) + w3 in double) evaluated by 64 lanes, so the results have the bits of
+// the separate launch.  The partials are read with agent-scope loads (they were published write-through by other workgroups
+// of the SAME launch).  stats: [2][C][P].
+__device__ __forceinline__ void bn_finalize_channel_by_wave(const float *stats, int P, int C, int c, double inv_count,
+                                                           const ds_bn_finalize_in_launch &f, const float *pivot) {
+    const int lane = threadIdx.x & 63;
+    double sw[4], qw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int pidx = 64 * w + lane;
+        double s = 0.0, q = 0.0;
+        if (pidx < P) {
+            const unsigned *sp = reinterpret_cast<const unsigned *>(stats + (int64_t)c * P + pidx);
+            const unsigned *qp = reinterpret_cast<const unsigned *>(stats + ((int64_t)C + c) * P + pidx);
+            s = (double)__uint_as_float(__hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            q = (double)__uint_as_float(__hip_atomic_load(qp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        sw[w] = wave_sum_f64(s);
+        qw[w] = wave_sum_f64(q);
+    }
+    if (lane == 0) {
+        const double s = ((sw[0] + sw[1]) + sw[2]) + sw[3];
+        const double q = ((qw[0] + qw[1]) + qw[2]) + qw[3];
+        const double du = s * inv_count;
+        const double mu = du + (pivot ? (double)pivot[c] : 0.0);      // pivot may alias mean: read before the write below
+        double var = q * inv_count - du * du;          // biased variance (A3)
+        if (var < 0.0) var = 0.0;
+        const float r = (float)(1.0 / sqrt(var + (double)f.eps));
+        f.mean[c] = (float)mu;
+        f.rstd[c] = r;
+        f.shift[c] = f.beta[c] - (float)mu * r;
+        if (f.moving_mean) f.moving_mean[c] = f.decay * f.moving_mean[c] + (1.f - f.decay) * (float)mu;     // assign_moving_average
+        if (f.moving_var) f.moving_var[c] = f.decay * f.moving_var[c] + (1.f - f.decay) * (float)var;
+    }
+}
+
 // slim.batch_norm (scale = False) + ReLU backward for one element: dz from the layer's pre-BatchNorm z, the gradient dy of
 // its activation and the per-channel rstd r, shift s, mean mu, column means a1 = mean(g), a2 = mean(g xhat).  ONE
 // definition, explicit fused multiply-adds: ds_bn_bwd_apply and the wide dgrad's on-load form give the same bits.

@@ -18,7 +18,7 @@ import os
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .ops import WgradPlan, gemm_plan, make_segments, same_pad, DS_EPI_BIAS, DS_EPI_STATS
 
 BN_EPS = 0.001         # slim/nets/inception_utils.py:35
@@ -141,6 +141,19 @@ class ConvBN:
         self.z, self.ldz, self.rstd, self.shift, self.skip_apply = zview, ld, rstd, shift, True
         self.fwd.d.ldz = ld
 
+    def plan_finalize(self):
+        """ds_bn_finalize inside the forward conv launch where the library can (wide 1x1 kernel, at most 256 partials: the
+        small per-GPU batches, where a dependent launch costs more than its work).  Called once the plan is final
+        (MixedStage.alloc may still switch Branch_3's conv to the pooling loader)."""
+        eng = self.eng
+        self.fin = None
+        n = self.fwd.finalize_tickets() if eng.fuse_finalize else 0
+        if n > 0:
+            self.fin_tickets = torch.zeros(n, dtype=torch.int32, device=eng.device)
+            f = _lib.BnFinalizeInLaunch()
+            f.ticket, f.eps, f.decay = self.fin_tickets.data_ptr(), BN_EPS, BN_DECAY
+            self.fin = f
+
     def bind(self):
         st = self.eng.store
         self.w_ptr = _vp(st.ptr(self.key + "/weights"))
@@ -150,6 +163,10 @@ class ConvBN:
         self.mean.copy_(self.mm)          # first pivot of the batch statistics (ConvBN.forward)
         eng = self.eng
         self.stats_buf, self.bwdp_buf, self.ws_buf = eng.stats_set[self.slot], eng.bwdp_set[self.slot], eng.ws_set[self.slot]
+        self.plan_finalize()
+        if self.fin is not None:
+            f = self.fin
+            f.beta, f.mean, f.rstd, f.shift = self.beta.data_ptr(), self.mean.data_ptr(), self.rstd.data_ptr(), self.shift.data_ptr()
         self.gw_ptr = _vp(st.grad_ptr(self.key + "/weights")) if self.trainable else None
         self.gbeta = st.grad_view(self.key + "/BatchNorm/beta") if self.eng.trainable_bn_beta else None
 
@@ -321,14 +338,22 @@ class ConvBN:
             # the column sums are taken about a pivot near the mean -- the previous step's batch mean, the
             # moving mean before the first step (bind) -- so channels with |mean| >> std keep their variance
             plan.d.flags = DS_EPI_STATS
-            plan.run(x_ptr, self.w_ptr, ops._p(self.z), stats=ops._p(self.stats_buf), pivot=ops._p(self.mean), x_amax=amax_p)
+            fin = None
+            if self.fin is not None and not eng.sync_bn:      # ds_bn_finalize runs inside the conv launch (plan_finalize)
+                f = self.fin
+                f.count = self.M
+                f.moving_mean = self.mm.data_ptr() if eng.update_moving else None
+                f.moving_var = self.mv.data_ptr() if eng.update_moving else None
+                fin = C.addressof(f)
+            plan.run(x_ptr, self.w_ptr, ops._p(self.z), stats=ops._p(self.stats_buf), pivot=ops._p(self.mean), x_amax=amax_p, fin=fin)
             count = self.M
             if eng.sync_bn:       # statistics of the GLOBAL batch: every rank's partials are about the same pivot, so they add
                 eng.all_reduce(self.stats_buf[:2 * self.cout * plan.partials])
                 count = self.M * eng.sync_world
-            ops.bn_finalize(self.stats_buf, plan.partials, count, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
-                            self.rstd, self.shift, self.mm if eng.update_moving else None,
-                            self.mv if eng.update_moving else None, pivot=self.mean)
+            if fin is None:
+                ops.bn_finalize(self.stats_buf, plan.partials, count, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
+                                self.rstd, self.shift, self.mm if eng.update_moving else None,
+                                self.mv if eng.update_moving else None, pivot=self.mean)
         else:                  # moving statistics (is_training=False: evaluate_* on the validation split)
             plan.d.flags = 0
             plan.run(x_ptr, self.w_ptr, ops._p(self.z), x_amax=amax_p)
@@ -892,6 +917,11 @@ class InceptionV1Engine:
         self.mul3 = os.environ.get("DS_MUL3", "0") == "1"     # opt-in: forward 1x1 convs with fp32 products on the bf16 matrix cores
         self.bnb_on_load = int(os.environ.get("DS_BNB", "1"))      # BatchNorm backward formed by the 1x1 dgrad's loader: see ConvBN.make_dgrad
         self.zcat = os.environ.get("DS_ZCAT", "1") != "0"     # 3x3 / Branch_3 convs write z into the concat, consumers normalise on load
+        # ds_bn_finalize inside the conv launch where the library can (ConvBN.plan_finalize; ds_conv_desc.fin).  Built, bit-identical
+        # (tests), measured, OFF: the last arriver of a column tile re-reads up to 256 columns x 196 partials alone while the
+        # separate launch spreads them over one workgroup per channel -- B = 32: 3.89 -> 4.36 ms, B = 64: 5.29 -> 5.59
+        # (profiles/r06_notes.md).  DS_FUSE_FIN=1 switches it on (A/B)
+        self.fuse_finalize = os.environ.get("DS_FUSE_FIN", "0") == "1" 
         self.fuse_branch3 = os.environ.get("DS_FUSE_B3", "1") != "0"      # Branch_3's 3x3/1 max pool formed on load by its 1x1 conv (MixedStage.alloc)
         self.winograd4 = os.environ.get("DS_WINO4", "1") != "0"      # ... and ds_conv_wino4 (F(4x4,3x3)) where it is faster
         self.weights_version = 0     # bumped by SentimentNet.after_load(): frozen layers redo their G g G^T

@@ -288,6 +288,10 @@ class LayerPlan:
         self.pool_argmax = argmax            # (kept alive: the descriptor holds its address)
         return True
 
+    def finalize_tickets(self):
+        """> 0: ds_conv_run can run ds_bn_finalize INSIDE this launch (run(fin=...)); the number of ticket words it needs."""
+        return int(_lib.load().ds_conv_plan_finalize_tickets(self._ref))
+
     def enable_bn_backward_on_load(self, mean, rstd, shift, coef, parts):
         """Conv2DBackpropInput of a 1x1 conv + BatchNorm + ReLU layer straight from z and the activation gradient: the
         layer's ds_bn_bwd_apply pass is formed on load (ds_conv_desc.bnb).  parts: [(c0, c1, address, ld)] of dy.
@@ -306,12 +310,13 @@ class LayerPlan:
         self.d.bnb = C.addressof(b)
         return True
 
-    def run(self, x, w_hwio, z, stats=None, pivot=None, mask=None, bias=None, x_amax=None):
+    def run(self, x, w_hwio, z, stats=None, pivot=None, mask=None, bias=None, x_amax=None, fin=None):
+        """fin: address of a _lib.BnFinalizeInLaunch (ds_bn_finalize inside the launch, finalize_tickets() > 0) or None."""
         t = CONV_TIMER
         if t is not None:
             t.begin()
         io = self.io
-        io.stats, io.pivot, io.mask, io.bias, io.x_amax = stats, pivot, mask, bias, x_amax
+        io.stats, io.pivot, io.mask, io.bias, io.x_amax, io.fin = stats, pivot, mask, bias, x_amax, fin
         _lib.check(self._run(self._ref, x, w_hwio if self.u is None else self.u.data_ptr(), z, self._io_ref, _stream()),
                    "ds_conv_run")
         if t is not None:
