@@ -472,6 +472,12 @@ int ds_bn_bwd_finalize_segs(const ds_bn_sum_segments *sg, int64_t M, int32_t C, 
 /* Inception concat buffer is differentiated in place there                                                          */
 int ds_bn_bwd_apply(const float *z, int32_t ldz, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
                     const float *rstd, const float *shift, const float *coef, float *dz, float *amax, void *stream);
+/* The same with dz written to a SEPARATE bf16 tensor (pixel stride lddz) and z left as it is: the 16-bit configurations' 1x1  */
+/* input gradients (ds_conv_bf16 with x_dtype = DS_DTYPE_BF16) read 2 instead of 4 bytes per element and get exactly the values */
+/* they would have rounded on load (RNE), so Conv2DBackpropInput has the same bits                                            */
+int ds_bn_bwd_apply_bf16(const float *z, int32_t ldz, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
+                         const float *rstd, const float *shift, const float *coef, void *dz16, int32_t lddz, float *amax,
+                         void *stream);
 
 /* slim.max_pool2d SAME/VALID (inception_v1.py:67,79,94,118,208) with arg-max record, and MaxPoolGrad. */
 /* act_dtype: storage type of x AND y (DS_DTYPE_F32 / DS_DTYPE_BF16; max and arg-max are exact in either).   */

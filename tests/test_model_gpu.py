@@ -661,6 +661,32 @@ def test_bn_sums_from_dgrad_epilogues_equal_the_separate_reduce_pass():
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+def test_bf16_dz_storage_step_is_bit_identical(dtype):
+    """InceptionV1Engine.dz16 (16-bit configurations, default): BatchNorm's backward writes dz of the frozen 1x1 layers -- every
+    block's fused Branch_0/1/2 conv, Branch_3's conv, Conv2d_2b -- into a separate bf16 tensor (ds_bn_bwd_apply_bf16) and the
+    register-direct bf16 dgrad reads it as its 16-bit operand.  That kernel rounds dz to bf16 (RNE) as it loads anyway, so
+    logits, loss, every gradient and the updated parameters of two steps are BIT-identical to the fp32-dz form, and the
+    switch really changes the path."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    batch = to_device(synthetic_batch_numpy(16, 10, 50, seed=5))
+    res, used = [], []
+    for on in (True, False):
+        net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10, dtype=dtype)
+        net.image.dz16 = on
+        net.initialize(seed=7)
+        net.train_step(batch, 1e-3)
+        g1 = net.store.grad.clone()
+        net.train_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        used.append(sum(1 for l in net.image.layers if getattr(l, "dz16", None) is not None))
+        res.append((net.logits.detach().clone(), net.total_loss_value(), g1, net.store.grad.clone(), net.store.theta.clone()))
+    assert used[0] >= 17 and used[1] == 0, used
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
 def test_bn_sums_from_the_16_bit_dgrad_epilogues(dtype):
     """The bf16 / fp8 configurations (BASELINE configs[4]) carry the fp32 path's backward fusions since round 4: the
     register-direct bf16 / fp8 3x3 dgrads (and Conv2d_2c's) emit the consumer layers' BatchNorm sums (DS_EPI_BNSUMS, y

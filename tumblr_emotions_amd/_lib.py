@@ -144,6 +144,7 @@ SIGNATURES = {
     "ds_bn_bwd_finalize_segs": (C.c_int, [_SS, _i64, _i32, _P, _P, _P, _P]),
     "ds_bn_bwd_finalize": (C.c_int, [_P, _i32, _i64, _i32, _P, _P, _P]),
     "ds_bn_bwd_apply": (C.c_int, [_P, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _P, _P, _P]),
+    "ds_bn_bwd_apply_bf16": (C.c_int, [_P, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _P, _i32, _P, _P]),
     "ds_maxpool_fwd": (C.c_int, [_P, _P, _P] + [_i32] * 11 + [_P]),
     "ds_maxpool_bn_relu_fwd": (C.c_int, [_P, _P, _P, _P, _P] + [_i32] * 11 + [_P, _P]),
     "ds_bn_pool_bwd_partials": (C.c_int, [_i32, _i32, _i32, _i32]),

@@ -326,9 +326,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_segs_kernel(SumSegDev sg,
     }
 }
 
+// OUT16: dz goes to a SEPARATE bf16 tensor (pixel stride lddz) instead of over z -- the 16-bit configurations' 1x1 input
+// gradients read it with one 16-byte load per eight channels (conv_bf16d_kernel<.., XB = true>); the values are the ones that
+// kernel would have rounded on load (RNE), so the dgrad's result has the same bits
+template <bool OUT16>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, int ldz, SegDev dy, int64_t M, int C,
                                                            const float *mean, const float *rstd, const float *shift,
-                                                           const float *coef, float *dz, float *amax, int drow) {
+                                                           const float *coef, float *dz, float *amax, int drow, int lddz) {
     // (thread = one float4 column group, rows row0, row0 + drow, ...: see bn_apply_relu_kernel)
     const int C4 = C >> 2;
     const int t0 = blockIdx.x * 256 + threadIdx.x;
@@ -357,7 +361,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, int l
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = ds::bn_bwd_dz(zz[j], dd[j], rr[j], ss[j], mm[j], a1[j], a2[j]);
-            *reinterpret_cast<float4 *>(dz + (u ? row1 : row) * ldz + c) = make_float4(o[0], o[1], o[2], o[3]);
+            if (OUT16) {
+                const f32x4_t ov = {o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<bf16x4_t *>(reinterpret_cast<__bf16 *>(dz) + (u ? row1 : row) * lddz + c) = __builtin_convertvector(ov, bf16x4_t);
+            } else {
+                *reinterpret_cast<float4 *>(dz + (u ? row1 : row) * ldz + c) = make_float4(o[0], o[1], o[2], o[3]);
+            }
             am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
         }
     }
@@ -510,7 +519,21 @@ extern "C" int ds_bn_bwd_apply(const float *z, int32_t ldz, const ds_segments *d
     if (int e = check_segments(dy, C, "ds_bn_bwd_apply")) return e;
     int drow;
     const int grid = column_grid(M, C / 4, &drow);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, ldz, to_dev(dy), M, C, mean, rstd,
-                       shift, coef, dz, amax, drow);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, ldz, to_dev(dy), M, C, mean, rstd,
+                       shift, coef, dz, amax, drow, ldz);
     return ds::check_launch("ds_bn_bwd_apply");
+}
+
+extern "C" int ds_bn_bwd_apply_bf16(const float *z, int32_t ldz, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
+                                    const float *rstd, const float *shift, const float *coef, void *dz16, int32_t lddz,
+                                    float *amax, void *stream) {
+    DS_REQUIRE(z && mean && rstd && shift && coef && dz16 && M > 0 && C > 0 && C % 4 == 0 && ldz >= C && ldz % 4 == 0 &&
+                   lddz >= C && lddz % 4 == 0 && (((uintptr_t)z) & 15) == 0 && (((uintptr_t)dz16) & 7) == 0,
+               "ds_bn_bwd_apply_bf16: bad argument (need C %% 4 == 0, ldz / lddz >= C and %% 4 == 0, aligned z / dz)");
+    if (int e = check_segments(dy, C, "ds_bn_bwd_apply_bf16")) return e;
+    int drow;
+    const int grid = column_grid(M, C / 4, &drow);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, ldz, to_dev(dy), M, C, mean,
+                       rstd, shift, coef, reinterpret_cast<float *>(dz16), amax, drow, lddz);
+    return ds::check_launch("ds_bn_bwd_apply_bf16");
 }

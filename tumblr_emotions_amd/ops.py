@@ -595,6 +595,12 @@ def bn_bwd_finalize(partials, P, M, C_, dbeta, coef):
 
 
 def bn_bwd_apply(z, segs, M, C_, mean, rstd, shift, coef, dz, amax=None, ldz=0):
+    """dz: fp32 (over z, or any tensor with z's row stride), or a SEPARATE dense bf16 tensor [M, C] -- the form the 16-bit
+    configurations' 1x1 input gradients read (ds_bn_bwd_apply_bf16)."""
+    if dz.dtype == torch.bfloat16:
+        _lib.check(_lib.load().ds_bn_bwd_apply_bf16(_p(z), ldz or C_, C.byref(segs), M, C_, _p(mean), _p(rstd), _p(shift),
+                                                    _p(coef), _p(dz), dz.stride(0), _p(amax), _stream()), "ds_bn_bwd_apply_bf16")
+        return
     _lib.check(_lib.load().ds_bn_bwd_apply(_p(z), ldz or C_, C.byref(segs), M, C_, _p(mean), _p(rstd), _p(shift), _p(coef),
                                            _p(dz), _p(amax), _stream()), "ds_bn_bwd_apply")
 
