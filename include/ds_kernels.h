@@ -320,6 +320,10 @@ int ds_wino4_transform_weights_bf16x2(const float *w, void *u2, int32_t Cin, int
 int ds_conv_wino4_bf16x2(const float *x, const void *u2, float *z, float *stats, const float *pivot, const void *ymask,
                          int32_t y_dtype /* of ymask: DS_DTYPE_F32 / DS_DTYPE_BF16 (16-bit activation storage) */, int32_t N,
                          int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz, int32_t flags, void *stream);
+/* ... with x in 16-bit storage (ldx in bf16 elements; the bf16 dz of ds_bn_bwd_apply_bf16): same bits, half the pixel bytes */
+int ds_conv_wino4_bf16x2_x16(const void *x16, const void *u2, float *z, float *stats, const float *pivot, const void *ymask,
+                             int32_t y_dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz,
+                             int32_t flags, void *stream);
 
 /* ---- ONE conv-layer interface over the kernel families above (the product path's conv entry points) ---------------
  * slim.conv2d (image_model/inception_v1.py:63-250) and its Conv2DBackpropInput, described in TensorFlow's terms; the

@@ -1,0 +1,8 @@
+#!/bin/bash
+mkdir -p gpurun_out/r06h
+python -m pytest tests/test_model_gpu.py -x -q -k "bf16_dz or 16_bit_dgrad or bf16" 2>&1 | tail -8 > gpurun_out/r06h/t1.txt
+python -m pytest tests/test_kernels_gpu.py -x -q -k "winograd_f4_on_bf16" 2>&1 | tail -4 >> gpurun_out/r06h/t1.txt
+for i in 1 2 3; do for e in 2 1 0; do
+  DS_DZ16=$e python bench.py --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-gather --no-conv-timing 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bf16 dz16=$e', d['ms_per_step'])"
+done; done > gpurun_out/r06h/ab.txt 2>&1
+cat gpurun_out/r06h/*.txt

@@ -1091,6 +1091,15 @@ def test_winograd_f4_on_bf16_matrix_cores_matches_bf16_rounding_oracle(case, nb,
                                                 N, H, W, Co, Co, Ci, Ci + 4, ops.DS_EPI_BNSUMS, st) == 0
                 torch.cuda.synchronize()
                 assert torch.equal(dx2, dx)
+                # the same launch reading dy from 16-bit storage (ds_conv_wino4_bf16x2_x16: the bf16 dz of ds_bn_bwd_apply_bf16):
+                # the stored values are the ones the fp32 form rounds on load, so output and sums have the same bits
+                dy16 = dyd.to(torch.bfloat16)
+                sums16 = torch.full((2, Ci, P), float("nan"), device="cuda")
+                dx3 = torch.zeros(M, Ci + 4, device="cuda")
+                assert lib.ds_conv_wino4_bf16x2_x16(ops._p(dy16), ops._p(ud), ops._p(dx3), ops._p(sums16), None, ops._p(yd), dt,
+                                                    N, H, W, Co, Co, Ci, Ci + 4, ops.DS_EPI_BNSUMS, st) == 0
+                torch.cuda.synchronize()
+                assert torch.equal(dx3, dx) and torch.equal(sums16, sums)
                 gm = dx[:, :Ci].cpu().numpy().astype(np.float64) * (y_seen > 0)          # sums of what the kernel stored
                 close(sums[0].sum(1), gm.sum(0), 2e-3)
                 close(sums[1].sum(1), (gm * y_seen).sum(0), 2e-3)

@@ -124,6 +124,7 @@ SIGNATURES = {
     "ds_conv_wino4_partials": (C.c_int, [_i32, _i32, _i32]),
     "ds_conv_wino4": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "ds_conv_wino4_bf16x2": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
+    "ds_conv_wino4_bf16x2_x16": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "ds_wino4_transform_weights_bf16x2": (C.c_int, [_P, _P, _i32, _i32, _i32, _P]),
     "ds_conv_plan": (C.c_int, [_LP, _i32, _i32, C.c_uint32] + [_i32] * 10),
     "ds_conv_plan_set_flags": (C.c_int, [_LP, _i32]),

@@ -157,7 +157,7 @@ extern "C" int ds_conv_plan(ds_conv_layer_plan *out, int32_t role, int32_t arith
     }
     out->family = fam;
     out->a_format = dgrad ? DS_FP8_E5M2 : DS_FP8_E4M3;
-    out->x16_ok = (fam == DS_FAM_BF16D || fam == DS_FAM_FP8D) ? 1 : 0;
+    out->x16_ok = (fam == DS_FAM_BF16D || fam == DS_FAM_FP8D || fam == DS_FAM_WINO4H) ? 1 : 0;
     const int taps = k * k;
     switch (fam) {
     case DS_FAM_WINO2: out->w_bytes = 4LL * 16 * cin * cout; break;
@@ -285,6 +285,9 @@ extern "C" int ds_conv_run(const ds_conv_layer_plan *p, const void *x, const voi
         return ds_conv_wino4((const float *)x, (const float *)w, z, io->stats, io->pivot, io->mask, d.N, d.H, d.W, d.Cin,
                              d.ldx, d.Cout, d.ldz, d.flags, stream);
     case DS_FAM_WINO4H:
+        if (d.x_dtype == DS_DTYPE_BF16)
+            return ds_conv_wino4_bf16x2_x16(x, w, z, io->stats, io->pivot, io->mask, (d.flags & DS_EPI_BNSUMS) ? d.mask_dtype : DS_DTYPE_F32,
+                                            d.N, d.H, d.W, d.Cin, d.ldx, d.Cout, d.ldz, d.flags, stream);
         return ds_conv_wino4_bf16x2((const float *)x, w, z, io->stats, io->pivot, io->mask,
                                     (d.flags & DS_EPI_BNSUMS) ? d.mask_dtype : DS_DTYPE_F32, d.N, d.H, d.W, d.Cin, d.ldx, d.Cout, d.ldz,
                                     d.flags, stream);

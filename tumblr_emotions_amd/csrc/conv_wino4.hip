@@ -196,8 +196,12 @@ __device__ __forceinline__ void out1d(float m1, f32x4 m0, f32x4 a1, f32x4 a2, f3
 // matrix cycles at ~2^-16 relative accuracy in the transform domain.  V in LDS: [xi][piece][tile][16 ci] bf16 (the same 2 KB per
 // position), U: [xi][K step][piece][Cout][16 ci] bf16 (ds_wino4_transform_weights_bf16x2; the same bytes as the fp32 form).
 // Everything else -- tiles, roles, software pipeline, epilogue -- is the fp32 kernel's.
-template <int NB, bool BNS, bool EDGE, int AR = 0, bool Y16 = false>      // EDGE: H or W is not a multiple of four (partial last tile row / column); Y16: the BatchNorm-sums activation is stored as bf16
+// X16 (AR = 1 only): x itself is stored as bf16 (the 16-bit configurations' dz, ds_bn_bwd_apply_bf16): a channel pair is one
+// 4-byte load and already the rounded operand -- the same bits as rounding the fp32 tensor on load, half the pixel bytes
+template <int NB, bool BNS, bool EDGE, int AR = 0, bool Y16 = false, bool X16 = false>      // EDGE: H or W is not a multiple of four (partial last tile row / column); Y16: the BatchNorm-sums activation is stored as bf16
 __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p) {
+    static_assert(!X16 || AR == 1, "16-bit x storage goes with the bf16 matrix cores");
+    constexpr unsigned EB = X16 ? 2u : 4u;          // bytes per element of x
     // K loop: V[2][36][32 tiles][16 ci] = 144 KB; epilogue: M[36][32 co][32 tiles] = 144 KB
     __shared__ __attribute__((aligned(128))) float smem[36 * 32 * 32];
     __shared__ __attribute__((aligned(16))) float red[2 * 32 * 32];      // statistics exchange: [sum | sum of squares][tile][channel]
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     // for every tile and the pixel (py, px) of the patch is a wave-uniform, non-negative scalar offset from it.
     const int lt = tid >> 3, cp = tid & 7;
     const int64_t shift = (int64_t)(p.W + 1) * p.ldx;
-    const __amdgpu_buffer_rsrc_t srd_x = w4srd(p.x - shift, p.x_bytes + (unsigned)(shift * 4));
+    const __amdgpu_buffer_rsrc_t srd_x = w4srd(reinterpret_cast<const char *>(p.x) - shift * EB, p.x_bytes + (unsigned)(shift * EB));
     const __amdgpu_buffer_rsrc_t srd_u = w4srd(p.u, p.u_bytes);
     unsigned rowoff[6];         // patch row py: the tile's base offset, or out of range (row outside the image / no tile)
     bool cv[6];                 // patch column px inside the image
@@ -233,8 +237,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
         const int n = (tv ? m : 0) / tpi;
         const int r = (tv ? m : 0) - n * tpi;
         const int th = r / p.TW, tw = r - th * p.TW;
-        const unsigned vbase = (unsigned)(((n * p.H + 4 * th) * p.W + 4 * tw) * p.ldx + 2 * cp) * 4u;
-        const unsigned rowstep = (unsigned)(p.W * p.ldx) * 4u;
+        const unsigned vbase = (unsigned)(((n * p.H + 4 * th) * p.W + 4 * tw) * p.ldx + 2 * cp) * EB;
+        const unsigned rowstep = (unsigned)(p.W * p.ldx) * EB;
         // the patch ROW's offset rides in the lane's vector offset (six registers that exist anyway), so the scalar offset of
         // a request is only (patch column, channel step): six values per K step instead of thirty-six multiply-add pairs --
         // with one wave per SIMD every scalar instruction is an issue slot too (~150 s_mul / s_add per K step before)
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
             cv[k] = (unsigned)(4 * tw - 1 + k) < (unsigned)p.W;
         }
     }
-    const int pixstep = p.ldx * 4;
+    const int pixstep = p.ldx * (int)EB;
 
     // ---- matrix role: B fragment offsets (column li of channel block nb, channels 4 kh .. of an 8-channel half step) ----
     const int ksteps = p.Cin >> 4, nhalf = 2 * ksteps;
@@ -285,8 +289,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
         const int py = q / 6, px = q - py * 6;
         if ((DS_W4_ABL & 2) && c0 >= 32) return;
         // (patch columns 1 .. 4 are image columns 4 tw .. 4 tw + 3: inside the image unless the map has a partial last tile)
-        raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(srd_x, (cv[px] || (!EDGE && px >= 1 && px <= 4)) ? ro[py] : kOOB,
-                                                                                 px * pixstep + c0 * 4, 0));
+        const unsigned vo = (cv[px] || (!EDGE && px >= 1 && px <= 4)) ? ro[py] : kOOB;
+        if constexpr (X16) raw[q] = unpk_bf16(__builtin_amdgcn_raw_buffer_load_b32(srd_x, vo, px * pixstep + c0 * 2, 0));
+        else raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(srd_x, vo, px * pixstep + c0 * 4, 0));
     };
     // AR: a slot holds one POSITION of a K step (hi and lo piece per channel block), requested RP positions ahead
     constexpr int RP = NB == 1 ? 9 : DS_W4H_RP2;
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     f32x2 t[36];
     auto col_chunk = [&](int px) {
         if (DS_W4_ABL & 4) return;
-        if constexpr (AR == 1) {          // the convolution's operand is bf16(x)
+        if constexpr (AR == 1 && !X16) {          // the convolution's operand is bf16(x) (X16: stored that way)
 #pragma unroll
             for (int k = 0; k < 6; ++k) raw[6 * k + px] = unpk_bf16(pk_bf16(raw[6 * k + px]));
         }
@@ -832,10 +837,11 @@ extern "C" int ds_conv_wino4_partials(int32_t N, int32_t H, int32_t W) {
 
 namespace {
 int w4_launch(int ar, bool y16, const float *x, const float *u, float *z, float *stats, const float *pivot, const float *ymask,
-              int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz, int32_t flags, void *stream) {
+              int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz, int32_t flags, void *stream,
+              bool x16 = false) {
     DS_REQUIRE(x && u && z && N > 0, "ds_conv_wino4: bad argument");
     DS_REQUIRE(ds_conv_wino4_supported(H, W, Cin, Cout) && ldx >= Cin && ldx % 2 == 0 && ldz >= Cout && ldz % 4 == 0 && ((((uintptr_t)u) | ((uintptr_t)z)) & 15) == 0 &&
-                   (((uintptr_t)x) & 7) == 0 && (!(flags & DS_EPI_BNSUMS) || (((uintptr_t)ymask) & 15) == 0) &&
+                   (((uintptr_t)x) & (x16 ? 3 : 7)) == 0 && (!x16 || ar == 1) && (!(flags & DS_EPI_BNSUMS) || (((uintptr_t)ymask) & 15) == 0) &&
                    (!(flags & DS_EPI_STATS) || !pivot || (((uintptr_t)pivot) & 15) == 0),
                "ds_conv_wino4: needs Cin %% 16 == 0, Cout %% 4 == 0, even ldx, ldz %% 4 == 0, 8-byte aligned x, 16-byte aligned u / z / y / pivot");
     DS_REQUIRE((flags & ~(DS_EPI_STATS | DS_EPI_BNSUMS)) == 0 && (!(flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) || stats),
@@ -851,7 +857,7 @@ int w4_launch(int ar, bool y16, const float *x, const float *u, float *z, float 
     const int64_t xb = ((int64_t)N * H * W - 1) * ldx + Cin + (int64_t)(W + 1) * ldx, ub = (int64_t)36 * Cin * Cout;
     DS_REQUIRE(mt < (1ll << 30) && xb * 4 < (1ll << 31) && ub * 4 < (1ll << 31), "ds_conv_wino4: operand larger than 2 GiB");
     p.Mt = (int)mt;
-    p.x_bytes = (unsigned)((((int64_t)N * H * W - 1) * ldx + Cin) * 4);
+    p.x_bytes = (unsigned)((((int64_t)N * H * W - 1) * ldx + Cin) * (x16 ? 2 : 4));
     p.u_bytes = (unsigned)(ub * 4);
     const int64_t zb = ((int64_t)N * H * W - 1) * ldz + Cout;
     DS_REQUIRE(zb * 4 < (1ll << 31), "ds_conv_wino4: output larger than 2 GiB");
@@ -869,7 +875,9 @@ int w4_launch(int ar, bool y16, const float *x, const float *u, float *z, float 
     const bool edge = (H % 4) != 0 || (W % 4) != 0;
 #define DS_W4_LAUNCH(NBV, BNSV, EDGEV)                                                                          \
     do {                                                                                                        \
-        if (ar && BNSV && y16) hipLaunchKernelGGL((conv_wino4_kernel<NBV, BNSV, EDGEV, 1, BNSV>), grid, dim3(256), 0, st, p); \
+        if (ar && x16 && BNSV && y16) hipLaunchKernelGGL((conv_wino4_kernel<NBV, BNSV, EDGEV, 1, BNSV, true>), grid, dim3(256), 0, st, p); \
+        else if (ar && x16) hipLaunchKernelGGL((conv_wino4_kernel<NBV, BNSV, EDGEV, 1, false, true>), grid, dim3(256), 0, st, p); \
+        else if (ar && BNSV && y16) hipLaunchKernelGGL((conv_wino4_kernel<NBV, BNSV, EDGEV, 1, BNSV>), grid, dim3(256), 0, st, p); \
         else if (ar) hipLaunchKernelGGL((conv_wino4_kernel<NBV, BNSV, EDGEV, 1>), grid, dim3(256), 0, st, p);   \
         else hipLaunchKernelGGL((conv_wino4_kernel<NBV, BNSV, EDGEV, 0>), grid, dim3(256), 0, st, p);           \
     } while (0)
@@ -899,4 +907,14 @@ extern "C" int ds_conv_wino4_bf16x2(const float *x, const void *u2, float *z, fl
     DS_REQUIRE(y_dtype == DS_DTYPE_F32 || y_dtype == DS_DTYPE_BF16, "ds_conv_wino4_bf16x2: y_dtype must be DS_DTYPE_F32 or DS_DTYPE_BF16");
     return w4_launch(1, y_dtype == DS_DTYPE_BF16, x, (const float *)u2, z, stats, pivot, (const float *)ymask, N, H, W, Cin, ldx, Cout, ldz,
                      flags, stream);
+}
+
+// ... reading x from 16-bit storage (ldx in bf16 elements): the 3x3 input gradients of the 16-bit configurations from the bf16 dz
+// that ds_bn_bwd_apply_bf16 wrote; the same bits as ds_conv_wino4_bf16x2 on the fp32 tensor those values were rounded from
+extern "C" int ds_conv_wino4_bf16x2_x16(const void *x16, const void *u2, float *z, float *stats, const float *pivot, const void *ymask,
+                                        int32_t y_dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout,
+                                        int32_t ldz, int32_t flags, void *stream) {
+    DS_REQUIRE(y_dtype == DS_DTYPE_F32 || y_dtype == DS_DTYPE_BF16, "ds_conv_wino4_bf16x2_x16: y_dtype must be DS_DTYPE_F32 or DS_DTYPE_BF16");
+    return w4_launch(1, y_dtype == DS_DTYPE_BF16, (const float *)x16, (const float *)u2, z, stats, pivot, (const float *)ymask, N, H, W, Cin,
+                     ldx, Cout, ldz, flags, stream, true);
 }

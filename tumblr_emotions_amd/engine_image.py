@@ -298,12 +298,13 @@ class ConvBN:
         # (219 -> 190 us): the second A stream and ~8 VALU per element are redone for every column tile and cost the
         # matrix-bound dgrads 25-65 % (profiles/r04_bnb_layers.txt: all fifteen 1x1 shapes; the whole step 15.2 -> 16.0 ms
         # with it everywhere).  bnb_on_load: 1 = where it wins (default), 2 = every frozen 1x1 layer (tests), 0 = off
-        # 16-bit configurations: dz of a frozen 1x1 layer goes to a SEPARATE bf16 tensor (ds_bn_bwd_apply_bf16) when its dgrad runs
-        # on the register-direct bf16 kernel, which rounds dz to bf16 as it loads anyway: same bits, 2 B less written and 2 B less
-        # read per element on the step's widest gradient streams (the fused 1x1 layers' [M, b0 + b1a + b2a])
+        # 16-bit configurations: dz of a frozen layer goes to a SEPARATE bf16 tensor (ds_bn_bwd_apply_bf16) when its dgrad runs on
+        # the register-direct bf16 kernel (1x1) or on F(4x4) with bf16 pieces (3x3), both of which round dz to bf16 as they load
+        # anyway: same bits, 2 B less written and 2 B less read per element of every gradient stream of the frozen tower
         self.dz16 = None
-        if (eng.dz16 and eng.act16 and self.k == 1 and not self.trainable and self.dgrad.family == ops.DS_FAM_BF16D
-                and self.dgrad.x16_ok and self.ldz == self.cout and self.cout % 8 == 0):
+        fam_ok = (self.k == 1 and self.dgrad.family == ops.DS_FAM_BF16D and self.cout % 8 == 0) or \
+                 (self.k == 3 and self.dgrad.family == ops.DS_FAM_WINO4H and eng.dz16 >= 2)
+        if (eng.dz16 and eng.act16 and not self.trainable and fam_ok and self.dgrad.x16_ok and self.ldz == self.cout):
             self.dz16 = torch.empty(self.M, self.cout, device=eng.device, dtype=torch.bfloat16)
             self.dgrad.d.ldx = self.cout
         auto = self.cin <= 64 and self.cout <= 64
@@ -397,7 +398,7 @@ class ConvBN:
         if need_dx:
             self._run_dgrad(dx_ptr)
 
-    def _run_dgrad(self, dx_ptr):
+    def _run_dgrad(self, dx_ptr, use16=False):
         sums = ops._p(self.dx_sums) if self.dx_sums is not None else None
         y = ops._p(self.dx_y) if self.dx_sums is not None else None
         am = None
@@ -405,10 +406,11 @@ class ConvBN:
             am = self.dz_amax if self._dz_amax_live else self.amax[1]
             if not self._dz_amax_live:          # dz came from a kernel that does not track max|dz| (pooled BatchNorm backward)
                 ops.absmax(self.z, self.M * self.cout, am)
-        if self.dz16 is not None:
+        if use16:                # dz sits in its own bf16 tensor (backward(): ds_bn_bwd_apply_bf16)
             self.dgrad.d.x_dtype = ops.DS_DTYPE_BF16
             self.dgrad.run(ops._p(self.dz16), self.w_ptr, dx_ptr, mask=y, stats=sums, x_amax=ops._p(am))
             return
+        self.dgrad.d.x_dtype = ops.DS_DTYPE_F32
         self.dgrad.run(ops._p(self.z), self.w_ptr, dx_ptr, mask=y, stats=sums, x_amax=ops._p(am))
 
     def backward(self, x_ptr=None, ldx=0, dx_ptr=None, need_dx=True):
@@ -446,7 +448,7 @@ class ConvBN:
             else:
                 self.wgrad.run(x_ptr, ops._p(self.z), self.gw_ptr, ops._p(self.ws_buf), eng.ws_bytes)
         if need_dx:
-            self._run_dgrad(dx_ptr)
+            self._run_dgrad(dx_ptr, use16=self.dz16 is not None)
 
 
 class Stage:
@@ -935,7 +937,7 @@ class InceptionV1Engine:
         # separate launch spreads them over one workgroup per channel -- B = 32: 3.89 -> 4.36 ms, B = 64: 5.29 -> 5.59
         # (profiles/r06_notes.md).  DS_FUSE_FIN=1 switches it on (A/B)
         self.fuse_finalize = os.environ.get("DS_FUSE_FIN", "0") == "1"
-        self.dz16 = os.environ.get("DS_DZ16", "1") != "0"      # 16-bit configurations: bf16 dz for the frozen 1x1 layers (ConvBN.make_dgrad)
+        self.dz16 = int(os.environ.get("DS_DZ16", "2"))      # 16-bit configurations: bf16 dz for the frozen 1x1 (1) and 3x3 (2) layers (ConvBN.make_dgrad)
         self.fuse_branch3 = os.environ.get("DS_FUSE_B3", "1") != "0"      # Branch_3's 3x3/1 max pool formed on load by its 1x1 conv (MixedStage.alloc)
         self.winograd4 = os.environ.get("DS_WINO4", "1") != "0"      # ... and ds_conv_wino4 (F(4x4,3x3)) where it is faster
         self.weights_version = 0     # bumped by SentimentNet.after_load(): frozen layers redo their G g G^T
