@@ -1134,12 +1134,23 @@ __global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void conv_bf16_kernel(const C
 // With norm_rstd / norm_shift the maximum is taken over the raw z and relu(max * rstd + shift) applied once (rstd > 0), as
 // ds_maxpool_bn_relu_fwd does.  The winners' bytes are the only thing besides z that is written: the pooled tensor
 // (4 B per element out of the pool kernel and 4 B back into this one) never exists.
-template <int NB, bool BNMAJOR, bool BNB = false, bool POOL = false>
+// AST > 0 (round 6 experiment): the A operand through an AST-stage LDS-DMA ring instead of registers.  A wave
+// DMAs its own 32 rows x 16 channels of K step ks + AST - 1 (two 1 KB instructions, 16-byte chunks XOR-swizzled on the source
+// side so the fragment reads are conflict-free) while K step ks runs; B is DMA'd AST - 2 steps ahead into AST - 1 buffers.  One
+// in-order memory counter: a step issues its B DMAs first and its A DMAs last, and the step's barrier waits with
+// vmcnt(2 (AST - 2) + DJ (AST - 3)) -- everything but the youngest requests -- so an A tile has AST - 1 K steps to arrive
+// (today: under one).  Same MFMA sequence per output element: bit-identical to the register form.
+template <int N>
+__device__ __forceinline__ void barrier_keep_vm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); }
+
+template <int NB, bool BNMAJOR, bool BNB = false, bool POOL = false, int AST = 0>
 __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const ConvParams p) {
     constexpr int BN = NB * 32, WK = 16;                       // K step: 16 channels = two float4 per lane
     constexpr int DJ = (WK * BN / 4 + 255) / 256;              // 16-byte DMA slots per thread per K step: ceil(NB / 2)
     constexpr int BSZ = DJ * 1024;                             // floats per B buffer (odd NB: the last DMA is half used)
-    __shared__ __attribute__((aligned(128))) float smem[2 * BSZ + 256];
+    constexpr int BST = AST > 0 ? AST - 1 : 2;                 // B buffers
+    static_assert(AST == 0 || (AST >= 3 && !BNB && !POOL), "the A ring is built for the plain and the normalising loader");
+    __shared__ __attribute__((aligned(128))) float smem[BST * BSZ + 256 + AST * 2048];
     // BatchNorm + ReLU on load (ds_conv_desc.norm_rstd / norm_shift): rstd and shift of all Cin reduction channels;
     // BNB: rstd, shift, mean, coef[0], coef[1]
     __shared__ __attribute__((aligned(16))) float nrm[BNB ? 5 : 2][1024 + WK];
@@ -1253,8 +1264,11 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
         }
         return bytes;
     };
-    f32x4 a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, 0, 0));
-    f32x4 a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, 32, 0));
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (AST == 0) {
+        a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, 0, 0));
+        a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff, 32, 0));
+    }
     if constexpr (POOL) load_ud(0);
     // BNB: the gradient dy of the layer's activation, per channel range its own descriptor and row offset
     const ds_bn_bwd_on_load &bb = p.bnb;
@@ -1282,8 +1296,10 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
         d0 = load_dy(0, 0);
         d1 = load_dy(0, 1);
     }
+    if constexpr (AST == 0) {
 #pragma unroll
-    for (int i = 0; i < DJ; ++i) dma_b(0, 0, i);
+        for (int i = 0; i < DJ; ++i) dma_b(0, 0, i);
+    }
     const int ksteps = (K + WK - 1) / WK;
     // x holds pre-BatchNorm conv outputs: the A fragment becomes relu(x * rstd[k] + shift[k]) as it is loaded (two
     // packed multiply-adds and two packed max per float4, against 4 NB MFMAs); channels past Cin get (0, 0) -> 0
@@ -1322,7 +1338,7 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
         __builtin_amdgcn_raw_buffer_store_b32(w1, srd_am, vam, c0 + 8, 0);
     };
     if constexpr (POOL) pool_step(0);
-    if (norm) {
+    if (norm && AST == 0) {
         apply_norm(a0, 4 * kh);
         apply_norm(a1, 8 + 4 * kh);
     }
@@ -1330,7 +1346,77 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
         apply_bnb(a0, d0, 4 * kh);
         apply_bnb(a1, d1, 8 + 4 * kh);
     }
-    for (int ks = 0; ks < ksteps; ++ks) {
+    if constexpr (AST > 0) {
+        // ---- the A ring (see the template's comment) ---------------------------------------------------------------------
+        float *const ring = smem + BST * BSZ + 256;
+        unsigned aoff[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 16 * j + (lane >> 2), chunk = (lane & 3) ^ ((row >> 1) & 3);
+            const int mr = mrow0 + row;
+            aoff[j] = (item && mr < Mw) ? ((unsigned)mr * (unsigned)d.ldx + 4u * chunk) * 4u : kOOB;
+        }
+        auto dma_a = [&](int stage, int c0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_x, (lds_ptr)(ring + (stage * 4 + wave) * 512 + j * 256), 16, aoff[j], c0 * 4, 0, 0);
+        };
+        auto dma_b_all = [&](int buf, int c0) {
+#pragma unroll
+            for (int i = 0; i < DJ; ++i) dma_b(buf, c0, i);
+        };
+        // requests in the order of the steady state: ..., B(j + AST - 2), A(j + AST - 1), ...
+#pragma unroll
+        for (int j = -(AST - 1); j < 0; ++j) {
+            if (j + AST - 2 >= 0 && j + AST - 2 < ksteps) dma_b_all((j + AST - 2) % BST, (j + AST - 2) * WK);
+            if (j + AST - 1 < ksteps) dma_a((j + AST - 1) % AST, (j + AST - 1) * WK);
+        }
+        constexpr int KEEP = 2 * (AST - 2) + DJ * (AST - 3);
+        if (ksteps > AST - 1) barrier_keep_vm<KEEP>(); else barrier_keep_vm<0>();
+        int bst = 0, ast = 0;
+        const int swz = (li >> 1) & 3;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const float *ra = ring + (ast * 4 + wave) * 512 + li * 16;
+            a0 = *reinterpret_cast<const f32x4 *>(ra + ((kh ^ swz) * 4));
+            a1 = *reinterpret_cast<const f32x4 *>(ra + (((2 + kh) ^ swz) * 4));
+            if (norm) {
+                apply_norm(a0, ks * WK + 4 * kh);
+                apply_norm(a1, ks * WK + 8 + 4 * kh);
+            }
+            const float *b_s = smem + bst * BSZ;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float bf[8];
+                if (BNMAJOR) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bf[j] = b_s[(4 * kh + j) * BN + 32 * b + li];
+                        bf[4 + j] = b_s[(8 + 4 * kh + j) * BN + 32 * b + li];
+                    }
+                } else {
+                    const int nl = 32 * b + li, sw = (nl >> 2) & 3;
+                    const f32x4 lo = *reinterpret_cast<const f32x4 *>(b_s + nl * 16 + ((kh ^ sw) * 4));
+                    const f32x4 hi = *reinterpret_cast<const f32x4 *>(b_s + nl * 16 + (((2 + kh) ^ sw) * 4));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { bf[j] = lo[j]; bf[4 + j] = hi[j]; }
+                }
+                if (b == 0) {
+                    if (ks + AST - 2 < ksteps) dma_b_all((bst + AST - 2) % BST, (ks + AST - 2) * WK);
+                    if (ks + AST - 1 < ksteps) dma_a((ast + AST - 1) % AST, (ks + AST - 1) * WK);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bf[j], acc[b], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bf[4 + j], acc[b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ks + AST - 1 < ksteps) barrier_keep_vm<KEEP>(); else barrier_keep_vm<0>();
+            bst = bst + 1 == BST ? 0 : bst + 1;
+            ast = ast + 1 == AST ? 0 : ast + 1;
+        }
+    }
+    for (int ks = 0; AST == 0 && ks < ksteps; ++ks) {
         const bool more = ks + 1 < ksteps;
         const int cn = (ks + 1) * WK;
         const float *b_s = smem + (ks & 1) * BSZ;
@@ -1396,7 +1482,7 @@ __global__ __launch_bounds__(256, NB <= 4 ? 3 : 2) void gemm_wide_kernel(const C
     // accumulator registers; (2) all stores.  With the stores of block b in front of the reads of block b + 1 every
     // block cost a memory round trip (a load behind a store waits for it: one in-order counter).
     const int flags = d.flags;
-    float *red = smem + 2 * BSZ;
+    float *red = smem + BST * BSZ;
     // (outputs of 2 GiB and more stay on the LDS-tile kernels: wide_nb)
     // POOL: the descriptors end with this wave's last real row (Mw, wave-uniform), so the rows a 28-pixel block leaves
     // unused -- they would alias the NEXT block's pixels -- are dropped by the same range check as the rows past M
@@ -1976,6 +2062,27 @@ void launch_wide(int nb, bool bnmajor, bool bnb, dim3 grid, hipStream_t st, cons
         else hipLaunchKernelGGL((gemm_wide_kernel<2, false, true>), grid, dim3(256), 0, st, p);
         return;
     }
+    // round-6 experiment (tuning build only: DS_WIDE_RING = 3 / 4): the A operand through an LDS-DMA ring, NB = 2 .. 4.
+    // Bit-identical and SLOWER on the sixteen 1x1 shapes of the step (profiles/r06_wide_ring.txt: forward with statistics
+    // 1705 -> 1804 us at three stages / 1957 at four, dgrad with accumulate + sums 2138 -> 2172 / 2482): the ring's LDS caps
+    // the kernel at three (two) workgroups per CU where the register form runs seven waves per SIMD -- it lives on occupancy
+#ifdef DS_TUNING
+    static int ring = -1;
+    if (ring < 0) {
+        const char *e = ds::tune_env("DS_WIDE_RING");
+        ring = e ? atoi(e) : 0;
+    }
+    if ((ring == 3 || ring == 4) && nb >= 2 && nb <= 4) {
+#define DS_RING(NBV, ASTV)                                                                                                   \
+        if (nb == NBV && ring == ASTV) {                                                                                     \
+            if (bnmajor) hipLaunchKernelGGL((gemm_wide_kernel<NBV, true, false, false, ASTV>), grid, dim3(256), 0, st, p);   \
+            else hipLaunchKernelGGL((gemm_wide_kernel<NBV, false, false, false, ASTV>), grid, dim3(256), 0, st, p);          \
+            return;                                                                                                          \
+        }
+        DS_RING(2, 3) DS_RING(3, 3) DS_RING(4, 3) DS_RING(2, 4) DS_RING(3, 4) DS_RING(4, 4)
+#undef DS_RING
+    }
+#endif
 #define DS_WIDE(NBV)                                                                                      \
     case NBV:                                                                                             \
         if (bnmajor) hipLaunchKernelGGL((gemm_wide_kernel<NBV, true>), grid, dim3(256), 0, st, p);        \
