@@ -509,6 +509,18 @@ class ConvStage(Stage):
                 src = self.layer.emit_dx_sums(self.prev.out)
                 if src is not None:
                     self.prev.layer.part_sums[0] = (src[0], src[1], 0, self.prev.C)
+            # ... and Conv2d_2b's dgrad writes the gradient of MaxPool_2a's output.  Behind the pooled stem that IS the stem's
+            # whole backward input (sum over windows of dpool (ypool > 0), ConvBN._bn_bwd_sums): its epilogue emits the sums
+            # (y rebuilt from the raw window maxima where the pool's output holds those) and the reduce pass over the pooled
+            # tensors -- the last launch on the backward chain -- disappears
+            if isinstance(self.prev, PoolStage) and self.prev.zmax is not None and eng.stem_sums_from_dgrad:
+                stem = self.prev.prev.layer
+                src = self.layer.emit_dx_sums(self.prev.out)
+                if src is not None:
+                    if self.prev.raw:
+                        self.layer.dgrad.d.mask_rstd, self.layer.dgrad.d.mask_shift = stem.rstd.data_ptr(), stem.shift.data_ptr()
+                    stem.part_sums[0] = (src[0], src[1], 0, self.prev.C)
+                    stem._sum_segs = None
 
     def forward(self):
         # fused_into_pool: this conv feeds nothing but the next max pool, which then reads z and applies BN + ReLU
@@ -937,6 +949,7 @@ class InceptionV1Engine:
         # separate launch spreads them over one workgroup per channel -- B = 32: 3.89 -> 4.36 ms, B = 64: 5.29 -> 5.59
         # (profiles/r06_notes.md).  DS_FUSE_FIN=1 switches it on (A/B)
         self.fuse_finalize = os.environ.get("DS_FUSE_FIN", "0") == "1"
+        self.stem_sums_from_dgrad = os.environ.get("DS_STEM_SUMS", "1") != "0"      # pooled stem: its BatchNorm sums from Conv2d_2b's dgrad epilogue
         self.dz16 = int(os.environ.get("DS_DZ16", "2"))      # 16-bit configurations: bf16 dz for the frozen 1x1 (1) and 3x3 (2) layers (ConvBN.make_dgrad)
         self.fuse_branch3 = os.environ.get("DS_FUSE_B3", "1") != "0"      # Branch_3's 3x3/1 max pool formed on load by its 1x1 conv (MixedStage.alloc)
         self.winograd4 = os.environ.get("DS_WINO4", "1") != "0"      # ... and ds_conv_wino4 (F(4x4,3x3)) where it is faster
