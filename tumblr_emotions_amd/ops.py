@@ -131,12 +131,18 @@ class ConvTimer:
     def end(self, plan):
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
-        self.records.append((self._start, e, plan.alg_flops))
+        # (launches that also carry a max pool -- the stem with MaxPool_2a inside, the Branch_3 convs with the pooling loader --
+        # are marked: their time is conv + pool, their FLOPs the conv's)
+        d = getattr(plan, "d", None)
+        pooled = getattr(plan, "family", None) == DS_FAM_STEM_POOL or bool(getattr(d, "pool_argmax", None))
+        self.records.append((self._start, e, plan.alg_flops, pooled))
 
-    def summary(self):
-        """(launches, total_ms, total_flops) -- call after a device synchronise."""
-        ms = sum(s.elapsed_time(e) for (s, e, _) in self.records)
-        return len(self.records), ms, sum(f for (_, _, f) in self.records)
+    def summary(self, pooled=None):
+        """(launches, total_ms, total_flops) -- call after a device synchronise.  pooled: None = every launch, True / False =
+        only the launches with / without a max pool inside."""
+        recs = [r for r in self.records if pooled is None or r[3] == pooled]
+        ms = sum(s.elapsed_time(e) for (s, e, _, _) in recs)
+        return len(recs), ms, sum(f for (_, _, f, _) in recs)
 
 
 CONV_TIMER = None      # set to a ConvTimer to time the dominant kernel
