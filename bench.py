@@ -455,7 +455,7 @@ def main():
         net.image.branch_streams = False
     if args.side_mode >= 0 and net.image is not None:
         net.image.side_mode = args.side_mode
-    if os.environ.get("DS_WGRAD_SIDE") == "0" and net.image is not None:
+    if os.environ.get("DS_LIB") and os.environ.get("DS_WGRAD_SIDE") == "0" and net.image is not None:
         net.image.wgrad_side = False
     if args.no_bwd_sums and net.image is not None:
         net.image.bwd_sums = False

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_LIB=${DS_LIB:-$(cd $(dirname $0)/.. && pwd)/tumblr_emotions_amd/libds_kernels_tuning.so}      # the DS_* A/B switches are honoured beside the tuning build only
 mkdir -p gpurun_out/r06f
 python -m pytest tests/test_dp_gpu.py -x -q -k "bench_self" 2>&1 | tail -40 > gpurun_out/r06f/t0.txt
 python -m pytest tests/test_kernels_gpu.py -x -q -k "finalize_inside or branch3 or wide_1x1" 2>&1 | tail -12 > gpurun_out/r06f/t1.txt

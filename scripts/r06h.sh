@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_LIB=${DS_LIB:-$(cd $(dirname $0)/.. && pwd)/tumblr_emotions_amd/libds_kernels_tuning.so}      # the DS_* A/B switches are honoured beside the tuning build only
 mkdir -p gpurun_out/r06h
 python -m pytest tests/test_model_gpu.py -x -q -k "bf16_dz or 16_bit_dgrad or bf16" 2>&1 | tail -8 > gpurun_out/r06h/t1.txt
 python -m pytest tests/test_kernels_gpu.py -x -q -k "winograd_f4_on_bf16" 2>&1 | tail -4 >> gpurun_out/r06h/t1.txt

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_LIB=${DS_LIB:-$(cd $(dirname $0)/.. && pwd)/tumblr_emotions_amd/libds_kernels_tuning.so}      # the DS_* A/B switches are honoured beside the tuning build only
 mkdir -p gpurun_out/r06j
 python -m pytest tests/test_model_gpu.py tests/test_golden_gpu.py -x -q 2>&1 | tail -6 > gpurun_out/r06j/t1.txt
 for i in 1 2 3; do for e in 1 0; do

@@ -58,6 +58,23 @@ def test_shipped_library_exports_only_the_contract_and_reads_no_environment(lib)
     assert not hasattr(ctypes.CDLL(lib.LIB_PATH), "ds_debug_conv_set_tile")
 
 
+def test_python_engine_switches_are_inert_beside_the_product_library(lib, monkeypatch):
+    """The Python engine's A/B switches (DS_ZCAT, DS_FUSE_B3, DS_STEM_POOL, ...) go through _lib.tuning_env: honoured only when
+    DS_LIB selects a tuning build, like the C library's knobs; no other DS_* variable is read under tumblr_emotions_amd/."""
+    monkeypatch.delenv("DS_LIB", raising=False)
+    monkeypatch.setenv("DS_ZCAT", "0")
+    assert lib.tuning_env("DS_ZCAT", "1") == "1"
+    monkeypatch.setenv("DS_LIB", lib.TUNING_LIB_PATH)
+    assert lib.tuning_env("DS_ZCAT", "1") == "0"
+    pkg = os.path.join(ROOT, "tumblr_emotions_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                for m in re.finditer(r'os\.environ\.get\("(DS_[A-Z0-9_]+)"', text):
+                    assert m.group(1) == "DS_LIB", (os.path.join(dirpath, f), m.group(1))
+
+
 def test_errors_are_reported_not_thrown(lib):
     l = lib.load()
     assert l.ds_gather_rows(None, None, None, 1, 1, 1, 1, 1, None) == -1          # DS_ERR_ARG

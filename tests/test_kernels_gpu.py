@@ -1940,7 +1940,8 @@ def test_lstm_exchange_is_placement_independent():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = []
     for xcd in ("1", "0"):
-        env = dict(os.environ, DS_LSTM_XCD=xcd)
+        # (the knob exists in the tuning build only: the subprocess loads libds_kernels_tuning.so)
+        env = dict(os.environ, DS_LSTM_XCD=xcd, DS_LIB=os.path.join(root, "tumblr_emotions_amd", "libds_kernels_tuning.so"))
         r = subprocess.run([sys.executable, "-c", _LSTM_PLACEMENT_SCRIPT % root], env=env, capture_output=True, text=True,
                            timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]

@@ -10,6 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DS_LIB: an alternatively built library (kernel variants measured side by side on one box; tuning aid)
 LIB_PATH = os.environ.get("DS_LIB") or os.path.join(_HERE, "libds_kernels.so")
 
+def tuning_env(name, default=None):
+    """The Python engine's A/B switches (DS_ZCAT, DS_FUSE_B3, DS_STEM_POOL, ...): like the C library's knobs they are honoured
+    only beside the tuning build (DS_LIB set, scripts/_tuning.py); the product path reads none of them and runs the defaults."""
+    return os.environ.get(name, default) if os.environ.get("DS_LIB") else default
+
+
 DS_EPI_BIAS, DS_EPI_RELU, DS_EPI_ACCUM, DS_EPI_STATS, DS_EPI_MASK, DS_EPI_BNSUMS = 1, 2, 4, 8, 16, 32
 DS_DTYPE_F32, DS_DTYPE_BF16 = 0, 1
 DS_FP8_E4M3, DS_FP8_E5M2 = 0, 1

@@ -735,7 +735,7 @@ class MixedStage(Stage):
         # dependent read-add-store chain costs more than the pass it saves: bf16 step 12.5 -> 14.0 ms, profiles/r04_notes.md)
         # DS_POOL_FIRST_16=1 (A/B): also for the register-direct bf16 / fp8 dgrads -- 12.98 -> 13.45 ms at bf16 even with the
         # accumulate reads requested up front (14.0 before that): two waves per SIMD cannot hide a read-modify-write epilogue
-        fams = (ops.DS_FAM_IGEMM, ops.DS_FAM_BF16D, ops.DS_FAM_FP8D) if os.environ.get("DS_POOL_FIRST_16") == "1" else (ops.DS_FAM_IGEMM,)
+        fams = (ops.DS_FAM_IGEMM, ops.DS_FAM_BF16D, ops.DS_FAM_FP8D) if _lib.tuning_env("DS_POOL_FIRST_16") == "1" else (ops.DS_FAM_IGEMM,)
         self.pool_first = bool(eng.pool_first and self.fused.dgrad.family in fams)
         if isinstance(p, MixedStage) and self.pool_first:
             src = self.fused.emit_dx_sums(p.out)
@@ -932,27 +932,27 @@ class InceptionV1Engine:
         self.wgrad_stream = None
         self.bwd_sums = True         # BatchNorm backward sums from the producing dgrad's epilogue (DS_EPI_BNSUMS) where it can
         self.stem_direct = True      # Conv2d_1a_7x7 from the packed RGB batch (ds_conv_stem; False: generic kernel on a 4-channel copy)
-        self.stem_pool = os.environ.get("DS_STEM_POOL", "1") != "0"      # ... with MaxPool_2a inside that kernel (ds_conv_stem_pool; ConvStage.alloc)
+        self.stem_pool = _lib.tuning_env("DS_STEM_POOL", "1") != "0"      # ... with MaxPool_2a inside that kernel (ds_conv_stem_pool; ConvStage.alloc)
         self.branch_streams = True   # Mixed blocks: Branch_2 and Branch_3 on side streams next to Branch_0/1 (False: one stream)
         self.side = None
-        self.fp8_everywhere = os.environ.get("DS_FP8_EVERYWHERE", "0") == "1"      # A/B: ds_conv_fp8 also where the bf16 kernels are faster
-        self.fp8_wide_rule = os.environ.get("DS_FP8_RULE", "0") == "1"             # A/B: the wider round-4 rule (a plan option)
+        self.fp8_everywhere = _lib.tuning_env("DS_FP8_EVERYWHERE", "0") == "1"      # A/B: ds_conv_fp8 also where the bf16 kernels are faster
+        self.fp8_wide_rule = _lib.tuning_env("DS_FP8_RULE", "0") == "1"             # A/B: the wider round-4 rule (a plan option)
         self.bf16_direct = True      # dtype bf16: ds_conv_bf16 where it wins (False: the LDS-staged bf16 kernel everywhere)
         # bf16 / fp8: the 3x3 input gradients through ds_conv_wino4_bf16x2 where ds_conv_plan's table prefers it (DS_WINO16=0: A/B)
-        self.wino16 = os.environ.get("DS_WINO16", "1") != "0"
+        self.wino16 = _lib.tuning_env("DS_WINO16", "1") != "0"
         self.winograd = True         # 3x3 layers through ds_conv_wino where it wins (False: implicit GEMM everywhere)
-        self.mul3 = os.environ.get("DS_MUL3", "0") == "1"     # opt-in: forward 1x1 convs with fp32 products on the bf16 matrix cores
-        self.bnb_on_load = int(os.environ.get("DS_BNB", "1"))      # BatchNorm backward formed by the 1x1 dgrad's loader: see ConvBN.make_dgrad
-        self.zcat = os.environ.get("DS_ZCAT", "1") != "0"     # 3x3 / Branch_3 convs write z into the concat, consumers normalise on load
+        self.mul3 = _lib.tuning_env("DS_MUL3", "0") == "1"     # opt-in: forward 1x1 convs with fp32 products on the bf16 matrix cores
+        self.bnb_on_load = int(_lib.tuning_env("DS_BNB", "1"))      # BatchNorm backward formed by the 1x1 dgrad's loader: see ConvBN.make_dgrad
+        self.zcat = _lib.tuning_env("DS_ZCAT", "1") != "0"     # 3x3 / Branch_3 convs write z into the concat, consumers normalise on load
         # ds_bn_finalize inside the conv launch where the library can (ConvBN.plan_finalize; ds_conv_desc.fin).  Built, bit-identical
         # (tests), measured, OFF: the last arriver of a column tile re-reads up to 256 columns x 196 partials alone while the
         # separate launch spreads them over one workgroup per channel -- B = 32: 3.89 -> 4.36 ms, B = 64: 5.29 -> 5.59
         # (profiles/r06_notes.md).  DS_FUSE_FIN=1 switches it on (A/B)
-        self.fuse_finalize = os.environ.get("DS_FUSE_FIN", "0") == "1"
-        self.stem_sums_from_dgrad = os.environ.get("DS_STEM_SUMS", "1") != "0"      # pooled stem: its BatchNorm sums from Conv2d_2b's dgrad epilogue
-        self.dz16 = int(os.environ.get("DS_DZ16", "2"))      # 16-bit configurations: bf16 dz for the frozen 1x1 (1) and 3x3 (2) layers (ConvBN.make_dgrad)
-        self.fuse_branch3 = os.environ.get("DS_FUSE_B3", "1") != "0"      # Branch_3's 3x3/1 max pool formed on load by its 1x1 conv (MixedStage.alloc)
-        self.winograd4 = os.environ.get("DS_WINO4", "1") != "0"      # ... and ds_conv_wino4 (F(4x4,3x3)) where it is faster
+        self.fuse_finalize = _lib.tuning_env("DS_FUSE_FIN", "0") == "1"
+        self.stem_sums_from_dgrad = _lib.tuning_env("DS_STEM_SUMS", "1") != "0"      # pooled stem: its BatchNorm sums from Conv2d_2b's dgrad epilogue
+        self.dz16 = int(_lib.tuning_env("DS_DZ16", "2"))      # 16-bit configurations: bf16 dz for the frozen 1x1 (1) and 3x3 (2) layers (ConvBN.make_dgrad)
+        self.fuse_branch3 = _lib.tuning_env("DS_FUSE_B3", "1") != "0"      # Branch_3's 3x3/1 max pool formed on load by its 1x1 conv (MixedStage.alloc)
+        self.winograd4 = _lib.tuning_env("DS_WINO4", "1") != "0"      # ... and ds_conv_wino4 (F(4x4,3x3)) where it is faster
         self.weights_version = 0     # bumped by SentimentNet.after_load(): frozen layers redo their G g G^T
         self._stats_n = self._bwdp_n = self._ws_bytes = 0
         self.B = None

@@ -152,7 +152,7 @@ def head_gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=False, flags=0, ldmask=
     """gemm_plan for the batch x features GEMMs of the heads (Logits, W_fc, W_softmax and their dgrads): with M <= 512 rows
     and K >= 256 a SplitGemm (split-K + fixed-order combine with the epilogue), else the plain plan.  DS_SPLIT_GEMM=0: always
     the plain plan (A/B aid).  `device`: the engine's device (the slabs live beside its tensors, not on the current device)."""
-    if M <= 512 and K >= 256 and os.environ.get("DS_SPLIT_GEMM", "1") != "0":
+    if M <= 512 and K >= 256 and _lib.tuning_env("DS_SPLIT_GEMM", "1") != "0":
         return SplitGemm(M, K, N, lda, ldc, w_ld, transposed_w, flags, ldmask, 8 if K >= 512 else 4, device)
     return gemm_plan(M, K, N, lda, ldc, w_ld, transposed_w=transposed_w, flags=flags, ldmask=ldmask)
 

@@ -17,10 +17,12 @@ import os
 
 import torch
 
+from . import _lib
+
 _ORDER = ("side1", "text", "comm", "side0")
 _by_device = {}      # device index -> {role: stream}
 # (A/B aid, measured neutral: DS_TEXT_PRIO=1 gives the text stream high priority)
-_PRIORITY = {"text": -1 if os.environ.get("DS_TEXT_PRIO", "0") == "1" else 0}
+_PRIORITY = {"text": -1 if _lib.tuning_env("DS_TEXT_PRIO", "0") == "1" else 0}
 
 
 def _index(device):
@@ -42,7 +44,7 @@ def reserve(device=None):
     dev = torch.device("cuda", idx)
     touch = torch.zeros(64, device=dev)
     touch.add_(1.0)                                   # the main (current) stream submits first
-    plan = os.environ.get("DS_STREAM_PLAN")           # experiment aid: creation order, "x" = a dummy stream
+    plan = _lib.tuning_env("DS_STREAM_PLAN")           # experiment aid: creation order, "x" = a dummy stream
     order = tuple(plan.split(",")) if plan else _ORDER
     for name in order:
         s = torch.cuda.Stream(device=dev, priority=_PRIORITY.get(name, 0))
