@@ -547,6 +547,13 @@ int ds_lstm_cell_bwd(const float *acts, const float *c_t, const float *c_prev, c
                      const int64_t *seq_len, int32_t t, int32_t B, int32_t H, float *dgates, float *dc_prev,
                      float *dh_carry, void *stream);
 
+/* Length-sorted batches for the text tower (round 6).  ds_seq_sort_desc: perm[j] = the sample that takes sorted position j
+ * (descending length, ties by ascending index: deterministic), len_sorted[j] = min(seq_len[perm[j]], T); one small launch,
+ * B <= 4096.  ds_permute_rows: dst row j = src row perm[j] (gather = 1) or dst row perm[j] = src row j (gather = 0); rows of
+ * `cols` elements of elem_bytes 4 or 8, row strides lds / ldd in elements.                                              */
+int ds_seq_sort_desc(const int64_t *seq_len, int32_t B, int32_t T, int32_t *perm, int64_t *len_sorted, void *stream);
+int ds_permute_rows(const void *src, int64_t lds, void *dst, int64_t ldd, const int32_t *perm, int32_t rows, int32_t cols,
+                    int32_t elem_bytes, int32_t gather, void *stream);
 /* The same recurrence for the WHOLE sequence in one launch per direction (lstm_seq: BasicLSTMCell +
  * tf.nn.dynamic_rnn(sequence_length) + the gather_nd of the last valid output, im_text_rnn_model.py:89-92):
  * the recurrent weights stay in registers as MFMA fragments partitioned over the workgroups, cell state and
@@ -576,6 +583,12 @@ int ds_lstm_cell_bwd(const float *acts, const float *c_t, const float *c_prev, c
  * (the words are sticky only until then).  The XCD-local grid is used only when min(row groups, 8) * H / 16 workgroups
  * fit the device at once; smaller or partitioned devices get the 2-D grid.  Re-entrant: no process-global state;
  * two sequences on two streams need two workspaces.                                                        */
+/* rows | DS_LSTM_SKIP_MASKED (round 6): a row group stops exchanging after its LONGEST row's last step -- past it dynamic_rnn
+ * only copies the state through (forward: carried h / c are written; backward: dgates = 0), so the steps cost a few stores
+ * instead of a recurrent GEMM and a hand-off.  Per-row results are unchanged to the bit (the activations stored in `gates` are
+ * not written for those steps: nothing reads them).  Pays when the rows of a group have similar lengths: sort the batch with
+ * ds_seq_sort_desc first.                                                                                              */
+#define DS_LSTM_SKIP_MASKED 256
 int ds_lstm_seq_supported(int32_t B, int32_t H);
 size_t ds_lstm_seq_workspace(int32_t B, int32_t H);
 int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float *h, float *c, const int64_t *seq_len, int32_t T,

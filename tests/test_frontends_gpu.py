@@ -122,7 +122,10 @@ def test_train_deep_sentiment_and_image_model_entry_points(tmp_path):
     m.net.predict(m.next_batch(0))
     cf = m.concat_features
     assert cf.shape == (4, 256 + 32)
-    assert torch.equal(cf[:, 256:], m.net.text.h[m.net.text.T])
+    tt = m.net.text          # (the tower works on the batch sorted by length; h_last is in the callers' sample order)
+    assert torch.equal(cf[:, 256:], tt.h_last if tt.sorted else tt.h[tt.T])
+    if tt.sorted:
+        assert torch.equal(tt.h_last[tt.perm.long()], tt.h[tt.T])
 
 
 def test_analysis_functions_row_8f3(tmp_path):
@@ -278,5 +281,10 @@ def test_full_size_properties_batch_256():
     np.testing.assert_allclose((xhat.var(0, unbiased=False) * (var + 1e-3) / var).cpu().numpy(), 1.0, atol=1e-3)
     # embedding gather at full size is a pure row copy: checksum equality with a torch index_select
     tx = net.text
-    want = net.store.view("Text/W_embedding")[batch["texts"].t().reshape(-1)]
+    ids = batch["texts"]
+    if tx.sorted:            # the tower works on the batch in descending order of length (ds_seq_sort_desc)
+        ids = ids[tx.perm.long()]
+        assert torch.equal(tx.texts, ids) and bool((tx.len_sorted[:-1] >= tx.len_sorted[1:]).all())
+        assert torch.equal(tx.len_sorted, batch["seq_lens"][tx.perm.long()])
+    want = net.store.view("Text/W_embedding")[ids.t().reshape(-1)]
     assert torch.equal(tx.x, want)

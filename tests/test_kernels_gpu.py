@@ -1275,6 +1275,63 @@ def test_lstm_sequence_kernels_match_oracle(case):
         assert float((dg3 - dg).abs().max()) <= 2e-6 * float(dg.abs().max()), rows
 
 
+@pytest.mark.parametrize("case", [(256, 32, 512, 1), (256, 32, 512, 4), (64, 12, 128, 1), (37, 9, 64, 2), (100, 20, 256, 1)])
+def test_lstm_sequence_skips_masked_steps_to_the_bit_on_length_sorted_batches(case):
+    """ds_seq_sort_desc + ds_permute_rows + DS_LSTM_SKIP_MASKED (round 6): the batch in descending order of length, every 32- /
+    16-row group stopping after its longest row -- h at every step, c at every step, the last valid output and every per-step
+    gate gradient have the bits of the plain launch on the same (sorted) batch; un-sorting the last output reproduces the
+    plain launch on the ORIGINAL batch sample by sample (rows are independent).  Lengths include 1, T, a whole group of equal
+    lengths and groups that end long before T."""
+    ops = _ops()
+    from tumblr_emotions_amd import _lib
+    B, T, H, rows = case
+    rng = np.random.RandomState(B + T + H)
+    seq = rng.randint(1, T + 1, size=B).astype(np.int64)
+    seq[0], seq[-1] = 1, T
+    seq[B // 2:B // 2 + min(40, B // 4)] = max(1, T // 3)
+    seqd = torch.from_numpy(seq).cuda()
+    perm = torch.empty(B, dtype=torch.int32, device="cuda")
+    lens = torch.empty(B, dtype=torch.int64, device="cuda")
+    ops.seq_sort_desc(seqd, B, T, perm, lens)
+    torch.cuda.synchronize()
+    order = np.array(sorted(range(B), key=lambda i: (-seq[i], i)))
+    assert np.array_equal(perm.cpu().numpy(), order) and np.array_equal(lens.cpu().numpy(), seq[order])
+    pre = torch.from_numpy((rng.normal(size=(T, B, 4 * H)) * 0.7).astype(np.float32)).cuda()      # original order
+    pre_s = pre[:, perm.long()].contiguous()
+    ids = torch.from_numpy(rng.randint(0, 99, size=(B, T)).astype(np.int64)).cuda()
+    ids_s = torch.empty_like(ids)
+    ops.permute_rows(ids, ids_s, perm, B, T, gather=True)
+    assert torch.equal(ids_s, ids[perm.long()])
+    wh = dev(rng.normal(size=(H, 4 * H)) * (0.5 / np.sqrt(H)))
+    dh = torch.from_numpy(rng.normal(size=(B, H)).astype(np.float32)).cuda()
+    dh_s = torch.empty_like(dh)
+    ops.permute_rows(dh, dh_s, perm, B, H, gather=True)
+    ws = torch.zeros(max(ops.lstm_seq_workspace(B, H) // 4, 4), dtype=torch.int32, device="cuda")
+
+    def run(gates, sl, dhl, flag):
+        g = gates.clone()
+        h, c = torch.zeros(T + 1, B, H, device="cuda"), torch.zeros(T + 1, B, H, device="cuda")
+        ops.lstm_seq_fwd(g, ops._p(wh), 4 * H, h, c, sl, T, B, H, S.FORGET_BIAS, ws, rows=rows | flag)
+        dg = torch.full((T, B, 4 * H), float("nan"), device="cuda")
+        ops.lstm_seq_bwd(g, ops._p(wh), 4 * H, c, dhl, dhl.stride(0), sl, T, B, H, dg, ws, rows=rows | flag)
+        torch.cuda.synchronize()
+        ops.lstm_seq_status(ws, B)
+        return h, c, dg
+
+    h0, c0, dg0 = run(pre_s, lens, dh_s, 0)
+    h1, c1, dg1 = run(pre_s, lens, dh_s, _lib.DS_LSTM_SKIP_MASKED)
+    assert torch.equal(h0, h1) and torch.equal(c0, c1) and torch.equal(dg0, dg1)
+    hu, _, dgu = run(pre, seqd, dh, 0)                              # the plain launch on the ORIGINAL order
+    back = torch.empty(B, H, device="cuda")
+    ops.permute_rows(h1[T], back, perm, B, H, gather=False)
+    torch.cuda.synchronize()
+    if B % 32 == 0 or rows == 1:          # (same MFMA form for every row: a ragged last group may change between 16- and 32-row groups)
+        assert torch.equal(back, hu[T])
+        assert torch.equal(dg1, dgu[:, perm.long()])
+    else:
+        assert float((back - hu[T]).abs().max()) <= 2e-6
+
+
 def test_lstm_sequence_is_reentrant_across_streams_and_row_settings():
     """no global mutable state.  Two text towers with DIFFERENT `rows` settings run at the same time on
     two streams (each with its own workspace) and give the bits each gives alone; the forward and the backward

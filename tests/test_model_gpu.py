@@ -660,6 +660,34 @@ def test_bn_sums_from_dgrad_epilogues_equal_the_separate_reduce_pass():
     assert worst <= 5e-5
 
 
+@pytest.mark.parametrize("mode", ["text", "joint"])
+def test_length_sorted_text_tower_step_follows_the_unsorted_one(mode):
+    """TextTowerEngine.sort_by_length (default): the text tower runs on the batch in descending order of length and its
+    persistent kernels skip the steps past a row group's longest row.  Per sample nothing changes -- the logits of the
+    text-only model are BIT-identical to the unsorted run -- and the weight gradients, which sum the rows in another order, agree
+    to fp32 summation order (1e-5 of their norm); two steps, lengths from 6 to T as the reference's data."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    B, T = 64, 24
+    batch = to_device(synthetic_batch_numpy(B, T, 50, seed=5, with_images=(mode == "joint")))
+    res = []
+    for on in (True, False):
+        net = SentimentNet(mode=mode, nb_emotions=15, rnn_size=64, vocab_size=50, embedding_dim=20, post_size=T)
+        net.text.sort_by_length = on
+        net.initialize(seed=7)
+        net.train_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        assert net.text.sorted == on
+        res.append((net.logits.detach().clone(), net.total_loss_value(), net.grads_state_dict()))
+    if mode == "text":
+        assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    else:
+        assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-6 and abs(res[0][1] - res[1][1]) <= 1e-6
+    for name in ("Text/rnn/basic_lstm_cell/kernel", "Text/rnn/basic_lstm_cell/bias", "W_softmax", "b_softmax"):
+        a, b = res[0][2][name], res[1][2][name]
+        assert np.linalg.norm(a - b) <= 1e-5 * np.linalg.norm(b), name
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp8"])
 def test_bf16_dz_storage_step_is_bit_identical(dtype):
     """InceptionV1Engine.dz16 (16-bit configurations, default): BatchNorm's backward writes dz of the frozen layers -- every

@@ -20,6 +20,7 @@ DS_EPI_BIAS, DS_EPI_RELU, DS_EPI_ACCUM, DS_EPI_STATS, DS_EPI_MASK, DS_EPI_BNSUMS
 DS_DTYPE_F32, DS_DTYPE_BF16 = 0, 1
 DS_FP8_E4M3, DS_FP8_E5M2 = 0, 1
 DS_CONV_FWD, DS_CONV_DGRAD = 0, 1
+DS_LSTM_SKIP_MASKED = 256
 DS_ARITH_F32, DS_ARITH_BF16, DS_ARITH_FP8, DS_ARITH_F32X3 = 0, 1, 2, 3
 DS_FAM_IGEMM, DS_FAM_WINO2, DS_FAM_WINO4, DS_FAM_STEM, DS_FAM_BF16D, DS_FAM_FP8D, DS_FAM_F32X3, DS_FAM_WINO4H, DS_FAM_STEM_POOL = range(9)
 DS_PLAN_NO_WINO, DS_PLAN_NO_WINO4, DS_PLAN_NO_STEM_DIRECT, DS_PLAN_NO_BF16_DIRECT, DS_PLAN_ACT16, DS_PLAN_PACKED_RGB = 1, 2, 4, 8, 16, 32
@@ -164,6 +165,8 @@ SIGNATURES = {
     "ds_embedding_grad": (C.c_int, [_P, _P, _P, _i32, _i32, _i32, _i64, _i32, _P]),
     "ds_lstm_cell_fwd": (C.c_int, [_P, _P, _i32, _i64, _P, _P, _P, _i32, _i32, _i32, _f32, _P, _P, _P]),
     "ds_lstm_cell_bwd": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i64, _P, _P, _i32, _i32, _i32, _P, _P, _P, _P]),
+    "ds_seq_sort_desc": (C.c_int, [_P, _i32, _i32, _P, _P, _P]),
+    "ds_permute_rows": (C.c_int, [_P, _i64, _P, _i64, _P, _i32, _i32, _i32, _i32, _P]),
     "ds_lstm_seq_supported": (C.c_int, [_i32, _i32]),
     "ds_lstm_seq_workspace": (C.c_size_t, [_i32, _i32]),
     "ds_lstm_seq_fwd": (C.c_int, [_P, _P, _i32, _P, _P, _P, _i32, _i32, _i32, _f32, _i32, _P, C.c_size_t, _P]),

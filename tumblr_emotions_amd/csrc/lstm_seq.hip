@@ -57,6 +57,7 @@ struct SeqParams {
     int nrg;
     int ncg, nrgw;             // unit blocks (H / 16); workgroup rows (ceil(nrg / R))
     int xcd_map;               // 1: 1-D XCD-local launch (see wg_coords)
+    int skip_masked;           // 1: a row group stops exchanging after its longest row's last step (DS_LSTM_SKIP_MASKED)
     unsigned long long *prof;  // tuning aid (ds_debug_lstm_seq_set_profile): workgroup (0,0) stamps its phases, [T][8]
 };
 
@@ -221,10 +222,36 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
     constexpr unsigned kSlot = (unsigned)(H / 4) * RB * 16u;           // bytes of one row group's slot
     constexpr unsigned kQuads = RB == 32 ? 2u : 4u;                    // K quads per A chunk (8 / 16 channels)
 
+    // DS_LSTM_SKIP_MASKED: past the LONGEST row of a row group every step only copies the state through (dynamic_rnn's
+    // masking): no recurrent GEMM, no exchange -- the workgroups of that row group (they all see the same lengths)
+    // write the carried h / c and go on.  With the batch sorted by length (ds_seq_sort_desc) a row group's rows have
+    // nearly the same length, so the launch does ~mean(length) / T of the steps; per-row results are unchanged to the bit.
+    __shared__ int tg_s[R > 8 ? R : 8];
+    if (tid < R) tg_s[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr)
+        if (valid[rr]) atomicMax(&tg_s[rr], (int)(sl[rr] < (int64_t)T ? sl[rr] : (int64_t)T));
+    __syncthreads();
+    int tg[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) tg[rr] = p.skip_masked ? tg_s[rr] : T;
+
     for (int t = 0; t < T; ++t) {
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             if (rg0 + rr >= p.nrg) continue;                    // (uniform) a last workgroup with fewer row groups
+            if (t >= tg[rr]) {                                  // (uniform) every row of the group is past its length
+                if (valid[rr]) {
+                    const int64_t o = ((int64_t)(t + 1) * B + grow[rr]) * H + u0 + cu;
+#pragma unroll
+                    for (int e = 0; e < UPT; ++e) {
+                        p.c[o + e] = cst[rr][e];
+                        p.h[o + e] = hst[rr][e];
+                    }
+                }
+                continue;
+            }
             unsigned *cnt = p.sync + rg0 + rr;
             // pre-activations of this thread's cells (hoisted x_t Wx + b): independent of the other workgroups
             float gp[4][UPT];
@@ -407,10 +434,34 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
     const __amdgpu_buffer_rsrc_t srd_x = srd_of(p.xchg, (unsigned)((int64_t)2 * p.nrg * RB * H4 * 4));
     constexpr unsigned kSlot = (unsigned)(H4 / 4) * RB * 16u;          // bytes of one row group's slot
 
+    // DS_LSTM_SKIP_MASKED (see the forward kernel): steps past the row group's longest row have dgates = 0 and carry the
+    // gradient of h through unchanged -- zeros are written, nothing is exchanged; the group's first real step (t = tg - 1)
+    // plays the role of t = T - 1: no recurrent term yet, no wait
+    __shared__ int tg_s[R > 8 ? R : 8];
+    if (tid < R) tg_s[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr)
+        if (valid[rr]) atomicMax(&tg_s[rr], (int)(sl[rr] < (int64_t)T ? sl[rr] : (int64_t)T));
+    __syncthreads();
+    int tg[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) tg[rr] = p.skip_masked ? tg_s[rr] : T;
+
     for (int t = T - 1; t >= 0; --t) {
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             if (rg0 + rr >= p.nrg) continue;
+            if (t >= tg[rr]) {                                  // (uniform) masked for every row of the group
+                if (valid[rr]) {
+                    const int64_t gz = ((int64_t)t * B + grow[rr]) * H4 + u0 + cu;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int e = 0; e < UPT; ++e) p.dgates[gz + k * H + e] = 0.f;
+                }
+                continue;
+            }
             unsigned *cnt = p.sync + rg0 + rr;
             float rec[UPT];
 #pragma unroll
@@ -430,8 +481,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
                 a_cp[e] = valid[rr] ? p.c[ci - (int64_t)B * H + e] : 0.f;
             }
             if (rr == 0) DS_STAMP(0);
-            if (t < T - 1) {
-                if (tid == 0) wait_counter(cnt, (unsigned)(T - 1 - t) * ncg, err);
+            if (t < tg[rr] - 1) {
+                if (tid == 0) wait_counter(cnt, (unsigned)(tg[rr] - 1 - t) * ncg, err);
                 __syncthreads();
                 if (rr == 0) DS_STAMP(1);
                 f32x4 acc[NRB];
@@ -699,6 +750,8 @@ extern "C" size_t ds_lstm_seq_workspace(int32_t B, int32_t H) {
 extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float *h, float *c, const int64_t *seq_len,
                                int32_t T, int32_t B, int32_t H, float forget_bias, int32_t rows_arg, void *ws,
                                size_t ws_bytes, void *stream) {
+    const int skip = (rows_arg & DS_LSTM_SKIP_MASKED) ? 1 : 0;
+    rows_arg &= ~DS_LSTM_SKIP_MASKED;
     if (int e = common_checks("ds_lstm_seq_fwd", gates, wh, h, T, B, H, ldw, rows_arg, ws, ws_bytes)) return e;
     DS_REQUIRE(c && seq_len, "ds_lstm_seq_fwd: null argument");
     SeqCfg cfg;
@@ -708,6 +761,7 @@ extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float
     SeqParams p = {};
     p.gates = gates; p.wh = wh; p.ldw = ldw; p.h = h; p.c = c; p.seq_len = seq_len;
     p.T = T; p.B = B; p.H = H; p.forget_bias = forget_bias;
+    p.skip_masked = skip;
     p.nrg = (B + rb - 1) / rb;
     p.sync = (unsigned *)ws;
     p.xcc = p.sync + ws_groups(B);
@@ -726,6 +780,8 @@ extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float
 extern "C" int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, const float *c, const float *dh_last,
                                int32_t ld_dh, const int64_t *seq_len, int32_t T, int32_t B, int32_t H, float *dgates,
                                int32_t rows_arg, void *ws, size_t ws_bytes, void *stream) {
+    const int skip = (rows_arg & DS_LSTM_SKIP_MASKED) ? 1 : 0;
+    rows_arg &= ~DS_LSTM_SKIP_MASKED;
     if (int e = common_checks("ds_lstm_seq_bwd", acts, wh, c, T, B, H, ldw, rows_arg, ws, ws_bytes)) return e;
     DS_REQUIRE(dh_last && seq_len && dgates && ld_dh >= H, "ds_lstm_seq_bwd: bad argument");
     SeqCfg cfg;
@@ -736,6 +792,7 @@ extern "C" int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, 
     p.gates = const_cast<float *>(acts); p.wh = wh; p.ldw = ldw; p.c = const_cast<float *>(c);
     p.dh_last = dh_last; p.ld_dh = ld_dh; p.dgates = dgates; p.seq_len = seq_len;
     p.T = T; p.B = B; p.H = H;
+    p.skip_masked = skip;
     p.nrg = (B + rb - 1) / rb;
     p.sync = (unsigned *)ws + dir_words(B);
     p.xcc = p.sync + ws_groups(B);

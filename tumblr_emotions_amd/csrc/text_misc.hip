@@ -479,6 +479,61 @@ extern "C" int ds_sumsq(const float *x, int64_t n, float *scratch, float *out, v
     return ds::check_launch("ds_sumsq");
 }
 
+// ---- length-sorted batches (ds_seq_sort_desc, ds_permute_rows) ------------------------------------------------------------
+// rank of sample i = #{j : len_j > len_i, or len_j == len_i and j < i}: descending length, stable.  One workgroup, B^2 / 256
+// comparisons per thread (B = 256: 256) -- the batch is tiny, the point is that nothing leaves the device.
+__global__ __launch_bounds__(256) void seq_sort_desc_kernel(const int64_t *seq_len, int B, int T, int *perm, int64_t *len_sorted) {
+    extern __shared__ int lens[];
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const int64_t l = seq_len[i];
+        lens[i] = (int)(l < 0 ? 0 : (l > T ? T : l));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const int li = lens[i];
+        int rank = 0;
+        for (int j = 0; j < B; ++j) {
+            const int lj = lens[j];
+            rank += (lj > li || (lj == li && j < i)) ? 1 : 0;
+        }
+        perm[rank] = i;
+        len_sorted[rank] = li;
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void permute_rows_kernel(const E *src, int64_t lds, E *dst, int64_t ldd, const int *perm,
+                                                           int rows, int cols, int gather) {
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+        const int pr = perm[r];
+        if (gather) dst[(int64_t)r * ldd + c] = src[(int64_t)pr * lds + c];
+        else dst[(int64_t)pr * ldd + c] = src[(int64_t)r * lds + c];
+    }
+}
+
+extern "C" int ds_seq_sort_desc(const int64_t *seq_len, int32_t B, int32_t T, int32_t *perm, int64_t *len_sorted, void *stream) {
+    DS_REQUIRE(seq_len && perm && len_sorted && B > 0 && B <= 4096 && T > 0, "ds_seq_sort_desc: bad argument (1 <= B <= 4096)");
+    hipLaunchKernelGGL(seq_sort_desc_kernel, dim3(1), dim3(256), (size_t)B * sizeof(int), (hipStream_t)stream, seq_len, B, T, perm,
+                       len_sorted);
+    return ds::check_launch("ds_seq_sort_desc");
+}
+
+extern "C" int ds_permute_rows(const void *src, int64_t lds, void *dst, int64_t ldd, const int32_t *perm, int32_t rows, int32_t cols,
+                               int32_t elem_bytes, int32_t gather, void *stream) {
+    DS_REQUIRE(src && dst && perm && rows > 0 && cols > 0 && lds >= cols && ldd >= cols && (elem_bytes == 4 || elem_bytes == 8),
+               "ds_permute_rows: bad argument (elem_bytes 4 or 8)");
+    const int grid = ds::stream_grid((int64_t)rows * cols, 256);
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL(permute_rows_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)src, lds,
+                           (float *)dst, ldd, perm, rows, cols, gather);
+    else
+        hipLaunchKernelGGL(permute_rows_kernel<int64_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const int64_t *)src, lds,
+                           (int64_t *)dst, ldd, perm, rows, cols, gather);
+    return ds::check_launch("ds_permute_rows");
+}
+
 extern "C" int ds_colsum(const float *x, int64_t M, int32_t C, int32_t ld, float *scratch, float *out, void *stream) {
     DS_REQUIRE(x && scratch && out && M > 0 && C > 0 && ld >= C, "ds_colsum: bad argument");
     int RS = (int)((M + 63) / 64);

@@ -20,7 +20,7 @@ import ctypes as C
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .ops import WgradPlan, gemm_plan, head_gemm_plan, DS_EPI_ACCUM, DS_EPI_BIAS, DS_EPI_MASK, DS_EPI_RELU
 
 FORGET_BIAS = 1.0     # tf.contrib.rnn.BasicLSTMCell default (im_text_rnn_model.py:89)
@@ -53,6 +53,11 @@ class TextTowerEngine:
         self.reducer = None          # dp.GradientReducer, set by SentimentNet
         self.persistent = True       # False: force the step-wise recurrence (A/B and tests)
         self.seq_rows = 1            # row groups per workgroup of the persistent kernels (`rows` of ds_lstm_seq_fwd/_bwd)
+        # Length-sorted batches (round 6): the tower works on the batch in descending order of length (device-side sort, ids
+        # permuted before the gather, h_last / its gradient permuted back) and the persistent kernels skip, per 32- / 16-row
+        # group, the steps past the group's longest row (DS_LSTM_SKIP_MASKED) -- dynamic_rnn only copies state there.  Per
+        # sample the results are the same bits; the weight gradients sum the rows in another order.
+        self.sort_by_length = _lib.tuning_env("DS_LSTM_SORT", "1") != "0" 
 
     def alloc(self, B):
         if self.B == B:
@@ -61,6 +66,13 @@ class TextTowerEngine:
         self.B = B
         self.alloc_gen = getattr(self, "alloc_gen", 0) + 1
         self.use_seq = self.persistent and ops.lstm_seq_supported(B, H)
+        self.sorted = bool(self.use_seq and self.sort_by_length)
+        if self.sorted:
+            self.perm = torch.empty(B, dtype=torch.int32, device=dev)
+            self.len_sorted = torch.empty(B, dtype=torch.int64, device=dev)
+            self.texts_sorted = torch.empty(B, T, dtype=torch.int64, device=dev)
+            self.h_last = torch.empty(B, H, device=dev)          # h at the last valid step, ORIGINAL sample order
+            self.dh_sorted = torch.empty(B, H, device=dev)
         self.seq_ws = torch.zeros(max(ops.lstm_seq_workspace(B, H) // 4, 4), dtype=torch.int32, device=dev)
         self.x = torch.empty(T * B, D, device=dev)                 # time-major embeddings
         self.gates = torch.empty(T, B, 4 * H, device=dev)          # pre-activations, then activations
@@ -105,12 +117,21 @@ class TextTowerEngine:
         B, T, H = texts.shape[0], self.T, self.H
         assert texts.shape[1] == T and texts.dtype == torch.int64 and seq_lens.dtype == torch.int64
         self.alloc(B)
+        if self.sorted:         # everything below works on the batch in descending order of length
+            if not seq_lens.is_contiguous() or not texts.is_contiguous():
+                seq_lens, texts = seq_lens.contiguous(), texts.contiguous()
+            ops.seq_sort_desc(seq_lens, B, T, self.perm, self.len_sorted)
+            ops.permute_rows(texts, self.texts_sorted, self.perm, B, T, gather=True)
+            seq_lens, texts = self.len_sorted, self.texts_sorted
         self.seq_lens, self.texts = seq_lens, texts
         ops.gather_rows(self.table, texts, self.x, B, T, self.D, time_major=True)
         self.xproj.run(ops._p(self.x), self.wx, ops._p(self.gates), bias=self.bias)
         if self.use_seq:
-            ops.lstm_seq_fwd(self.gates, self.wh, 4 * H, self.h, self.c, seq_lens, T, B, H, FORGET_BIAS, self.seq_ws,
-                             rows=self.seq_rows)
+            rows = self.seq_rows | (_lib.DS_LSTM_SKIP_MASKED if self.sorted else 0)
+            ops.lstm_seq_fwd(self.gates, self.wh, 4 * H, self.h, self.c, seq_lens, T, B, H, FORGET_BIAS, self.seq_ws, rows=rows)
+            if self.sorted:
+                ops.permute_rows(self.h[T], self.h_last, self.perm, B, H, gather=False)
+                return self.h_last
             return self.h[T]
         slab = B * 4 * H
         for t in range(T):
@@ -131,8 +152,12 @@ class TextTowerEngine:
     def backward(self, dh_last):
         B, T, H = self.B, self.T, self.H
         if self.use_seq:
+            rows = self.seq_rows
+            if self.sorted:
+                ops.permute_rows(dh_last, self.dh_sorted, self.perm, B, H, gather=True)
+                dh_last, rows = self.dh_sorted, rows | _lib.DS_LSTM_SKIP_MASKED
             ops.lstm_seq_bwd(self.gates, self.wh, 4 * H, self.c, dh_last, dh_last.stride(0), self.seq_lens, T, B, H,
-                             self.dgates, self.seq_ws, rows=self.seq_rows)
+                             self.dgates, self.seq_ws, rows=rows)
             return self._weight_grads()
         dh, dh2 = self.dh
         ops.copy2d(dh_last, dh_last.stride(0), dh, H, B, H)

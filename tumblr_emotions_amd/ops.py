@@ -719,6 +719,18 @@ def lstm_seq_bwd(acts, wh_ptr, ldw, c, dh_last, ld_dh, seq_len, T, B, H, dgates,
                "ds_lstm_seq_bwd")
 
 
+def seq_sort_desc(seq_len, B, T, perm, len_sorted):
+    """perm [B] int32, len_sorted [B] int64: the batch in descending order of length (ties by index), on the device."""
+    _lib.check(_lib.load().ds_seq_sort_desc(_p(seq_len), B, T, _p(perm), _p(len_sorted), _stream()), "ds_seq_sort_desc")
+
+
+def permute_rows(src, dst, perm, rows, cols, gather=True):
+    """gather: dst[j] = src[perm[j]]; scatter (gather=False): dst[perm[j]] = src[j].  fp32 or int64 rows."""
+    assert src.element_size() == dst.element_size() and src.element_size() in (4, 8)
+    _lib.check(_lib.load().ds_permute_rows(_p(src), src.stride(0), _p(dst), dst.stride(0), _p(perm), rows, cols, src.element_size(),
+                                           int(bool(gather)), _stream()), "ds_permute_rows")
+
+
 def lstm_seq_status(ws, B):
     """0 = ok; call after a synchronise (it copies two words to the host).  Raises on a hand-off timeout of any
     forward (bit 0) or backward (bit 1) launch since the last read: the error words are sticky until reported, then cleared."""
