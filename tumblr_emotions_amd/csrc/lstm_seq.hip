@@ -57,6 +57,7 @@ struct SeqParams {
     int nrg;
     int ncg, nrgw;             // unit blocks (H / 16); workgroup rows (ceil(nrg / R))
     int xcd_map;               // 1: 1-D XCD-local launch (see wg_coords)
+    int strided;               // row groups of a workgroup strided over the workgroup rows (skip_masked launches)
     int skip_masked;           // 1: a row group stops exchanging after its longest row's last step (DS_LSTM_SKIP_MASKED)
     unsigned long long *prof;  // tuning aid (ds_debug_lstm_seq_set_profile): workgroup (0,0) stamps its phases, [T][8]
 };
@@ -170,7 +171,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
     const int li = RB == 32 ? lane & 31 : lane & 15, kh = RB == 32 ? lane >> 5 : lane >> 4;     // RB = 16: kh = k quarter
     int cg, yb;
     if (!wg_coords(p, cg, yb)) return;                  // (uniform) surplus workgroup of the XCD-local launch
-    const int rg0 = yb * R;
+    // Row groups of this workgroup: rgb + rr * rgs.  Contiguous (yb * R + rr) normally; on length-sorted batches with the masked
+    // steps skipped (skip_masked) strided over the workgroup rows, so every workgroup walks long AND short row groups and all of
+    // them finish together (contiguous: the first workgroup row holds the longest R groups and sets the launch's duration)
+    const bool strided = R > 1 && p.strided;
+    const int rg0 = strided ? yb : yb * R, rgs = strided ? p.nrgw : 1;
     const int u0 = cg * 16;
     const int ncg = p.ncg;
     const int B = p.B, T = p.T;
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
     float cst[R][UPT], hst[R][UPT];
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
-        const int r0 = (rg0 + rr) * RB;
+        const int r0 = (rg0 + rr * rgs) * RB;
         grow[rr] = r0 + crow;
         valid[rr] = grow[rr] < B;
         sl[rr] = valid[rr] ? p.seq_len[grow[rr]] : 0;
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
     for (int t = 0; t < T; ++t) {
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            if (rg0 + rr >= p.nrg) continue;                    // (uniform) a last workgroup with fewer row groups
+            if (rg0 + rr * rgs >= p.nrg) continue;                    // (uniform) a last workgroup with fewer row groups
             if (t >= tg[rr]) {                                  // (uniform) every row of the group is past its length
                 if (valid[rr]) {
                     const int64_t o = ((int64_t)(t + 1) * B + grow[rr]) * H + u0 + cu;
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
                 }
                 continue;
             }
-            unsigned *cnt = p.sync + rg0 + rr;
+            unsigned *cnt = p.sync + rg0 + rr * rgs;
             // pre-activations of this thread's cells (hoisted x_t Wx + b): independent of the other workgroups
             float gp[4][UPT];
             if (valid[rr]) {
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
             // write-through ring stores would be 8-byte pieces 512 bytes apart: forward launch 0.91 -> 1.08 ms beside the
             // image tower; the backward launch, which reads four times the bytes, gains even so)
             const bool ring = l2_local && t > 0;
-            const unsigned abase = ring ? ((unsigned)(t & 1) * (unsigned)p.nrg + (unsigned)(rg0 + rr)) * kSlot +
+            const unsigned abase = ring ? ((unsigned)(t & 1) * (unsigned)p.nrg + (unsigned)(rg0 + rr * rgs)) * kSlot +
                                               (unsigned)(((wave * (KQ / 4) + kh) * RB + li) * 16)
                                         : (unsigned)((((int64_t)t * B + arow[rr]) * H + wave * KQ + 4 * kh) * 4);
             const unsigned qstep = ring ? kQuads * RB * 16u : (RB == 32 ? 32u : 64u);
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_fwd_kernel(const Seq
                 }
                 // the hand-off payload goes first ...
                 if (l2_local) {
-                    float *xs = p.xchg + ((int64_t)(((t + 1) & 1) * p.nrg + rg0 + rr) * (H / 4) * RB) * 4 +
+                    float *xs = p.xchg + ((int64_t)(((t + 1) & 1) * p.nrg + rg0 + rr * rgs) * (H / 4) * RB) * 4 +
                                 (((u0 + cu) >> 2) * RB + crow) * 4 + ((u0 + cu) & 3);
 #pragma unroll
                     for (int e = 0; e < UPT; ++e) xs[e] = hn[e];
@@ -393,7 +398,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
     const int li = lane & 15, kb = lane >> 4;
     int cg, yb;
     if (!wg_coords(p, cg, yb)) return;
-    const int rg0 = yb * R;
+    // Row groups of this workgroup: rgb + rr * rgs.  Contiguous (yb * R + rr) normally; on length-sorted batches with the masked
+    // steps skipped (skip_masked) strided over the workgroup rows, so every workgroup walks long AND short row groups and all of
+    // them finish together (contiguous: the first workgroup row holds the longest R groups and sets the launch's duration)
+    const bool strided = R > 1 && p.strided;
+    const int rg0 = strided ? yb : yb * R, rgs = strided ? p.nrgw : 1;
     const int u0 = cg * 16;
     const int ncg = p.ncg;
     const int B = p.B, T = p.T;
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
     float dcs[R][UPT], dhc[R][UPT];
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
-        const int r0 = (rg0 + rr) * RB;
+        const int r0 = (rg0 + rr * rgs) * RB;
         grow[rr] = r0 + crow;
         valid[rr] = grow[rr] < B;
         sl[rr] = valid[rr] ? p.seq_len[grow[rr]] : 0;
@@ -451,7 +460,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
     for (int t = T - 1; t >= 0; --t) {
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            if (rg0 + rr >= p.nrg) continue;
+            if (rg0 + rr * rgs >= p.nrg) continue;
             if (t >= tg[rr]) {                                  // (uniform) masked for every row of the group
                 if (valid[rr]) {
                     const int64_t gz = ((int64_t)t * B + grow[rr]) * H4 + u0 + cu;
@@ -462,7 +471,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
                 }
                 continue;
             }
-            unsigned *cnt = p.sync + rg0 + rr;
+            unsigned *cnt = p.sync + rg0 + rr * rgs;
             float rec[UPT];
 #pragma unroll
             for (int e = 0; e < UPT; ++e) rec[e] = 0.f;
@@ -491,7 +500,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
                 unsigned abase[NRB];
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
-                    abase[rb] = ((unsigned)((t + 1) & 1) * (unsigned)p.nrg + (unsigned)(rg0 + rr)) * kSlot +
+                    abase[rb] = ((unsigned)((t + 1) & 1) * (unsigned)p.nrg + (unsigned)(rg0 + rr * rgs)) * kSlot +
                                 (unsigned)(((wave * (KQ / 4) + kb) * RB + 16 * rb + li) * 16);
                 constexpr unsigned qstep = 4u * RB * 16u;                    // bytes between 16-channel chunks
                 f32x4 a[2][NRB][GQ];                            // [buffer][row block][chunk]
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void lstm_seq_bwd_kernel(const Seq
                     }
                 }
                 // the hand-off payload, in fragment order: plain stores where the row group shares an L2, else write-through
-                float *xs = p.xchg + ((int64_t)((t & 1) * p.nrg + rg0 + rr) * (H4 / 4) * RB) * 4;
+                float *xs = p.xchg + ((int64_t)((t & 1) * p.nrg + rg0 + rr * rgs) * (H4 / 4) * RB) * 4;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int col = k * H + u0 + cu;                    // (UPT = 2: cu is even, one 8-byte piece)
@@ -762,6 +771,7 @@ extern "C" int ds_lstm_seq_fwd(float *gates, const float *wh, int32_t ldw, float
     p.gates = gates; p.wh = wh; p.ldw = ldw; p.h = h; p.c = c; p.seq_len = seq_len;
     p.T = T; p.B = B; p.H = H; p.forget_bias = forget_bias;
     p.skip_masked = skip;
+    p.strided = skip && !ds::tune_env("DS_LSTM_CONTIG");          // (DS_LSTM_CONTIG: A/B aid, tuning library only)
     p.nrg = (B + rb - 1) / rb;
     p.sync = (unsigned *)ws;
     p.xcc = p.sync + ws_groups(B);
@@ -793,6 +803,7 @@ extern "C" int ds_lstm_seq_bwd(const float *acts, const float *wh, int32_t ldw, 
     p.dh_last = dh_last; p.ld_dh = ld_dh; p.dgates = dgates; p.seq_len = seq_len;
     p.T = T; p.B = B; p.H = H;
     p.skip_masked = skip;
+    p.strided = skip && !ds::tune_env("DS_LSTM_CONTIG");          // (DS_LSTM_CONTIG: A/B aid, tuning library only)
     p.nrg = (B + rb - 1) / rb;
     p.sync = (unsigned *)ws + dir_words(B);
     p.xcc = p.sync + ws_groups(B);
