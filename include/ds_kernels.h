@@ -424,6 +424,20 @@ int ds_bn_finalize(const float *stats, int32_t P, int64_t count, int32_t C, cons
                    float eps, float decay, float *mean, float *rstd, float *shift, float *moving_mean,
                    float *moving_var, void *stream);
 
+/* The same for up to four layers in ONE launch (the three convs that close an Inception block -- Branch_1 / Branch_2 3x3 and
+ * Branch_3 1x1, inception_v1.py:86-95 -- finish on three streams; their finalizes ran as three single-purpose launches of one
+ * workgroup per channel each).  Per channel the arithmetic is ds_bn_finalize's: bit-identical.                            */
+typedef struct ds_bn_finalize_job {
+    const float *stats;       /* float[2][C][P] about `pivot`                                          */
+    int32_t P, C;
+    int64_t count;
+    const float *beta;
+    const float *pivot;       /* nullable; may alias mean                                               */
+    float *mean, *rstd, *shift;
+    float *moving_mean, *moving_var;      /* nullable                                                   */
+} ds_bn_finalize_job;
+int ds_bn_finalize_multi(const ds_bn_finalize_job *jobs, int32_t njobs, float eps, float decay, void *stream);
+
 /* y = relu(z*rstd + shift) scattered to up to 4 channel segments (branch outputs written
  * straight into the concat buffer: replaces tf.concat, inception_v1.py:96 ... :248).       */
 typedef struct ds_segments {
@@ -471,6 +485,11 @@ typedef struct ds_bn_sum_segments {
 } ds_bn_sum_segments;
 int ds_bn_bwd_finalize_segs(const ds_bn_sum_segments *sg, int64_t M, int32_t C, const float *beta, float *dbeta,
                             float *coef, void *stream);
+/* ... and when the segments are different LAYERS (the block-closing convs above, whose z and dy are column slices of the
+ * block's concat buffers): beta[i] / dbeta[i] (dbeta or dbeta[i] nullable) are segment i's own vectors, indexed from its
+ * first channel; coef is float[2][C] over the concatenated columns -- what ONE ds_bn_bwd_apply over those columns reads.  */
+int ds_bn_bwd_finalize_multi(const ds_bn_sum_segments *sg, int64_t M, int32_t C, const float *const *beta,
+                             float *const *dbeta, float *coef, void *stream);
 /* amax (nullable): device word that receives max|dz| by atomic max (zeroed by the caller): the scale of an fp8 dgrad */
 /* ldz: row stride of z AND dz in floats (>= C, % 4 == 0): a layer whose conv writes straight into its slice of the   */
 /* Inception concat buffer is differentiated in place there                                                          */

@@ -733,6 +733,103 @@ def test_bn_backward_sums_from_mixed_sources_match_the_single_pass():
     close(coef[1], coef0[1].cpu().numpy().astype(np.float64), 1e-4)
 
 
+def test_batch_norm_launches_of_three_layers_as_one_are_bit_identical():
+    """ds_bn_finalize_multi / ds_bn_bwd_finalize_multi (round 6): the three convs that close an Inception block (Branch_1 /
+    Branch_2 3x3, Branch_3 1x1, image_model/inception_v1.py:86-95) keep z and dy in column slices of one concat pair, so
+    their BatchNorm finalizes go out as one launch each way and ONE ds_bn_bwd_apply covers the slices.  Layers with
+    different partial counts, pivots, their own beta / dbeta / moving vectors; every output equals the per-layer launches'
+    to the bit."""
+    ops = _ops()
+    rng = np.random.RandomState(17)
+    M, b0, widths = 3000, 32, (96, 48, 32)
+    Ct = b0 + sum(widths)
+    Cb = Ct - b0
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    # ---- forward ----
+    Ps = (24, 7, 130)
+    layers = []
+    for n, P in zip(widths, Ps):
+        layers.append(dict(n=n, P=P, stats=dev(rng.normal(size=(2, n, P)) * 5 + np.array([0.0, 40.0])[:, None, None]),
+                           beta=dev(rng.normal(size=n)), pivot=dev(rng.normal(size=n)), mm=dev(rng.normal(size=n)),
+                           mv=dev(rng.uniform(0.5, 2, size=n))))
+    outs = []
+    for multi in (False, True):
+        mean_cat, rs_cat = torch.zeros(Ct, device="cuda"), torch.zeros(2, Ct, device="cuda")
+        jobs, off, keep = [], b0, []
+        for l in layers:
+            n = l["n"]
+            mean = mean_cat[off:off + n]
+            mean.copy_(l["pivot"])                       # the pivot aliases the mean, as in the engine
+            mm, mv = l["mm"].clone(), l["mv"].clone()
+            keep += [mm, mv]
+            args = (l["stats"], l["P"], M, n, l["beta"], mean, mean, rs_cat[0, off:off + n], rs_cat[1, off:off + n], mm, mv)
+            if multi:
+                jobs.append(args)
+            else:
+                ops.bn_finalize(args[0], args[1], args[2], args[3], args[4], 1e-3, 0.9997, mean, args[7], args[8], mm, mv, pivot=mean)
+            off += n
+        if multi:
+            ops.BnFinalizeJobs(jobs).run(1e-3, 0.9997)
+        torch.cuda.synchronize()
+        outs.append([mean_cat, rs_cat] + keep)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert float(outs[0][1][0, b0:].abs().min()) > 0
+    # ---- backward: sums from a dgrad epilogue (kind 1) for two layers, reduced (kind 0) for one; then one apply ----
+    mean_cat, rs_cat = outs[0][0], outs[0][1]
+    z = dev(rng.normal(size=(M, Ct)))
+    dy = dev(rng.normal(size=(M, Ct)))
+    P1 = 11
+    nxt = dev(rng.normal(size=(2, Ct, P1)))                     # [2][Ctot][P] of the next block's fused dgrad
+    P0 = ops.bn_bwd_partials(M, widths[1])
+    res = []
+    for multi in (False, True):
+        zc = z.clone()
+        coef_cat = torch.zeros(2, Cb, device="cuda")
+        dbetas = [torch.zeros(n, device="cuda") for n in widths]
+        sgm = ops.SumSegments()
+        sgm.nseg = 3
+        off, keep = b0, []
+        for i, l in enumerate(layers):
+            n = l["n"]
+            sg = ops.SumSegments()
+            sg.nseg = 1
+            sg.c_begin[0], sg.c_end[0] = 0, n
+            if i == 1:
+                scratch = torch.empty(2 * n * P0, device="cuda")
+                ops.bn_bwd_reduce(C.c_void_p(zc.data_ptr() + 4 * off), ops.make_segments([(0, n, dy.data_ptr() + 4 * off, Ct)]), M, n,
+                                  mean_cat[off:off + n], rs_cat[0, off:off + n], rs_cat[1, off:off + n], scratch, ldz=Ct)
+                sg.P[0], sg.kind[0], sg.s[0], sg.q[0] = P0, 0, scratch.data_ptr(), scratch.data_ptr() + 4 * n * P0
+                keep.append(scratch)
+            else:
+                sg.P[0], sg.kind[0] = P1, 1
+                sg.s[0], sg.q[0] = nxt.data_ptr() + 4 * off * P1, nxt.data_ptr() + 4 * (Ct + off) * P1
+            if multi:
+                sgm.c_begin[i], sgm.c_end[i] = off - b0, off - b0 + n
+                sgm.P[i], sgm.kind[i], sgm.s[i], sgm.q[i] = sg.P[0], sg.kind[0], sg.s[0], sg.q[0]
+            else:
+                coef = torch.empty(2, n, device="cuda")
+                ops.bn_bwd_finalize_segs(sg, M, n, l["beta"], dbetas[i], coef)
+                zs = zc[:, off:off + n]
+                ops.bn_bwd_apply(zs, ops.make_segments([(0, n, dy.data_ptr() + 4 * off, Ct)]), M, n, mean_cat[off:off + n],
+                                 rs_cat[0, off:off + n], rs_cat[1, off:off + n], coef, zs, ldz=Ct)
+                coef_cat[:, off - b0:off - b0 + n] = coef
+            off += n
+        if multi:
+            ops.bn_bwd_finalize_multi(sgm, M, Cb, [l["beta"] for l in layers], dbetas, coef_cat)
+            zs = zc[:, b0:]
+            ops.bn_bwd_apply(zs, ops.make_segments([(0, Cb, dy.data_ptr() + 4 * b0, Ct)]), M, Cb, mean_cat[b0:], rs_cat[0, b0:],
+                             rs_cat[1, b0:], coef_cat, zs, ldz=Ct)
+        torch.cuda.synchronize()
+        res.append([zc, coef_cat] + dbetas)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[0][0][:, :b0], z[:, :b0]) and not torch.equal(res[0][0][:, b0:], z[:, b0:])
+    # a dbeta that is not wanted (the layer's beta is frozen): None in the list
+    ops.bn_bwd_finalize_multi(sgm, M, Cb, [l["beta"] for l in layers], [None, res[1][3], None], torch.empty(2, Cb, device="cuda"))
+    torch.cuda.synchronize()
+
+
 def _fp8_round(a, fmax, mant, emin):
     """saturating round-to-nearest-even to an OCP fp8 format (e4m3fn: 448, 3, -6; e5m2: 57344, 2, -14), as float64"""
     a = np.asarray(a, np.float64)

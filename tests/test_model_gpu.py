@@ -524,6 +524,34 @@ def test_zcat_step_is_bit_identical():
         assert torch.equal(a, b) if torch.is_tensor(a) else a == b
 
 
+def test_block_batched_batch_norm_launches_step_is_bit_identical():
+    """InceptionV1Engine.batch_bn (default): in the zcat blocks Mixed_3b .. 4f the three block-closing
+    layers (Branch_1 / Branch_2 3x3, Branch_3 1x1: inception_v1.py:86-95) keep z and dy in the columns [b0, Ct) of the block's
+    concat buffers, so their BatchNorm launches go out once per BLOCK: forward one ds_bn_finalize_multi behind the join of
+    the three streams, backward one ds_bn_bwd_finalize_multi + one ds_bn_bwd_apply over those columns in front of the fork
+    (7 x (2 + 4) launches fewer per step).  Per-channel arithmetic unchanged: two training steps -- logits, loss, every
+    gradient, the updated parameters, the moving statistics -- and an inference pass are BIT-identical to the per-layer
+    launches, and the switch really changes the path."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    batch = to_device(synthetic_batch_numpy(32, 10, 50, seed=5))
+    res, blocks = [], []
+    for on in (True, False):
+        net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10)
+        net.image.batch_bn = 3 if on else 0
+        net.initialize(seed=7)
+        net.train_step(batch, 1e-3)
+        g1 = net.store.grad.clone()
+        net.train_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        blocks.append([st.name for st in net.image.stages if getattr(st, "batch_bn", False)])
+        res.append((net.logits.clone(), net.total_loss_value(), g1, net.store.grad.clone(), net.store.theta.clone(),
+                    net.store.frozen.clone(), net.predict(batch, is_training=False).clone()))
+    assert blocks[0] == ["Mixed_3b", "Mixed_3c", "Mixed_4b", "Mixed_4c", "Mixed_4d", "Mixed_4e", "Mixed_4f"] and blocks[1] == [], blocks
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+
+
 def test_branch3_pool_on_load_step_follows_the_two_pass_form():
     """InceptionV1Engine.fuse_branch3 (default): Branch_3 of Mixed_3b .. 5b (inception_v1.py:94-95 ... :227) runs as ONE
     launch -- the 1x1 conv's loader takes the 3x3 / 1 maximum of the block input as it reads it and records the winners

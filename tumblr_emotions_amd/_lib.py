@@ -74,6 +74,13 @@ class Segments(C.Structure):
                 ("amax", C.c_void_p * 4)]
 
 
+class BnFinalizeJob(C.Structure):
+    """ds_bn_finalize_job"""
+    _fields_ = [("stats", C.c_void_p), ("P", C.c_int32), ("C", C.c_int32), ("count", C.c_int64), ("beta", C.c_void_p),
+                ("pivot", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("shift", C.c_void_p),
+                ("moving_mean", C.c_void_p), ("moving_var", C.c_void_p)]
+
+
 class SumSegments(C.Structure):
     _fields_ = [("nseg", C.c_int32), ("c_begin", C.c_int32 * 4), ("c_end", C.c_int32 * 4), ("P", C.c_int32 * 4),
                 ("kind", C.c_int32 * 4), ("s", C.c_void_p * 4), ("q", C.c_void_p * 4)]
@@ -151,6 +158,8 @@ SIGNATURES = {
     "ds_bn_bwd_reduce": (C.c_int, [_P, _i32, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _P]),
     "ds_bn_bwd_finalize_segs": (C.c_int, [_SS, _i64, _i32, _P, _P, _P, _P]),
     "ds_bn_bwd_finalize": (C.c_int, [_P, _i32, _i64, _i32, _P, _P, _P]),
+    "ds_bn_bwd_finalize_multi": (C.c_int, [_SS, _i64, _i32, _P, _P, _P, _P]),
+    "ds_bn_finalize_multi": (C.c_int, [_P, _i32, _f32, _f32, _P]),
     "ds_bn_bwd_apply": (C.c_int, [_P, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _P, _P, _P]),
     "ds_bn_bwd_apply_bf16": (C.c_int, [_P, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _P, _i32, _P, _P]),
     "ds_maxpool_fwd": (C.c_int, [_P, _P, _P] + [_i32] * 11 + [_P]),

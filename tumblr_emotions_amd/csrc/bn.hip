@@ -59,16 +59,14 @@ __device__ __forceinline__ float4 ldz4<__bf16>(const __bf16 *p) {
 using ds::wave_sum_f64;
 
 // ---- forward ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *stats, int P, double inv_count, int C,
-                                                          const float *beta, const float *pivot, float eps,
-                                                          float decay, float *mean, float *rstd, float *shift,
-                                                          float *mm, float *mv) {
-    // one workgroup per channel; partials are laid out [2][C][P] so the threads read contiguous floats
-    // (P is a few hundred for the persistent conv launches, one per row tile -- up to 2048 -- otherwise);
-    // combined in double in a fixed order: strided per thread, butterfly per wave, waves 0..3 (deterministic)
+// one workgroup per channel; partials are laid out [2][C][P] so the threads read contiguous floats
+// (P is a few hundred for the persistent conv launches, one per row tile -- up to 2048 -- otherwise);
+// combined in double in a fixed order: strided per thread, butterfly per wave, waves 0..3 (deterministic)
+__device__ __forceinline__ void finalize_channel(const float *stats, int P, double inv_count, int C, int c, const float *beta,
+                                                 const float *pivot, float eps, float decay, float *mean, float *rstd,
+                                                 float *shift, float *mm, float *mv) {
     __shared__ double red[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
     for (int p = threadIdx.x; p < P; p += 256) {
         s += (double)stats[(int64_t)c * P + p];
@@ -97,6 +95,32 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *stats, in
         if (mm) mm[c] = decay * mm[c] + (1.f - decay) * (float)mu;     // assign_moving_average
         if (mv) mv[c] = decay * mv[c] + (1.f - decay) * (float)var;
     }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *stats, int P, double inv_count, int C,
+                                                          const float *beta, const float *pivot, float eps,
+                                                          float decay, float *mean, float *rstd, float *shift,
+                                                          float *mm, float *mv) {
+    finalize_channel(stats, P, inv_count, C, (int)blockIdx.x, beta, pivot, eps, decay, mean, rstd, shift, mm, mv);
+}
+
+// ds_bn_finalize_multi: the channels of up to four layers in one grid (workgroup -> job by the running channel count)
+struct FinJobsDev {
+    int njobs;
+    int first[4];              // first workgroup of the job
+    int C[4], P[4];
+    double inv_count[4];
+    const float *stats[4], *beta[4], *pivot[4];
+    float *mean[4], *rstd[4], *shift[4], *mm[4], *mv[4];
+};
+
+__global__ __launch_bounds__(256) void bn_finalize_multi_kernel(FinJobsDev jb, float eps, float decay) {
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < jb.njobs && (int)blockIdx.x >= jb.first[i]) j = i;
+    finalize_channel(jb.stats[j], jb.P[j], jb.inv_count[j], jb.C[j], (int)blockIdx.x - jb.first[j], jb.beta[j], jb.pivot[j], eps,
+                     decay, jb.mean[j], jb.rstd[j], jb.shift[j], jb.mm[j], jb.mv[j]);
 }
 
 // Streaming kernels (bn_apply_relu, bn_bwd_apply): the launch has gridDim.x * 256 = drow * (C / 4) threads, so a thread
@@ -287,15 +311,17 @@ struct SumSegDev {
     int nseg;
     int c_begin[4], c_end[4], P[4], kind[4];
     const float *s[4], *q[4];
+    const float *beta[4];      // the segment's beta / dbeta, indexed from its first channel (ds_bn_bwd_finalize_segs: one
+    float *dbeta[4];           // vector offset per segment; ds_bn_bwd_finalize_multi: the layers' own vectors); nullable
 };
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_segs_kernel(SumSegDev sg, double inv_count, int C, const float *beta,
-                                                                   float *dbeta, float *coef) {
+__global__ __launch_bounds__(256) void bn_bwd_finalize_segs_kernel(SumSegDev sg, double inv_count, int C, float *coef) {
     __shared__ double red[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x;
     int P = 0, kind = 0;
-    const float *sp = nullptr, *qp = nullptr;
+    const float *sp = nullptr, *qp = nullptr, *beta = nullptr;
+    float *dbeta = nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (i < sg.nseg && c >= sg.c_begin[i] && c < sg.c_end[i]) {
@@ -303,6 +329,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_segs_kernel(SumSegDev sg,
             kind = sg.kind[i];
             sp = sg.s[i] + (int64_t)(c - sg.c_begin[i]) * P;
             qp = sg.q[i] + (int64_t)(c - sg.c_begin[i]) * P;
+            beta = sg.beta[i] ? sg.beta[i] + (c - sg.c_begin[i]) : nullptr;
+            dbeta = sg.dbeta[i] ? sg.dbeta[i] + (c - sg.c_begin[i]) : nullptr;
         }
     double s = 0.0, q = 0.0;
     for (int p = threadIdx.x; p < P; p += 256) {
@@ -319,8 +347,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_segs_kernel(SumSegDev sg,
     if (threadIdx.x == 0) {
         s = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
         q = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
-        if (kind == 1) q -= (double)beta[c] * s;
-        if (dbeta) dbeta[c] = (float)s;
+        if (kind == 1) q -= (double)*beta * s;
+        if (dbeta) *dbeta = (float)s;
         coef[c] = (float)(s * inv_count);
         coef[C + c] = (float)(q * inv_count);
     }
@@ -424,6 +452,26 @@ extern "C" int ds_bn_finalize(const float *stats, int32_t P, int64_t count, int3
     return ds::check_launch("ds_bn_finalize");
 }
 
+extern "C" int ds_bn_finalize_multi(const ds_bn_finalize_job *jobs, int32_t njobs, float eps, float decay, void *stream) {
+    DS_REQUIRE(jobs && njobs >= 1 && njobs <= 4, "ds_bn_finalize_multi: 1..4 jobs required");
+    FinJobsDev jb = {};
+    jb.njobs = njobs;
+    int total = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const ds_bn_finalize_job &j = jobs[i];
+        DS_REQUIRE(j.stats && j.beta && j.mean && j.rstd && j.shift && j.P > 0 && j.count > 0 && j.C > 0,
+                   "ds_bn_finalize_multi: job %d is malformed", i);
+        jb.first[i] = total;
+        jb.C[i] = j.C; jb.P[i] = j.P;
+        jb.inv_count[i] = 1.0 / (double)j.count;
+        jb.stats[i] = j.stats; jb.beta[i] = j.beta; jb.pivot[i] = j.pivot;
+        jb.mean[i] = j.mean; jb.rstd[i] = j.rstd; jb.shift[i] = j.shift; jb.mm[i] = j.moving_mean; jb.mv[i] = j.moving_var;
+        total += j.C;
+    }
+    hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, jb, eps, decay);
+    return ds::check_launch("ds_bn_finalize_multi");
+}
+
 __global__ __launch_bounds__(256) void bn_infer_prepare_kernel(const float *beta, const float *mm, const float *mv,
                                                                float eps, int C, float *rstd, float *shift) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -488,26 +536,41 @@ extern "C" int ds_bn_bwd_finalize(const float *partials, int32_t P, int64_t M, i
     return ds::check_launch("ds_bn_bwd_finalize");
 }
 
-extern "C" int ds_bn_bwd_finalize_segs(const ds_bn_sum_segments *sg, int64_t M, int32_t C, const float *beta,
-                                       float *dbeta, float *coef, void *stream) {
-    DS_REQUIRE(sg && coef && M > 0 && C > 0 && sg->nseg >= 1 && sg->nseg <= 4, "ds_bn_bwd_finalize_segs: bad argument");
+namespace {
+int launch_finalize_segs(const char *who, const ds_bn_sum_segments *sg, int64_t M, int32_t C, const float *beta, float *dbeta,
+                         const float *const *beta_v, float *const *dbeta_v, float *coef, void *stream) {
+    DS_REQUIRE(sg && coef && M > 0 && C > 0 && sg->nseg >= 1 && sg->nseg <= 4, "%s: bad argument", who);
     SumSegDev d;
     d.nseg = sg->nseg;
     int covered = 0;
     for (int i = 0; i < 4; ++i) {
         d.c_begin[i] = sg->c_begin[i]; d.c_end[i] = sg->c_end[i]; d.P[i] = sg->P[i]; d.kind[i] = sg->kind[i];
         d.s[i] = sg->s[i]; d.q[i] = sg->q[i];
+        d.beta[i] = nullptr; d.dbeta[i] = nullptr;
         if (i < sg->nseg) {
             DS_REQUIRE(sg->s[i] && sg->q[i] && sg->P[i] > 0 && sg->c_end[i] > sg->c_begin[i] && (sg->kind[i] == 0 || sg->kind[i] == 1),
-                       "ds_bn_bwd_finalize_segs: segment %d is malformed", i);
-            DS_REQUIRE(sg->kind[i] == 0 || beta, "ds_bn_bwd_finalize_segs: DS_EPI_BNSUMS partials need beta");
+                       "%s: segment %d is malformed", who, i);
+            d.beta[i] = beta_v ? beta_v[i] : (beta ? beta + sg->c_begin[i] : nullptr);
+            d.dbeta[i] = dbeta_v ? dbeta_v[i] : (dbeta ? dbeta + sg->c_begin[i] : nullptr);
+            DS_REQUIRE(sg->kind[i] == 0 || d.beta[i], "%s: DS_EPI_BNSUMS partials need beta", who);
             covered += sg->c_end[i] - sg->c_begin[i];
         }
     }
-    DS_REQUIRE(covered == C, "ds_bn_bwd_finalize_segs: segments cover %d of %d channels", covered, C);
-    hipLaunchKernelGGL(bn_bwd_finalize_segs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, d, 1.0 / (double)M, C,
-                       beta, dbeta, coef);
-    return ds::check_launch("ds_bn_bwd_finalize_segs");
+    DS_REQUIRE(covered == C, "%s: segments cover %d of %d channels", who, covered, C);
+    hipLaunchKernelGGL(bn_bwd_finalize_segs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, d, 1.0 / (double)M, C, coef);
+    return ds::check_launch(who);
+}
+}  // namespace
+
+extern "C" int ds_bn_bwd_finalize_segs(const ds_bn_sum_segments *sg, int64_t M, int32_t C, const float *beta,
+                                       float *dbeta, float *coef, void *stream) {
+    return launch_finalize_segs("ds_bn_bwd_finalize_segs", sg, M, C, beta, dbeta, nullptr, nullptr, coef, stream);
+}
+
+extern "C" int ds_bn_bwd_finalize_multi(const ds_bn_sum_segments *sg, int64_t M, int32_t C, const float *const *beta,
+                                        float *const *dbeta, float *coef, void *stream) {
+    DS_REQUIRE(beta, "ds_bn_bwd_finalize_multi: the segments' beta vectors are required");
+    return launch_finalize_segs("ds_bn_bwd_finalize_multi", sg, M, C, nullptr, nullptr, beta, dbeta, coef, stream);
 }
 
 extern "C" int ds_bn_bwd_apply(const float *z, int32_t ldz, const ds_segments *dy, int64_t M, int32_t C, const float *mean,

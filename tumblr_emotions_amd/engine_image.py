@@ -133,12 +133,14 @@ class ConvBN:
                 self.wgrad = WgradPlan(B, self.H, self.W, cin, 0, k, k, self.stride, cout, cout)
             eng.need_ws(self.wgrad.ws_bytes)
 
-    def use_concat_slice(self, zview, ld, rstd, shift):
+    def use_concat_slice(self, zview, ld, rstd, shift, mean=None):
         """The conv output goes straight into this layer's channel slice of the block's concat buffer (row stride ld)
         and stays PRE-BatchNorm there: the consumers of the concat apply relu(z*rstd + shift) as they load it
         (MixedStage zcat), so the layer's BatchNorm-apply pass and its dense z buffer disappear.  rstd / shift: this
         layer's slices of the block's per-channel arrays."""
         self.z, self.ldz, self.rstd, self.shift, self.skip_apply = zview, ld, rstd, shift, True
+        if mean is not None:          # (MixedStage batch_bn: one ds_bn_bwd_apply over the three block-closing layers' columns)
+            self.mean = mean
         self.fwd.d.ldz = ld
 
     def plan_finalize(self):
@@ -197,9 +199,9 @@ class ConvBN:
         self.dx_y = y
         return self.dx_sums, P
 
-    def _bn_bwd_sums(self):
-        """Sum g and sum g*xhat of this layer: parts whose producer emitted them are taken as they are, the others
-        are reduced over their column range; one finalize launch."""
+    def _sum_plan(self):
+        """Where sum g and sum g*xhat of this layer come from: parts whose producer emitted them are taken as they are, the
+        others are reduced over their column range (_run_reduce_jobs).  Built once per allocation."""
         eng = self.eng
         M, Cc = self.M, self.cout
         if self._sum_segs is None:
@@ -251,6 +253,11 @@ class ConvBN:
                     self._reduce_jobs.append(("full", i, c0, n, _vp(scratch)))
                     scratch += 4 * 2 * n * P0
             self._sum_segs = sg
+        return self._sum_segs
+
+    def _run_reduce_jobs(self):
+        eng = self.eng
+        M = self.M
         for job in self._reduce_jobs:
             if job[0] == "pool":
                 _, seg, Mp, n, yp, ldy, stat, dst, ydt = job
@@ -260,6 +267,13 @@ class ConvBN:
             off = 4 * c0
             ops.bn_bwd_reduce(_vp(self.z.data_ptr() + off), self.part_segs[i], M, n, _vp(self.mean.data_ptr() + off),
                               _vp(self.rstd.data_ptr() + off), _vp(self.shift.data_ptr() + off), dst, ldz=self.ldz)
+
+    def _bn_bwd_sums(self):
+        """Sum g and sum g*xhat of this layer (_sum_plan, _run_reduce_jobs) and one finalize launch."""
+        eng = self.eng
+        M, Cc = self.M, self.cout
+        self._sum_plan()
+        self._run_reduce_jobs()
         if eng.sync_bn:
             # beta's gradient stays this rank's own sum (the gradient all-reduce adds the ranks); the two column MEANS of the
             # backward formula are over the global batch: finalize once locally for dbeta, all-reduce, finalize again
@@ -326,7 +340,9 @@ class ConvBN:
 
     # x_ptr: input activations [B,H,W,ldx]; segs: where relu(bn(conv)) is scattered (None: the consumer, a max
     # pool, applies BatchNorm + ReLU to its own output instead -- PoolStage.forward)
-    def forward(self, x_ptr, ldx, segs, x_dtype=ops.DS_DTYPE_F32, x_amax=None):
+    def forward(self, x_ptr, ldx, segs, x_dtype=ops.DS_DTYPE_F32, x_amax=None, defer_finalize=False):
+        """defer_finalize: the caller runs ds_bn_finalize for this layer (MixedStage: one ds_bn_finalize_multi launch for the
+        three convs that close the block)."""
         eng = self.eng
         plan = self.fwd
         if not self.fold:
@@ -359,7 +375,7 @@ class ConvBN:
             if eng.sync_bn:       # statistics of the GLOBAL batch: every rank's partials are about the same pivot, so they add
                 eng.all_reduce(self.stats_buf[:2 * self.cout * plan.partials])
                 count = self.M * eng.sync_world
-            if fin is None:
+            if fin is None and not defer_finalize:
                 ops.bn_finalize(self.stats_buf, plan.partials, count, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
                                 self.rstd, self.shift, self.mm if eng.update_moving else None,
                                 self.mv if eng.update_moving else None, pivot=self.mean)
@@ -703,14 +719,28 @@ class MixedStage(Stage):
         # it comes out of the fused layer's apply pass together with the two reduce outputs).  Bit-identical values.
         self.zcat = self._zcat_ok(B)
         self.rs_cat = None
+        # batch_bn (zcat blocks): the three block-closing layers' z and dy are the columns [b0, Ct) of ONE pair of buffers, so
+        # their BatchNorm launches go out once per block instead of once per layer and stream -- forward one ds_bn_finalize_multi
+        # behind the join, backward one ds_bn_bwd_finalize_multi + one ds_bn_bwd_apply in front of the fork (per-channel
+        # arithmetic unchanged: bit-identical).  7 blocks x (2 + 4) launches fewer per step.  Measured (profiles/r06_notes.md): the
+        # backward half -0.05 ms at B = 128, -0.10 at B = 64, nothing at B = 256; the forward half another -0.04 at B <= 128 but
+        # +0.06 ms at B = 256 -- the joint finalize waits for the LAST of the three chains, one more dependent launch on the
+        # critical path per block -- so it is on up to 128 samples only (bit 0 forward, bit 1 backward)
+        self.batch_bn = 0
         if self.zcat:
             self.rs_cat = torch.empty(2, Ct, device=dev)
             self.rs_cat[0].fill_(1.0)
             self.rs_cat[1].zero_()
+            self.mean_cat = torch.zeros(Ct, device=dev)
+            self.coef_cat = torch.empty(2, Ct - b0, device=dev)
             zc = self.out.view(M, Ct)
             for layer, off in ((self.c1, off1), (self.c2, off2), (self.c3, off3)):
                 n = layer.cout
-                layer.use_concat_slice(zc[:, off:off + n], Ct, self.rs_cat[0, off:off + n], self.rs_cat[1, off:off + n])
+                layer.use_concat_slice(zc[:, off:off + n], Ct, self.rs_cat[0, off:off + n], self.rs_cat[1, off:off + n],
+                                       self.mean_cat[off:off + n])
+            self.batch_bn = (3 if B <= 128 else 2) if eng.batch_bn is None else int(eng.batch_bn)
+            self._fin_jobs = {}
+            self._close_plan = None
         if getattr(self.prev, "zcat", False):    # this block reads a zcat concat
             self.fused.fwd.d.norm_rstd = self.prev.rs_cat[0].data_ptr()
             self.fused.fwd.d.norm_shift = self.prev.rs_cat[1].data_ptr()
@@ -786,6 +816,55 @@ class MixedStage(Stage):
         else:
             ops.maxpool_fwd(p.out, self.pooled, self.argmax, self.B, p.H, p.W, p.C, 3, 1, "SAME")
 
+    def _batch_forward(self):
+        """One ds_bn_finalize_multi for the block-closing layers?  (training with per-rank statistics, no in-launch finalize)"""
+        eng = self.eng
+        return bool((self.batch_bn & 1) and eng.training and not eng.sync_bn
+                    and all(l.fin is None for l in (self.c1, self.c2, self.c3)))
+
+    def _finalize_closing(self):
+        eng = self.eng
+        jobs = self._fin_jobs.get(eng.update_moving)
+        if jobs is None:
+            jobs = ops.BnFinalizeJobs([(l.stats_buf, l.fwd.partials, l.M, l.cout, l.beta, l.mean, l.mean, l.rstd, l.shift,
+                                        l.mm if eng.update_moving else None, l.mv if eng.update_moving else None)
+                                       for l in (self.c1, self.c2, self.c3)])
+            self._fin_jobs[eng.update_moving] = jobs
+        jobs.run(BN_EPS, BN_DECAY)
+
+    def _batch_backward(self, need_dx):
+        eng = self.eng
+        return bool((self.batch_bn & 2) and need_dx and not eng.sync_bn
+                    and all(l.dz16 is None and not l.bnb and l.dgrad.family != ops.DS_FAM_FP8D for l in (self.c1, self.c2, self.c3)))
+
+    def _bn_backward_closing(self):
+        """BatchNorm + ReLU backward of the three block-closing layers as one pass over the columns [b0, Ct) of the concat:
+        their sums (from the next block's dgrad epilogue, or reduced per layer), ONE finalize, ONE apply that leaves dz over z."""
+        b0 = self.b[0]
+        Ct, Cb = self.C, self.C - b0
+        M = self.B * self.H * self.W
+        layers = (self.c1, self.c2, self.c3)
+        if self._close_plan is None:
+            sg = ops.SumSegments()
+            sg.nseg = 3
+            off = 0
+            for i, l in enumerate(layers):
+                ls = l._sum_plan()
+                assert ls.nseg == 1
+                sg.c_begin[i], sg.c_end[i] = off, off + l.cout
+                sg.P[i], sg.kind[i], sg.s[i], sg.q[i] = ls.P[0], ls.kind[0], ls.s[0], ls.q[0]
+                off += l.cout
+            assert off == Cb
+            dy = make_segments([(0, Cb, self.dout.data_ptr() + 4 * b0, Ct)])
+            self._close_plan = (sg, dy, self.out.view(M, Ct)[:, b0:])
+        sg, dy, z = self._close_plan
+        for l in layers:
+            l._run_reduce_jobs()
+        ops.bn_bwd_finalize_multi(sg, M, Cb, [l.beta for l in layers], [l.gbeta for l in layers], self.coef_cat)
+        ops.bn_bwd_apply(z, dy, M, Cb, self.mean_cat[b0:], self.rs_cat[0, b0:], self.rs_cat[1, b0:], self.coef_cat, z, ldz=Ct)
+        for l in layers:
+            l._dz_amax_live = False
+
     def forward(self):
         p = self.prev
         b0, b1a, b1b, b2a, b2b, b3 = self.b
@@ -793,12 +872,15 @@ class MixedStage(Stage):
         eng = self.eng
         dx_, dr_ = ops.act_dtype(p.out), ops.act_dtype(self.r1)
         ax_, a1_, a2_ = getattr(p, "out_amax", None), self.r1_amax, self.r2_amax      # fp8: max|.| words of the inputs
+        defer = self._batch_forward()
         if not (eng.branch_streams and eng.side):
             self.fused.forward(x, p.C, self.seg_f, dx_, ax_)
-            self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_, a1_)
-            self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_, a2_)
+            self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_, a1_, defer)
+            self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_, a2_, defer)
             self._pool_fwd()
-            self.c3.forward(x if self.fuse_b3 else ops._p(self.pooled), p.C, self.seg_3, dx_, ax_)
+            self.c3.forward(x if self.fuse_b3 else ops._p(self.pooled), p.C, self.seg_3, dx_, ax_, defer)
+            if defer:
+                self._finalize_closing()
             return
         main = torch.cuda.current_stream()
         s1, s2 = eng.side
@@ -809,26 +891,30 @@ class MixedStage(Stage):
         with torch.cuda.stream(s2):
             s2.wait_event(e_in)
             self._pool_fwd()
-            self.c3.forward(x if self.fuse_b3 else ops._p(self.pooled), p.C, self.seg_3, dx_, ax_)
+            self.c3.forward(x if self.fuse_b3 else ops._p(self.pooled), p.C, self.seg_3, dx_, ax_, defer)
             if not eng.one_side_stream:
                 e_3.record(s2)
         self.fused.forward(x, p.C, self.seg_f, dx_, ax_)
         if eng.one_side_stream == 2:        # only the Branch_3 chain on the side stream
             with torch.cuda.stream(s2):
                 e_2.record(s2)
-            self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_, a2_)
-            self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_, a1_)
+            self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_, a2_, defer)
+            self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_, a1_, defer)
             main.wait_event(e_2)
+            if defer:
+                self._finalize_closing()
             return
         e_f.record(main)
         with torch.cuda.stream(s1):
             s1.wait_event(e_f)
-            self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_, a2_)
+            self.c2.forward(ops._p(self.r2), b2a, self.seg_2, dr_, a2_, defer)
             e_2.record(s1)
-        self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_, a1_)
+        self.c1.forward(ops._p(self.r1), b1a, self.seg_1, dr_, a1_, defer)
         main.wait_event(e_2)
         if not eng.one_side_stream:
             main.wait_event(e_3)
+        if defer:
+            self._finalize_closing()
 
     def backward(self, need_dx):
         p = self.prev
@@ -842,15 +928,25 @@ class MixedStage(Stage):
         keep = self.fused.dgrad.d.flags & ops.DS_EPI_BNSUMS
         self.fused.dgrad.d.flags = (ops.DS_EPI_ACCUM if pool_first else 0) | keep
 
+        batched = self._batch_backward(need_dx)
+        if batched:                  # BatchNorm backward of the three block-closing layers: two launches in front of the fork
+            self._bn_backward_closing()
+
+        def closing(layer, x_ptr, ldx, dx_ptr, ndx):
+            if batched:
+                layer._run_dgrad(dx_ptr)
+            else:
+                layer.backward(x_ptr, ldx, dx_ptr, ndx)
+
         def branch3():
-            self.c3.backward(None if self.fuse_b3 else ops._p(self.pooled), p.C, ops._p(self.dpooled), need_dx)      # (x: weight gradient only)
+            closing(self.c3, None if self.fuse_b3 else ops._p(self.pooled), p.C, ops._p(self.dpooled), need_dx)      # (x: weight gradient only)
             if pool_first:
                 ops.maxpool_bwd(self.dpooled, self.argmax, p.dout, False, self.B, p.H, p.W, p.C, 3, 1, "SAME")
 
         if not (eng.branch_streams and eng.side):
             branch3()
-            self.c1.backward(ops._p(self.r1), b1a, ops._p(self.dr1), True)
-            self.c2.backward(ops._p(self.r2), b2a, ops._p(self.dr2), True)
+            closing(self.c1, ops._p(self.r1), b1a, ops._p(self.dr1), True)
+            closing(self.c2, ops._p(self.r2), b2a, ops._p(self.dr2), True)
         else:
             main = torch.cuda.current_stream()
             s1, s2 = eng.side
@@ -866,14 +962,14 @@ class MixedStage(Stage):
             if eng.one_side_stream == 2:
                 with torch.cuda.stream(s2):
                     e_2.record(s2)
-                self.c2.backward(ops._p(self.r2), b2a, ops._p(self.dr2), True)
+                closing(self.c2, ops._p(self.r2), b2a, ops._p(self.dr2), True)
             else:
                 with torch.cuda.stream(s1):
                     if not eng.one_side_stream:
                         s1.wait_event(e_in)
-                    self.c2.backward(ops._p(self.r2), b2a, ops._p(self.dr2), True)
+                    closing(self.c2, ops._p(self.r2), b2a, ops._p(self.dr2), True)
                     e_2.record(s1)
-            self.c1.backward(ops._p(self.r1), b1a, ops._p(self.dr1), True)
+            closing(self.c1, ops._p(self.r1), b1a, ops._p(self.dr1), True)
             main.wait_event(e_2)
             if not eng.one_side_stream:
                 main.wait_event(e_3)
@@ -949,6 +1045,10 @@ class InceptionV1Engine:
         # separate launch spreads them over one workgroup per channel -- B = 32: 3.89 -> 4.36 ms, B = 64: 5.29 -> 5.59
         # (profiles/r06_notes.md).  DS_FUSE_FIN=1 switches it on (A/B)
         self.fuse_finalize = _lib.tuning_env("DS_FUSE_FIN", "0") == "1"
+        # zcat blocks: the BatchNorm launches of the three block-closing layers once per block (MixedStage.alloc); DS_BATCH_BN=0: A/B
+        # bit 0: the forward finalizes, bit 1: the backward finalize + apply; None = by batch size (MixedStage.alloc)
+        e = _lib.tuning_env("DS_BATCH_BN")
+        self.batch_bn = int(e) if e else None
         self.stem_sums_from_dgrad = _lib.tuning_env("DS_STEM_SUMS", "1") != "0"      # pooled stem: its BatchNorm sums from Conv2d_2b's dgrad epilogue
         self.dz16 = int(_lib.tuning_env("DS_DZ16", "2"))      # 16-bit configurations: bf16 dz for the frozen 1x1 (1) and 3x3 (2) layers (ConvBN.make_dgrad)
         self.fuse_branch3 = _lib.tuning_env("DS_FUSE_B3", "1") != "0"      # Branch_3's 3x3/1 max pool formed on load by its 1x1 conv (MixedStage.alloc)

@@ -595,6 +595,35 @@ def bn_bwd_finalize_segs(sum_segs, M, C_, beta, dbeta, coef):
                "ds_bn_bwd_finalize_segs")
 
 
+class BnFinalizeJobs:
+    """ds_bn_finalize_multi: the finalizes of up to four layers as one launch.  jobs: (stats, P, count, C, beta, pivot, mean,
+    rstd, shift, moving_mean, moving_var) tensors / ints; the moving statistics may be None."""
+
+    def __init__(self, jobs):
+        self.n = len(jobs)
+        self.arr = (_lib.BnFinalizeJob * self.n)()
+        self._keep = jobs
+        for a, (stats, P, count, C_, beta, pivot, mean, rstd, shift, mm, mv) in zip(self.arr, jobs):
+            a.stats, a.P, a.C, a.count = stats.data_ptr(), P, C_, count
+            a.beta, a.pivot = beta.data_ptr(), (pivot.data_ptr() if pivot is not None else None)
+            a.mean, a.rstd, a.shift = mean.data_ptr(), rstd.data_ptr(), shift.data_ptr()
+            a.moving_mean = mm.data_ptr() if mm is not None else None
+            a.moving_var = mv.data_ptr() if mv is not None else None
+
+    def run(self, eps, decay):
+        _lib.check(_lib.load().ds_bn_finalize_multi(C.cast(self.arr, C.c_void_p), self.n, eps, decay, _stream()),
+                   "ds_bn_finalize_multi")
+
+
+def bn_bwd_finalize_multi(sum_segs, M, C_, betas, dbetas, coef):
+    """ds_bn_bwd_finalize_multi: segment i of sum_segs is a LAYER with its own beta / dbeta vector (dbetas[i] may be None)."""
+    n = sum_segs.nseg
+    b = (C.c_void_p * 4)(*[t.data_ptr() for t in betas[:n]])
+    d = (C.c_void_p * 4)(*[(t.data_ptr() if t is not None else None) for t in dbetas[:n]])
+    _lib.check(_lib.load().ds_bn_bwd_finalize_multi(C.byref(sum_segs), M, C_, C.cast(b, C.c_void_p), C.cast(d, C.c_void_p),
+                                                    _p(coef), _stream()), "ds_bn_bwd_finalize_multi")
+
+
 def bn_bwd_finalize(partials, P, M, C_, dbeta, coef):
     _lib.check(_lib.load().ds_bn_bwd_finalize(_p(partials), P, M, C_, _p(dbeta), _p(coef), _stream()),
                "ds_bn_bwd_finalize")
