@@ -528,6 +528,15 @@ int ds_maxpool_bwd(const float *dy, const uint8_t *argmax, float *dx, int32_t ac
                    int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
                    int32_t OH, int32_t OW, void *stream);
 
+/* MaxPoolGrad of a 3x3 / 1 SAME pool (Branch_3, inception_v1.py:94 ... :246) that ALSO emits the BatchNorm-backward sums of
+ * the layer(s) whose activation y the pool read: with accumulate = 1 and dx holding the other paths' gradient the launch sees
+ * the complete dL/dy, so per channel   partials[0][c][p] = sum g,  partials[1][c][p] = sum g*y,  g = dx (y > 0)
+ * over workgroup p's pixels -- the DS_EPI_BNSUMS form (ds_bn_bwd_finalize_segs kind 1), float[2][C][P] with
+ * P = ds_maxpool3_bwd_sums_partials(N, W, C).  y: [N, H, W, C] fp32 or bf16 (y_dtype); dx is bit-identical to ds_maxpool_bwd's. */
+int ds_maxpool3_bwd_sums_partials(int32_t N, int32_t W, int32_t C);
+int ds_maxpool3_bwd_sums(const float *dy, const uint8_t *argmax, float *dx, int32_t accumulate, const void *y,
+                         int32_t y_dtype, int32_t N, int32_t H, int32_t W, int32_t C, float *partials, void *stream);
+
 /* slim.avg_pool2d 7x7 VALID + slim.dropout (inception_v1.py:299-301).  mask_in==NULL: draw
  * Bernoulli(keep) from a counter-based generator keyed by (seed, element); the mask used is
  * written to mask_out (needed by the backward).  keep>=1 disables dropout.  seed_dev (nullable)

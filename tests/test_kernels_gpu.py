@@ -830,6 +830,44 @@ def test_batch_norm_launches_of_three_layers_as_one_are_bit_identical():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("case", [(5, 14, 14, 480, "f32"), (3, 28, 28, 256, "bf16"), (9, 7, 7, 832, "f32"), (2, 9, 5, 12, "bf16"),
+                                  (300, 7, 7, 64, "bf16")])
+def test_max_pool_gradient_that_also_emits_the_batch_norm_sums(case):
+    """ds_maxpool3_bwd_sums (round 6): MaxPoolGrad of Branch_3's 3x3 / 1 pool (inception_v1.py:94 ... :246) added LAST onto the
+    block-input gradient also leaves the previous block's BatchNorm-backward sums -- sum g and sum g*y with g = dx (y > 0),
+    the DS_EPI_BNSUMS form -- so that block's ds_bn_bwd_reduce passes go.  dx is bit-identical to ds_maxpool_bwd (accumulating
+    and not); the partials add up to the fp64 sums; fp32 and bf16 activations; widths that leave threads idle (832, 12)."""
+    ops = _ops()
+    N, H, W, Cc, dt = case
+    rng = np.random.RandomState(N + Cc)
+    x = torch.from_numpy(rng.normal(size=(N, H, W, Cc)).astype(np.float32)).cuda()
+    pooled, am = torch.empty_like(x), torch.empty(N, H, W, Cc, dtype=torch.uint8, device="cuda")
+    ops.maxpool_fwd(x, pooled, am, N, H, W, Cc, 3, 1, "SAME")
+    dy = torch.from_numpy(rng.normal(size=(N, H, W, Cc)).astype(np.float32)).cuda()
+    base = torch.from_numpy(rng.normal(size=(N, H, W, Cc)).astype(np.float32)).cuda()
+    y = torch.relu(torch.from_numpy(rng.normal(size=(N, H, W, Cc)).astype(np.float32)).cuda())
+    if dt == "bf16":
+        y = y.to(torch.bfloat16)
+    P = ops.maxpool3_bwd_sums_partials(N, W, Cc)
+    assert 1 <= P <= N * W
+    for acc in (True, False):
+        want, got = base.clone(), base.clone()
+        ops.maxpool_bwd(dy, am, want, acc, N, H, W, Cc, 3, 1, "SAME")
+        part = torch.full((2, Cc, P), float("nan"), device="cuda")
+        ops.maxpool3_bwd_sums(dy, am, got, acc, y, N, H, W, Cc, part)
+        torch.cuda.synchronize()
+        assert torch.equal(want, got)
+        g = (want.double() * (y.double() > 0)).reshape(-1, Cc)
+        yy = y.double().reshape(-1, Cc)
+        s_ref, q_ref = g.sum(0).cpu().numpy(), (g * yy).sum(0).cpu().numpy()
+        scale_s = float(g.abs().sum(0).max()) + 1e-30
+        scale_q = float((g * yy).abs().sum(0).max()) + 1e-30
+        s_got, q_got = part[0].double().sum(1).cpu().numpy(), part[1].double().sum(1).cpu().numpy()
+        assert np.isfinite(s_got).all() and np.isfinite(q_got).all()
+        assert np.abs(s_got - s_ref).max() <= 2e-6 * scale_s, np.abs(s_got - s_ref).max() / scale_s
+        assert np.abs(q_got - q_ref).max() <= 2e-6 * scale_q, np.abs(q_got - q_ref).max() / scale_q
+
+
 def _fp8_round(a, fmax, mant, emin):
     """saturating round-to-nearest-even to an OCP fp8 format (e4m3fn: 448, 3, -6; e5m2: 57344, 2, -14), as float64"""
     a = np.asarray(a, np.float64)

@@ -552,6 +552,42 @@ def test_block_batched_batch_norm_launches_step_is_bit_identical():
         assert torch.equal(a, b) if torch.is_tensor(a) else a == b
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_batch_norm_sums_from_the_branch3_pool_gradient_step_follows_the_reduce_passes(dtype):
+    """InceptionV1Engine.pool_sums (default): where the fused 1x1 dgrad of a block cannot accumulate (the 16-bit configurations;
+    here also fp32 with pool_first and zcat off) Branch_3's pool gradient is the LAST addend of the block-input gradient, and that launch
+    (ds_maxpool3_bwd_sums) emits the previous block's BatchNorm-backward sums: its four ds_bn_bwd_reduce passes go.  The forward
+    pass is untouched -- logits and loss of the first step are bit-identical; the sums are added in another order (and, with
+    16-bit activation storage, against the bf16-rounded y the other epilogues of that configuration also use), so the gradients
+    differ in rounding: relative L2 per variable at most 1e-4 in fp32 (measured 4.2e-5 on the stem's beta, median 3.8e-6 -- what
+    the dgrad-epilogue sums of test_bn_sums_from_dgrad_epilogues_equal_the_separate_reduce_pass differ from the reduce passes
+    by, scripts/diag_pool_sums.py); bf16: worst 6e-2, median 3e-3 as in test_bn_sums_from_the_16_bit_dgrad_epilogues (measured
+    4.2e-2 / 4.3e-4; that configuration's own epilogue sums on / off: 4.4e-2 / 2.0e-3)."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    batch = to_device(synthetic_batch_numpy(32, 10, 50, seed=5))
+    res, used = [], []
+    for on in (True, False):
+        net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10, dtype=dtype)
+        net.image.pool_sums = on
+        if dtype == "f32":
+            net.image.pool_first, net.image.zcat = False, False          # (a zcat concat holds z, not the activation)
+        net.initialize(seed=7)
+        net.train_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        used.append([st.name for st in net.image.stages if getattr(st, "pool_sums", None) is not None])
+        res.append((net.logits.detach().clone(), net.total_loss_value(), net.grads_state_dict()))
+    assert used[0] == ["Mixed_3c", "Mixed_4c", "Mixed_4d", "Mixed_4e", "Mixed_4f", "Mixed_5c"] and used[1] == [], used
+    assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    rels = [np.linalg.norm(res[0][2][name].astype(np.float64) - g) / max(np.linalg.norm(g), 1e-30) for name, g in res[1][2].items()]
+    worst, med = max(rels), float(np.median(rels))
+    print("pool_sums vs reduce passes (%s): gradient rel L2 median %.2e, worst %.2e" % (dtype, med, worst))
+    if dtype == "f32":
+        assert 0 < worst <= 1e-4
+    else:
+        assert 0 < worst <= 6e-2 and med <= 3e-3
+
+
 def test_branch3_pool_on_load_step_follows_the_two_pass_form():
     """InceptionV1Engine.fuse_branch3 (default): Branch_3 of Mixed_3b .. 5b (inception_v1.py:94-95 ... :227) runs as ONE
     launch -- the 1x1 conv's loader takes the 3x3 / 1 maximum of the block input as it reads it and records the winners

@@ -3,6 +3,7 @@
 //              TF SAME geometry: pad_before = pad_total/2, padded cells never win (A1).
 //   MaxPoolGrad as a gather over the recorded arg-max (no atomics, deterministic).
 //   avg pool 7x7 VALID + dropout(keep 0.8)   image_model/inception_v1.py:299-301
+#include <type_traits>
 #include "ds_common.h"
 
 namespace {
@@ -345,6 +346,103 @@ __global__ __launch_bounds__(256) void maxpool3s1_bwd_rolling(const float *dy, c
             w1 = w2;
         }
     }
+}
+
+// The same walk when the pool path is the LAST addend of an Inception block's input gradient (16-bit configurations: the fused
+// 1x1 dgrad writes first, Branch_3's pool gradient is added here): the launch then holds the complete gradient of the previous
+// block's concat output y, so it also emits that block's BatchNorm-backward sums -- per channel sum g and sum g*y with
+// g = dx (y > 0), what DS_EPI_BNSUMS leaves behind (ds_bn_bwd_finalize_segs kind 1) -- and the previous block's four
+// ds_bn_bwd_reduce passes over z and dy (8 B/element, two of them on the critical chain) disappear for 2 B/element of y here.
+// Layout as bn_bwd_reduce_kernel: thread = (channel quad cg, unit group rg) keeps its channels for the whole launch, a unit =
+// one image column (n, iw) walked down its H rows; workgroup b takes units [b * upb, (b + 1) * upb); partials [2][C][gridDim.x],
+// summed per thread in unit order and over the unit groups in a fixed order (deterministic).
+template <typename TY>
+__global__ __launch_bounds__(256) void maxpool3s1_bwd_sums_kernel(const float *dy, const uint8_t *am, float *dx, int accumulate,
+                                                                  const TY *y, int N, int H, int W, int C, float *partials,
+                                                                  int upb) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // [RG][C4][8]
+    const int C4 = C >> 2;
+    const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
+    const int tid = threadIdx.x;
+    const int cg = tid % C4, rg = tid / C4;
+    const bool active = tid < RG * C4;
+    const int units = N * W;
+    const int u0 = blockIdx.x * upb;
+    const int u1 = u0 + upb < units ? u0 + upb : units;
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sy[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const int c = cg * 4;
+        for (int u = u0 + rg; u < u1; u += RG) {
+            const int n = u / W, iw = u - n * W;
+            const int64_t img = (int64_t)n * H;
+            WinRow w0, w1, w2;      // output rows ih-1, ih, ih+1
+            w0 = load_win_row(dy, am, (img - 1) * W, iw, W, C, c, false);
+            w1 = load_win_row(dy, am, img * W, iw, W, C, c, true);
+            for (int ih = 0; ih < H; ++ih) {
+                w2 = load_win_row(dy, am, (img + ih + 1) * W, iw, W, C, c, ih + 1 < H);
+                const int64_t o = ((img + ih) * W + iw) * C + c;
+                float yy[4];
+                if constexpr (std::is_same<TY, float>::value) {
+                    const float4 t = *reinterpret_cast<const float4 *>(y + o);
+                    yy[0] = t.x; yy[1] = t.y; yy[2] = t.z; yy[3] = t.w;
+                } else {
+                    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                    const f32x4_t t = __builtin_convertvector(*reinterpret_cast<const bf16x4_t *>(y + o), f32x4_t);
+                    yy[0] = t[0]; yy[1] = t[1]; yy[2] = t[2]; yy[3] = t[3];
+                }
+                float g[4] = {0.f, 0.f, 0.f, 0.f};
+                win_row_grad(w0, 0, g);
+                win_row_grad(w1, 1, g);
+                win_row_grad(w2, 2, g);
+                float4 *dst = reinterpret_cast<float4 *>(dx + o);
+                float4 out = make_float4(g[0], g[1], g[2], g[3]);
+                if (accumulate) {
+                    const float4 e = *dst;
+                    out.x += e.x; out.y += e.y; out.z += e.z; out.w += e.w;
+                }
+                *dst = out;
+                const float oo[4] = {out.x, out.y, out.z, out.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gm = yy[j] > 0.f ? oo[j] : 0.f;
+                    sg[j] += gm;
+                    sy[j] += gm * yy[j];
+                }
+                w0 = w1;
+                w1 = w2;
+            }
+        }
+        float *o = sh + ((int64_t)rg * C4 + cg) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = sg[j];
+            o[4 + j] = sy[j];
+        }
+    }
+    __syncthreads();
+    if (tid < C4) {
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int g = 0; g < RG; ++g)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += sh[((int64_t)g * C4 + tid) * 8 + j];
+        const int P = gridDim.x;                       // partials laid out [2][C][P]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            partials[(int64_t)(tid * 4 + j) * P + blockIdx.x] = a[j];
+            partials[((int64_t)C + tid * 4 + j) * P + blockIdx.x] = a[4 + j];
+        }
+    }
+}
+
+// units (image columns) per workgroup: one per unit group of the workgroup (every thread walks ONE column, the parallelism of
+// maxpool3s1_bwd_rolling -- with four workgroups per CU and several columns per thread the launch was latency-bound: 119 us
+// against 79) unless that makes more than 2048 workgroups (partials)
+inline int pool_sums_upb(int N, int W, int C) {
+    const int units = N * W, C4 = C / 4;
+    const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
+    const int cap = (units + 2047) / 2048;
+    return RG > cap ? RG : cap;
 }
 
 // MaxPoolGrad of the 3x3 stride-2 pools: a thread owns the 2x2 input patch
@@ -716,6 +814,33 @@ extern "C" int ds_maxpool_bwd(const float *dy, const uint8_t *argmax, float *dx,
         hipLaunchKernelGGL((maxpool_bwd_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, dy, argmax, dx,
                            accumulate, N, H, W, C, k, stride, pad_t, pad_l, OH, OW);
     return ds::check_launch("ds_maxpool_bwd");
+}
+
+extern "C" int ds_maxpool3_bwd_sums_partials(int32_t N, int32_t W, int32_t C) {
+    if (N <= 0 || W <= 0 || C < 4) return 0;
+    const int upb = pool_sums_upb(N, W, C);
+    return (N * W + upb - 1) / upb;
+}
+
+extern "C" int ds_maxpool3_bwd_sums(const float *dy, const uint8_t *argmax, float *dx, int32_t accumulate, const void *y,
+                                    int32_t y_dtype, int32_t N, int32_t H, int32_t W, int32_t C, float *partials,
+                                    void *stream) {
+    DS_REQUIRE(dy && argmax && dx && y && partials && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024,
+               "ds_maxpool3_bwd_sums: bad argument (C %% 4 == 0, C <= 1024)");
+    DS_REQUIRE(y_dtype == DS_DTYPE_F32 || y_dtype == DS_DTYPE_BF16, "ds_maxpool3_bwd_sums: y_dtype must be DS_DTYPE_F32 or DS_DTYPE_BF16");
+    DS_REQUIRE((int64_t)N * H * W * C < (1ll << 40), "ds_maxpool3_bwd_sums: tensor too large");
+    const int upb = pool_sums_upb(N, W, C);
+    const int P = (N * W + upb - 1) / upb;
+    const int C4 = C / 4;
+    const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
+    const size_t shmem = (size_t)RG * C4 * 8 * sizeof(float);
+    if (y_dtype == DS_DTYPE_BF16)
+        hipLaunchKernelGGL(maxpool3s1_bwd_sums_kernel<__bf16>, dim3(P), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
+                           accumulate, (const __bf16 *)y, N, H, W, C, partials, upb);
+    else
+        hipLaunchKernelGGL(maxpool3s1_bwd_sums_kernel<float>, dim3(P), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
+                           accumulate, (const float *)y, N, H, W, C, partials, upb);
+    return ds::check_launch("ds_maxpool3_bwd_sums");
 }
 
 extern "C" int ds_avgpool_dropout_fwd(const float *x, int32_t N, int32_t HW, int32_t C, float keep, uint64_t seed,

@@ -777,6 +777,18 @@ class MixedStage(Stage):
                 for layer, off in ((p.fused, 0), (p.c1, pb0), (p.c2, pb0 + pb1b), (p.c3, pb0 + pb1b + pb2b)):
                     layer.part_sums[0] = (src[0], src[1], off, cin)
                     layer._sum_segs = None
+        #  * where the fused dgrad cannot accumulate (the 16-bit configurations' register-direct kernels) the order is the
+        #    reverse: the dgrad writes, Branch_3's pool gradient is added LAST -- and that launch, which then holds the complete
+        #    gradient of the previous block's output, emits the sums instead (ds_maxpool3_bwd_sums)
+        self.pool_sums = None
+        if isinstance(p, MixedStage) and not self.pool_first and eng.bwd_sums and eng.pool_sums and cin <= 1024 \
+                and not getattr(p, "zcat", False):          # (a zcat concat holds z, not y: the dgrad epilogue's business)
+            P = ops.maxpool3_bwd_sums_partials(B, p.W, cin)
+            self.pool_sums = torch.empty(2 * cin * P, device=dev)
+            pb0, _, pb1b, _, pb2b, pb3 = p.b
+            for layer, off in ((p.fused, 0), (p.c1, pb0), (p.c2, pb0 + pb1b), (p.c3, pb0 + pb1b + pb2b)):
+                layer.part_sums[0] = (self.pool_sums, P, off, cin)
+                layer._sum_segs = None
 
     # The three chains behind the block input -- [fused 1x1 -> Branch_1 3x3], [... -> Branch_2 3x3] and
     # [3x3/1 pool -> Branch_3 1x1] -- are independent: Branch_3 and then Branch_2 are issued on a side stream (fork /
@@ -975,7 +987,10 @@ class MixedStage(Stage):
                 main.wait_event(e_3)
         self.fused.backward(x, p.C, ops._p(p.dout) if need_dx else None, need_dx)
         if need_dx and not pool_first:
-            ops.maxpool_bwd(self.dpooled, self.argmax, p.dout, True, self.B, p.H, p.W, p.C, 3, 1, "SAME")
+            if self.pool_sums is not None:          # ... and the previous block's BatchNorm-backward sums (alloc)
+                ops.maxpool3_bwd_sums(self.dpooled, self.argmax, p.dout, True, p.out, self.B, p.H, p.W, p.C, self.pool_sums)
+            else:
+                ops.maxpool_bwd(self.dpooled, self.argmax, p.dout, True, self.B, p.H, p.W, p.C, 3, 1, "SAME")
 
 
 class InceptionV1Engine:
@@ -1049,6 +1064,7 @@ class InceptionV1Engine:
         # bit 0: the forward finalizes, bit 1: the backward finalize + apply; None = by batch size (MixedStage.alloc)
         e = _lib.tuning_env("DS_BATCH_BN")
         self.batch_bn = int(e) if e else None
+        self.pool_sums = _lib.tuning_env("DS_POOL_SUMS", "1") != "0"      # ... or from the Branch_3 pool gradient where that is the last addend (MixedStage.alloc)
         self.stem_sums_from_dgrad = _lib.tuning_env("DS_STEM_SUMS", "1") != "0"      # pooled stem: its BatchNorm sums from Conv2d_2b's dgrad epilogue
         self.dz16 = int(_lib.tuning_env("DS_DZ16", "2"))      # 16-bit configurations: bf16 dz for the frozen 1x1 (1) and 3x3 (2) layers (ConvBN.make_dgrad)
         self.fuse_branch3 = _lib.tuning_env("DS_FUSE_B3", "1") != "0"      # Branch_3's 3x3/1 max pool formed on load by its 1x1 conv (MixedStage.alloc)

@@ -693,6 +693,16 @@ def maxpool_bwd(dy, argmax, dx, accumulate, N, H, W, C_, k, stride, mode="SAME")
                                           pl, OH, OW, _stream()), "ds_maxpool_bwd")
 
 
+def maxpool3_bwd_sums_partials(N, W, C_):
+    return _lib.load().ds_maxpool3_bwd_sums_partials(N, W, C_)
+
+
+def maxpool3_bwd_sums(dy, argmax, dx, accumulate, y, N, H, W, C_, partials):
+    """ds_maxpool_bwd of a 3x3 / 1 SAME pool + the BatchNorm-backward sums (sum g, sum g*y over y > 0) of the activation y."""
+    _lib.check(_lib.load().ds_maxpool3_bwd_sums(_p(dy), _p(argmax), _p(dx), int(accumulate), _p(y), act_dtype(y), N, H, W, C_,
+                                                _p(partials), _stream()), "ds_maxpool3_bwd_sums")
+
+
 def avgpool_dropout_fwd(x, N, HW, C_, keep, seed, mask_in, mask_out, out, seed_dev=None):
     _lib.check(_lib.load().ds_avgpool_dropout_fwd(_p(x), N, HW, C_, keep, seed, _p(seed_dev), _p(mask_in),
                                                   _p(mask_out), _p(out), _stream()), "ds_avgpool_dropout_fwd")
