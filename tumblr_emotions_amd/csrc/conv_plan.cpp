@@ -149,7 +149,7 @@ extern "C" int ds_conv_plan(ds_conv_layer_plan *out, int32_t role, int32_t arith
         // 1756 against 2516 (direct), Conv2d_2c's 496 against 854; the two exceptions are the 14 x 14 layers with >= 288
         // reduction channels (direct: 130 / 141 against 144 / 155)
         if (!fp8 && dgrad && k == 3 && stride == 1 && !(options & DS_PLAN_NO_WINO4H) && ds_conv_wino4_supported(H, W, cin, cout)) {
-            if (!(H == 14 && cin >= 288)) fam = DS_FAM_WINO4H;
+            if (!(H == 14 && W == 14 && cin >= 288)) fam = DS_FAM_WINO4H;
             else if (!(options & DS_PLAN_NO_BF16_DIRECT) && cin % 8 == 0) fam = DS_FAM_BF16D;      // (the staged kernel: 141 / 155, no sums epilogue)
         }
         if (fam == DS_FAM_BF16D && !ds_conv_bf16_supported(&d)) fam = DS_FAM_IGEMM;

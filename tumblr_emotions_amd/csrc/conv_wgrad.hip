@@ -212,6 +212,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 // summed by splitk_reduce_kernel in a fixed order (deterministic, no atomics).
 // The transposed stores put component b back next to its neighbours: out[ci][co0 + BJ*li + 0..BJ-1] is one store.
 // ================================================================================================
+#ifndef DS_WG_U
+#define DS_WG_U 4          // K steps of operands in flight per wave (tuning builds: -DDS_WG_U=8)
+#endif
 template <int W>
 __device__ __forceinline__ f32x4 loadw(__amdgpu_buffer_rsrc_t r, unsigned off) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -230,7 +233,7 @@ __device__ __forceinline__ f32x4 loadw(__amdgpu_buffer_rsrc_t r, unsigned off) {
 
 template <int AI, int BJ>
 __global__ __launch_bounds__(256, (AI * BJ > 8) ? 1 : 2) void wgrad_direct_kernel(const WgradParams p) {
-    constexpr int NACC = AI * BJ, U = 4;
+    constexpr int NACC = AI * BJ, U = DS_WG_U;
     __shared__ __attribute__((aligned(16))) float red[2 * NACC * 16 * 64];
     const ds_conv_desc &d = p.d;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -463,13 +466,14 @@ bool direct_ok(const ds_conv_desc *d, int64_t M) {
 // Tile shape and slab count by a cycle model of the launch: rounds of resident workgroups x (K steps x MFMA cycles
 // + epilogue), plus the split-K reduction's traffic.  Slabs are 1, 2, 4 or a multiple of 8 (XCD-aligned, see the
 // kernel); a slab keeps >= 64 pixels per wave.
-WgradPlan plan_direct(const ds_conv_desc *d, int64_t M, int wx, int wz) {
+WgradPlan plan_direct(const ds_conv_desc *d, int64_t M, int wx, int wz, int only_ai = 0, int only_bj = 0) {
     WgradPlan best = {};
     double best_cost = 1e30;
     static const int kSlabs[] = {1, 2, 4, 8, 16, 24, 32, 40, 48, 56, 64};
     const double wbytes = (double)d->KH * d->KW * d->Cin * d->Cout * 4.0;
     for (int ai = 1; ai <= wx; ai *= 2)
         for (int bj = 1; bj <= wz; bj *= 2) {
+            if ((only_ai && ai != only_ai) || (only_bj && bj != only_bj)) continue;
             const int nacc = ai * bj;
             const int occ = nacc > 8 ? 1 : (nacc > 4 ? 2 : 3);
             const int tiles = d->KH * d->KW * ((d->Cin + 32 * ai - 1) / (32 * ai)) * ((d->Cout + 32 * bj - 1) / (32 * bj));
@@ -501,12 +505,15 @@ WgradPlan plan_wgrad(const ds_conv_desc *d, int64_t M, const float *x, const flo
     if (direct_ok(d, M)) {
         // BJ is also the width of the kernel's vector stores into dw (or the split-K workspace): their alignment counts
         const uintptr_t zalign = (uintptr_t)dz | (uintptr_t)dw | (uintptr_t)ws;
-        WgradPlan pl = plan_direct(d, M, max_width(d->Cin, d->ldx, (uintptr_t)x), max_width(d->Cout, lddz, zalign));
+        const int wx = max_width(d->Cin, d->ldx, (uintptr_t)x), wz = max_width(d->Cout, lddz, zalign);
+        WgradPlan pl = plan_direct(d, M, wx, wz);
         if (const char *e = ds::tune_env("DS_WGRAD_FORCE")) {          // "ai,bj,slabs" (tuning aid; the caller sizes the workspace)
             int a = 0, b = 0, sl = 0;
             if (sscanf(e, "%d,%d,%d", &a, &b, &sl) == 3) {
-                if (a) pl.ai = a;
-                if (b) pl.bj = b;
+                if ((a && a <= wx) || (b && b <= wz)) {          // the slab count the model gives THAT tile shape
+                    const WgradPlan f = plan_direct(d, M, wx, wz, a <= wx ? a : 0, b <= wz ? b : 0);
+                    if (f.direct) pl = f;
+                }
                 if (sl) pl.splits = sl;
             }
         }
