@@ -438,6 +438,15 @@ typedef struct ds_bn_finalize_job {
 } ds_bn_finalize_job;
 int ds_bn_finalize_multi(const ds_bn_finalize_job *jobs, int32_t njobs, float eps, float decay, void *stream);
 
+/* ds_bn_finalize and the ds_bn_apply_relu pass that reads its result as ONE launch: the first C workgroups finalize a channel
+ * each and publish, the others wait for all C (device-side ticket) and stream.  Saves the dependent-launch boundary between
+ * the two (~4 us of idle GPU per layer).  ticket: two zero-initialised uint32 owned by the caller, one pair per layer that
+ * may be in flight at a time (the launch leaves them zero).  Results bit-identical to the two launches.                   */
+int ds_bn_finalize_apply_relu(const float *stats, int32_t P, int64_t count, int32_t C, const float *beta, const float *pivot,
+                              float eps, float decay, float *mean, float *rstd, float *shift, float *moving_mean,
+                              float *moving_var, const float *z, int64_t M, const struct ds_segments *dst, uint32_t *ticket,
+                              void *stream);
+
 /* y = relu(z*rstd + shift) scattered to up to 4 channel segments (branch outputs written
  * straight into the concat buffer: replaces tf.concat, inception_v1.py:96 ... :248).       */
 typedef struct ds_segments {
@@ -490,6 +499,13 @@ int ds_bn_bwd_finalize_segs(const ds_bn_sum_segments *sg, int64_t M, int32_t C, 
  * first channel; coef is float[2][C] over the concatenated columns -- what ONE ds_bn_bwd_apply over those columns reads.  */
 int ds_bn_bwd_finalize_multi(const ds_bn_sum_segments *sg, int64_t M, int32_t C, const float *const *beta,
                              float *const *dbeta, float *coef, void *stream);
+/* ds_bn_bwd_finalize_segs / _multi and the ds_bn_bwd_apply (dz_dtype DS_DTYPE_F32: dz [M, ldz]) / ds_bn_bwd_apply_bf16
+ * (DS_DTYPE_BF16: dz [M, lddz]) pass behind it as ONE launch (see ds_bn_finalize_apply_relu; ticket as there).  beta / dbeta:
+ * one vector for all columns, or -- beta_v non-null -- the segments' own (ds_bn_bwd_finalize_multi).  Bit-identical.     */
+int ds_bn_bwd_finalize_apply(const ds_bn_sum_segments *sg, const float *beta, float *dbeta, const float *const *beta_v,
+                             float *const *dbeta_v, float *coef, const float *z, int32_t ldz, const ds_segments *dy, int64_t M,
+                             int32_t C, const float *mean, const float *rstd, const float *shift, void *dz, int32_t dz_dtype,
+                             int32_t lddz, float *amax, uint32_t *ticket, void *stream);
 /* amax (nullable): device word that receives max|dz| by atomic max (zeroed by the caller): the scale of an fp8 dgrad */
 /* ldz: row stride of z AND dz in floats (>= C, % 4 == 0): a layer whose conv writes straight into its slice of the   */
 /* Inception concat buffer is differentiated in place there                                                          */

@@ -830,6 +830,79 @@ def test_batch_norm_launches_of_three_layers_as_one_are_bit_identical():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("case", [(3000, 176, 24), (25088, 624, 196), (70, 16, 3), (200704, 64, 1568)])
+def test_batch_norm_finalize_and_apply_as_one_launch_are_bit_identical(case):
+    """ds_bn_finalize_apply_relu / ds_bn_bwd_finalize_apply (round 6): the finalize (one workgroup per channel) and the apply pass
+    that reads its result as ONE launch -- the apply workgroups wait on a device-side ticket instead of a dependent-launch
+    boundary (slim.batch_norm + relu of every conv, slim/nets/inception_utils.py:48-70).  Every output -- statistics, moving
+    averages, activations in fp32 and bf16 segments, dbeta, coefficients, dz in fp32 (in place) and bf16 -- equals the two
+    launches' to the bit; called three times in a row (the launch leaves its ticket words zero)."""
+    ops = _ops()
+    M, Cc, P = case
+    rng = np.random.RandomState(M % 1000 + Cc)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    z = dev(rng.normal(size=(M, Cc)) * 2 + 0.3)
+    stats = dev(rng.normal(size=(2, Cc, P)) * 5 + np.array([0.0, 40.0])[:, None, None])
+    beta, pivot = dev(rng.normal(size=Cc)), dev(rng.normal(size=Cc))
+    c1 = (Cc // 8) * 4
+    ticket = torch.zeros(4, dtype=torch.int32, device="cuda")
+
+    def forward(merged):
+        mean, rstd, shift = pivot.clone(), torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+        mm, mv = beta.clone(), beta.abs() + 1
+        ya, yb = torch.zeros(M, c1, device="cuda"), torch.zeros(M, Cc, device="cuda", dtype=torch.bfloat16)
+        segs = ops.make_segments([(0, c1, ya.data_ptr(), c1), (c1, Cc, yb.data_ptr() + 2 * c1, Cc, ops.DS_DTYPE_BF16, None)])
+        if merged:
+            ops.bn_finalize_apply_relu(stats, P, M, Cc, beta, 1e-3, 0.9997, mean, rstd, shift, mm, mv, mean, z, M, segs, ticket[0:2])
+        else:
+            ops.bn_finalize(stats, P, M, Cc, beta, 1e-3, 0.9997, mean, rstd, shift, mm, mv, pivot=mean)
+            ops.bn_apply_relu(z, M, Cc, rstd, shift, segs)
+        torch.cuda.synchronize()
+        return [mean, rstd, shift, mm, mv, ya, yb]
+
+    want = forward(False)
+    for _ in range(3):
+        got = forward(True)
+        assert all(torch.equal(a, b) for a, b in zip(want, got))
+        assert int(ticket.abs().sum()) == 0
+    assert float(want[5].abs().max()) > 0 and float(want[6][:, c1:].float().abs().max()) > 0
+    mean, rstd, shift = want[0], want[1], want[2]
+    # ---- backward: one segment from reduce partials (kind 0), one in the DS_EPI_BNSUMS form (kind 1); dz fp32 in place / bf16
+    dy = dev(rng.normal(size=(M, Cc)))
+    dy_segs = ops.make_segments([(0, Cc, dy.data_ptr(), Cc)])
+    P0 = ops.bn_bwd_partials(M, c1)
+    scratch = torch.empty(2 * c1 * P0, device="cuda")
+    ops.bn_bwd_reduce(C.c_void_p(z.data_ptr()), ops.make_segments([(0, c1, dy.data_ptr(), Cc)]), M, c1, mean, rstd, shift, scratch, ldz=Cc)
+    P1 = 9
+    nxt = dev(rng.normal(size=(2, Cc, P1)))
+    sg = ops.SumSegments()
+    sg.nseg = 2
+    sg.c_begin[0], sg.c_end[0], sg.P[0], sg.kind[0] = 0, c1, P0, 0
+    sg.s[0], sg.q[0] = scratch.data_ptr(), scratch.data_ptr() + 4 * c1 * P0
+    sg.c_begin[1], sg.c_end[1], sg.P[1], sg.kind[1] = c1, Cc, P1, 1
+    sg.s[1], sg.q[1] = nxt.data_ptr() + 4 * c1 * P1, nxt.data_ptr() + 4 * (Cc + c1) * P1
+
+    def backward(merged, out16):
+        zc = z.clone()
+        dz = torch.zeros(M, Cc, device="cuda", dtype=torch.bfloat16) if out16 else zc
+        dbeta, coef = torch.zeros(Cc, device="cuda"), torch.zeros(2, Cc, device="cuda")
+        if merged:
+            ops.bn_bwd_finalize_apply(sg, M, Cc, beta, dbeta, coef, zc, dy_segs, mean, rstd, shift, dz, ticket[2:4])
+        else:
+            ops.bn_bwd_finalize_segs(sg, M, Cc, beta, dbeta, coef)
+            ops.bn_bwd_apply(zc, dy_segs, M, Cc, mean, rstd, shift, coef, dz)
+        torch.cuda.synchronize()
+        return [dbeta, coef, dz, zc]
+
+    for out16 in (False, True):
+        want = backward(False, out16)
+        for _ in range(3):
+            got = backward(True, out16)
+            assert all(torch.equal(a, b) for a, b in zip(want, got)), out16
+            assert int(ticket.abs().sum()) == 0
+        assert not torch.equal(want[2].float(), z)
+
+
 @pytest.mark.parametrize("case", [(5, 14, 14, 480, "f32"), (3, 28, 28, 256, "bf16"), (9, 7, 7, 832, "f32"), (2, 9, 5, 12, "bf16"),
                                   (300, 7, 7, 64, "bf16")])
 def test_max_pool_gradient_that_also_emits_the_batch_norm_sums(case):

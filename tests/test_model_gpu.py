@@ -553,6 +553,32 @@ def test_block_batched_batch_norm_launches_step_is_bit_identical():
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_finalize_and_apply_as_one_launch_step_is_bit_identical(dtype):
+    """InceptionV1Engine.fuse_fin_apply (built and measured, off by default: slower than the launch boundary it removes,
+    profiles/r06_notes.md): every BatchNorm finalize whose result the next launch on the stream applies --
+    forward the reduce layers' (ds_bn_finalize_apply_relu), backward every layer's, the block-batched one included
+    (ds_bn_bwd_finalize_apply) -- runs as the first workgroups of that apply launch, which waits on a device-side ticket
+    instead of a launch boundary (slim.batch_norm, slim/nets/inception_utils.py:48-70).  Same arithmetic in the same order:
+    two training steps and an inference pass are BIT-identical to the separate launches, fp32 and bf16."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    batch = to_device(synthetic_batch_numpy(32, 10, 50, seed=5))
+    res = []
+    for on in (True, False):
+        net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10, dtype=dtype)
+        net.image.fuse_fin_apply = on
+        net.initialize(seed=7)
+        net.train_step(batch, 1e-3)
+        g1 = net.store.grad.clone()
+        net.train_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        res.append((net.logits.detach().clone(), net.total_loss_value(), g1, net.store.grad.clone(), net.store.theta.clone(),
+                    net.store.frozen.clone(), net.predict(batch, is_training=False).clone()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_batch_norm_sums_from_the_branch3_pool_gradient_step_follows_the_reduce_passes(dtype):
     """InceptionV1Engine.pool_sums (default): where the fused 1x1 dgrad of a block cannot accumulate (the 16-bit configurations;
     here also fp32 with pool_first and zcat off) Branch_3's pool gradient is the LAST addend of the block-input gradient, and that launch

@@ -160,6 +160,8 @@ SIGNATURES = {
     "ds_bn_bwd_finalize": (C.c_int, [_P, _i32, _i64, _i32, _P, _P, _P]),
     "ds_bn_bwd_finalize_multi": (C.c_int, [_SS, _i64, _i32, _P, _P, _P, _P]),
     "ds_bn_finalize_multi": (C.c_int, [_P, _i32, _f32, _f32, _P]),
+    "ds_bn_finalize_apply_relu": (C.c_int, [_P, _i32, _i64, _i32, _P, _P, _f32, _f32, _P, _P, _P, _P, _P, _P, _i64, _SG, _P, _P]),
+    "ds_bn_bwd_finalize_apply": (C.c_int, [_SS, _P, _P, _P, _P, _P, _P, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _i32, _i32, _P, _P, _P]),
     "ds_bn_bwd_apply": (C.c_int, [_P, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _P, _P, _P]),
     "ds_bn_bwd_apply_bf16": (C.c_int, [_P, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _P, _i32, _P, _P]),
     "ds_maxpool_fwd": (C.c_int, [_P, _P, _P] + [_i32] * 11 + [_P]),

@@ -58,10 +58,34 @@ __device__ __forceinline__ float4 ldz4<__bf16>(const __bf16 *p) {
 
 using ds::wave_sum_f64;
 
+// Hand-off INSIDE a launch (the finalize + apply kernels below): the producer's few per-channel results go out as agent-scope
+// relaxed atomic stores (write-through: visible at the device's coherence point once vmcnt drains), the consumers read them
+// with agent-scope relaxed atomic loads (never a stale line of their XCD's L2).  No release / acquire fences: at agent scope
+// those write back / invalidate a whole L2 per workgroup (measured: +80 us per launch).
+template <bool COH>
+__device__ __forceinline__ void st_res(float *p, float v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ float4 ld_res4(const float *p) {
+    if constexpr (COH) {
+        float4 v;
+        v.x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.z = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.w = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    } else {
+        return *reinterpret_cast<const float4 *>(p);
+    }
+}
+
 // ---- forward ------------------------------------------------------------------------------------
 // one workgroup per channel; partials are laid out [2][C][P] so the threads read contiguous floats
 // (P is a few hundred for the persistent conv launches, one per row tile -- up to 2048 -- otherwise);
 // combined in double in a fixed order: strided per thread, butterfly per wave, waves 0..3 (deterministic)
+template <bool COH = false>
 __device__ __forceinline__ void finalize_channel(const float *stats, int P, double inv_count, int C, int c, const float *beta,
                                                  const float *pivot, float eps, float decay, float *mean, float *rstd,
                                                  float *shift, float *mm, float *mv) {
@@ -90,8 +114,8 @@ __device__ __forceinline__ void finalize_channel(const float *stats, int P, doub
         if (var < 0.0) var = 0.0;
         const float r = (float)(1.0 / sqrt(var + (double)eps));
         mean[c] = (float)mu;
-        rstd[c] = r;
-        shift[c] = beta[c] - (float)mu * r;
+        st_res<COH>(rstd + c, r);
+        st_res<COH>(shift + c, beta[c] - (float)mu * r);
         if (mm) mm[c] = decay * mm[c] + (1.f - decay) * (float)mu;     // assign_moving_average
         if (mv) mv[c] = decay * mv[c] + (1.f - decay) * (float)var;
     }
@@ -128,12 +152,13 @@ __global__ __launch_bounds__(256) void bn_finalize_multi_kernel(FinJobsDev jb, f
 // segment lookup happen once, the loop has no division, and consecutive threads still read consecutive addresses.  Tensors
 // that are read once come in with the non-temporal hint (scripts/microbench/stream_bw.hip: 5.3 -> 6.4 TB/s for "two in,
 // one out"); two rows per pass with both rows' loads before either store (a load behind a store waits for it).
-__global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *z, int64_t M, int C, const float *rstd,
-                                                            const float *shift, SegDev dst, int drow) {
+template <bool COH = false>
+__device__ __forceinline__ void apply_relu_body(int bid, const float *z, int64_t M, int C, const float *rstd,
+                                                const float *shift, const SegDev &dst, int drow) {
     const int C4 = C >> 2;
-    const int t0 = blockIdx.x * 256 + threadIdx.x;
+    const int t0 = bid * 256 + threadIdx.x;
     const int row0 = t0 / C4, c = (t0 - row0 * C4) * 4;
-    const float4 r = *reinterpret_cast<const float4 *>(rstd + c), s = *reinterpret_cast<const float4 *>(shift + c);
+    const float4 r = ld_res4<COH>(rstd + c), s = ld_res4<COH>(shift + c);
     int sgi = 0;                                 // this column group's destination segment
 #pragma unroll
     for (int i = 1; i < 4; ++i)
@@ -178,6 +203,69 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *z, int6
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if ((threadIdx.x & 63) == 0) ds::atomic_max_nonneg(dst.amax[i], m);
     }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *z, int64_t M, int C, const float *rstd,
+                                                            const float *shift, SegDev dst, int drow) {
+    apply_relu_body((int)blockIdx.x, z, M, C, rstd, shift, dst, drow);
+}
+
+// ---- finalize + apply as ONE launch --------------------------------------------------------------------------------------
+// A finalize is one workgroup per channel and ~1 us of work; the apply pass that reads its result used to be the next launch
+// on the same stream, i.e. a dependent-launch boundary (~4 us of idle GPU + the launch's own ramp) for every BatchNorm layer
+// and direction -- at 32 samples per GPU a tenth of the step.  Here the first C workgroups of the launch finalize their
+// channel and publish (release increment of ticket[0]); the others are the apply pass: thread 0 spins on ticket[0] == C
+// (acquire), then the workgroup reads the per-channel vectors and streams as before.  No deadlock: a grid's workgroups are
+// dispatched in id order, so whenever an apply workgroup occupies a slot every finalize workgroup has been placed already
+// and runs to completion.  The last apply workgroup to pass its end (ticket[1]) zeroes both words for the next launch.
+// Arithmetic and summation order are the separate launches': bit-identical.
+__device__ __forceinline__ void fa_publish(unsigned *ticket) {
+    if (threadIdx.x == 0) {          // (thread 0 wrote the channel's results: st_res<true>)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void fa_wait(unsigned *ticket, unsigned need) {
+    if (threadIdx.x == 0) {
+        unsigned n = 0;
+        // (a thousand workgroups polling one word every few hundred ns queue up at its memory channel in front of the very
+        // increments they wait for: first poll after ~3 us, then every ~1.5 us)
+        __builtin_amdgcn_s_sleep(127);
+        while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(60);
+            if (++n > (1u << 21)) __builtin_trap();          // (seconds: cannot happen, see above -- fail loudly, never hang)
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void fa_leave(unsigned *ticket, unsigned napply) {
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == napply - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+struct FinApplyArgs {
+    const float *stats; int P; double inv_count; int C;
+    const float *beta, *pivot; float eps, decay;
+    float *mean, *rstd, *shift, *mm, *mv;
+    const float *z; int64_t M; SegDev dst; int drow;
+    unsigned *ticket;
+};
+
+__global__ __launch_bounds__(256) void bn_finalize_apply_relu_kernel(const FinApplyArgs a) {
+    if ((int)blockIdx.x < a.C) {
+        finalize_channel<true>(a.stats, a.P, a.inv_count, a.C, (int)blockIdx.x, a.beta, a.pivot, a.eps, a.decay, a.mean, a.rstd,
+                               a.shift, a.mm, a.mv);
+        fa_publish(a.ticket);
+        return;
+    }
+    fa_wait(a.ticket, (unsigned)a.C);
+    apply_relu_body<true>((int)blockIdx.x - a.C, a.z, a.M, a.C, a.rstd, a.shift, a.dst, a.drow);
+    fa_leave(a.ticket, gridDim.x - (unsigned)a.C);
 }
 
 // ---- backward -----------------------------------------------------------------------------------
@@ -315,10 +403,10 @@ struct SumSegDev {
     float *dbeta[4];           // vector offset per segment; ds_bn_bwd_finalize_multi: the layers' own vectors); nullable
 };
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_segs_kernel(SumSegDev sg, double inv_count, int C, float *coef) {
+template <bool COH = false>
+__device__ __forceinline__ void bwd_finalize_segs_channel(const SumSegDev &sg, double inv_count, int C, float *coef, int c) {
     __shared__ double red[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x;
     int P = 0, kind = 0;
     const float *sp = nullptr, *qp = nullptr, *beta = nullptr;
     float *dbeta = nullptr;
@@ -349,25 +437,29 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_segs_kernel(SumSegDev sg,
         q = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
         if (kind == 1) q -= (double)*beta * s;
         if (dbeta) *dbeta = (float)s;
-        coef[c] = (float)(s * inv_count);
-        coef[C + c] = (float)(q * inv_count);
+        st_res<COH>(coef + c, (float)(s * inv_count));
+        st_res<COH>(coef + C + c, (float)(q * inv_count));
     }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_segs_kernel(SumSegDev sg, double inv_count, int C, float *coef) {
+    bwd_finalize_segs_channel(sg, inv_count, C, coef, (int)blockIdx.x);
 }
 
 // OUT16: dz goes to a SEPARATE bf16 tensor (pixel stride lddz) instead of over z -- the 16-bit configurations' 1x1 input
 // gradients read it with one 16-byte load per eight channels (conv_bf16d_kernel<.., XB = true>); the values are the ones that
 // kernel would have rounded on load (RNE), so the dgrad's result has the same bits
-template <bool OUT16>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, int ldz, SegDev dy, int64_t M, int C,
-                                                           const float *mean, const float *rstd, const float *shift,
-                                                           const float *coef, float *dz, float *amax, int drow, int lddz) {
+template <bool OUT16, bool COH = false>
+__device__ __forceinline__ void bwd_apply_body(int bid, const float *z, int ldz, const SegDev &dy, int64_t M, int C,
+                                               const float *mean, const float *rstd, const float *shift,
+                                               const float *coef, float *dz, float *amax, int drow, int lddz) {
     // (thread = one float4 column group, rows row0, row0 + drow, ...: see bn_apply_relu_kernel)
     const int C4 = C >> 2;
-    const int t0 = blockIdx.x * 256 + threadIdx.x;
+    const int t0 = bid * 256 + threadIdx.x;
     const int row0 = t0 / C4, c = (t0 - row0 * C4) * 4;
     const float4 r4 = *reinterpret_cast<const float4 *>(rstd + c), s4 = *reinterpret_cast<const float4 *>(shift + c);
     const float4 m4 = *reinterpret_cast<const float4 *>(mean + c);
-    const float4 k14 = *reinterpret_cast<const float4 *>(coef + c), k24 = *reinterpret_cast<const float4 *>(coef + C + c);
+    const float4 k14 = ld_res4<COH>(coef + c), k24 = ld_res4<COH>(coef + C + c);
     const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
     const float a1[4] = {k14.x, k14.y, k14.z, k14.w}, a2[4] = {k24.x, k24.y, k24.z, k24.w};
     int sgi = 0;
@@ -403,6 +495,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, int l
         for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
         if ((threadIdx.x & 63) == 0) ds::atomic_max_nonneg(amax, am);
     }
+}
+
+template <bool OUT16>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, int ldz, SegDev dy, int64_t M, int C,
+                                                           const float *mean, const float *rstd, const float *shift,
+                                                           const float *coef, float *dz, float *amax, int drow, int lddz) {
+    bwd_apply_body<OUT16>((int)blockIdx.x, z, ldz, dy, M, C, mean, rstd, shift, coef, dz, amax, drow, lddz);
+}
+
+// ds_bn_bwd_finalize_apply: the backward finalize (segments, per-segment beta / dbeta) and the apply pass as one launch
+// (see bn_finalize_apply_relu_kernel)
+struct BwdFinApplyArgs {
+    SumSegDev sg; double inv_count; int C; float *coef;
+    const float *z; int ldz; SegDev dy; int64_t M;
+    const float *mean, *rstd, *shift;
+    float *dz, *amax; int drow, lddz;
+    unsigned *ticket;
+};
+
+template <bool OUT16>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(const BwdFinApplyArgs a) {
+    if ((int)blockIdx.x < a.C) {
+        bwd_finalize_segs_channel<true>(a.sg, a.inv_count, a.C, a.coef, (int)blockIdx.x);
+        fa_publish(a.ticket);
+        return;
+    }
+    fa_wait(a.ticket, (unsigned)a.C);
+    bwd_apply_body<OUT16, true>((int)blockIdx.x - a.C, a.z, a.ldz, a.dy, a.M, a.C, a.mean, a.rstd, a.shift, a.coef, a.dz, a.amax, a.drow,
+                          a.lddz);
+    fa_leave(a.ticket, gridDim.x - (unsigned)a.C);
 }
 
 // Launch shape of the fixed-column streaming kernels: gridDim.x * 256 threads = drow rows of C4 column groups each, i.e. the
@@ -501,6 +623,24 @@ extern "C" int ds_bn_apply_relu(const float *z, int64_t M, int32_t C, const floa
     return ds::check_launch("ds_bn_apply_relu");
 }
 
+extern "C" int ds_bn_finalize_apply_relu(const float *stats, int32_t P, int64_t count, int32_t C, const float *beta,
+                                         const float *pivot, float eps, float decay, float *mean, float *rstd, float *shift,
+                                         float *moving_mean, float *moving_var, const float *z, int64_t M,
+                                         const ds_segments *dst, uint32_t *ticket, void *stream) {
+    DS_REQUIRE(stats && beta && mean && rstd && shift && P > 0 && count > 0 && C > 0 && C % 4 == 0 && z && M > 0 && ticket,
+               "ds_bn_finalize_apply_relu: bad argument (C %% 4 != 0?)");
+    if (int e = check_segments(dst, C, "ds_bn_finalize_apply_relu", true)) return e;
+    FinApplyArgs a;
+    a.stats = stats; a.P = P; a.inv_count = 1.0 / (double)count; a.C = C;
+    a.beta = beta; a.pivot = pivot; a.eps = eps; a.decay = decay;
+    a.mean = mean; a.rstd = rstd; a.shift = shift; a.mm = moving_mean; a.mv = moving_var;
+    a.z = z; a.M = M; a.dst = to_dev(dst);
+    a.ticket = ticket;
+    const int grid = column_grid(M, C / 4, &a.drow);
+    hipLaunchKernelGGL(bn_finalize_apply_relu_kernel, dim3(C + grid), dim3(256), 0, (hipStream_t)stream, a);
+    return ds::check_launch("ds_bn_finalize_apply_relu");
+}
+
 extern "C" int ds_bn_bwd_partials(int64_t M, int32_t C) {
     (void)C;
     const int rpb = bwd_rows_per_block(M);
@@ -537,10 +677,9 @@ extern "C" int ds_bn_bwd_finalize(const float *partials, int32_t P, int64_t M, i
 }
 
 namespace {
-int launch_finalize_segs(const char *who, const ds_bn_sum_segments *sg, int64_t M, int32_t C, const float *beta, float *dbeta,
-                         const float *const *beta_v, float *const *dbeta_v, float *coef, void *stream) {
+int build_sum_segs(const char *who, const ds_bn_sum_segments *sg, int64_t M, int32_t C, const float *beta, float *dbeta,
+                   const float *const *beta_v, float *const *dbeta_v, float *coef, SumSegDev &d) {
     DS_REQUIRE(sg && coef && M > 0 && C > 0 && sg->nseg >= 1 && sg->nseg <= 4, "%s: bad argument", who);
-    SumSegDev d;
     d.nseg = sg->nseg;
     int covered = 0;
     for (int i = 0; i < 4; ++i) {
@@ -557,6 +696,13 @@ int launch_finalize_segs(const char *who, const ds_bn_sum_segments *sg, int64_t 
         }
     }
     DS_REQUIRE(covered == C, "%s: segments cover %d of %d channels", who, covered, C);
+    return DS_OK;
+}
+
+int launch_finalize_segs(const char *who, const ds_bn_sum_segments *sg, int64_t M, int32_t C, const float *beta, float *dbeta,
+                         const float *const *beta_v, float *const *dbeta_v, float *coef, void *stream) {
+    SumSegDev d;
+    if (int e = build_sum_segs(who, sg, M, C, beta, dbeta, beta_v, dbeta_v, coef, d)) return e;
     hipLaunchKernelGGL(bn_bwd_finalize_segs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, d, 1.0 / (double)M, C, coef);
     return ds::check_launch(who);
 }
@@ -571,6 +717,29 @@ extern "C" int ds_bn_bwd_finalize_multi(const ds_bn_sum_segments *sg, int64_t M,
                                         float *const *dbeta, float *coef, void *stream) {
     DS_REQUIRE(beta, "ds_bn_bwd_finalize_multi: the segments' beta vectors are required");
     return launch_finalize_segs("ds_bn_bwd_finalize_multi", sg, M, C, nullptr, nullptr, beta, dbeta, coef, stream);
+}
+
+extern "C" int ds_bn_bwd_finalize_apply(const ds_bn_sum_segments *sg, const float *beta, float *dbeta, const float *const *beta_v,
+                                        float *const *dbeta_v, float *coef, const float *z, int32_t ldz, const ds_segments *dy,
+                                        int64_t M, int32_t C, const float *mean, const float *rstd, const float *shift, void *dz,
+                                        int32_t dz_dtype, int32_t lddz, float *amax, uint32_t *ticket, void *stream) {
+    const bool out16 = dz_dtype == DS_DTYPE_BF16;
+    DS_REQUIRE(z && mean && rstd && shift && coef && dz && ticket && M > 0 && C > 0 && C % 4 == 0 && ldz >= C && ldz % 4 == 0 &&
+                   (((uintptr_t)z) & 15) == 0 && (dz_dtype == DS_DTYPE_F32 || out16) &&
+                   (((uintptr_t)dz) & (out16 ? 7 : 15)) == 0 && (!out16 || (lddz >= C && lddz % 4 == 0)),
+               "ds_bn_bwd_finalize_apply: bad argument (see ds_bn_bwd_apply / ds_bn_bwd_apply_bf16)");
+    if (int e = check_segments(dy, C, "ds_bn_bwd_finalize_apply")) return e;
+    BwdFinApplyArgs a;
+    if (int e = build_sum_segs("ds_bn_bwd_finalize_apply", sg, M, C, beta, dbeta, beta_v, dbeta_v, coef, a.sg)) return e;
+    a.inv_count = 1.0 / (double)M; a.C = C; a.coef = coef;
+    a.z = z; a.ldz = ldz; a.dy = to_dev(dy); a.M = M;
+    a.mean = mean; a.rstd = rstd; a.shift = shift;
+    a.dz = reinterpret_cast<float *>(dz); a.amax = amax; a.lddz = out16 ? lddz : ldz;
+    a.ticket = ticket;
+    const int grid = column_grid(M, C / 4, &a.drow);
+    if (out16) hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<true>, dim3(C + grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<false>, dim3(C + grid), dim3(256), 0, (hipStream_t)stream, a);
+    return ds::check_launch("ds_bn_bwd_finalize_apply");
 }
 
 extern "C" int ds_bn_bwd_apply(const float *z, int32_t ldz, const ds_segments *dy, int64_t M, int32_t C, const float *mean,

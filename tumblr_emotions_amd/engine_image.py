@@ -88,6 +88,8 @@ class ConvBN:
         self.rstd = torch.empty(cout, device=dev)
         self.shift = torch.empty(cout, device=dev)
         self.coef = torch.empty(2, cout, device=dev)
+        self.fa_ticket = torch.zeros(4, dtype=torch.int32, device=dev)      # finalize + apply as one launch: [0:2] forward, [2:4] backward
+        self._plain_segs = None
         # The library plans the launch (ds_conv_plan): kernel family per shape and arithmetic -- implicit GEMM / wide 1x1,
         # fused Winograd F(2x2) / F(4x4) by its launch-time model, the packed-RGB stem kernel, the register-direct bf16 /
         # fp8 / f32x3 kernels -- the BatchNorm partial count and the prepared filter form.  The engine only says what the
@@ -376,9 +378,15 @@ class ConvBN:
                 eng.all_reduce(self.stats_buf[:2 * self.cout * plan.partials])
                 count = self.M * eng.sync_world
             if fin is None and not defer_finalize:
+                mm, mv = (self.mm, self.mv) if eng.update_moving else (None, None)
+                if eng.fuse_fin_apply and not eng.sync_bn and segs is not None and not self.skip_apply:
+                    # ds_bn_finalize and the apply pass that reads its result as ONE launch (no dependent-launch boundary)
+                    ops.bn_finalize_apply_relu(self.stats_buf, plan.partials, count, self.cout, self.beta, BN_EPS, BN_DECAY,
+                                               self.mean, self.rstd, self.shift, mm, mv, self.mean, self.z, self.M, segs,
+                                               self.fa_ticket[0:2])
+                    return
                 ops.bn_finalize(self.stats_buf, plan.partials, count, self.cout, self.beta, BN_EPS, BN_DECAY, self.mean,
-                                self.rstd, self.shift, self.mm if eng.update_moving else None,
-                                self.mv if eng.update_moving else None, pivot=self.mean)
+                                self.rstd, self.shift, mm, mv, pivot=self.mean)
         else:                  # moving statistics (is_training=False: evaluate_* on the validation split)
             plan.d.flags = 0
             plan.run(x_ptr, self.w_ptr, ops._p(self.z), x_amax=amax_p)
@@ -435,20 +443,38 @@ class ConvBN:
         dy_segs = self.dy_segs
         if self.gbeta is None and not need_dx and not self.trainable:
             return
-        if any(ps is not None for ps in self.part_sums) or any(pp is not None for pp in self.part_pool):
-            self._bn_bwd_sums()
-        else:
-            ops.bn_bwd_reduce(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.bwdp_buf, ldz=self.ldz)
-            self._finalize_plain(self.bwd_P)
-        if not (need_dx or self.trainable):
-            return
-        if self.bnb:              # z stays as it is: the dgrad's loader forms dz
-            self._run_dgrad(dx_ptr)
-            return
+        from_parts = any(ps is not None for ps in self.part_sums) or any(pp is not None for pp in self.part_pool)
         track = self.dgrad is not None and self.dgrad.family == ops.DS_FAM_FP8D
-        ops.bn_bwd_apply(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.coef,
-                         self.z if self.dz16 is None else self.dz16,          # dz over z, or into its own bf16 tensor
-                         amax=self.dz_amax if track else None, ldz=self.ldz)
+        dz = self.z if self.dz16 is None else self.dz16          # dz over z, or into its own bf16 tensor
+        if eng.fuse_fin_apply and not eng.sync_bn and (need_dx or self.trainable) and not self.bnb:
+            # the finalize and the apply pass behind it as ONE launch (ds_bn_bwd_finalize_apply)
+            if from_parts:
+                sg = self._sum_plan()
+                self._run_reduce_jobs()
+            else:
+                ops.bn_bwd_reduce(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.bwdp_buf, ldz=self.ldz)
+                if self._plain_segs is None:
+                    sg = ops.SumSegments()
+                    sg.nseg = 1
+                    sg.c_begin[0], sg.c_end[0], sg.P[0], sg.kind[0] = 0, Cc, self.bwd_P, 0
+                    sg.s[0], sg.q[0] = self.bwdp_buf.data_ptr(), self.bwdp_buf.data_ptr() + 4 * Cc * self.bwd_P
+                    self._plain_segs = sg
+                sg = self._plain_segs
+            ops.bn_bwd_finalize_apply(sg, M, Cc, self.beta, self.gbeta, self.coef, self.z, dy_segs, self.mean, self.rstd,
+                                      self.shift, dz, self.fa_ticket[2:4], amax=self.dz_amax if track else None, ldz=self.ldz)
+        else:
+            if from_parts:
+                self._bn_bwd_sums()
+            else:
+                ops.bn_bwd_reduce(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.bwdp_buf, ldz=self.ldz)
+                self._finalize_plain(self.bwd_P)
+            if not (need_dx or self.trainable):
+                return
+            if self.bnb:              # z stays as it is: the dgrad's loader forms dz
+                self._run_dgrad(dx_ptr)
+                return
+            ops.bn_bwd_apply(self.z, dy_segs, M, Cc, self.mean, self.rstd, self.shift, self.coef, dz,
+                             amax=self.dz_amax if track else None, ldz=self.ldz)
         self._dz_amax_live = track
         if self.trainable:
             self.wgrad.d.ldx = ldx
@@ -741,6 +767,7 @@ class MixedStage(Stage):
             self.batch_bn = (3 if B <= 128 else 2) if eng.batch_bn is None else int(eng.batch_bn)
             self._fin_jobs = {}
             self._close_plan = None
+            self.fa_ticket = torch.zeros(2, dtype=torch.int32, device=dev)
         if getattr(self.prev, "zcat", False):    # this block reads a zcat concat
             self.fused.fwd.d.norm_rstd = self.prev.rs_cat[0].data_ptr()
             self.fused.fwd.d.norm_shift = self.prev.rs_cat[1].data_ptr()
@@ -872,8 +899,13 @@ class MixedStage(Stage):
         sg, dy, z = self._close_plan
         for l in layers:
             l._run_reduce_jobs()
-        ops.bn_bwd_finalize_multi(sg, M, Cb, [l.beta for l in layers], [l.gbeta for l in layers], self.coef_cat)
-        ops.bn_bwd_apply(z, dy, M, Cb, self.mean_cat[b0:], self.rs_cat[0, b0:], self.rs_cat[1, b0:], self.coef_cat, z, ldz=Ct)
+        if self.eng.fuse_fin_apply:      # ... and those two as one (ds_bn_bwd_finalize_apply)
+            ops.bn_bwd_finalize_apply(sg, M, Cb, None, None, self.coef_cat, z, dy, self.mean_cat[b0:], self.rs_cat[0, b0:],
+                                      self.rs_cat[1, b0:], z, self.fa_ticket, ldz=Ct, betas=[l.beta for l in layers],
+                                      dbetas=[l.gbeta for l in layers])
+        else:
+            ops.bn_bwd_finalize_multi(sg, M, Cb, [l.beta for l in layers], [l.gbeta for l in layers], self.coef_cat)
+            ops.bn_bwd_apply(z, dy, M, Cb, self.mean_cat[b0:], self.rs_cat[0, b0:], self.rs_cat[1, b0:], self.coef_cat, z, ldz=Ct)
         for l in layers:
             l._dz_amax_live = False
 
@@ -1061,6 +1093,12 @@ class InceptionV1Engine:
         # (profiles/r06_notes.md).  DS_FUSE_FIN=1 switches it on (A/B)
         self.fuse_finalize = _lib.tuning_env("DS_FUSE_FIN", "0") == "1"
         # zcat blocks: the BatchNorm launches of the three block-closing layers once per block (MixedStage.alloc); DS_BATCH_BN=0: A/B
+        # a BatchNorm finalize and the apply pass that reads its result as ONE launch, both directions (ds_bn_finalize_apply_relu,
+        # ds_bn_bwd_finalize_apply: device-side ticket instead of a dependent-launch boundary).  Built, bit-identical (tests),
+        # measured, OFF: a cross-XCD hand-off (write-through results, ticket, poll, coherent reads) costs ~15 us where the launch
+        # boundary costs ~9 -- B = 256 13.23 -> 13.61 ms, B = 32 3.81 -> 4.11 (with release / acquire fences, which write back and
+        # invalidate a whole L2 per workgroup: 17.4 / 6.6; profiles/r06_notes.md).  DS_FIN_APPLY=1 switches it on (A/B)
+        self.fuse_fin_apply = _lib.tuning_env("DS_FIN_APPLY", "0") == "1"
         # bit 0: the forward finalizes, bit 1: the backward finalize + apply; None = by batch size (MixedStage.alloc)
         e = _lib.tuning_env("DS_BATCH_BN")
         self.batch_bn = int(e) if e else None

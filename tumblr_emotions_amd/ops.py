@@ -624,6 +624,29 @@ def bn_bwd_finalize_multi(sum_segs, M, C_, betas, dbetas, coef):
                                                     _p(coef), _stream()), "ds_bn_bwd_finalize_multi")
 
 
+def bn_finalize_apply_relu(stats, P, count, C_, beta, eps, decay, mean, rstd, shift, mm, mv, pivot, z, M, segs, ticket):
+    """ds_bn_finalize + ds_bn_apply_relu as one launch (ticket: two zero-initialised int32 words of the layer)."""
+    _lib.check(_lib.load().ds_bn_finalize_apply_relu(_p(stats), P, count, C_, _p(beta), _p(pivot), eps, decay, _p(mean), _p(rstd),
+                                                     _p(shift), _p(mm), _p(mv), _p(z), M, C.byref(segs), _p(ticket), _stream()),
+               "ds_bn_finalize_apply_relu")
+
+
+def bn_bwd_finalize_apply(sum_segs, M, C_, beta, dbeta, coef, z, segs, mean, rstd, shift, dz, ticket, amax=None, ldz=0,
+                          betas=None, dbetas=None):
+    """ds_bn_bwd_finalize_segs (beta / dbeta: one vector) or ds_bn_bwd_finalize_multi (betas / dbetas: the segments' own) and
+    the ds_bn_bwd_apply pass behind it as one launch.  dz: fp32 over z's layout, or a dense bf16 tensor."""
+    bv = dv = None
+    if betas is not None:
+        n = sum_segs.nseg
+        bv = C.cast((C.c_void_p * 4)(*[t.data_ptr() for t in betas[:n]]), C.c_void_p)
+        dv = C.cast((C.c_void_p * 4)(*[(t.data_ptr() if t is not None else None) for t in dbetas[:n]]), C.c_void_p)
+    out16 = dz.dtype == torch.bfloat16
+    _lib.check(_lib.load().ds_bn_bwd_finalize_apply(C.byref(sum_segs), _p(beta), _p(dbeta), bv, dv, _p(coef), _p(z), ldz or C_,
+                                                    C.byref(segs), M, C_, _p(mean), _p(rstd), _p(shift), _p(dz),
+                                                    DS_DTYPE_BF16 if out16 else DS_DTYPE_F32, dz.stride(0) if out16 else 0,
+                                                    _p(amax), _p(ticket), _stream()), "ds_bn_bwd_finalize_apply")
+
+
 def bn_bwd_finalize(partials, P, M, C_, dbeta, coef):
     _lib.check(_lib.load().ds_bn_bwd_finalize(_p(partials), P, M, C_, _p(dbeta), _p(coef), _stream()),
                "ds_bn_bwd_finalize")
