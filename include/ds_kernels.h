@@ -310,6 +310,19 @@ int ds_conv_wino4_partials(int32_t N, int32_t H, int32_t W);
 int ds_conv_wino4(const float *x, const float *u, float *z, float *stats, const float *pivot, const float *ymask,
                   int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz, int32_t flags,
                   void *stream);
+/* The same with the reduction channels SPLIT over `splits` workgroups per output block (small per-GPU batches: with fewer
+ * workgroups than CUs the launch lasts as long as ONE workgroup's Cin / 16 K steps -- 68 us for the 7x7 320 -> 160 input
+ * gradient at 256 samples and at 32 alike).  Two launches: the conv kernel writes the slices' partial outputs into ws
+ * (dense [splits][N H W][Cout], ds_conv_wino4_splitk_workspace bytes), a reduce launch adds them in slice order, writes z
+ * (pixel stride ldz) and runs the DS_EPI_STATS / DS_EPI_BNSUMS epilogue on the sums (partials float[2][Cout][P] with
+ * P = ds_conv_wino4_splitk_partials; y_dtype: storage of the BNSUMS activation).  ds_conv_wino4_splitk_choose: the slice count
+ * the launch-time model picks (1 = use ds_conv_wino4).  z differs from ds_conv_wino4's by fp32 summation order only.   */
+int ds_conv_wino4_splitk_choose(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
+int ds_conv_wino4_splitk_partials(int32_t N, int32_t H, int32_t W);
+size_t ds_conv_wino4_splitk_workspace(int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t splits);
+int ds_conv_wino4_splitk(const float *x, const float *u, float *z, float *stats, const float *pivot, const float *ymask,
+                         int32_t y_dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz,
+                         int32_t flags, int32_t splits, void *ws, size_t ws_bytes, void *stream);
 /* ds_conv_wino4 for the 16-bit configurations (bf16 / fp8 labels): the convolution of the bf16-ROUNDED operands (x is rounded
  * as it is loaded, the filter before G g G^T) evaluated through F(4x4, 3x3) on the bf16 matrix cores, every Winograd-domain
  * value carried as two bf16 pieces (three v_mfma_f32_32x32x16_bf16 per product: ~2^-16 relative in the transform domain).
@@ -375,6 +388,7 @@ int ds_conv_wino4_bf16x2_x16(const void *x16, const void *u2, float *z, float *s
 #define DS_PLAN_FP8_WIDE_RULE 128u  /* A/B: fp8 for every 1x1 / 3x3 layer with >= 64 reduction channels into >= 96 columns  */
 #define DS_PLAN_NO_WINO4H 256u      /* A/B: the 16-bit configurations' 3x3 input gradients on the direct bf16 kernels only  */
 #define DS_PLAN_STEM_POOL 512u      /* with DS_PLAN_PACKED_RGB: MaxPool_2a_3x3 inside the stem kernel where the map allows  */
+#define DS_PLAN_NO_SPLITK 1024u     /* A/B: never split the reduction of a fused-Winograd launch (ds_conv_wino4_splitk)      */
 #define DS_PLAN_PACKED_RGB 32u      /* Conv2d_1a_7x7: x is the packed [N, H, W, 3] batch, filter stored [7][7][4][Cout]   */
 typedef struct ds_conv_layer_plan {
     ds_conv_desc d;          /* descriptor of the chosen launch (dgrad: channel roles swapped, flipped taps)            */
@@ -387,6 +401,9 @@ typedef struct ds_conv_layer_plan {
     int64_t w_bytes;         /* bytes of the prepared filter; 0: the family reads the HWIO tensor in place               */
     int64_t wscale_floats;   /* fp8: floats of the filter's scale record                                                 */
     double alg_flops;        /* algorithmic FLOPs of one launch (2 M N K of the convolution, stem with Cin = 3)          */
+    int32_t splitk;          /* > 1: DS_FAM_WINO4 runs as ds_conv_wino4_splitk with that many reduction slices            */
+    int32_t reserved0;
+    int64_t ws_bytes;        /* ... and ds_conv_run needs io.ws of that many bytes (0: none)                              */
 } ds_conv_layer_plan;
 typedef struct ds_conv_io {
     const float *bias;       /* DS_EPI_BIAS                                                                              */
@@ -396,6 +413,8 @@ typedef struct ds_conv_io {
     const float *x_amax;     /* fp8: max|x| record of the activation operand                                             */
     const float *wscale;     /* fp8: the filter's scale record (ds_conv_prepare_weights)                                 */
     const ds_bn_finalize_in_launch *fin;   /* nullable: ds_bn_finalize inside the launch (ds_conv_plan_finalize_tickets > 0)   */
+    void *ws;                /* plan.ws_bytes > 0: scratch of at least that many bytes (16-byte aligned), private to the stream  */
+    size_t ws_bytes;
 } ds_conv_io;
 int ds_conv_plan(ds_conv_layer_plan *plan, int32_t role, int32_t arith, uint32_t options, int32_t N, int32_t H, int32_t W,
                  int32_t w_cin, int32_t w_cout, int32_t k, int32_t stride, int32_t ldx, int32_t ldz, int32_t flags);

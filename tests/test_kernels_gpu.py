@@ -1315,6 +1315,76 @@ def test_winograd_f4_on_bf16_matrix_cores_matches_bf16_rounding_oracle(case, nb,
         lib.ds_debug_conv_wino4_set_nb(0)
 
 
+@pytest.mark.parametrize("case", [(2, 7, 7, 160, 320, 4), (5, 7, 7, 320, 160, 3), (2, 14, 14, 96, 208, 2), (1, 14, 14, 208, 96, 13), (3, 5, 6, 48, 44, 2),
+                                  (2, 8, 8, 32, 32, 2)])
+def test_winograd_f4_with_the_reduction_split_over_workgroups(case):
+    """ds_conv_wino4_splitk (round 6; small per-GPU batches, image_model/inception_v1.py:122-247): the reduction channels of an
+    F(4x4, 3x3) launch in `splits` slices, one workgroup each, their partial outputs added by a second launch that also runs the
+    DS_EPI_STATS / DS_EPI_BNSUMS epilogue.  Against the fp64 convolution at the unsplit kernel's bound (2e-4 of max|ref|) and
+    against ds_conv_wino4 itself (fp32 summation order: 2e-5); uneven slices, slice counts up to Cin / 16, border tiles,
+    strided output rows, y in fp32 and bf16 storage."""
+    ops = _ops()
+    from tumblr_emotions_amd import _lib
+    lib = _lib.load()
+    N, H, W, Ci, Co, S_ = case
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.RandomState(21)
+    x = rng.normal(size=(N, H, W, Ci))
+    w = rng.normal(size=(3, 3, Ci, Co)) * 0.1
+    ref = S.conv2d_same(x, w, 1)
+    M = N * H * W
+    xd, wd = dev(x), dev(w)
+    P0, P = lib.ds_conv_wino4_partials(N, H, W), lib.ds_conv_wino4_splitk_partials(N, H, W)
+    wsb = lib.ds_conv_wino4_splitk_workspace(N, H, W, max(Ci, Co), S_)
+    assert wsb == S_ * M * max(Ci, Co) * 4 and P >= 1
+    ws = torch.full((wsb // 4,), float("nan"), device="cuda")
+    u = torch.empty(36 * Ci * Co, device="cuda")
+    assert lib.ds_wino4_transform_weights(ops._p(wd), ops._p(u), Ci, Co, 0, st) == 0
+    pivot = dev(rng.normal(size=Co) * 0.1)
+    z0, z = torch.zeros(M, Co + 4, device="cuda"), torch.zeros(M, Co + 4, device="cuda")
+    st0, st1 = torch.zeros(2, Co, P0, device="cuda"), torch.full((2, Co, P), float("nan"), device="cuda")
+    assert lib.ds_conv_wino4(ops._p(xd), ops._p(u), ops._p(z0), ops._p(st0), ops._p(pivot), None, N, H, W, Ci, Ci, Co, Co + 4,
+                             ops.DS_EPI_STATS, st) == 0
+    assert lib.ds_conv_wino4_splitk(ops._p(xd), ops._p(u), ops._p(z), ops._p(st1), ops._p(pivot), None, ops.DS_DTYPE_F32, N, H, W, Ci, Ci,
+                                    Co, Co + 4, ops.DS_EPI_STATS, S_, ops._p(ws), wsb, st) == 0
+    torch.cuda.synchronize()
+    zz = ref.reshape(M, Co)
+    close(z[:, :Co], zz, 2e-4)
+    close(z[:, :Co], z0[:, :Co].cpu().numpy().astype(np.float64), 2e-5)
+    assert float(z[:, Co:].abs().max()) == 0.0
+    pv = pivot.cpu().numpy().astype(np.float64)
+    close(st1[0].sum(1), (zz - pv).sum(0), 1e-3)
+    close(st1[1].sum(1), ((zz - pv) ** 2).sum(0), 1e-3)
+    close(st1[1].sum(1), st0[1].sum(1).cpu().numpy().astype(np.float64), 1e-4)
+    # plain launch (no epilogue) and the input gradient with the BatchNorm-sums epilogue
+    z2 = torch.zeros(M, Co, device="cuda")
+    assert lib.ds_conv_wino4_splitk(ops._p(xd), ops._p(u), ops._p(z2), None, None, None, ops.DS_DTYPE_F32, N, H, W, Ci, Ci, Co, Co, 0, S_,
+                                    ops._p(ws), wsb, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(z2, z[:, :Co])
+    if Co % 16 == 0 and S_ <= Co // 16:
+        dy = rng.normal(size=ref.shape)
+        dyd = dev(dy)
+        ud = torch.empty(36 * Ci * Co, device="cuda")
+        assert lib.ds_wino4_transform_weights(ops._p(wd), ops._p(ud), Ci, Co, 1, st) == 0
+        dx_ref = S.conv2d_same_bwd_input(dy, w, (N, H, W, Ci), 1).reshape(-1, Ci)
+        yv = np.maximum(rng.normal(size=(M, Ci)), 0.0) * (rng.uniform(size=(M, Ci)) < 0.7)
+        for dt, yd in ((ops.DS_DTYPE_F32, dev(yv)), (ops.DS_DTYPE_BF16, dev(yv, torch.bfloat16))):
+            y_seen = yd.float().cpu().numpy().astype(np.float64)
+            sums = torch.full((2, Ci, P), float("nan"), device="cuda")
+            dx = torch.zeros(M, Ci, device="cuda")
+            assert lib.ds_conv_wino4_splitk(ops._p(dyd), ops._p(ud), ops._p(dx), ops._p(sums), None, ops._p(yd), dt, N, H, W, Co, Co, Ci, Ci,
+                                            ops.DS_EPI_BNSUMS, S_, ops._p(ws), wsb, st) == 0
+            torch.cuda.synchronize()
+            close(dx, dx_ref, 2e-4)
+            gm = dx.cpu().numpy().astype(np.float64) * (y_seen > 0)
+            close(sums[0].sum(1), gm.sum(0), 1e-4)
+            close(sums[1].sum(1), (gm * y_seen).sum(0), 1e-4)
+    # the launch-time model: never at the headline batch's big maps, yes for the 7x7 input gradient of a small batch
+    assert lib.ds_conv_wino4_splitk_choose(256, 28, 28, 128, 192) == 1
+    assert lib.ds_conv_wino4_splitk_choose(32, 7, 7, 320, 160) >= 2
+
+
 @pytest.mark.parametrize("case", BF16D_CASES)
 def test_conv_bf16_register_direct_forward_dgrad_match_oracle(case):
     """ds_conv_bf16 (register-direct A, pre-converted weights): forward with BatchNorm statistics about a pivot and

@@ -552,6 +552,35 @@ def test_block_batched_batch_norm_launches_step_is_bit_identical():
         assert torch.equal(a, b) if torch.is_tensor(a) else a == b
 
 
+def test_split_k_winograd_step_follows_the_unsplit_one():
+    """InceptionV1Engine.splitk (default): at small per-GPU batches the F(4x4) launches of the 14x14 / 7x7 layers are one partial
+    round of workgroups, so ds_conv_plan splits their reduction over several workgroups per output block
+    (ds_conv_wino4_splitk: conv launch into slabs + a reduce launch with the statistics / BatchNorm-sums epilogue).  Sums in
+    another order: logits within 1e-4, loss 1e-5, gradients 3e-2 in relative L2 of the unsplit step (the tolerances of the other
+    regrouping switches, test_branch3_pool_on_load_step_follows_the_two_pass_form), and the switch really changes the plans."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    batch = to_device(synthetic_batch_numpy(32, 10, 50, seed=5))
+    res, split = [], []
+    for on in (True, False):
+        net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10)
+        net.image.splitk = on
+        net.initialize(seed=7)
+        net.train_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        split.append(sum(1 for l in net.image.layers for pl in (l.fwd, l.dgrad) if pl is not None and pl.splitk > 1))
+        res.append((net.logits.detach().clone(), net.total_loss_value(), net.grads_state_dict()))
+    assert split[0] >= 8 and split[1] == 0, split
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-4
+    assert abs(res[0][1] - res[1][1]) <= 1e-5
+    worst = 0.0
+    for name, g in res[1][2].items():
+        rel = np.linalg.norm(res[0][2][name] - g) / max(np.linalg.norm(g), 1e-30)
+        worst = max(worst, rel)
+        assert rel <= 3e-2, (name, rel)
+    print("split-K F(4x4) in %d plans: max|dlogits| %.2e, worst gradient rel L2 %.2e" % (split[0], float((res[0][0] - res[1][0]).abs().max()), worst))
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_finalize_and_apply_as_one_launch_step_is_bit_identical(dtype):
     """InceptionV1Engine.fuse_fin_apply (built and measured, off by default: slower than the launch boundary it removes,

@@ -25,6 +25,7 @@ DS_ARITH_F32, DS_ARITH_BF16, DS_ARITH_FP8, DS_ARITH_F32X3 = 0, 1, 2, 3
 DS_FAM_IGEMM, DS_FAM_WINO2, DS_FAM_WINO4, DS_FAM_STEM, DS_FAM_BF16D, DS_FAM_FP8D, DS_FAM_F32X3, DS_FAM_WINO4H, DS_FAM_STEM_POOL = range(9)
 DS_PLAN_NO_WINO, DS_PLAN_NO_WINO4, DS_PLAN_NO_STEM_DIRECT, DS_PLAN_NO_BF16_DIRECT, DS_PLAN_ACT16, DS_PLAN_PACKED_RGB = 1, 2, 4, 8, 16, 32
 DS_PLAN_FP8_EVERYWHERE, DS_PLAN_FP8_WIDE_RULE, DS_PLAN_NO_WINO4H, DS_PLAN_STEM_POOL = 64, 128, 256, 512
+DS_PLAN_NO_SPLITK = 1024
 
 
 class ConvDesc(C.Structure):
@@ -59,13 +60,14 @@ class LayerPlanStruct(C.Structure):
     """ds_conv_layer_plan"""
     _fields_ = [("d", ConvDesc), ("family", C.c_int32), ("role", C.c_int32), ("arith", C.c_int32), ("partials", C.c_int32),
                 ("w_cin", C.c_int32), ("w_cout", C.c_int32), ("k", C.c_int32), ("a_format", C.c_int32), ("x16_ok", C.c_int32),
-                ("w_bytes", C.c_int64), ("wscale_floats", C.c_int64), ("alg_flops", C.c_double)]
+                ("w_bytes", C.c_int64), ("wscale_floats", C.c_int64), ("alg_flops", C.c_double), ("splitk", C.c_int32),
+                ("reserved0", C.c_int32), ("ws_bytes", C.c_int64)]
 
 
 class ConvIO(C.Structure):
     """ds_conv_io"""
     _fields_ = [("bias", C.c_void_p), ("mask", C.c_void_p), ("stats", C.c_void_p), ("pivot", C.c_void_p),
-                ("x_amax", C.c_void_p), ("wscale", C.c_void_p), ("fin", C.c_void_p)]
+                ("x_amax", C.c_void_p), ("wscale", C.c_void_p), ("fin", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
 
 
 class Segments(C.Structure):
@@ -136,6 +138,10 @@ SIGNATURES = {
     "ds_conv_wino4_prefer": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "ds_wino4_transform_weights": (C.c_int, [_P, _P, _i32, _i32, _i32, _P]),
     "ds_conv_wino4_partials": (C.c_int, [_i32, _i32, _i32]),
+    "ds_conv_wino4_splitk_choose": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),
+    "ds_conv_wino4_splitk_partials": (C.c_int, [_i32, _i32, _i32]),
+    "ds_conv_wino4_splitk_workspace": (C.c_size_t, [_i32, _i32, _i32, _i32, _i32]),
+    "ds_conv_wino4_splitk": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P, C.c_size_t, _P]),
     "ds_conv_wino4": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "ds_conv_wino4_bf16x2": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "ds_conv_wino4_bf16x2_x16": (C.c_int, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),

@@ -43,6 +43,8 @@ int plan_partials(const ds_conv_layer_plan *p) {
     switch (p->family) {
     case DS_FAM_WINO2: return ds_conv_wino_partials(d.N, d.H, d.W);
     case DS_FAM_WINO4:
+        if (p->splitk > 1) return ds_conv_wino4_splitk_partials(d.N, d.H, d.W);      // (the reduce launch's row blocks)
+        return ds_conv_wino4_partials(d.N, d.H, d.W);
     case DS_FAM_WINO4H: return ds_conv_wino4_partials(d.N, d.H, d.W);
     case DS_FAM_STEM: return d.dtype == DS_DTYPE_BF16 ? ds_conv_stem_bf16_partials(d.N, d.OH, d.OW) : ds_conv_stem_partials(d.N, d.OH, d.OW);
     case DS_FAM_STEM_POOL: return ds_conv_stem_pool_partials(d.N, d.OH, d.OW);
@@ -156,6 +158,12 @@ extern "C" int ds_conv_plan(ds_conv_layer_plan *out, int32_t role, int32_t arith
         if (fam == DS_FAM_FP8D && !ds_conv_fp8_supported(&d)) fam = DS_FAM_IGEMM;
     }
     out->family = fam;
+    // small per-GPU batches: the reduction of a fused-Winograd launch split over several workgroups per output block
+    out->splitk = 1;
+    if (fam == DS_FAM_WINO4 && !(options & DS_PLAN_NO_SPLITK)) {
+        out->splitk = ds_conv_wino4_splitk_choose(N, H, W, cin, cout);
+        out->ws_bytes = (int64_t)ds_conv_wino4_splitk_workspace(N, H, W, cout, out->splitk);
+    }
     out->a_format = dgrad ? DS_FP8_E5M2 : DS_FP8_E4M3;
     out->x16_ok = (fam == DS_FAM_BF16D || fam == DS_FAM_FP8D || fam == DS_FAM_WINO4H) ? 1 : 0;
     const int taps = k * k;
@@ -282,6 +290,12 @@ extern "C" int ds_conv_run(const ds_conv_layer_plan *p, const void *x, const voi
         return ds_conv_wino((const float *)x, (const float *)w, z, io->stats, io->pivot, io->mask, d.N, d.H, d.W, d.Cin,
                             d.ldx, d.Cout, d.ldz, d.flags, stream);
     case DS_FAM_WINO4:
+        if (p->splitk > 1) {
+            PLAN_REQUIRE(io->ws && io->ws_bytes >= (size_t)p->ws_bytes, "ds_conv_run: this plan needs io.ws of %lld bytes", (long long)p->ws_bytes);
+            return ds_conv_wino4_splitk((const float *)x, (const float *)w, z, io->stats, io->pivot, io->mask,
+                                        (d.flags & DS_EPI_BNSUMS) ? d.mask_dtype : DS_DTYPE_F32, d.N, d.H, d.W, d.Cin, d.ldx, d.Cout,
+                                        d.ldz, d.flags, p->splitk, io->ws, io->ws_bytes, stream);
+        }
         return ds_conv_wino4((const float *)x, (const float *)w, z, io->stats, io->pivot, io->mask, d.N, d.H, d.W, d.Cin,
                              d.ldx, d.Cout, d.ldz, d.flags, stream);
     case DS_FAM_WINO4H:

@@ -58,7 +58,9 @@ struct Wino4Params {
     const float *y;         // DS_EPI_BNSUMS: forward activation of the layer that consumes z (= dy), pixel stride ldz
     int N, H, W, Cin, ldx, Cout, ldz;
     int TH, TW, Mt;         // output tiles per column / row / in total
-    int groups, ncol;       // 32-tile groups, (32 NB)-channel blocks
+    int groups, ncol;       // 32-tile groups, (32 NB)-channel blocks (x ksplit: a workgroup per block AND reduction slice)
+    int ksplit, kchunk;     // split K (ds_conv_wino4_splitk): reduction slices per output block, K steps per slice; 1 = off
+    long long zslab;        // ... floats between the slices' partial outputs (z then points at slab 0, pixel stride ldz)
     unsigned x_bytes, u_bytes, z_bytes;
     int flags;
 #ifdef DS_W4_PROF
@@ -216,8 +218,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     // 1-D XCD-aware launch as conv_wino.hip: the channel blocks of a tile group run back to back on one XCD
     const int id = blockIdx.x;
     const int lin = (id & 7) * (int)(gridDim.x >> 3) + (id >> 3);
-    const int group = lin / p.ncol, cblk = lin - group * p.ncol;
+    const int group = lin / p.ncol;
+    int cblk = lin - group * p.ncol;
     if (group >= p.groups) return;                          // (uniform) surplus workgroup
+    // split K (small batches: fewer workgroups than CUs, so a launch lasts as long as ONE workgroup's Cin / 16 K steps): slice
+    // `split` of the reduction channels, its partial output into slab `split`; wino4_splitk_reduce_kernel adds the slabs
+    int split = 0;
+    if (p.ksplit > 1) {
+        split = cblk % p.ksplit;
+        cblk /= p.ksplit;
+    }
+    const int kst_tot = p.Cin >> 4;                         // K steps of the whole reduction (strides of U)
+    const int k0 = split * p.kchunk;
     const int co0 = cblk * 32 * NB;
     const int m0 = group * 32;
     const int tpi = p.TH * p.TW;
@@ -227,8 +239,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     // for every tile and the pixel (py, px) of the patch is a wave-uniform, non-negative scalar offset from it.
     const int lt = tid >> 3, cp = tid & 7;
     const int64_t shift = (int64_t)(p.W + 1) * p.ldx;
-    const __amdgpu_buffer_rsrc_t srd_x = w4srd(reinterpret_cast<const char *>(p.x) - shift * EB, p.x_bytes + (unsigned)(shift * EB));
-    const __amdgpu_buffer_rsrc_t srd_u = w4srd(p.u, p.u_bytes);
+    const unsigned xk0 = (unsigned)k0 * 16u * EB;          // this slice's first channel (bytes); the range still ends at the tensor's end
+    const __amdgpu_buffer_rsrc_t srd_x = w4srd(reinterpret_cast<const char *>(p.x) - shift * EB + xk0, p.x_bytes + (unsigned)(shift * EB) - xk0);
     unsigned rowoff[6];         // patch row py: the tile's base offset, or out of range (row outside the image / no tile)
     bool cv[6];                 // patch column px inside the image
     {
@@ -251,7 +263,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     const int pixstep = p.ldx * (int)EB;
 
     // ---- matrix role: B fragment offsets (column li of channel block nb, channels 4 kh .. of an 8-channel half step) ----
-    const int ksteps = p.Cin >> 4, nhalf = 2 * ksteps;
+    const int ksteps = p.ksplit > 1 ? (kst_tot - k0 < p.kchunk ? kst_tot - k0 : p.kchunk) : kst_tot;      // of THIS workgroup
+    const int nhalf = 2 * kst_tot;
     unsigned boff[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -260,6 +273,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     }
     const int ustep = p.Cout * 32;                                 // bytes between half steps (AR: pieces) of one position
     const int upos = nhalf * ustep;                                // bytes between positions
+    const unsigned uk0 = (unsigned)k0 * 2u * (unsigned)ustep;      // this slice's first half step
+    const __amdgpu_buffer_rsrc_t srd_u = w4srd(reinterpret_cast<const char *>(p.u) + uk0, p.u_bytes - uk0);
 
     // NB = 2: 18 accumulators but 256 accumulation registers -- left to the compiler, two accumulators share 16 of them
     // and are swapped through the vector registers around their MFMAs (192 moves and two pipeline drains per K step:
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     constexpr int RP = NB == 1 ? 9 : DS_W4H_RP2;
     f32x4 bh[AR ? RP : 1][NB], bl[AR ? RP : 1][NB];
     auto load_b_h = [&](int slot, int pi, int ks) {
-        const int so = ((wave * 9 + pi) * ksteps + ks) * 2 * ustep;
+        const int so = ((wave * 9 + pi) * kst_tot + ks) * 2 * ustep;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             bh[slot][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_u, boff[nb], so, 0));
@@ -553,7 +568,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const Wino4Params p)
     const int et = tid >> 3, eq = tid & 7;
     float neg1 = -1.f;
     asm volatile("" : "+s"(neg1));          // opaque -1 (see out1d)
-    const __amdgpu_buffer_rsrc_t srd_z = w4srd(p.z, p.z_bytes);
+    const __amdgpu_buffer_rsrc_t srd_z = w4srd(p.z + (int64_t)split * p.zslab, p.z_bytes);
     const __amdgpu_buffer_rsrc_t srd_y = w4srd(BNS ? p.y : p.z, Y16 ? p.z_bytes / 2 : p.z_bytes);
     const int orow = p.W * p.ldz * 4, opix = p.ldz * 4;
     int tbase, hrem, wrem;      // pixel index of the tile's top-left output (or -1); EDGE: rows / columns inside the image
@@ -787,6 +802,115 @@ W4Choice w4_choose(int N, int H, int W, int Cin, int Cout, int ar = 0) {
     return c;
 }
 
+// ---- split K: the second launch ------------------------------------------------------------------------------------------
+// z[row][c] = sum over the slices' slabs, in slice order (deterministic), + the epilogue the conv launch could not run on
+// partial sums: DS_EPI_STATS (column sums of z - pivot and its square) or DS_EPI_BNSUMS (sum g, sum g*y with g = z (y > 0)).
+// Thread = (channel quad, row group) as bn_bwd_reduce_kernel; workgroup b takes rows [b * rpb, (b + 1) * rpb); partials
+// [2][Cout][gridDim.x].  MODE 0: plain, 1: STATS, 2: BNSUMS (Y16: y in bf16 storage).
+template <int MODE, bool Y16>
+__global__ __launch_bounds__(256) void wino4_splitk_reduce_kernel(const float *slab, int S, int64_t zslab, float *z, int ldz,
+                                                                  int64_t M, int C, const float *pivot, const void *yv,
+                                                                  float *partials, int rpb) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // [RG][C4][8]
+    const int C4 = C >> 2;
+    const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
+    const int tid = threadIdx.x;
+    const int cg = tid % C4, rg = tid / C4;
+    const bool active = tid < RG * C4;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    int64_t r1 = r0 + rpb;
+    if (r1 > M) r1 = M;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const int c = cg * 4;
+        f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == 1 && pivot) pv = *reinterpret_cast<const f32x4 *>(pivot + c);
+        for (int64_t row = r0 + rg; row < r1; row += RG) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(slab + row * C + c);
+            for (int k = 1; k < S; ++k) v += *reinterpret_cast<const f32x4 *>(slab + k * zslab + row * C + c);
+            *reinterpret_cast<f32x4 *>(z + row * ldz + c) = v;
+            if constexpr (MODE == 1) {
+                const f32x4 u = v - pv;
+                s += u;
+                q += u * u;
+            } else if constexpr (MODE == 2) {
+                f32x4 y;
+                if constexpr (Y16) {
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    y = __builtin_convertvector(*reinterpret_cast<const bf16x4 *>(reinterpret_cast<const __bf16 *>(yv) + row * ldz + c), f32x4);
+                } else {
+                    y = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(yv) + row * ldz + c);
+                }
+                f32x4 g;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = y[j] > 0.f ? v[j] : 0.f;
+                s += g;
+                q += g * y;
+            }
+        }
+        if constexpr (MODE != 0) {
+            float *o = sh + ((int64_t)rg * C4 + cg) * 8;
+            *reinterpret_cast<f32x4 *>(o) = s;
+            *reinterpret_cast<f32x4 *>(o + 4) = q;
+        }
+    }
+    if constexpr (MODE != 0) {
+        __syncthreads();
+        if (tid < C4) {
+            float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int g = 0; g < RG; ++g)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] += sh[((int64_t)g * C4 + tid) * 8 + j];
+            const int P = gridDim.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                partials[(int64_t)(tid * 4 + j) * P + blockIdx.x] = a[j];
+                partials[((int64_t)C + tid * 4 + j) * P + blockIdx.x] = a[4 + j];
+            }
+        }
+    }
+}
+
+// rows per workgroup of the reduce launch: about 512 workgroups, at least 8 rows (a thread then walks 2-4 rows of S slabs: with
+// 64 rows per workgroup the 7x7 maps of 32 samples gave 25 workgroups and the reduce launch took longer than the conv it followed)
+inline int splitk_rpb(int64_t M) {
+    int64_t r = (M + 511) / 512;
+    r = (r + 7) / 8 * 8;
+    return (int)(r < 8 ? 8 : r);
+}
+
+// Split K?  Only where the unsplit launch is ONE partial round of workgroups (fewer than half the CUs), i.e. lasts as long as
+// one workgroup's Cin / 16 K steps whatever the batch: S slices cut that to ceil(ksteps / S) steps + a second launch
+// (~9 us with its boundary).  us per K step / fixed part as w4_choose (NB = 1: such launches never choose NB = 2).
+int w4_splitk_choose(int N, int H, int W, int Cin, int Cout) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = ds::tune_env("DS_WINO4_SPLITK");
+        forced = e ? atoi(e) : 0;
+    }
+    const int ksteps = Cin / 16;
+    if (Cout > 1024) return 1;
+    if (forced == 1) return 1;
+    if (forced > 1) return forced < ksteps ? forced : (ksteps > 1 ? ksteps : 1);
+    // (up to 32 samples per launch only: in the step the other branch chains run beside this launch, and from 64 samples on the
+    // slices' extra prologues / epilogues and the reduce launch take more from them than the shorter latency gives back --
+    // B = 64 5.16 -> 5.20 ms, B = 128 7.92 -> 7.95, B = 32 3.88 -> 3.76, profiles/r06_notes.md)
+    if (N > 32) return 1;
+    const W4Choice c = w4_choose(N, H, W, Cin, Cout);
+    if (c.nb != 1) return 1;
+    const int64_t mt4 = (int64_t)N * ((H + 3) / 4) * ((W + 3) / 4), g4 = (mt4 + 31) / 32;
+    const int64_t wgs = g4 * ((Cout + 31) / 32);
+    if (wgs * 2 > 256 || ksteps < 6) return 1;
+    int S = (int)(256 / wgs);
+    if (S > 4) S = 4;
+    if (S > ksteps / 3) S = ksteps / 3;
+    if (S < 2) return 1;
+    const int chunk = (ksteps + S - 1) / S;
+    S = (ksteps + chunk - 1) / chunk;                  // no empty slice
+    const double t1 = ksteps * W4_STEP1 + W4_FIX1, ts = chunk * W4_STEP1 + W4_FIX1 + 9.0;
+    return (S >= 2 && ts < 0.85 * t1) ? S : 1;
+}
+
 }  // namespace
 
 #ifdef DS_W4_PROF
@@ -838,8 +962,9 @@ extern "C" int ds_conv_wino4_partials(int32_t N, int32_t H, int32_t W) {
 namespace {
 int w4_launch(int ar, bool y16, const float *x, const float *u, float *z, float *stats, const float *pivot, const float *ymask,
               int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz, int32_t flags, void *stream,
-              bool x16 = false) {
+              bool x16 = false, int ksplit = 1, float *slabs = nullptr) {
     DS_REQUIRE(x && u && z && N > 0, "ds_conv_wino4: bad argument");
+    DS_REQUIRE(ksplit == 1 || (ar == 0 && slabs && ksplit >= 2 && ksplit <= Cin / 16), "ds_conv_wino4_splitk: 2 .. Cin / 16 slices, fp32, with a workspace");
     DS_REQUIRE(ds_conv_wino4_supported(H, W, Cin, Cout) && ldx >= Cin && ldx % 2 == 0 && ldz >= Cout && ldz % 4 == 0 && ((((uintptr_t)u) | ((uintptr_t)z)) & 15) == 0 &&
                    (((uintptr_t)x) & (x16 ? 3 : 7)) == 0 && (!x16 || ar == 1) && (!(flags & DS_EPI_BNSUMS) || (((uintptr_t)ymask) & 15) == 0) &&
                    (!(flags & DS_EPI_STATS) || !pivot || (((uintptr_t)pivot) & 15) == 0),
@@ -867,10 +992,22 @@ int w4_launch(int ar, bool y16, const float *x, const float *u, float *z, float 
     p.prof = g_w4_prof;
 #endif
     p.groups = (int)((mt + 31) / 32);
-    const int nb = w4_choose(N, H, W, Cin, Cout, ar).nb;
+    const int nb = ksplit > 1 ? 1 : w4_choose(N, H, W, Cin, Cout, ar).nb;
     p.ncol = (Cout + 32 * nb - 1) / (32 * nb);
+    p.ksplit = 1; p.kchunk = Cin / 16; p.zslab = 0;
+    const int64_t Mpix = (int64_t)N * H * W;
+    if (ksplit > 1) {
+        // the conv launch writes the slices' partial outputs, dense [ksplit][N H W][Cout], and runs no epilogue
+        p.kchunk = (Cin / 16 + ksplit - 1) / ksplit;
+        p.ksplit = (Cin / 16 + p.kchunk - 1) / p.kchunk;
+        p.ncol *= p.ksplit;
+        p.zslab = Mpix * Cout;
+        DS_REQUIRE(p.zslab * 4 < (1ll << 31), "ds_conv_wino4_splitk: a slab larger than 2 GiB");
+        p.z = slabs; p.ldz = Cout; p.z_bytes = (unsigned)(p.zslab * 4);
+        p.flags = 0; p.stats = nullptr; p.pivot = nullptr; p.y = nullptr;
+    }
     const dim3 grid((unsigned)(((int64_t)p.groups * p.ncol + 7) / 8 * 8));
-    const bool bns = (flags & DS_EPI_BNSUMS) != 0;
+    const bool bns = ksplit == 1 && (flags & DS_EPI_BNSUMS) != 0;
     hipStream_t st = (hipStream_t)stream;
     const bool edge = (H % 4) != 0 || (W % 4) != 0;
 #define DS_W4_LAUNCH(NBV, BNSV, EDGEV)                                                                          \
@@ -889,9 +1026,48 @@ int w4_launch(int ar, bool y16, const float *x, const float *u, float *z, float 
         else { if (edge) DS_W4_LAUNCH(1, false, true); else DS_W4_LAUNCH(1, false, false); }
     }
 #undef DS_W4_LAUNCH
+    if (ksplit > 1) {
+        const int rpb = splitk_rpb(Mpix), P = (int)((Mpix + rpb - 1) / rpb);
+        const int C4 = Cout / 4, RG = 256 / C4 > 0 ? 256 / C4 : 1;
+        const size_t shm = (size_t)RG * C4 * 8 * sizeof(float);
+        if (flags & DS_EPI_BNSUMS) {
+            if (y16) hipLaunchKernelGGL((wino4_splitk_reduce_kernel<2, true>), dim3(P), dim3(256), shm, st, slabs, p.ksplit, (int64_t)p.zslab, z, ldz, Mpix, Cout, nullptr, (const void *)ymask, stats, rpb);
+            else hipLaunchKernelGGL((wino4_splitk_reduce_kernel<2, false>), dim3(P), dim3(256), shm, st, slabs, p.ksplit, (int64_t)p.zslab, z, ldz, Mpix, Cout, nullptr, (const void *)ymask, stats, rpb);
+        } else if (flags & DS_EPI_STATS) {
+            hipLaunchKernelGGL((wino4_splitk_reduce_kernel<1, false>), dim3(P), dim3(256), shm, st, slabs, p.ksplit, (int64_t)p.zslab, z, ldz, Mpix, Cout, pivot, nullptr, stats, rpb);
+        } else {
+            hipLaunchKernelGGL((wino4_splitk_reduce_kernel<0, false>), dim3(P), dim3(256), 0, st, slabs, p.ksplit, (int64_t)p.zslab, z, ldz, Mpix, Cout, nullptr, nullptr, nullptr, rpb);
+        }
+        return ds::check_launch("ds_conv_wino4_splitk");
+    }
     return ds::check_launch(ar ? "ds_conv_wino4_bf16x2" : "ds_conv_wino4");
 }
 }  // namespace
+
+extern "C" int ds_conv_wino4_splitk_choose(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+    if (!ds_conv_wino4_supported(H, W, Cin, Cout) || N <= 0) return 1;
+    return w4_splitk_choose(N, H, W, Cin, Cout);
+}
+
+extern "C" int ds_conv_wino4_splitk_partials(int32_t N, int32_t H, int32_t W) {
+    const int64_t M = (int64_t)N * H * W;
+    const int rpb = splitk_rpb(M);
+    return (int)((M + rpb - 1) / rpb);
+}
+
+extern "C" size_t ds_conv_wino4_splitk_workspace(int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t splits) {
+    return splits > 1 ? (size_t)splits * N * H * W * Cout * sizeof(float) : 0;
+}
+
+extern "C" int ds_conv_wino4_splitk(const float *x, const float *u, float *z, float *stats, const float *pivot, const float *ymask,
+                                    int32_t y_dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout,
+                                    int32_t ldz, int32_t flags, int32_t splits, void *ws, size_t ws_bytes, void *stream) {
+    DS_REQUIRE(splits >= 2 && ws && ws_bytes >= ds_conv_wino4_splitk_workspace(N, H, W, Cout, splits) && (((uintptr_t)ws) & 15) == 0,
+               "ds_conv_wino4_splitk: needs >= 2 slices and a 16-byte aligned workspace of ds_conv_wino4_splitk_workspace bytes");
+    DS_REQUIRE(Cout <= 1024 && (y_dtype == DS_DTYPE_F32 || y_dtype == DS_DTYPE_BF16), "ds_conv_wino4_splitk: Cout <= 1024, y in fp32 / bf16");
+    return w4_launch(0, y_dtype == DS_DTYPE_BF16, x, u, z, stats, pivot, ymask, N, H, W, Cin, ldx, Cout, ldz, flags, stream, false,
+                     splits, (float *)ws);
+}
 
 extern "C" int ds_conv_wino4(const float *x, const float *u, float *z, float *stats, const float *pivot, const float *ymask,
                              int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Cout, int32_t ldz,

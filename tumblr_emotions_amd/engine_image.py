@@ -167,6 +167,9 @@ class ConvBN:
         self.mean.copy_(self.mm)          # first pivot of the batch statistics (ConvBN.forward)
         eng = self.eng
         self.stats_buf, self.bwdp_buf, self.ws_buf = eng.stats_set[self.slot], eng.bwdp_set[self.slot], eng.ws_set[self.slot]
+        for plan in (self.fwd, self.dgrad):          # split-K Winograd launches: the slices' partial outputs
+            if plan is not None and plan.ws_bytes:
+                plan.set_workspace(eng.cws_set[self.slot])
         self.plan_finalize()
         if self.fin is not None:
             f = self.fin
@@ -1107,6 +1110,9 @@ class InceptionV1Engine:
         self.dz16 = int(_lib.tuning_env("DS_DZ16", "2"))      # 16-bit configurations: bf16 dz for the frozen 1x1 (1) and 3x3 (2) layers (ConvBN.make_dgrad)
         self.fuse_branch3 = _lib.tuning_env("DS_FUSE_B3", "1") != "0"      # Branch_3's 3x3/1 max pool formed on load by its 1x1 conv (MixedStage.alloc)
         self.winograd4 = _lib.tuning_env("DS_WINO4", "1") != "0"      # ... and ds_conv_wino4 (F(4x4,3x3)) where it is faster
+        # small per-GPU batches: the reduction of an F(4x4) launch that is one partial round of workgroups split over several
+        # workgroups per output block (ds_conv_wino4_splitk; the library's launch-time model decides per layer).  DS_SPLITK=0: A/B
+        self.splitk = _lib.tuning_env("DS_SPLITK", "1") != "0"
         self.weights_version = 0     # bumped by SentimentNet.after_load(): frozen layers redo their G g G^T
         self._stats_n = self._bwdp_n = self._ws_bytes = 0
         self.B = None
@@ -1167,6 +1173,8 @@ class InceptionV1Engine:
             o |= ops.DS_PLAN_FP8_WIDE_RULE
         if not self.wino16:
             o |= ops.DS_PLAN_NO_WINO4H
+        if not self.splitk:
+            o |= ops.DS_PLAN_NO_SPLITK
         return o
 
     def all_reduce(self, t):
@@ -1255,6 +1263,8 @@ class InceptionV1Engine:
         self.stats_set = [torch.empty(max(self._stats_n, 4), device=dev) for _ in range(3)]
         self.bwdp_set = [torch.empty(max(self._bwdp_n, 4), device=dev) for _ in range(3)]
         self.ws_set = [torch.empty(max(self._ws_bytes // 4, 4), device=dev) for _ in range(4)]      # [3]: weight-gradient stream
+        cws = max([pl.ws_bytes for l in self.layers for pl in (l.fwd, l.dgrad) if pl is not None] + [16])
+        self.cws_set = [torch.empty(cws // 4, device=dev) for _ in range(3)]
         self.stats, self.bwd_partials, self.ws = self.stats_set[0], self.bwdp_set[0], self.ws_set[0]
         if self.side is None and self.device.type == "cuda":
             from . import streams

@@ -14,7 +14,7 @@ from ._lib import (ConvDesc, Segments, SumSegments, DS_EPI_ACCUM, DS_EPI_BIAS, D
                    DS_EPI_STATS,
                    DS_DTYPE_BF16, DS_DTYPE_F32, DS_FP8_E4M3, DS_FP8_E5M2, DS_CONV_FWD, DS_CONV_DGRAD, DS_ARITH_F32, DS_ARITH_BF16,
                    DS_ARITH_FP8, DS_ARITH_F32X3, DS_FAM_IGEMM, DS_FAM_WINO2, DS_FAM_WINO4, DS_FAM_STEM, DS_FAM_BF16D, DS_FAM_FP8D,
-                   DS_FAM_F32X3, DS_FAM_WINO4H, DS_FAM_STEM_POOL, DS_PLAN_STEM_POOL, DS_PLAN_NO_WINO4H, DS_PLAN_NO_WINO, DS_PLAN_NO_WINO4, DS_PLAN_NO_STEM_DIRECT, DS_PLAN_NO_BF16_DIRECT, DS_PLAN_ACT16,
+                   DS_FAM_F32X3, DS_FAM_WINO4H, DS_FAM_STEM_POOL, DS_PLAN_STEM_POOL, DS_PLAN_NO_SPLITK, DS_PLAN_NO_WINO4H, DS_PLAN_NO_WINO, DS_PLAN_NO_WINO4, DS_PLAN_NO_STEM_DIRECT, DS_PLAN_NO_BF16_DIRECT, DS_PLAN_ACT16,
                    DS_PLAN_PACKED_RGB, DS_PLAN_FP8_EVERYWHERE, DS_PLAN_FP8_WIDE_RULE)
 
 
@@ -252,6 +252,9 @@ class LayerPlan:
         self.u = None                        # the prepared filter (alloc_weights), None: the family reads HWIO in place
         self.wscale = None
         self.io = _lib.ConvIO()
+        self.ws_bytes = int(self.p.ws_bytes)     # > 0: run() needs a scratch tensor of that size (set_workspace): split-K Winograd
+        self.splitk = int(self.p.splitk)
+        self._ws = None
         self._run = _lib.load().ds_conv_run
         self._ref = C.byref(self.p)
         self._io_ref = C.byref(self.io)
@@ -270,6 +273,12 @@ class LayerPlan:
         if self.p.wscale_floats:
             self.wscale = torch.zeros(self.p.wscale_floats, device=device)
             self.io.wscale = self.wscale.data_ptr()
+
+    def set_workspace(self, t):
+        """Scratch for plans with ws_bytes > 0 (private to the stream the plan runs on; at least ws_bytes long)."""
+        assert t.numel() * t.element_size() >= self.ws_bytes
+        self._ws = t
+        self.io.ws, self.io.ws_bytes = t.data_ptr(), t.numel() * t.element_size()
 
     def prepare(self, w_hwio):
         """Filter -> the form the chosen family reads (no-op for the families that read HWIO in place)."""
