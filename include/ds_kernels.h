@@ -480,6 +480,11 @@ typedef struct ds_segments {
     float *amax[4];           /* ds_bn_apply_relu only, nullable: device word that receives max(y) of the segment by  */
                               /* atomic max (the caller zeroes it once per step): the per-tensor scale of the fp8     */
                               /* conv that reads the segment, without a separate ds_absmax pass                     */
+    const float *ptr2[4];     /* ds_bn_bwd_apply / _bf16 only, nullable: a SECOND addend of the segment's gradient with */
+                              /* the same layout (dy = *ptr + *ptr2).  An Inception block's input gradient is the sum of */
+                              /* the fused 1x1 dgrad's output and Branch_3's pool gradient: where the dgrad cannot        */
+                              /* accumulate (16-bit configurations) the two stay separate tensors, written concurrently   */
+                              /* on two streams, and the one consumer adds them as it reads                              */
 } ds_segments;
 int ds_bn_apply_relu(const float *z, int64_t M, int32_t C, const float *rstd, const float *shift,
                      const ds_segments *dst, void *stream);
@@ -510,6 +515,9 @@ typedef struct ds_bn_sum_segments {
     int32_t kind[4];
     const float *s[4];
     const float *q[4];
+    int32_t P2[4];            /* > 0: a SECOND source of the same kind for the segment (the sums are linear in the gradient: */
+    const float *s2[4];       /* with dy = a + b in two tensors, each producer emits the sums of its own addend), P2[i]    */
+    const float *q2[4];       /* partials per channel at s2[i] / q2[i]; added behind the first source's                     */
 } ds_bn_sum_segments;
 int ds_bn_bwd_finalize_segs(const ds_bn_sum_segments *sg, int64_t M, int32_t C, const float *beta, float *dbeta,
                             float *coef, void *stream);

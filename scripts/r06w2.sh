@@ -1,0 +1,14 @@
+#!/bin/bash
+R=$(cd $(dirname $0)/.. && pwd)
+export DS_LIB=${DS_LIB:-$R/tumblr_emotions_amd/libds_kernels_tuning.so}
+mkdir -p gpurun_out/r06w
+run() { timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-gather --no-conv-timing "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])"; }
+for i in 1 2 3; do for sm in 1 0 2; do for e in 1 0; do echo "bf16_side$sm split_dout=$e $(DS_SPLIT_DOUT=$e run --dtype bf16 --side-mode $sm)"; done; done; done > gpurun_out/r06w/ab2.txt 2>&1
+python - <<'PY'
+import collections, statistics
+d = collections.defaultdict(list)
+for l in open("gpurun_out/r06w/ab2.txt"):
+    a = l.split()
+    if len(a) == 3: d[(a[0], a[1])].append(float(a[2]))
+for k in sorted(d): print(k, " ".join("%.3f" % v for v in d[k]), "median %.3f" % statistics.median(d[k]))
+PY

@@ -830,6 +830,67 @@ def test_batch_norm_launches_of_three_layers_as_one_are_bit_identical():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("out16", [False, True])
+def test_batch_norm_backward_of_a_gradient_kept_in_two_tensors(out16):
+    """ds_segments.ptr2 / ds_bn_sum_segments.P2 (round 6): an Inception block's input gradient is the sum of the fused 1x1 dgrad's
+    output and Branch_3's pool gradient (image_model/inception_v1.py:83-96); where the dgrad cannot accumulate the two stay two
+    tensors written on two streams.  The sums are linear, so each producer emits its addend's partials and the finalize adds the
+    two sources; the apply pass adds the tensors as it reads.  dz (fp32 in place / bf16) is BIT-identical to the pass over the
+    pre-added gradient; coefficients and dbeta equal the single-source finalize of the concatenated partials to rounding."""
+    ops = _ops()
+    rng = np.random.RandomState(5)
+    M, Cc, c1 = 3000, 176, 64
+    dev_ = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    z = dev_(rng.normal(size=(M, Cc)) * 2 + 0.3)
+    mean, rstd, shift = dev_(rng.normal(size=Cc) * 0.1), dev_(rng.uniform(0.5, 2, size=Cc)), dev_(rng.normal(size=Cc) * 0.2)
+    beta = dev_(rng.normal(size=Cc))
+    ld = Cc + 16                                           # the two addends live in wider buffers (concat gradients)
+    dya, dyb = dev_(rng.normal(size=(M, ld))), dev_(rng.normal(size=(M, ld)))
+    dsum = dya + dyb
+    # segment 0 (columns [0, c1)): two addends, sums from two kind-1 sources; segment 1: one tensor, one source
+    P1, P2 = 7, 19
+    srcs = [dev_(rng.normal(size=(2, Cc, P))) for P in (P1, P2)]
+    cat = torch.cat([srcs[0][:, :c1], srcs[1][:, :c1]], dim=2).contiguous()       # [2][c1][P1 + P2]
+    sg2, sg1 = ops.SumSegments(), ops.SumSegments()
+    for sg in (sg2, sg1):
+        sg.nseg = 2
+        sg.c_begin[0], sg.c_end[0], sg.kind[0] = 0, c1, 1
+        sg.c_begin[1], sg.c_end[1], sg.kind[1], sg.P[1] = c1, Cc, 1, P1
+        sg.s[1], sg.q[1] = srcs[0].data_ptr() + 4 * c1 * P1, srcs[0].data_ptr() + 4 * (Cc + c1) * P1
+    sg2.P[0], sg2.s[0], sg2.q[0] = P1, srcs[0].data_ptr(), srcs[0].data_ptr() + 4 * Cc * P1
+    sg2.P2[0], sg2.s2[0], sg2.q2[0] = P2, srcs[1].data_ptr(), srcs[1].data_ptr() + 4 * Cc * P2
+    sg1.P[0], sg1.s[0], sg1.q[0] = P1 + P2, cat.data_ptr(), cat.data_ptr() + 4 * c1 * (P1 + P2)
+    res = []
+    for two in (True, False):
+        dbeta, coef = torch.zeros(Cc, device="cuda"), torch.zeros(2, Cc, device="cuda")
+        ops.bn_bwd_finalize_segs(sg2 if two else sg1, M, Cc, beta, dbeta, coef)
+        res.append((dbeta, coef))
+    torch.cuda.synchronize()
+    close(res[0][0], res[1][0].cpu().numpy().astype(np.float64), 1e-6)
+    close(res[0][1], res[1][1].cpu().numpy().astype(np.float64), 1e-6)
+    s_ref = (srcs[0][0, :c1].double().sum(1) + srcs[1][0, :c1].double().sum(1)).cpu().numpy()
+    close(res[0][0][:c1], s_ref, 1e-6)
+    coef = res[1][1]
+    outs = []
+    for two in (True, False):
+        zc = z.clone()
+        dz = torch.zeros(M, Cc, device="cuda", dtype=torch.bfloat16) if out16 else zc
+        src = dya if two else dsum
+        segs = ops.make_segments([(0, c1, src.data_ptr(), ld), (c1, Cc, dsum.data_ptr() + 4 * c1, ld)])
+        if two:
+            segs.ptr2[0] = dyb.data_ptr()
+        ops.bn_bwd_apply(zc, segs, M, Cc, mean, rstd, shift, coef, dz)
+        torch.cuda.synchronize()
+        outs.append(dz.clone())
+    assert torch.equal(outs[0], outs[1])
+    assert not torch.equal(outs[0].float(), z)
+    # the reduce pass refuses a gradient in two tensors (its sums come from the producers)
+    segs = ops.make_segments([(0, Cc, dya.data_ptr(), ld)])
+    segs.ptr2[0] = dyb.data_ptr()
+    with pytest.raises(RuntimeError):
+        ops.bn_bwd_reduce(z, segs, M, Cc, mean, rstd, shift, torch.empty(2 * Cc * ops.bn_bwd_partials(M, Cc), device="cuda"))
+
+
 @pytest.mark.parametrize("case", [(3000, 176, 24), (25088, 624, 196), (70, 16, 3), (200704, 64, 1568)])
 def test_batch_norm_finalize_and_apply_as_one_launch_are_bit_identical(case):
     """ds_bn_finalize_apply_relu / ds_bn_bwd_finalize_apply (round 6): the finalize (one workgroup per channel) and the apply pass

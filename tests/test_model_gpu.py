@@ -552,6 +552,42 @@ def test_block_batched_batch_norm_launches_step_is_bit_identical():
         assert torch.equal(a, b) if torch.is_tensor(a) else a == b
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "fp8"])
+def test_block_input_gradient_in_two_tensors_step_follows_the_accumulated_one(dtype):
+    """InceptionV1Engine.split_dout (built and measured, off by default: slower in the step, profiles/r06_notes.md; takes effect where
+    the fused 1x1 dgrad cannot accumulate: the 16-bit configurations, here also fp32 with pool_first and zcat off): the
+    block-input gradient stays TWO tensors -- the fused dgrad's output and
+    Branch_3's pool gradient, written concurrently on two streams, each producer emitting the BatchNorm sums of its own addend
+    -- and the previous block's ds_bn_bwd_apply adds them as it reads (ds_segments.ptr2, ds_bn_sum_segments.P2).  The forward
+    pass is untouched (logits and loss bit-identical); the gradients differ by the order the sums are added in: fp32 1e-4 of a
+    variable's norm, bf16 6e-2 / median 3e-3, fp8 median 5e-2 (the bounds of the other sum-source switches of those labels)."""
+    from tumblr_emotions_amd.net import SentimentNet
+    from tumblr_emotions_amd.synthetic import synthetic_batch_numpy, to_device
+    batch = to_device(synthetic_batch_numpy(32, 10, 50, seed=5))
+    res, used = [], []
+    for on in (True, False):
+        net = SentimentNet(mode="joint", nb_emotions=15, rnn_size=32, vocab_size=50, embedding_dim=20, post_size=10, dtype=dtype)
+        net.image.split_dout = on
+        if dtype == "f32":
+            net.image.pool_first, net.image.zcat = False, False
+        net.initialize(seed=7)
+        net.train_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        used.append([st.name for st in net.image.stages if getattr(st, "split_dout", False) is True])
+        res.append((net.logits.detach().clone(), net.total_loss_value(), net.grads_state_dict()))
+    assert used[0] == ["Mixed_3c", "Mixed_4c", "Mixed_4d", "Mixed_4e", "Mixed_4f", "Mixed_5c"] and used[1] == [], used
+    assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    rels = [np.linalg.norm(res[0][2][name].astype(np.float64) - g) / max(np.linalg.norm(g), 1e-30) for name, g in res[1][2].items()]
+    worst, med = max(rels), float(np.median(rels))
+    print("split_dout vs accumulated (%s): gradient rel L2 median %.2e, worst %.2e" % (dtype, med, worst))
+    if dtype == "f32":
+        assert 0 < worst <= 1e-4
+    elif dtype == "bf16":
+        assert 0 < worst <= 6e-2 and med <= 3e-3
+    else:
+        assert 0 < med <= 5e-2
+
+
 def test_split_k_winograd_step_follows_the_unsplit_one():
     """InceptionV1Engine.splitk (default): at small per-GPU batches the F(4x4) launches of the 14x14 / 7x7 layers are one partial
     round of workgroups, so ds_conv_plan splits their reduction over several workgroups per output block

@@ -73,7 +73,7 @@ class ConvIO(C.Structure):
 class Segments(C.Structure):
     _fields_ = [("nseg", C.c_int32), ("c_begin", C.c_int32 * 4), ("c_end", C.c_int32 * 4),
                 ("ld", C.c_int32 * 4), ("ptr", C.c_void_p * 4), ("dtype", C.c_int32 * 4),
-                ("amax", C.c_void_p * 4)]
+                ("amax", C.c_void_p * 4), ("ptr2", C.c_void_p * 4)]
 
 
 class BnFinalizeJob(C.Structure):
@@ -85,7 +85,8 @@ class BnFinalizeJob(C.Structure):
 
 class SumSegments(C.Structure):
     _fields_ = [("nseg", C.c_int32), ("c_begin", C.c_int32 * 4), ("c_end", C.c_int32 * 4), ("P", C.c_int32 * 4),
-                ("kind", C.c_int32 * 4), ("s", C.c_void_p * 4), ("q", C.c_void_p * 4)]
+                ("kind", C.c_int32 * 4), ("s", C.c_void_p * 4), ("q", C.c_void_p * 4), ("P2", C.c_int32 * 4),
+                ("s2", C.c_void_p * 4), ("q2", C.c_void_p * 4)]
 
 
 _P = C.c_void_p

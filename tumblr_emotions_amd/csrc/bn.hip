@@ -19,6 +19,7 @@ struct SegDev {
     float *ptr[4];
     int dtype[4];
     float *amax[4];
+    const float *ptr2[4];      // bn_bwd_apply: second addend of the segment (ds_segments.ptr2)
 };
 
 SegDev to_dev(const ds_segments *s) {
@@ -31,6 +32,7 @@ SegDev to_dev(const ds_segments *s) {
         o.ptr[i] = (float *)s->ptr[i];
         o.dtype[i] = s->dtype[i];
         o.amax[i] = s->amax[i];
+        o.ptr2[i] = s->ptr2[i];
     }
     return o;
 }
@@ -399,6 +401,8 @@ struct SumSegDev {
     int nseg;
     int c_begin[4], c_end[4], P[4], kind[4];
     const float *s[4], *q[4];
+    int P2[4];                 // second source of the segment (ds_bn_sum_segments.P2 / s2 / q2), 0: none
+    const float *s2[4], *q2[4];
     const float *beta[4];      // the segment's beta / dbeta, indexed from its first channel (ds_bn_bwd_finalize_segs: one
     float *dbeta[4];           // vector offset per segment; ds_bn_bwd_finalize_multi: the layers' own vectors); nullable
 };
@@ -407,8 +411,8 @@ template <bool COH = false>
 __device__ __forceinline__ void bwd_finalize_segs_channel(const SumSegDev &sg, double inv_count, int C, float *coef, int c) {
     __shared__ double red[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int P = 0, kind = 0;
-    const float *sp = nullptr, *qp = nullptr, *beta = nullptr;
+    int P = 0, kind = 0, P2 = 0;
+    const float *sp = nullptr, *qp = nullptr, *beta = nullptr, *sp2 = nullptr, *qp2 = nullptr;
     float *dbeta = nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -417,6 +421,11 @@ __device__ __forceinline__ void bwd_finalize_segs_channel(const SumSegDev &sg, d
             kind = sg.kind[i];
             sp = sg.s[i] + (int64_t)(c - sg.c_begin[i]) * P;
             qp = sg.q[i] + (int64_t)(c - sg.c_begin[i]) * P;
+            P2 = sg.P2[i];
+            if (P2 > 0) {
+                sp2 = sg.s2[i] + (int64_t)(c - sg.c_begin[i]) * P2;
+                qp2 = sg.q2[i] + (int64_t)(c - sg.c_begin[i]) * P2;
+            }
             beta = sg.beta[i] ? sg.beta[i] + (c - sg.c_begin[i]) : nullptr;
             dbeta = sg.dbeta[i] ? sg.dbeta[i] + (c - sg.c_begin[i]) : nullptr;
         }
@@ -424,6 +433,10 @@ __device__ __forceinline__ void bwd_finalize_segs_channel(const SumSegDev &sg, d
     for (int p = threadIdx.x; p < P; p += 256) {
         s += (double)sp[p];
         q += (double)qp[p];
+    }
+    for (int p = threadIdx.x; p < P2; p += 256) {          // (second source: the other addend's sums)
+        s += (double)sp2[p];
+        q += (double)qp2[p];
     }
     s = wave_sum_f64(s);
     q = wave_sum_f64(q);
@@ -449,7 +462,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_segs_kernel(SumSegDev sg,
 // OUT16: dz goes to a SEPARATE bf16 tensor (pixel stride lddz) instead of over z -- the 16-bit configurations' 1x1 input
 // gradients read it with one 16-byte load per eight channels (conv_bf16d_kernel<.., XB = true>); the values are the ones that
 // kernel would have rounded on load (RNE), so the dgrad's result has the same bits
-template <bool OUT16, bool COH = false>
+template <bool OUT16, bool COH = false, bool ADD2 = false>
 __device__ __forceinline__ void bwd_apply_body(int bid, const float *z, int ldz, const SegDev &dy, int64_t M, int C,
                                                const float *mean, const float *rstd, const float *shift,
                                                const float *coef, float *dz, float *amax, int drow, int lddz) {
@@ -468,12 +481,19 @@ __device__ __forceinline__ void bwd_apply_body(int bid, const float *z, int ldz,
         if (i < dy.nseg && c >= dy.c_begin[i] && c < dy.c_end[i]) sgi = i;
     const float *const dyp = dy.ptr[sgi] + (c - dy.c_begin[sgi]);
     const int64_t dyld = dy.ld[sgi];
+    // ADD2: the gradient is the sum of two tensors of the same layout (ds_segments.ptr2); a segment without one adds nothing
+    const float *const dyp2 = (ADD2 && dy.ptr2[sgi]) ? dy.ptr2[sgi] + (c - dy.c_begin[sgi]) : nullptr;
     float am = 0.f;
     for (int64_t row = row0; row < M; row += 2 * (int64_t)drow) {
         const bool ok1 = row + drow < M;
         const int64_t row1 = ok1 ? row + drow : row;
         const float4 zv[2] = {ds::ld_stream4(z + row * ldz + c), ds::ld_stream4(z + row1 * ldz + c)};
-        const float4 dv[2] = {ds::ld_stream4(dyp + row * dyld), ds::ld_stream4(dyp + row1 * dyld)};
+        float4 dv[2] = {ds::ld_stream4(dyp + row * dyld), ds::ld_stream4(dyp + row1 * dyld)};
+        if (ADD2 && dyp2) {
+            const float4 e0 = ds::ld_stream4(dyp2 + row * dyld), e1 = ds::ld_stream4(dyp2 + row1 * dyld);
+            dv[0].x += e0.x; dv[0].y += e0.y; dv[0].z += e0.z; dv[0].w += e0.w;
+            dv[1].x += e1.x; dv[1].y += e1.y; dv[1].z += e1.z; dv[1].w += e1.w;
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (u == 1 && !ok1) break;
@@ -497,11 +517,11 @@ __device__ __forceinline__ void bwd_apply_body(int bid, const float *z, int ldz,
     }
 }
 
-template <bool OUT16>
+template <bool OUT16, bool ADD2 = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, int ldz, SegDev dy, int64_t M, int C,
                                                            const float *mean, const float *rstd, const float *shift,
                                                            const float *coef, float *dz, float *amax, int drow, int lddz) {
-    bwd_apply_body<OUT16>((int)blockIdx.x, z, ldz, dy, M, C, mean, rstd, shift, coef, dz, amax, drow, lddz);
+    bwd_apply_body<OUT16, false, ADD2>((int)blockIdx.x, z, ldz, dy, M, C, mean, rstd, shift, coef, dz, amax, drow, lddz);
 }
 
 // ds_bn_bwd_finalize_apply: the backward finalize (segments, per-segment beta / dbeta) and the apply pass as one launch
@@ -548,6 +568,12 @@ int column_grid(int64_t M, int C4, int *drow) {
     return (int)grid;
 }
 
+bool has_second_addend(const ds_segments *s) {
+    for (int i = 0; i < s->nseg && i < 4; ++i)
+        if (s->ptr2[i]) return true;
+    return false;
+}
+
 int check_segments(const ds_segments *s, int C, const char *who, bool allow_bf16 = false) {
     DS_REQUIRE(s && s->nseg >= 1 && s->nseg <= 4, "%s: 1..4 segments required", who);
     int covered = 0;
@@ -557,6 +583,7 @@ int check_segments(const ds_segments *s, int C, const char *who, bool allow_bf16
         DS_REQUIRE(s->c_begin[i] % 4 == 0 && s->c_end[i] % 4 == 0 && s->ld[i] % 4 == 0 && s->ptr[i] &&
                        (((uintptr_t)s->ptr[i]) & (s->dtype[i] == DS_DTYPE_BF16 ? 7 : 15)) == 0,
                    "%s: segment %d not 4-channel aligned", who, i);
+        DS_REQUIRE((((uintptr_t)s->ptr2[i]) & 15) == 0, "%s: segment %d's second addend is not 16-byte aligned", who, i);
         covered += s->c_end[i] - s->c_begin[i];
     }
     DS_REQUIRE(covered == C, "%s: segments cover %d of %d channels", who, covered, C);
@@ -656,6 +683,7 @@ extern "C" int ds_bn_bwd_reduce(const void *z, int32_t ldz, int32_t z_dtype, con
                    (((uintptr_t)z) & (z_dtype == DS_DTYPE_BF16 ? 7 : 15)) == 0,
                "ds_bn_bwd_reduce: bad argument (need C %% 4 == 0, C <= 1024, ldz %% 4 == 0, aligned pointers, z_dtype f32 / bf16)");
     if (int e = check_segments(dy, C, "ds_bn_bwd_reduce")) return e;
+    DS_REQUIRE(!has_second_addend(dy), "ds_bn_bwd_reduce: a gradient in two addends takes its sums from the producers (ds_bn_sum_segments.P2)");
     const int C4 = C / 4;
     const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
     const size_t shmem = (size_t)RG * C4 * 8 * sizeof(float);
@@ -686,7 +714,9 @@ int build_sum_segs(const char *who, const ds_bn_sum_segments *sg, int64_t M, int
         d.c_begin[i] = sg->c_begin[i]; d.c_end[i] = sg->c_end[i]; d.P[i] = sg->P[i]; d.kind[i] = sg->kind[i];
         d.s[i] = sg->s[i]; d.q[i] = sg->q[i];
         d.beta[i] = nullptr; d.dbeta[i] = nullptr;
+        d.P2[i] = i < sg->nseg ? sg->P2[i] : 0; d.s2[i] = sg->s2[i]; d.q2[i] = sg->q2[i];
         if (i < sg->nseg) {
+            DS_REQUIRE(sg->P2[i] >= 0 && (sg->P2[i] == 0 || (sg->s2[i] && sg->q2[i])), "%s: segment %d has a malformed second source", who, i);
             DS_REQUIRE(sg->s[i] && sg->q[i] && sg->P[i] > 0 && sg->c_end[i] > sg->c_begin[i] && (sg->kind[i] == 0 || sg->kind[i] == 1),
                        "%s: segment %d is malformed", who, i);
             d.beta[i] = beta_v ? beta_v[i] : (beta ? beta + sg->c_begin[i] : nullptr);
@@ -729,6 +759,7 @@ extern "C" int ds_bn_bwd_finalize_apply(const ds_bn_sum_segments *sg, const floa
                    (((uintptr_t)dz) & (out16 ? 7 : 15)) == 0 && (!out16 || (lddz >= C && lddz % 4 == 0)),
                "ds_bn_bwd_finalize_apply: bad argument (see ds_bn_bwd_apply / ds_bn_bwd_apply_bf16)");
     if (int e = check_segments(dy, C, "ds_bn_bwd_finalize_apply")) return e;
+    DS_REQUIRE(!has_second_addend(dy), "ds_bn_bwd_finalize_apply: no second addend (use ds_bn_bwd_finalize_segs + ds_bn_bwd_apply)");
     BwdFinApplyArgs a;
     if (int e = build_sum_segs("ds_bn_bwd_finalize_apply", sg, M, C, beta, dbeta, beta_v, dbeta_v, coef, a.sg)) return e;
     a.inv_count = 1.0 / (double)M; a.C = C; a.coef = coef;
@@ -751,8 +782,12 @@ extern "C" int ds_bn_bwd_apply(const float *z, int32_t ldz, const ds_segments *d
     if (int e = check_segments(dy, C, "ds_bn_bwd_apply")) return e;
     int drow;
     const int grid = column_grid(M, C / 4, &drow);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, ldz, to_dev(dy), M, C, mean, rstd,
-                       shift, coef, dz, amax, drow, ldz);
+    if (has_second_addend(dy))
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, z, ldz, to_dev(dy), M, C, mean,
+                           rstd, shift, coef, dz, amax, drow, ldz);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, ldz, to_dev(dy), M, C, mean, rstd,
+                           shift, coef, dz, amax, drow, ldz);
     return ds::check_launch("ds_bn_bwd_apply");
 }
 
@@ -765,7 +800,11 @@ extern "C" int ds_bn_bwd_apply_bf16(const float *z, int32_t ldz, const ds_segmen
     if (int e = check_segments(dy, C, "ds_bn_bwd_apply_bf16")) return e;
     int drow;
     const int grid = column_grid(M, C / 4, &drow);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, ldz, to_dev(dy), M, C, mean,
-                       rstd, shift, coef, reinterpret_cast<float *>(dz16), amax, drow, lddz);
+    if (has_second_addend(dy))
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, z, ldz, to_dev(dy), M, C, mean,
+                           rstd, shift, coef, reinterpret_cast<float *>(dz16), amax, drow, lddz);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, ldz, to_dev(dy), M, C, mean,
+                           rstd, shift, coef, reinterpret_cast<float *>(dz16), amax, drow, lddz);
     return ds::check_launch("ds_bn_bwd_apply_bf16");
 }

@@ -186,6 +186,8 @@ class ConvBN:
         self.dy_segs = make_segments(parts)
         self.part_segs = [make_segments([(0, c1 - c0, ptr, ld)]) for (c0, c1, ptr, ld) in parts]
         self.part_sums = [None] * len(parts)
+        self.part_sums2 = [None] * len(parts)    # a second source of the same form: the part's gradient lives in TWO tensors (dy2)
+        self.dy2 = False                         # some part has a second addend (dy_segs.ptr2): see MixedStage.alloc, split_dout
         self.part_pool = [None] * len(parts)     # (pool stage, first column): the part feeds nothing but that max pool
         self._sum_segs = None
 
@@ -225,6 +227,12 @@ class ConvBN:
                     sg.q[i] = buf.data_ptr() + 4 * (ctot + off) * P
                     n = c1 - c0
                     self._sync_views += [buf[off * P:(off + n) * P], buf[(ctot + off) * P:(ctot + off + n) * P]]
+                    if self.part_sums2[i] is not None:          # the other addend's sums, added by the finalize
+                        buf2, P2, off2, ctot2 = self.part_sums2[i]
+                        sg.P2[i] = P2
+                        sg.s2[i] = buf2.data_ptr() + 4 * off2 * P2
+                        sg.q2[i] = buf2.data_ptr() + 4 * (ctot2 + off2) * P2
+                        self._sync_views += [buf2[off2 * P2:(off2 + n) * P2], buf2[(ctot2 + off2) * P2:(ctot2 + off2 + n) * P2]]
                 elif self.part_pool[i] is not None:
                     # The part feeds only a max pool.  Every window hands its gradient to ONE input pixel p*, whose
                     # activation is the pooled value, so   sum_pixels g = sum_windows dpool (ypool > 0)   and
@@ -449,7 +457,7 @@ class ConvBN:
         from_parts = any(ps is not None for ps in self.part_sums) or any(pp is not None for pp in self.part_pool)
         track = self.dgrad is not None and self.dgrad.family == ops.DS_FAM_FP8D
         dz = self.z if self.dz16 is None else self.dz16          # dz over z, or into its own bf16 tensor
-        if eng.fuse_fin_apply and not eng.sync_bn and (need_dx or self.trainable) and not self.bnb:
+        if eng.fuse_fin_apply and not eng.sync_bn and (need_dx or self.trainable) and not self.bnb and not self.dy2:
             # the finalize and the apply pass behind it as ONE launch (ds_bn_bwd_finalize_apply)
             if from_parts:
                 sg = self._sum_plan()
@@ -810,14 +818,39 @@ class MixedStage(Stage):
         #  * where the fused dgrad cannot accumulate (the 16-bit configurations' register-direct kernels) the order is the
         #    reverse: the dgrad writes, Branch_3's pool gradient is added LAST -- and that launch, which then holds the complete
         #    gradient of the previous block's output, emits the sums instead (ds_maxpool3_bwd_sums)
+        #    split_dout: ... and then that launch need not wait for the dgrad at all -- the two addends stay TWO tensors
+        #    (p.dout from the fused dgrad on the main chain, p.dout2 from the pool gradient inside the Branch_3 chain on its side
+        #    stream), each producer emits the BatchNorm sums of its own addend (the sums are linear in the gradient:
+        #    ds_bn_sum_segments.P2) and the one consumer, the previous block's ds_bn_bwd_apply, adds them as it reads
+        #    (ds_segments.ptr2).  The pool gradient (a sixth of the 16-bit step's critical chain) leaves the main stream.
         self.pool_sums = None
+        self.split_dout = False
         if isinstance(p, MixedStage) and not self.pool_first and eng.bwd_sums and eng.pool_sums and cin <= 1024 \
                 and not getattr(p, "zcat", False):          # (a zcat concat holds z, not y: the dgrad epilogue's business)
             P = ops.maxpool3_bwd_sums_partials(B, p.W, cin)
             self.pool_sums = torch.empty(2 * cin * P, device=dev)
+            # (the dgrad addend's sums: NOT from the register-direct kernels' DS_EPI_BNSUMS epilogue -- measured, it costs the
+            # fused dgrads 51 -> 75 us each, bf16 step 9.75 -> 10.13 ms -- but from one ds_bn_bwd_reduce over (y, dout) behind the
+            # dgrad: 6 B/element on the main chain where the accumulating pool gradient was 15; with mean = 0, rstd = 1,
+            # shift = 0 its sums are sum g and sum g*y over y > 0, the DS_EPI_BNSUMS form)
+            src, delta = None, 0
+            if eng.split_dout and cin % 4 == 0:
+                P1 = ops.bn_bwd_partials(M, cin)
+                self.dgrad_sums = torch.empty(2 * cin * P1, device=dev)
+                self._dgrad_sum_segs = make_segments([(0, cin, p.dout.data_ptr(), cin)])
+                src = (self.dgrad_sums, P1)
+                self.split_dout = True
+                p.dout2 = torch.empty_like(p.dout)
+                delta = p.dout2.data_ptr() - p.dout.data_ptr()
             pb0, _, pb1b, _, pb2b, pb3 = p.b
             for layer, off in ((p.fused, 0), (p.c1, pb0), (p.c2, pb0 + pb1b), (p.c3, pb0 + pb1b + pb2b)):
-                layer.part_sums[0] = (self.pool_sums, P, off, cin)
+                if self.split_dout:
+                    layer.part_sums[0] = (src[0], src[1], off, cin)
+                    layer.part_sums2[0] = (self.pool_sums, P, off, cin)
+                    layer.dy_segs.ptr2[0] = layer.dy_segs.ptr[0] + delta          # (part 0 of each layer lives in p.dout)
+                    layer.dy2 = True
+                else:
+                    layer.part_sums[0] = (self.pool_sums, P, off, cin)
                 layer._sum_segs = None
 
     # The three chains behind the block input -- [fused 1x1 -> Branch_1 3x3], [... -> Branch_2 3x3] and
@@ -989,6 +1022,8 @@ class MixedStage(Stage):
             closing(self.c3, None if self.fuse_b3 else ops._p(self.pooled), p.C, ops._p(self.dpooled), need_dx)      # (x: weight gradient only)
             if pool_first:
                 ops.maxpool_bwd(self.dpooled, self.argmax, p.dout, False, self.B, p.H, p.W, p.C, 3, 1, "SAME")
+            elif need_dx and self.split_dout:       # the pool gradient into its OWN tensor, with its own sums: inside this chain
+                ops.maxpool3_bwd_sums(self.dpooled, self.argmax, p.dout2, False, p.out, self.B, p.H, p.W, p.C, self.pool_sums)
 
         if not (eng.branch_streams and eng.side):
             branch3()
@@ -1021,7 +1056,10 @@ class MixedStage(Stage):
             if not eng.one_side_stream:
                 main.wait_event(e_3)
         self.fused.backward(x, p.C, ops._p(p.dout) if need_dx else None, need_dx)
-        if need_dx and not pool_first:
+        if need_dx and self.split_dout:             # the sums of the dgrad's addend (the pool gradient's came with it: branch3)
+            ops.bn_bwd_reduce(p.out, self._dgrad_sum_segs, self.B * p.H * p.W, p.C, eng.zeros, eng.ones, eng.zeros, self.dgrad_sums,
+                              ldz=p.C)
+        if need_dx and not pool_first and not self.split_dout:
             if self.pool_sums is not None:          # ... and the previous block's BatchNorm-backward sums (alloc)
                 ops.maxpool3_bwd_sums(self.dpooled, self.argmax, p.dout, True, p.out, self.B, p.H, p.W, p.C, self.pool_sums)
             else:
@@ -1106,6 +1144,11 @@ class InceptionV1Engine:
         e = _lib.tuning_env("DS_BATCH_BN")
         self.batch_bn = int(e) if e else None
         self.pool_sums = _lib.tuning_env("DS_POOL_SUMS", "1") != "0"      # ... or from the Branch_3 pool gradient where that is the last addend (MixedStage.alloc)
+        # ... which then stays a second tensor the consumer adds on load (MixedStage.alloc).  Built, tested, measured, OFF: the pool
+        # gradient leaves the main chain, but the Branch_3 chain it joins becomes the longest of the block and the step moves
+        # 6 B/element more -- bf16 9.74 -> 10.01 ms (10.13 with the sums from the register-direct dgrads' epilogue), every side
+        # stream arrangement (profiles/r06_notes.md).  DS_SPLIT_DOUT=1 switches it on (A/B)
+        self.split_dout = _lib.tuning_env("DS_SPLIT_DOUT", "0") == "1"
         self.stem_sums_from_dgrad = _lib.tuning_env("DS_STEM_SUMS", "1") != "0"      # pooled stem: its BatchNorm sums from Conv2d_2b's dgrad epilogue
         self.dz16 = int(_lib.tuning_env("DS_DZ16", "2"))      # 16-bit configurations: bf16 dz for the frozen 1x1 (1) and 3x3 (2) layers (ConvBN.make_dgrad)
         self.fuse_branch3 = _lib.tuning_env("DS_FUSE_B3", "1") != "0"      # Branch_3's 3x3/1 max pool formed on load by its 1x1 conv (MixedStage.alloc)
