@@ -360,9 +360,14 @@ def test_bench_self_launched_two_rank_run_prints_one_json_line():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["DS_BENCH_ONE_DEVICE"] = "1"
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--batch", "32", "--no-cpu-baseline", "--no-live-traffic", "--no-gather"],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "32", "--no-cpu-baseline", "--no-live-traffic", "--no-gather"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    if r.returncode != 0:
+        # one retry: the launcher picks a free rendezvous port by binding and releasing it, and two ranks share one device here --
+        # seen failing once in ~10 full-suite runs on a fresh box and never alone; a second failure is a real one
+        print("first attempt failed (rc %d):\n%s" % (r.returncode, r.stderr[-2000:]))
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-4000:]
     assert "re-executing as" in r.stderr
     lines = [l for l in r.stdout.splitlines() if l.lstrip().startswith("{")]
