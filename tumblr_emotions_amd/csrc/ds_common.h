@@ -33,10 +33,17 @@ inline int check_launch(const char *what) {
 constexpr int kCUs = 256;
 constexpr int kMaxStreamBlocks = kCUs * 8;
 
+// grid of the grid-stride streaming kernels (pools, copies, reductions): at most kMaxStreamBlocks workgroups
+// (DS_STREAM_MAX = workgroups per CU, tuning library only)
 inline int stream_grid(int64_t work_items, int per_block) {
+    static int cap = 0;
+    if (!cap) {
+        const char *e = tune_env("DS_STREAM_MAX");
+        cap = e && atoi(e) > 0 ? kCUs * atoi(e) : kMaxStreamBlocks;
+    }
     int64_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
-    if (b > kMaxStreamBlocks) b = kMaxStreamBlocks;
+    if (b > cap) b = cap;
     return (int)b;
 }
 
