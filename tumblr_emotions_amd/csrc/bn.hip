@@ -60,6 +60,10 @@ __device__ __forceinline__ float4 ldz4<__bf16>(const __bf16 *p) {
 
 using ds::wave_sum_f64;
 
+#ifndef DS_BN_ROWS
+#define DS_BN_ROWS 2          // rows per pass of the fixed-column streaming kernels (tuning builds: -DDS_BN_ROWS=4)
+#endif
+
 // Hand-off INSIDE a launch (the finalize + apply kernels below): the producer's few per-channel results go out as agent-scope
 // relaxed atomic stores (write-through: visible at the device's coherence point once vmcnt drains), the consumers read them
 // with agent-scope relaxed atomic loads (never a stale line of their XCD's L2).  No release / acquire fences: at agent scope
@@ -170,14 +174,19 @@ __device__ __forceinline__ void apply_relu_body(int bid, const float *z, int64_t
     const int64_t dld = dst.ld[sgi];
     const int dc = c - dst.c_begin[sgi];
     float smax = 0.f;                            // max(y) of this segment (y >= 0), if it asks
-    for (int64_t row = row0; row < M; row += 2 * (int64_t)drow) {
-        const bool ok1 = row + drow < M;
-        const float4 v0 = ds::ld_stream4(z + row * C + c);
-        const float4 v1 = ds::ld_stream4(z + (ok1 ? row + drow : row) * C + c);
+    constexpr int NR = DS_BN_ROWS;
+    for (int64_t row = row0; row < M; row += NR * (int64_t)drow) {
+        bool ok[NR];
+        float4 vv[NR];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u == 1 && !ok1) break;
-            const float4 v = u ? v1 : v0;
+        for (int u = 0; u < NR; ++u) {
+            ok[u] = row + u * (int64_t)drow < M;
+            vv[u] = ds::ld_stream4(z + (ok[u] ? row + u * (int64_t)drow : row) * C + c);
+        }
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            if (u > 0 && !ok[u]) break;
+            const float4 v = vv[u];
             float4 y;
             y.x = fmaxf(v.x * r.x + s.x, 0.f);
             y.y = fmaxf(v.y * r.y + s.y, 0.f);
@@ -484,28 +493,40 @@ __device__ __forceinline__ void bwd_apply_body(int bid, const float *z, int ldz,
     // ADD2: the gradient is the sum of two tensors of the same layout (ds_segments.ptr2); a segment without one adds nothing
     const float *const dyp2 = (ADD2 && dy.ptr2[sgi]) ? dy.ptr2[sgi] + (c - dy.c_begin[sgi]) : nullptr;
     float am = 0.f;
-    for (int64_t row = row0; row < M; row += 2 * (int64_t)drow) {
-        const bool ok1 = row + drow < M;
-        const int64_t row1 = ok1 ? row + drow : row;
-        const float4 zv[2] = {ds::ld_stream4(z + row * ldz + c), ds::ld_stream4(z + row1 * ldz + c)};
-        float4 dv[2] = {ds::ld_stream4(dyp + row * dyld), ds::ld_stream4(dyp + row1 * dyld)};
+    constexpr int NR = DS_BN_ROWS;          // rows per pass: every load of the pass before any of its stores
+    for (int64_t row = row0; row < M; row += NR * (int64_t)drow) {
+        int64_t rws[NR];
+        bool ok[NR];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            ok[u] = row + u * (int64_t)drow < M;
+            rws[u] = ok[u] ? row + u * (int64_t)drow : row;
+        }
+        float4 zv[NR], dv[NR];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            zv[u] = ds::ld_stream4(z + rws[u] * ldz + c);
+            dv[u] = ds::ld_stream4(dyp + rws[u] * dyld);
+        }
         if (ADD2 && dyp2) {
-            const float4 e0 = ds::ld_stream4(dyp2 + row * dyld), e1 = ds::ld_stream4(dyp2 + row1 * dyld);
-            dv[0].x += e0.x; dv[0].y += e0.y; dv[0].z += e0.z; dv[0].w += e0.w;
-            dv[1].x += e1.x; dv[1].y += e1.y; dv[1].z += e1.z; dv[1].w += e1.w;
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                const float4 e = ds::ld_stream4(dyp2 + rws[u] * dyld);
+                dv[u].x += e.x; dv[u].y += e.y; dv[u].z += e.z; dv[u].w += e.w;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u == 1 && !ok1) break;
+        for (int u = 0; u < NR; ++u) {
+            if (u > 0 && !ok[u]) break;
             const float zz[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w}, dd[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = ds::bn_bwd_dz(zz[j], dd[j], rr[j], ss[j], mm[j], a1[j], a2[j]);
             if (OUT16) {
                 const f32x4_t ov = {o[0], o[1], o[2], o[3]};
-                *reinterpret_cast<bf16x4_t *>(reinterpret_cast<__bf16 *>(dz) + (u ? row1 : row) * lddz + c) = __builtin_convertvector(ov, bf16x4_t);
+                *reinterpret_cast<bf16x4_t *>(reinterpret_cast<__bf16 *>(dz) + rws[u] * lddz + c) = __builtin_convertvector(ov, bf16x4_t);
             } else {
-                *reinterpret_cast<float4 *>(dz + (u ? row1 : row) * ldz + c) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4 *>(dz + rws[u] * ldz + c) = make_float4(o[0], o[1], o[2], o[3]);
             }
             am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
         }
