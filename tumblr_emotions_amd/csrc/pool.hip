@@ -165,6 +165,9 @@ __device__ __forceinline__ RowMax row_max3(const TI *x, int64_t row_base, int iw
 // rows is one dependent chain (load -> max -> store, and a load behind a store waits for it: one in-order memory counter),
 // i.e. the kernel's time was rows x memory latency -- 4.9 TB/s.  With the next rows' loads issued two rows ahead, before
 // the stores of the current one, twice the bytes are in flight per thread.
+#ifndef DS_POOL_PF16
+#define DS_POOL_PF16 2          // rows in flight per thread of the 3x3/1 pools on 16-bit input (4 and 6 measured slower: bf16 step 9.52 -> 9.58 / 9.63)
+#endif
 struct RawRow3 {
     float4 v[3];
     bool ok[3];
@@ -228,14 +231,20 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_rolling(const TI *x, TO *y, 
         auto req = [&](int ih) { return load_row3(x, (img + ih) * W, iw0, W, C, c, (unsigned)ih < (unsigned)H); };
         r0 = row_max3(x, (img + ih0) * W, iw0, W, C, c, (unsigned)ih0 < (unsigned)H);
         r1 = row_max3(x, (img + ih0 + 1) * W, iw0, W, C, c, (unsigned)(ih0 + 1) < (unsigned)H);
-        // STRIDE 1: rows requested ahead of their use -- qa = row ih0 + 2 (this output row's new row), qb = ih0 + 3 (the next one's)
-        RawRow3 qa, qb;
-        if (STRIDE == 1) { qa = req(ih0 + 2); qb = req(ih0 + 3); }
+        // STRIDE 1: rows requested ahead of their use -- q[0] = row ih0 + 2 (this output row's new row), q[1] = ih0 + 3 (the next
+        // one's), ...  D rows in flight: two.  (16-bit input, whose rows are half the bytes and whose Branch_3 pools run at
+        // 2.9 TB/s against 5.5 for the fp32 ones: four / six rows in flight measured SLOWER, DS_POOL_PF16 -- not the bytes in flight)
+        constexpr int D = STRIDE == 1 ? (sizeof(TI) == 2 ? DS_POOL_PF16 : 2) : 1;
+        RawRow3 q[D];
+        if (STRIDE == 1) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) q[u] = req(ih0 + 2 + u);
+        }
         for (int oh = 0; oh < OH; ++oh) {
             RawRow3 na;
             if (STRIDE == 1) {
-                na = req(ih0 + 4);         // the load of a LATER output row goes out before this one's stores
-                r2 = reduce_row3(qa);
+                na = req(ih0 + 2 + D);     // the load of a LATER output row goes out before this one's stores
+                r2 = reduce_row3(q[0]);
             } else {                       // (3x3/2: measured mixed -- 112x112 and 28x28 gain, 56x56 loses: kept as it was)
                 r2 = row_max3(x, (img + ih0 + 2) * W, iw0, W, C, c, (unsigned)(ih0 + 2) < (unsigned)H);
             }
@@ -263,8 +272,9 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_rolling(const TI *x, TO *y, 
             if (STRIDE == 1) {
                 r0 = r1;
                 r1 = r2;
-                qa = qb;          // row ih0 + 3 becomes the next output row's new row ...
-                qb = na;          // ... and row ih0 + 4, requested above, the one after
+#pragma unroll
+                for (int u = 0; u + 1 < D; ++u) q[u] = q[u + 1];      // row ih0 + 3 becomes the next output row's new row ...
+                q[D - 1] = na;                                        // ... and the row requested above the last in the queue
             } else {
                 r0 = r2;
                 r1 = row_max3(x, (img + ih0 + 3) * W, iw0, W, C, c, (unsigned)(ih0 + 3) < (unsigned)H);
