@@ -1156,6 +1156,11 @@ class InceptionV1Engine:
         # small per-GPU batches: the reduction of an F(4x4) launch that is one partial round of workgroups split over several
         # workgroups per output block (ds_conv_wino4_splitk; the library's launch-time model decides per layer).  DS_SPLITK=0: A/B
         self.splitk = _lib.tuning_env("DS_SPLITK", "1") != "0"
+        # A/B: the text tower's forward kernels held back until the image tower has passed stage `text_gate` (index into
+        # TOPOLOGY; None: both towers start together)
+        e = _lib.tuning_env("DS_TEXT_GATE")
+        self.text_gate = int(e) if e else None
+        self.text_gate_event = None
         self.weights_version = 0     # bumped by SentimentNet.after_load(): frozen layers redo their G g G^T
         self._stats_n = self._bwdp_n = self._ws_bytes = 0
         self.B = None
@@ -1346,8 +1351,12 @@ class InceptionV1Engine:
         if not stem.stem_direct or (stem.trainable and self.training):
             # the generic stem kernel and the stem's wgrad (train_all) read a zero-padded 4-channel copy
             ops.pad_channels(images, 3, self.input.out, 4, B * self.input.H * self.input.W)
-        for s in self.stages:
+        gate = self.text_gate
+        for i, s in enumerate(self.stages):
             s.forward()
+            if gate is not None and i == gate:      # the text tower's stream may start here (SentimentNet.forward)
+                self.text_gate_event = torch.cuda.Event()
+                self.text_gate_event.record(torch.cuda.current_stream())
         last = self.last
         ops.avgpool_dropout_fwd(last.out, B, last.H * last.W, self.feat, self.keep if self.training else 1.0, seed,
                                 dropout_mask, self.mask, self.pooled, seed_dev=self.seed_dev)

@@ -198,6 +198,8 @@ class SentimentNet:
             if side is not None:
                 main = torch.cuda.current_stream()
                 side.wait_event(inputs_ready)          # NOT wait_stream: the image tower is already enqueued on main
+                if self.image.text_gate is not None and self.image.text_gate_event is not None:
+                    side.wait_event(self.image.text_gate_event)      # (A/B: start behind a stage of the image tower)
                 with torch.cuda.stream(side):
                     tx = TextTowerFunction.apply(self.text, batch["texts"], batch["seq_lens"], L[self.text.KERNEL],
                                                  L[self.text.BIAS])
