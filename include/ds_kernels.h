@@ -97,6 +97,11 @@ typedef struct ds_conv_desc {
     const struct ds_bn_bwd_on_load *bnb;   /* HOST pointer, nullable: BatchNorm + ReLU backward applied ON LOAD (below)  */
     int32_t mask_dtype;       /* DS_EPI_BNSUMS in ds_conv_bf16 / ds_conv_fp8: storage type of `mask` (DS_DTYPE_F32 or, under     */
                               /* 16-bit activation storage, DS_DTYPE_BF16: ldmask then counts bf16 elements)                    */
+    int32_t z_dtype;          /* ds_conv_bf16 forward only: DS_DTYPE_BF16 stores z - pivot ROUNDED to bf16 (RNE; pixel stride    */
+                              /* ldz in elements; pivot = the DS_EPI_STATS pivot, 0 without one) -- the 16-bit configurations'  */
+                              /* frozen layers, whose BatchNorm passes then move 2 instead of 4 bytes per element of z.  The    */
+                              /* statistics come from the fp32 accumulators; centring keeps xhat = (z - mean) rstd free of      */
+                              /* cancellation (ds_bn_finalize_centered gives the consumers mean - pivot and the matching shift) */
     /* MaxPool 3x3 / 1 SAME applied ON LOAD (wide 1x1 kernel only, ds_conv_igemm_pool3_supported; nullable): an Inception   */
     /* block's Branch_3 = slim.max_pool2d(net, [3, 3], stride 1) -> slim.conv2d(., [1, 1]) (image_model/inception_v1.py:94-95  */
     /* ... :246-247) as ONE launch.  The reduction operand of pixel (h, w) is the maximum of x over its 3x3 neighbourhood     */
@@ -443,6 +448,11 @@ int ds_bn_finalize(const float *stats, int32_t P, int64_t count, int32_t C, cons
                    float eps, float decay, float *mean, float *rstd, float *shift, float *moving_mean,
                    float *moving_var, void *stream);
 
+/* ... for a layer whose z is stored CENTRED about the pivot (ds_conv_desc.z_dtype): additionally mean_c = mean - pivot and
+ * shift_c = beta - mean_c * rstd, the vectors ds_bn_apply_relu_z16 / ds_bn_bwd_reduce / ds_bn_bwd_apply_z16 take with that z.  */
+int ds_bn_finalize_centered(const float *stats, int32_t P, int64_t count, int32_t C, const float *beta, const float *pivot,
+                            float eps, float decay, float *mean, float *rstd, float *shift, float *moving_mean,
+                            float *moving_var, float *mean_c, float *shift_c, void *stream);
 /* The same for up to four layers in ONE launch (the three convs that close an Inception block -- Branch_1 / Branch_2 3x3 and
  * Branch_3 1x1, inception_v1.py:86-95 -- finish on three streams; their finalizes ran as three single-purpose launches of one
  * workgroup per channel each).  Per channel the arithmetic is ds_bn_finalize's: bit-identical.                            */
@@ -488,6 +498,9 @@ typedef struct ds_segments {
 } ds_segments;
 int ds_bn_apply_relu(const float *z, int64_t M, int32_t C, const float *rstd, const float *shift,
                      const ds_segments *dst, void *stream);
+/* The same reading z from bf16 storage (ds_conv_desc.z_dtype = DS_DTYPE_BF16: the 16-bit configurations' frozen layers). */
+int ds_bn_apply_relu_z16(const void *z16, int64_t M, int32_t C, const float *rstd, const float *shift,
+                         const ds_segments *dst, void *stream);
 /* slim.batch_norm with is_training=False (evaluate_*, mode != 'train': im_text_rnn_model.py:65,171-207):
  * rstd = rsqrt(moving_variance + eps), shift = beta - moving_mean*rstd, then ds_bn_apply_relu.  */
 int ds_bn_infer_prepare(const float *beta, const float *moving_mean, const float *moving_var, float eps,
@@ -544,6 +557,11 @@ int ds_bn_bwd_apply(const float *z, int32_t ldz, const ds_segments *dy, int64_t 
 int ds_bn_bwd_apply_bf16(const float *z, int32_t ldz, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
                          const float *rstd, const float *shift, const float *coef, void *dz16, int32_t lddz, float *amax,
                          void *stream);
+
+/* ... and with z itself in bf16 storage (ds_conv_desc.z_dtype): dz always goes to the separate bf16 tensor               */
+int ds_bn_bwd_apply_z16(const void *z16, int32_t ldz, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
+                        const float *rstd, const float *shift, const float *coef, void *dz16, int32_t lddz, float *amax,
+                        void *stream);
 
 /* slim.max_pool2d SAME/VALID (inception_v1.py:67,79,94,118,208) with arg-max record, and MaxPoolGrad. */
 /* act_dtype: storage type of x AND y (DS_DTYPE_F32 / DS_DTYPE_BF16; max and arg-max are exact in either).   */

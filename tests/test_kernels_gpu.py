@@ -830,6 +830,83 @@ def test_batch_norm_launches_of_three_layers_as_one_are_bit_identical():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("case", [(2, 14, 14, 96, 208, 1), (3, 7, 7, 160, 320, 3), (1, 28, 28, 64, 96, 3)])
+def test_conv_and_batch_norm_passes_with_z_in_centred_bf16_storage(case):
+    """ds_conv_desc.z_dtype = DS_DTYPE_BF16 + ds_bn_finalize_centered + ds_bn_apply_relu_z16 / ds_bn_bwd_reduce / ds_bn_bwd_apply_z16
+    (round 6, the 16-bit labels): ds_conv_bf16 stores bf16(z - pivot) -- exactly the fp32 launch's z minus the pivot, rounded
+    to nearest even -- with the SAME statistics; the finalize gives mean - pivot and beta - (mean - pivot) rstd beside the
+    unchanged mean / rstd / shift; every BatchNorm pass over the bf16 tensor has the bits of the fp32-input pass over the same
+    values.  And the point of the centring: xhat rebuilt from the stored z is within 2^-8 |xhat| + 2^-8 of the exact one however
+    far the channel means are from zero (here a pivot that is NOT near the means is also covered: the error then follows
+    |z - pivot|, which the assertion's bound on the stored value checks)."""
+    ops = _ops()
+    N, H, W, Ci, Co, k = case
+    rng = np.random.RandomState(Ci + Co)
+    M = N * H * W
+    x = torch.relu(torch.from_numpy(rng.normal(size=(N, H, W, Ci)).astype(np.float32))).cuda()
+    w = torch.from_numpy((rng.normal(size=(k, k, Ci, Co)) * 0.05).astype(np.float32)).cuda()
+    # the pivot as the engine has it: the previous step's mean, i.e. close to this step's (here: the exact mean + 2 % of sigma)
+    zref = torch.from_numpy(S.conv2d_same(_bf16_round(x.cpu().numpy().astype(np.float64)), _bf16_round(w.cpu().numpy().astype(np.float64)), 1).reshape(M, Co))
+    pivot = (zref.mean(0) + 0.02 * zref.std(0)).float().cuda()
+    outs = []
+    for z16 in (False, True):
+        pl = ops.LayerPlan(ops.DS_CONV_FWD, ops.DS_ARITH_BF16, ops.DS_PLAN_ACT16, N, H, W, Ci, Co, k, 1, Ci, Co, ops.DS_EPI_STATS)
+        assert pl.family == ops.DS_FAM_BF16D
+        pl.alloc_weights(x.device)
+        pl.prepare(ops._p(w))
+        z = torch.zeros(M, Co, device="cuda", dtype=torch.bfloat16 if z16 else torch.float32)
+        pl.d.z_dtype = ops.DS_DTYPE_BF16 if z16 else ops.DS_DTYPE_F32
+        stats = torch.zeros(2 * Co * pl.partials, device="cuda")
+        pl.run(ops._p(x), ops._p(w), ops._p(z), stats=ops._p(stats), pivot=ops._p(pivot))
+        torch.cuda.synchronize()
+        outs.append((z, stats, pl.partials))
+    z32, zc16, P = outs[0][0], outs[1][0], outs[0][2]
+    close(z32, zref.numpy(), 5e-4)
+    assert torch.equal(outs[0][1], outs[1][1])                                   # the statistics do not see the storage
+    assert torch.equal(zc16, (z32 - pivot).to(torch.bfloat16))                   # bf16(z - pivot), RNE
+    # finalize: unchanged outputs + the centred pair
+    beta = torch.from_numpy(rng.normal(size=Co).astype(np.float32)).cuda()
+    fin = []
+    for centred in (False, True):
+        mean, rstd, shift = pivot.clone(), torch.empty(Co, device="cuda"), torch.empty(Co, device="cuda")
+        mm, mv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
+        mc, sc = torch.zeros(Co, device="cuda"), torch.zeros(Co, device="cuda")
+        if centred:
+            ops.bn_finalize_centered(outs[0][1], P, M, Co, beta, 1e-3, 0.9997, mean, rstd, shift, mm, mv, mean, mc, sc)
+        else:
+            ops.bn_finalize(outs[0][1], P, M, Co, beta, 1e-3, 0.9997, mean, rstd, shift, mm, mv, pivot=mean)
+        torch.cuda.synchronize()
+        fin.append((mean, rstd, shift, mm, mv, mc, sc))
+    for a, b in zip(fin[0][:5], fin[1][:5]):
+        assert torch.equal(a, b)
+    mean, rstd, shift, mc, sc = fin[1][0], fin[1][1], fin[1][2], fin[1][5], fin[1][6]
+    assert float((mc.double() - (mean.double() - pivot.double())).abs().max()) <= 1e-6 * float(zref.std(0).max())
+    close(sc, (beta.double() - mc.double() * rstd.double()).cpu().numpy(), 1e-6)
+    # the passes over the bf16 tensor = the fp32-input passes over the same (centred, rounded) values
+    zf = zc16.float()
+    ya, yb = torch.zeros(M, Co, device="cuda"), torch.zeros(M, Co, device="cuda")
+    ops.bn_apply_relu(zc16, M, Co, rstd, sc, ops.make_segments([(0, Co, ya.data_ptr(), Co)]))
+    ops.bn_apply_relu(zf, M, Co, rstd, sc, ops.make_segments([(0, Co, yb.data_ptr(), Co)]))
+    dy = torch.from_numpy(rng.normal(size=(M, Co)).astype(np.float32)).cuda()
+    dy_segs = ops.make_segments([(0, Co, dy.data_ptr(), Co)])
+    P0 = ops.bn_bwd_partials(M, Co)
+    pa, pb = torch.zeros(2 * Co * P0, device="cuda"), torch.zeros(2 * Co * P0, device="cuda")
+    ops.bn_bwd_reduce(zc16, dy_segs, M, Co, mc, rstd, sc, pa)
+    ops.bn_bwd_reduce(zf, dy_segs, M, Co, mc, rstd, sc, pb)
+    coef = torch.from_numpy(rng.normal(size=(2, Co)).astype(np.float32) * 0.01).cuda()
+    da, db = torch.zeros(M, Co, device="cuda", dtype=torch.bfloat16), torch.zeros(M, Co, device="cuda", dtype=torch.bfloat16)
+    ops.bn_bwd_apply(zc16, dy_segs, M, Co, mc, rstd, sc, coef, da)
+    ops.bn_bwd_apply(zf.clone(), dy_segs, M, Co, mc, rstd, sc, coef, db)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb) and torch.equal(pa, pb) and torch.equal(da, db)
+    assert float(ya.abs().max()) > 0 and float(da.float().abs().max()) > 0
+    # no cancellation: xhat from the stored z against the exact one, although the means are many sigma from zero in some channels
+    xh_exact = (z32.double() - mean.double()) * rstd.double()
+    xh_stored = (zc16.double() - mc.double()) * rstd.double()
+    err = (xh_stored - xh_exact).abs()
+    assert float((err - 2.0 ** -8 * xh_exact.abs()).max()) <= 2.0 ** -8, float(err.max())
+
+
 @pytest.mark.parametrize("out16", [False, True])
 def test_batch_norm_backward_of_a_gradient_kept_in_two_tensors(out16):
     """ds_segments.ptr2 / ds_bn_sum_segments.P2 (round 6): an Inception block's input gradient is the sum of the fused 1x1 dgrad's

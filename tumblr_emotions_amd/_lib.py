@@ -39,7 +39,7 @@ class ConvDesc(C.Structure):
         ("tile_nt", C.c_int32), ("grid_x", C.c_int32), ("dtype", C.c_int32), ("x_dtype", C.c_int32),
         ("partials", C.c_int32),
         ("norm_rstd", C.c_void_p), ("norm_shift", C.c_void_p), ("mask_rstd", C.c_void_p), ("mask_shift", C.c_void_p),
-        ("bnb", C.c_void_p), ("mask_dtype", C.c_int32), ("pool_argmax", C.c_void_p), ("fin", C.c_void_p),
+        ("bnb", C.c_void_p), ("mask_dtype", C.c_int32), ("z_dtype", C.c_int32), ("pool_argmax", C.c_void_p), ("fin", C.c_void_p),
     ]
 
 
@@ -159,7 +159,10 @@ SIGNATURES = {
     "ds_conv_wgrad_workspace": (C.c_size_t, [_CD]),
     "ds_conv_wgrad": (C.c_int, [_CD, _P, _P, _i32, _P, _P, C.c_size_t, _P]),
     "ds_bn_finalize": (C.c_int, [_P, _i32, _i64, _i32, _P, _P, _f32, _f32, _P, _P, _P, _P, _P, _P]),
+    "ds_bn_finalize_centered": (C.c_int, [_P, _i32, _i64, _i32, _P, _P, _f32, _f32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ds_bn_apply_relu": (C.c_int, [_P, _i64, _i32, _P, _P, _SG, _P]),
+    "ds_bn_apply_relu_z16": (C.c_int, [_P, _i64, _i32, _P, _P, _SG, _P]),
+    "ds_bn_bwd_apply_z16": (C.c_int, [_P, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _P, _i32, _P, _P]),
     "ds_bn_infer_prepare": (C.c_int, [_P, _P, _P, _f32, _i32, _P, _P, _P]),
     "ds_bn_bwd_partials": (C.c_int, [_i64, _i32]),
     "ds_bn_bwd_reduce": (C.c_int, [_P, _i32, _i32, _SG, _i64, _i32, _P, _P, _P, _P, _P]),

@@ -94,7 +94,8 @@ __device__ __forceinline__ float4 ld_res4(const float *p) {
 template <bool COH = false>
 __device__ __forceinline__ void finalize_channel(const float *stats, int P, double inv_count, int C, int c, const float *beta,
                                                  const float *pivot, float eps, float decay, float *mean, float *rstd,
-                                                 float *shift, float *mm, float *mv) {
+                                                 float *shift, float *mm, float *mv, float *mean_c = nullptr,
+                                                 float *shift_c = nullptr) {
     __shared__ double red[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double s = 0.0, q = 0.0;
@@ -122,6 +123,10 @@ __device__ __forceinline__ void finalize_channel(const float *stats, int P, doub
         mean[c] = (float)mu;
         st_res<COH>(rstd + c, r);
         st_res<COH>(shift + c, beta[c] - (float)mu * r);
+        if (mean_c) {                 // z stored centred about the pivot (ds_bn_finalize_centered)
+            mean_c[c] = (float)du;
+            shift_c[c] = beta[c] - (float)du * r;
+        }
         if (mm) mm[c] = decay * mm[c] + (1.f - decay) * (float)mu;     // assign_moving_average
         if (mv) mv[c] = decay * mv[c] + (1.f - decay) * (float)var;
     }
@@ -130,8 +135,8 @@ __device__ __forceinline__ void finalize_channel(const float *stats, int P, doub
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *stats, int P, double inv_count, int C,
                                                           const float *beta, const float *pivot, float eps,
                                                           float decay, float *mean, float *rstd, float *shift,
-                                                          float *mm, float *mv) {
-    finalize_channel(stats, P, inv_count, C, (int)blockIdx.x, beta, pivot, eps, decay, mean, rstd, shift, mm, mv);
+                                                          float *mm, float *mv, float *mean_c, float *shift_c) {
+    finalize_channel(stats, P, inv_count, C, (int)blockIdx.x, beta, pivot, eps, decay, mean, rstd, shift, mm, mv, mean_c, shift_c);
 }
 
 // ds_bn_finalize_multi: the channels of up to four layers in one grid (workgroup -> job by the running channel count)
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256) void bn_finalize_multi_kernel(FinJobsDev jb, f
 // segment lookup happen once, the loop has no division, and consecutive threads still read consecutive addresses.  Tensors
 // that are read once come in with the non-temporal hint (scripts/microbench/stream_bw.hip: 5.3 -> 6.4 TB/s for "two in,
 // one out"); two rows per pass with both rows' loads before either store (a load behind a store waits for it).
-template <bool COH = false>
+template <bool COH = false, bool Z16 = false>
 __device__ __forceinline__ void apply_relu_body(int bid, const float *z, int64_t M, int C, const float *rstd,
                                                 const float *shift, const SegDev &dst, int drow) {
     const int C4 = C >> 2;
@@ -181,7 +186,9 @@ __device__ __forceinline__ void apply_relu_body(int bid, const float *z, int64_t
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
             ok[u] = row + u * (int64_t)drow < M;
-            vv[u] = ds::ld_stream4(z + (ok[u] ? row + u * (int64_t)drow : row) * C + c);
+            const int64_t zo = (ok[u] ? row + u * (int64_t)drow : row) * C + c;
+            if constexpr (Z16) vv[u] = ldz4<__bf16>(reinterpret_cast<const __bf16 *>(z) + zo);      // z stored as bf16 (ds_conv_desc.z_dtype)
+            else vv[u] = ds::ld_stream4(z + zo);
         }
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
@@ -216,9 +223,10 @@ __device__ __forceinline__ void apply_relu_body(int bid, const float *z, int64_t
     }
 }
 
+template <bool Z16 = false>
 __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *z, int64_t M, int C, const float *rstd,
                                                             const float *shift, SegDev dst, int drow) {
-    apply_relu_body((int)blockIdx.x, z, M, C, rstd, shift, dst, drow);
+    apply_relu_body<false, Z16>((int)blockIdx.x, z, M, C, rstd, shift, dst, drow);
 }
 
 // ---- finalize + apply as ONE launch --------------------------------------------------------------------------------------
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_segs_kernel(SumSegDev sg,
 // OUT16: dz goes to a SEPARATE bf16 tensor (pixel stride lddz) instead of over z -- the 16-bit configurations' 1x1 input
 // gradients read it with one 16-byte load per eight channels (conv_bf16d_kernel<.., XB = true>); the values are the ones that
 // kernel would have rounded on load (RNE), so the dgrad's result has the same bits
-template <bool OUT16, bool COH = false, bool ADD2 = false>
+template <bool OUT16, bool COH = false, bool ADD2 = false, bool Z16 = false>
 __device__ __forceinline__ void bwd_apply_body(int bid, const float *z, int ldz, const SegDev &dy, int64_t M, int C,
                                                const float *mean, const float *rstd, const float *shift,
                                                const float *coef, float *dz, float *amax, int drow, int lddz) {
@@ -505,7 +513,8 @@ __device__ __forceinline__ void bwd_apply_body(int bid, const float *z, int ldz,
         float4 zv[NR], dv[NR];
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
-            zv[u] = ds::ld_stream4(z + rws[u] * ldz + c);
+            if constexpr (Z16) zv[u] = ldz4<__bf16>(reinterpret_cast<const __bf16 *>(z) + rws[u] * ldz + c);
+            else zv[u] = ds::ld_stream4(z + rws[u] * ldz + c);
             dv[u] = ds::ld_stream4(dyp + rws[u] * dyld);
         }
         if (ADD2 && dyp2) {
@@ -538,11 +547,11 @@ __device__ __forceinline__ void bwd_apply_body(int bid, const float *z, int ldz,
     }
 }
 
-template <bool OUT16, bool ADD2 = false>
+template <bool OUT16, bool ADD2 = false, bool Z16 = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *z, int ldz, SegDev dy, int64_t M, int C,
                                                            const float *mean, const float *rstd, const float *shift,
                                                            const float *coef, float *dz, float *amax, int drow, int lddz) {
-    bwd_apply_body<OUT16, false, ADD2>((int)blockIdx.x, z, ldz, dy, M, C, mean, rstd, shift, coef, dz, amax, drow, lddz);
+    bwd_apply_body<OUT16, false, ADD2, Z16>((int)blockIdx.x, z, ldz, dy, M, C, mean, rstd, shift, coef, dz, amax, drow, lddz);
 }
 
 // ds_bn_bwd_finalize_apply: the backward finalize (segments, per-segment beta / dbeta) and the apply pass as one launch
@@ -618,8 +627,20 @@ extern "C" int ds_bn_finalize(const float *stats, int32_t P, int64_t count, int3
                               float *moving_mean, float *moving_var, void *stream) {
     DS_REQUIRE(stats && beta && mean && rstd && shift && P > 0 && count > 0 && C > 0, "ds_bn_finalize: bad argument");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, P,
-                       1.0 / (double)count, C, beta, pivot, eps, decay, mean, rstd, shift, moving_mean, moving_var);
+                       1.0 / (double)count, C, beta, pivot, eps, decay, mean, rstd, shift, moving_mean, moving_var,
+                       (float *)nullptr, (float *)nullptr);
     return ds::check_launch("ds_bn_finalize");
+}
+
+extern "C" int ds_bn_finalize_centered(const float *stats, int32_t P, int64_t count, int32_t C, const float *beta,
+                                       const float *pivot, float eps, float decay, float *mean, float *rstd, float *shift,
+                                       float *moving_mean, float *moving_var, float *mean_c, float *shift_c, void *stream) {
+    DS_REQUIRE(stats && beta && mean && rstd && shift && mean_c && shift_c && P > 0 && count > 0 && C > 0,
+               "ds_bn_finalize_centered: bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, P,
+                       1.0 / (double)count, C, beta, pivot, eps, decay, mean, rstd, shift, moving_mean, moving_var, mean_c,
+                       shift_c);
+    return ds::check_launch("ds_bn_finalize_centered");
 }
 
 extern "C" int ds_bn_finalize_multi(const ds_bn_finalize_job *jobs, int32_t njobs, float eps, float decay, void *stream) {
@@ -666,7 +687,7 @@ extern "C" int ds_bn_apply_relu(const float *z, int64_t M, int32_t C, const floa
     if (int e = check_segments(dst, C, "ds_bn_apply_relu", true)) return e;
     int drow;
     const int grid = column_grid(M, C / 4, &drow);
-    hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, M, C, rstd, shift, to_dev(dst),
+    hipLaunchKernelGGL(bn_apply_relu_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, M, C, rstd, shift, to_dev(dst),
                        drow);
     return ds::check_launch("ds_bn_apply_relu");
 }
@@ -687,6 +708,18 @@ extern "C" int ds_bn_finalize_apply_relu(const float *stats, int32_t P, int64_t 
     const int grid = column_grid(M, C / 4, &a.drow);
     hipLaunchKernelGGL(bn_finalize_apply_relu_kernel, dim3(C + grid), dim3(256), 0, (hipStream_t)stream, a);
     return ds::check_launch("ds_bn_finalize_apply_relu");
+}
+
+extern "C" int ds_bn_apply_relu_z16(const void *z16, int64_t M, int32_t C, const float *rstd, const float *shift,
+                                    const ds_segments *dst, void *stream) {
+    DS_REQUIRE(z16 && rstd && shift && M > 0 && C > 0 && C % 4 == 0 && (((uintptr_t)z16) & 7) == 0,
+               "ds_bn_apply_relu_z16: bad argument (C %% 4 != 0, or z not 8-byte aligned?)");
+    if (int e = check_segments(dst, C, "ds_bn_apply_relu_z16", true)) return e;
+    int drow;
+    const int grid = column_grid(M, C / 4, &drow);
+    hipLaunchKernelGGL(bn_apply_relu_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float *>(z16), M, C, rstd, shift, to_dev(dst), drow);
+    return ds::check_launch("ds_bn_apply_relu_z16");
 }
 
 extern "C" int ds_bn_bwd_partials(int64_t M, int32_t C) {
@@ -810,6 +843,25 @@ extern "C" int ds_bn_bwd_apply(const float *z, int32_t ldz, const ds_segments *d
         hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, ldz, to_dev(dy), M, C, mean, rstd,
                            shift, coef, dz, amax, drow, ldz);
     return ds::check_launch("ds_bn_bwd_apply");
+}
+
+extern "C" int ds_bn_bwd_apply_z16(const void *z16, int32_t ldz, const ds_segments *dy, int64_t M, int32_t C, const float *mean,
+                                   const float *rstd, const float *shift, const float *coef, void *dz16, int32_t lddz,
+                                   float *amax, void *stream) {
+    DS_REQUIRE(z16 && mean && rstd && shift && coef && dz16 && M > 0 && C > 0 && C % 4 == 0 && ldz >= C && ldz % 4 == 0 &&
+                   lddz >= C && lddz % 4 == 0 && (((uintptr_t)z16) & 7) == 0 && (((uintptr_t)dz16) & 7) == 0 && z16 != dz16,
+               "ds_bn_bwd_apply_z16: bad argument (need C %% 4 == 0, ldz / lddz >= C and %% 4 == 0, 8-byte aligned z / dz, dz != z)");
+    if (int e = check_segments(dy, C, "ds_bn_bwd_apply_z16")) return e;
+    int drow;
+    const int grid = column_grid(M, C / 4, &drow);
+    const float *zf = reinterpret_cast<const float *>(z16);
+    if (has_second_addend(dy))
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, zf, ldz, to_dev(dy), M, C,
+                           mean, rstd, shift, coef, reinterpret_cast<float *>(dz16), amax, drow, lddz);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, zf, ldz, to_dev(dy), M, C,
+                           mean, rstd, shift, coef, reinterpret_cast<float *>(dz16), amax, drow, lddz);
+    return ds::check_launch("ds_bn_bwd_apply_z16");
 }
 
 extern "C" int ds_bn_bwd_apply_bf16(const float *z, int32_t ldz, const ds_segments *dy, int64_t M, int32_t C, const float *mean,

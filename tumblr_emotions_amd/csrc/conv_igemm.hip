@@ -1803,10 +1803,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
     // (as gemm_wide_kernel) z / accumulate / activation accesses through buffer descriptors: 32-bit lane offset + row offset
     // in the vector offset, hardware range check for rows past M and columns past Cout (kOOB)
     const bool m16 = d.mask_dtype == DS_DTYPE_BF16;      // (uniform) BatchNorm-sums activation in bf16 storage
-    const __amdgpu_buffer_rsrc_t srd_z = make_srd(p.z, (unsigned)(((int64_t)(p.M - 1) * d.ldz + d.Cout) * 4));
+    const bool z16 = d.z_dtype == DS_DTYPE_BF16;         // (uniform) z stored rounded to bf16 (forward, no accumulate)
+    const unsigned zeb = z16 ? 2u : 4u;
+    const __amdgpu_buffer_rsrc_t srd_z = make_srd(p.z, (unsigned)(((int64_t)(p.M - 1) * d.ldz + d.Cout) * zeb));
     const __amdgpu_buffer_rsrc_t srd_m = make_srd((flags & DS_EPI_BNSUMS) ? p.mask : p.z,
                                                   (flags & DS_EPI_BNSUMS) ? (unsigned)(((int64_t)(p.M - 1) * d.ldmask + d.Cout) * (m16 ? 2 : 4)) : 0u);
-    const int rz = d.ldz * 4, rm = d.ldmask * (m16 ? 2 : 4);
+    const int rz = d.ldz * (int)zeb, rm = d.ldmask * (m16 ? 2 : 4);
     const int rbase = mrow0 + 4 * kh;
     auto roff = [](int r, int row_bytes) -> unsigned { return (unsigned)(((r & 3) + 8 * (r >> 2)) * row_bytes); };
     float pss[NB], pqq[NB];
@@ -1815,7 +1817,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
         const int col = n0 + 32 * b + li;
         const bool colok = item && col < d.Cout;
         const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
-        const unsigned vz = colok ? (unsigned)(rbase * d.ldz + col) * 4u : kOOB;
+        const unsigned vz = colok ? (unsigned)(rbase * d.ldz + col) * zeb : kOOB;
         const unsigned vm = colok ? (unsigned)(rbase * d.ldmask + col) * (m16 ? 2u : 4u) : kOOB;
         float s = 0.f, q = 0.f;
         if (flags & DS_EPI_ACCUM) {
@@ -1884,11 +1886,24 @@ __global__ __launch_bounds__(256, 2) void conv_bf16d_kernel(const ConvParams p) 
     for (int b = 0; b < NB; ++b) {
         const int col = n0 + 32 * b + li;
         const bool colok = item && col < d.Cout;
-        const unsigned vz = colok ? (unsigned)(rbase * d.ldz + col) * 4u : kOOB;
+        const unsigned vz = colok ? (unsigned)(rbase * d.ldz + col) * zeb : kOOB;
+        if (z16) {
+            // z CENTRED about the pivot before it is rounded: the BatchNorm passes use z - mean, and for a channel with
+            // |mean| >> sigma a bf16 z would carry (|mean| / sigma) 2^-9 of error into xhat; z - pivot (pivot = the previous
+            // step's mean) is of the size of sigma, its rounding error 2^-9 of xhat itself.  The consumers get mean - pivot and
+            // beta - (mean - pivot) rstd (ds_bn_finalize_centered)
+            const float pvz = (p.pivot && colok) ? p.pivot[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float val = acc[b][r];          // (bit_cast of a vector-element lvalue reads element 0: copy first)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_z, vz + roff(r, rz), 0, 2 /* nt */);
+            for (int r = 0; r < 16; ++r) {
+                const __bf16 hv = (__bf16)(acc[b][r] - pvz);          // round to nearest even
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), srd_z, vz + roff(r, rz), 0, 2 /* nt */);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float val = acc[b][r];          // (bit_cast of a vector-element lvalue reads element 0: copy first)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_z, vz + roff(r, rz), 0, 2 /* nt */);
+            }
         }
         if ((flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) && tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
             p.stats[(int64_t)(n0 + 32 * b + tid) * t0.stride + t0.row] = pss[b];
@@ -2573,6 +2588,8 @@ extern "C" int ds_conv_bf16(const ds_conv_desc *d, const void *x, const void *wb
                             "DS_EPI_ACCUM | DS_EPI_BNSUMS for a dgrad");
     DS_REQUIRE(((((uintptr_t)x | (uintptr_t)wb) & 15) == 0) && conv_M(d) < (1ll << 31), "ds_conv_bf16: operands must be 16-byte aligned");
     DS_REQUIRE(!(d->flags & DS_EPI_STATS) || stats, "ds_conv_bf16: DS_EPI_STATS without stats buffer");
+    DS_REQUIRE(d->z_dtype == DS_DTYPE_F32 || (d->z_dtype == DS_DTYPE_BF16 && !(d->flags & (DS_EPI_ACCUM | DS_EPI_BNSUMS)) && !d->flip),
+               "ds_conv_bf16: z in bf16 storage is for the forward conv (no accumulate / BatchNorm-sums epilogue)");
     ConvParams p = {};
     p.d = *d;
     p.x = (const float *)x; p.w = (const float *)wb; p.z = z; p.stats = stats; p.mask = (const float *)mask;

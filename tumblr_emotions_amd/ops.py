@@ -575,7 +575,18 @@ def bn_finalize(stats, P, count, C_, beta, eps, decay, mean, rstd, shift, mm, mv
                                           _p(rstd), _p(shift), _p(mm), _p(mv), _stream()), "ds_bn_finalize")
 
 
+def bn_finalize_centered(stats, P, count, C_, beta, eps, decay, mean, rstd, shift, mm, mv, pivot, mean_c, shift_c):
+    """ds_bn_finalize for a layer whose z is stored centred about the pivot: also mean - pivot and the matching shift."""
+    _lib.check(_lib.load().ds_bn_finalize_centered(_p(stats), P, count, C_, _p(beta), _p(pivot), eps, decay, _p(mean), _p(rstd),
+                                                   _p(shift), _p(mm), _p(mv), _p(mean_c), _p(shift_c), _stream()),
+               "ds_bn_finalize_centered")
+
+
 def bn_apply_relu(z, M, C_, rstd, shift, segs):
+    if z.dtype == torch.bfloat16:          # z in bf16 storage (ds_conv_desc.z_dtype)
+        _lib.check(_lib.load().ds_bn_apply_relu_z16(_p(z), M, C_, _p(rstd), _p(shift), C.byref(segs), _stream()),
+                   "ds_bn_apply_relu_z16")
+        return
     _lib.check(_lib.load().ds_bn_apply_relu(_p(z), M, C_, _p(rstd), _p(shift), C.byref(segs), _stream()),
                "ds_bn_apply_relu")
 
@@ -664,6 +675,11 @@ def bn_bwd_finalize(partials, P, M, C_, dbeta, coef):
 def bn_bwd_apply(z, segs, M, C_, mean, rstd, shift, coef, dz, amax=None, ldz=0):
     """dz: fp32 (over z, or any tensor with z's row stride), or a SEPARATE dense bf16 tensor [M, C] -- the form the 16-bit
     configurations' 1x1 input gradients read (ds_bn_bwd_apply_bf16)."""
+    if z.dtype == torch.bfloat16:          # z in bf16 storage: dz into its own bf16 tensor
+        assert dz.dtype == torch.bfloat16
+        _lib.check(_lib.load().ds_bn_bwd_apply_z16(_p(z), ldz or C_, C.byref(segs), M, C_, _p(mean), _p(rstd), _p(shift),
+                                                   _p(coef), _p(dz), dz.stride(0), _p(amax), _stream()), "ds_bn_bwd_apply_z16")
+        return
     if dz.dtype == torch.bfloat16:
         _lib.check(_lib.load().ds_bn_bwd_apply_bf16(_p(z), ldz or C_, C.byref(segs), M, C_, _p(mean), _p(rstd), _p(shift),
                                                     _p(coef), _p(dz), dz.stride(0), _p(amax), _stream()), "ds_bn_bwd_apply_bf16")
