@@ -178,6 +178,19 @@ def batch_norm_train(z, beta, eps=S.BN_EPS):
     return y, mean, var
 
 
+def batch_norm_train_stored(z, pivot, beta, eps=S.BN_EPS):
+    """batch_norm_train for a layer whose conv output the build keeps in 16-bit storage (ds_conv_desc.z_dtype, the 16-bit
+    labels only -- no reference counterpart): the statistics come from the exact z, the value that is normalised is
+    bf16(z - pivot) + pivot (pivot: the build's statistics pivot), and the gradient passes the rounding straight through, as the
+    build's backward does (it uses the stored value for xhat and the ReLU mask and differentiates as if it were z)."""
+    mean = z.mean(dim=(0, 2, 3))
+    var = ((z - mean[None, :, None, None]) ** 2).mean(dim=(0, 2, 3))
+    piv = pivot.detach()[None, :, None, None]
+    z_eff = z + ((_bf16(z.detach() - piv) + piv) - z.detach())
+    y = (z_eff - mean[None, :, None, None]) * torch.rsqrt(var + eps)[None, :, None, None] + beta[None, :, None, None]
+    return y, mean, var
+
+
 def batch_norm_infer(z, beta, mm, mv, eps=S.BN_EPS):
     return (z - mm[None, :, None, None]) * torch.rsqrt(mv + eps)[None, :, None, None] + beta[None, :, None, None]
 
@@ -226,6 +239,9 @@ class DeepSentimentRef:
         # "bf16": the 57 BatchNorm convs multiply bf16-rounded operands in forward and dgrad (the build's
         # dtype='bf16' switch, BASELINE configs[4] groundwork; no reference counterpart -- the reference is fp32)
         self.conv_multiply = "f32"
+        # scopes whose conv output the build stores as bf16(z - pivot) (InceptionV1Engine.z16, 16-bit labels): set by the tests
+        # from the build's own plan; the first step's pivot is the moving mean (ConvBN.bind)
+        self.z_storage_bf16 = None
 
     @staticmethod
     def _is_trainable(name, trainable_bn_beta):
@@ -258,7 +274,10 @@ class DeepSentimentRef:
             z = conv2d_same(x, self.p[scope + "/weights"], stride)
         beta = self.p[scope + "/BatchNorm/beta"]
         if self.is_training:
-            y, mean, var = batch_norm_train(z, beta)
+            if self.z_storage_bf16 and scope in self.z_storage_bf16:
+                y, mean, var = batch_norm_train_stored(z, self.p[scope + "/BatchNorm/moving_mean"], beta)
+            else:
+                y, mean, var = batch_norm_train(z, beta)
             self.bn_batch_stats[scope] = (mean.detach(), var.detach())
         else:
             y = batch_norm_infer(z, beta, self.p[scope + "/BatchNorm/moving_mean"],

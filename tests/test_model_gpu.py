@@ -321,7 +321,8 @@ def test_joint_step_bf16_multiply_matches_bf16_emulating_oracle():
     pipe, everything else stays fp32.  NOT the 1e-3 parity path; its kernels are held to the oracle exactly in
     tests/test_kernels_gpu.py (bf16-rounded operands, fp32-accumulation tolerance) and its wiring is the fp32 path's.
     Here the whole step is compared with the fp64 oracle twice, along the HIP decisions: with the oracle rounding the
-    same operands to bf16 (DeepSentimentRef.conv_multiply = 'bf16'), and with exact multiplies.  This randomly
+    same operands to bf16 (DeepSentimentRef.conv_multiply = 'bf16') and keeping the conv output of the layers the build
+    keeps in centred bf16 storage the same way (z_storage_bf16, round 6), and with exact multiplies.  This randomly
     initialised 57-layer BatchNorm stack amplifies a forward perturbation ~100x (fp32 rounding alone shows as 1e-5 on
     the logits), so even the emulating oracle is matched only to ~2e-2 on the logits -- ~1 % of the operands sit close
     enough to a bf16 rounding boundary to round differently in fp32 than in fp64 -- and the exact one to ~1e-1.
@@ -344,10 +345,14 @@ def test_joint_step_bf16_multiply_matches_bf16_emulating_oracle():
     logits = net.logits.detach().cpu().numpy()
     grads = net.grads_state_dict()
     decisions = hip_decisions(net)
+    z16_scopes = {sc for l in net.image.layers if l.z16 for (sc, _, _) in l.scopes}
+    assert len(z16_scopes) >= 30          # (fused 1x1 layers count three scopes)
     report = {}
     for kind in ("bf16", "f32"):
         ref = R.DeepSentimentRef(params, emb, "joint", torch.float64)
         ref.inject, ref.conv_multiply = decisions, kind
+        if kind == "bf16":      # ... and keeping the same layers' conv output in centred bf16 storage (InceptionV1Engine.z16)
+            ref.z_storage_bf16 = z16_scopes
         out = ref.train_step(batch, 1e-3)
         dl = float(np.abs(logits - out["logits"].numpy()).max())
         dloss = abs(net.total_loss_value() - out["loss"])
