@@ -97,7 +97,7 @@ typedef struct ds_conv_desc {
     const struct ds_bn_bwd_on_load *bnb;   /* HOST pointer, nullable: BatchNorm + ReLU backward applied ON LOAD (below)  */
     int32_t mask_dtype;       /* DS_EPI_BNSUMS in ds_conv_bf16 / ds_conv_fp8: storage type of `mask` (DS_DTYPE_F32 or, under     */
                               /* 16-bit activation storage, DS_DTYPE_BF16: ldmask then counts bf16 elements)                    */
-    int32_t z_dtype;          /* ds_conv_bf16 forward only: DS_DTYPE_BF16 stores z - pivot ROUNDED to bf16 (RNE; pixel stride    */
+    int32_t z_dtype;          /* ds_conv_bf16 without accumulate / sums epilogue: DS_DTYPE_BF16 stores z - pivot ROUNDED to bf16 (RNE; pixel stride */
                               /* ldz in elements; pivot = the DS_EPI_STATS pivot, 0 without one) -- the 16-bit configurations'  */
                               /* frozen layers, whose BatchNorm passes then move 2 instead of 4 bytes per element of z.  The    */
                               /* statistics come from the fp32 accumulators; centring keeps xhat = (z - mean) rstd free of      */
@@ -597,6 +597,12 @@ int ds_maxpool_bwd(const float *dy, const uint8_t *argmax, float *dx, int32_t ac
 int ds_maxpool3_bwd_sums_partials(int32_t N, int32_t W, int32_t C);
 int ds_maxpool3_bwd_sums(const float *dy, const uint8_t *argmax, float *dx, int32_t accumulate, const void *y,
                          int32_t y_dtype, int32_t N, int32_t H, int32_t W, int32_t C, float *partials, void *stream);
+
+/* The same MaxPoolGrad with its output gradient dy in bf16 storage (the 16-bit labels: Branch_3's 1x1 Conv2DBackpropInput writes
+ * it rounded, ds_conv_desc.z_dtype on that launch -- 2 B written and 2 B read per element instead of 4).  partials == NULL: the
+ * plain pass (what ds_maxpool_bwd does for k = 3, stride 1, SAME; y ignored); else with the sums, as ds_maxpool3_bwd_sums.     */
+int ds_maxpool3_bwd_dy16(const void *dy16, const uint8_t *argmax, float *dx, int32_t accumulate, const void *y, int32_t y_dtype,
+                         int32_t N, int32_t H, int32_t W, int32_t C, float *partials, void *stream);
 
 /* slim.avg_pool2d 7x7 VALID + slim.dropout (inception_v1.py:299-301).  mask_in==NULL: draw
  * Bernoulli(keep) from a counter-based generator keyed by (seed, element); the mask used is

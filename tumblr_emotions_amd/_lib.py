@@ -182,6 +182,7 @@ SIGNATURES = {
     "ds_maxpool_bwd": (C.c_int, [_P, _P, _P] + [_i32] * 11 + [_P]),
     "ds_maxpool3_bwd_sums_partials": (C.c_int, [_i32, _i32, _i32]),
     "ds_maxpool3_bwd_sums": (C.c_int, [_P, _P, _P, _i32, _P, _i32, _i32, _i32, _i32, _i32, _P, _P]),
+    "ds_maxpool3_bwd_dy16": (C.c_int, [_P, _P, _P, _i32, _P, _i32, _i32, _i32, _i32, _i32, _P, _P]),
     "ds_avgpool_dropout_fwd": (C.c_int, [_P, _i32, _i32, _i32, _f32, _u64, _P, _P, _P, _P, _P]),
     "ds_avgpool_dropout_bwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _f32, _P, _P]),
     "ds_gather_rows": (C.c_int, [_P, _P, _P, _i32, _i32, _i32, _i64, _i32, _P]),

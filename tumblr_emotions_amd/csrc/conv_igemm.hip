@@ -2588,8 +2588,8 @@ extern "C" int ds_conv_bf16(const ds_conv_desc *d, const void *x, const void *wb
                             "DS_EPI_ACCUM | DS_EPI_BNSUMS for a dgrad");
     DS_REQUIRE(((((uintptr_t)x | (uintptr_t)wb) & 15) == 0) && conv_M(d) < (1ll << 31), "ds_conv_bf16: operands must be 16-byte aligned");
     DS_REQUIRE(!(d->flags & DS_EPI_STATS) || stats, "ds_conv_bf16: DS_EPI_STATS without stats buffer");
-    DS_REQUIRE(d->z_dtype == DS_DTYPE_F32 || (d->z_dtype == DS_DTYPE_BF16 && !(d->flags & (DS_EPI_ACCUM | DS_EPI_BNSUMS)) && !d->flip),
-               "ds_conv_bf16: z in bf16 storage is for the forward conv (no accumulate / BatchNorm-sums epilogue)");
+    DS_REQUIRE(d->z_dtype == DS_DTYPE_F32 || (d->z_dtype == DS_DTYPE_BF16 && !(d->flags & (DS_EPI_ACCUM | DS_EPI_BNSUMS))),
+               "ds_conv_bf16: the output in bf16 storage excludes the accumulate / BatchNorm-sums epilogues");
     ConvParams p = {};
     p.d = *d;
     p.x = (const float *)x; p.w = (const float *)wb; p.z = z; p.stats = stats; p.mask = (const float *)mask;

@@ -296,7 +296,8 @@ struct WinRow {
     unsigned a[3];      // packed uchar4 arg-max of the three windows of one output row
 };
 
-__device__ __forceinline__ WinRow load_win_row(const float *dy, const uint8_t *am, int64_t row_base, int iw, int W, int C,
+template <typename TD>          // TD: storage of the pool's output gradient (float; __bf16: a dgrad wrote it rounded, ds_conv_desc.z_dtype)
+__device__ __forceinline__ WinRow load_win_row(const TD *dy, const uint8_t *am, int64_t row_base, int iw, int W, int C,
                                                int c, bool row_ok) {
     WinRow r;
 #pragma unroll
@@ -309,7 +310,7 @@ __device__ __forceinline__ WinRow load_win_row(const float *dy, const uint8_t *a
         if (ok) {
             const int64_t o = (row_base + ow) * C + c;
             r.a[q] = *reinterpret_cast<const unsigned *>(am + o);
-            const float4 v = *reinterpret_cast<const float4 *>(dy + o);
+            const float4 v = ld4<TD>(dy + o);
             r.d[q][0] = v.x; r.d[q][1] = v.y; r.d[q][2] = v.z; r.d[q][3] = v.w;
         }
     }
@@ -327,7 +328,8 @@ __device__ __forceinline__ void win_row_grad(const WinRow &w, int p, float g[4])
     }
 }
 
-__global__ __launch_bounds__(256) void maxpool3s1_bwd_rolling(const float *dy, const uint8_t *am, float *dx,
+template <typename TD = float>
+__global__ __launch_bounds__(256) void maxpool3s1_bwd_rolling(const TD *dy, const uint8_t *am, float *dx,
                                                               int accumulate, int N, int H, int W, int C) {
     const int C4 = C >> 2;
     const int64_t total = (int64_t)N * W * C4;
@@ -366,8 +368,8 @@ __global__ __launch_bounds__(256) void maxpool3s1_bwd_rolling(const float *dy, c
 // Layout as bn_bwd_reduce_kernel: thread = (channel quad cg, unit group rg) keeps its channels for the whole launch, a unit =
 // one image column (n, iw) walked down its H rows; workgroup b takes units [b * upb, (b + 1) * upb); partials [2][C][gridDim.x],
 // summed per thread in unit order and over the unit groups in a fixed order (deterministic).
-template <typename TY>
-__global__ __launch_bounds__(256) void maxpool3s1_bwd_sums_kernel(const float *dy, const uint8_t *am, float *dx, int accumulate,
+template <typename TY, typename TD = float>
+__global__ __launch_bounds__(256) void maxpool3s1_bwd_sums_kernel(const TD *dy, const uint8_t *am, float *dx, int accumulate,
                                                                   const TY *y, int N, int H, int W, int C, float *partials,
                                                                   int upb) {
     extern __shared__ __attribute__((aligned(16))) float sh[];   // [RG][C4][8]
@@ -804,7 +806,7 @@ extern "C" int ds_maxpool_bwd(const float *dy, const uint8_t *argmax, float *dx,
                               int32_t OH, int32_t OW, void *stream) {
     DS_REQUIRE(dy && argmax && dx && C % 4 == 0, "ds_maxpool_bwd: bad argument");
     if (k == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && OH == H && OW == W) {
-        hipLaunchKernelGGL(maxpool3s1_bwd_rolling, dim3(ds::stream_grid((int64_t)N * W * (C / 4), 256)), dim3(256), 0,
+        hipLaunchKernelGGL(maxpool3s1_bwd_rolling<float>, dim3(ds::stream_grid((int64_t)N * W * (C / 4), 256)), dim3(256), 0,
                            (hipStream_t)stream, dy, argmax, dx, accumulate, N, H, W, C);
         return ds::check_launch("ds_maxpool_bwd");
     }
@@ -832,6 +834,34 @@ extern "C" int ds_maxpool3_bwd_sums_partials(int32_t N, int32_t W, int32_t C) {
     return (N * W + upb - 1) / upb;
 }
 
+// The 3x3 / 1 MaxPoolGrad reading its output gradient from bf16 storage (a Conv2DBackpropInput wrote it rounded:
+// ds_conv_desc.z_dtype on the dgrad): partials == nullptr: the plain pass (ds_maxpool_bwd), else with the sums (ds_maxpool3_bwd_sums)
+extern "C" int ds_maxpool3_bwd_dy16(const void *dy16, const uint8_t *argmax, float *dx, int32_t accumulate, const void *y,
+                                    int32_t y_dtype, int32_t N, int32_t H, int32_t W, int32_t C, float *partials,
+                                    void *stream) {
+    DS_REQUIRE(dy16 && argmax && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (((uintptr_t)dy16) & 7) == 0,
+               "ds_maxpool3_bwd_dy16: bad argument (C %% 4 == 0, 8-byte aligned dy)");
+    const __bf16 *dy = reinterpret_cast<const __bf16 *>(dy16);
+    if (!partials) {
+        hipLaunchKernelGGL(maxpool3s1_bwd_rolling<__bf16>, dim3(ds::stream_grid((int64_t)N * W * (C / 4), 256)), dim3(256), 0,
+                           (hipStream_t)stream, dy, argmax, dx, accumulate, N, H, W, C);
+        return ds::check_launch("ds_maxpool3_bwd_dy16");
+    }
+    DS_REQUIRE(y && C <= 1024 && (y_dtype == DS_DTYPE_F32 || y_dtype == DS_DTYPE_BF16), "ds_maxpool3_bwd_dy16: the sums need y (fp32 / bf16), C <= 1024");
+    const int upb = pool_sums_upb(N, W, C);
+    const int P = (N * W + upb - 1) / upb;
+    const int C4 = C / 4;
+    const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
+    const size_t shmem = (size_t)RG * C4 * 8 * sizeof(float);
+    if (y_dtype == DS_DTYPE_BF16)
+        hipLaunchKernelGGL((maxpool3s1_bwd_sums_kernel<__bf16, __bf16>), dim3(P), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
+                           accumulate, (const __bf16 *)y, N, H, W, C, partials, upb);
+    else
+        hipLaunchKernelGGL((maxpool3s1_bwd_sums_kernel<float, __bf16>), dim3(P), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
+                           accumulate, (const float *)y, N, H, W, C, partials, upb);
+    return ds::check_launch("ds_maxpool3_bwd_dy16");
+}
+
 extern "C" int ds_maxpool3_bwd_sums(const float *dy, const uint8_t *argmax, float *dx, int32_t accumulate, const void *y,
                                     int32_t y_dtype, int32_t N, int32_t H, int32_t W, int32_t C, float *partials,
                                     void *stream) {
@@ -845,10 +875,10 @@ extern "C" int ds_maxpool3_bwd_sums(const float *dy, const uint8_t *argmax, floa
     const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
     const size_t shmem = (size_t)RG * C4 * 8 * sizeof(float);
     if (y_dtype == DS_DTYPE_BF16)
-        hipLaunchKernelGGL(maxpool3s1_bwd_sums_kernel<__bf16>, dim3(P), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
+        hipLaunchKernelGGL((maxpool3s1_bwd_sums_kernel<__bf16, float>), dim3(P), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
                            accumulate, (const __bf16 *)y, N, H, W, C, partials, upb);
     else
-        hipLaunchKernelGGL(maxpool3s1_bwd_sums_kernel<float>, dim3(P), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
+        hipLaunchKernelGGL((maxpool3s1_bwd_sums_kernel<float, float>), dim3(P), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
                            accumulate, (const float *)y, N, H, W, C, partials, upb);
     return ds::check_launch("ds_maxpool3_bwd_sums");
 }

@@ -819,6 +819,12 @@ class MixedStage(Stage):
         self.c1.make_dgrad(b1a, allow_z16=True)
         self.c2.make_dgrad(b2a, allow_z16=True)
         self.c3.make_dgrad(cin, allow_z16=True)
+        # 16-bit labels: Branch_3's Conv2DBackpropInput output lives between that launch and the pool gradient only -- in bf16
+        # storage (ds_conv_desc.z_dtype on the dgrad, ds_maxpool3_bwd_dy16): 2 B written and 2 B read per element instead of 4
+        self.dpooled16 = bool(eng.dpooled16 and eng.act16 and self.c3.dgrad.family == ops.DS_FAM_BF16D)
+        if self.dpooled16:
+            self.dpooled = torch.empty(M, cin, device=dev, dtype=torch.bfloat16)
+            self.c3.dgrad.d.z_dtype = ops.DS_DTYPE_BF16
         # BatchNorm backward sums from the epilogue of the dgrad that produces the gradient (DS_EPI_BNSUMS) instead of
         # a separate pass over z and dy:
         #  * the Branch_1 / Branch_2 3x3 dgrads write dr1 / dr2, the gradients of the fused 1x1 layer's reduce outputs;
@@ -1184,6 +1190,9 @@ class InceptionV1Engine:
         # element of z instead of 4 -- bf16 step 9.58 -> 9.38 ms.  Like the 16-bit activation storage it is a rounding the fp64
         # reference emulation of the tests does not model; the labels' gates hold with it (profiles/r06_notes.md).  DS_Z16=0: A/B
         self.z16 = _lib.tuning_env("DS_Z16", "1") != "0"
+        # ... and Branch_3's dgrad output (MixedStage.alloc).  Built, measured, OFF: -0.66 GB/step but no time (bf16 9.35 -> 9.37 ms:
+        # the 2-byte stores of the register-direct epilogue and the 8-byte loads of the pool gradient are instruction-rate bound)
+        self.dpooled16 = _lib.tuning_env("DS_DPOOLED16", "0") == "1"
         self.stem_sums_from_dgrad = _lib.tuning_env("DS_STEM_SUMS", "1") != "0"      # pooled stem: its BatchNorm sums from Conv2d_2b's dgrad epilogue
         self.dz16 = int(_lib.tuning_env("DS_DZ16", "2"))      # 16-bit configurations: bf16 dz for the frozen 1x1 (1) and 3x3 (2) layers (ConvBN.make_dgrad)
         self.fuse_branch3 = _lib.tuning_env("DS_FUSE_B3", "1") != "0"      # Branch_3's 3x3/1 max pool formed on load by its 1x1 conv (MixedStage.alloc)

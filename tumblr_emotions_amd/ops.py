@@ -732,6 +732,11 @@ def bn_pool_bwd_apply(z, dpool, argmax, N, H, W, C_, mean, rstd, shift, coef, dz
 
 
 def maxpool_bwd(dy, argmax, dx, accumulate, N, H, W, C_, k, stride, mode="SAME"):
+    if dy.dtype == torch.bfloat16:          # (3x3 / 1 SAME only: Branch_3's pool behind a dgrad that writes bf16)
+        assert k == 3 and stride == 1 and mode == "SAME"
+        _lib.check(_lib.load().ds_maxpool3_bwd_dy16(_p(dy), _p(argmax), _p(dx), int(accumulate), None, DS_DTYPE_F32, N, H, W, C_,
+                                                    None, _stream()), "ds_maxpool3_bwd_dy16")
+        return
     if mode == "SAME":
         OH, pt = same_pad(H, k, stride)
         OW, pl = same_pad(W, k, stride)
@@ -747,6 +752,10 @@ def maxpool3_bwd_sums_partials(N, W, C_):
 
 def maxpool3_bwd_sums(dy, argmax, dx, accumulate, y, N, H, W, C_, partials):
     """ds_maxpool_bwd of a 3x3 / 1 SAME pool + the BatchNorm-backward sums (sum g, sum g*y over y > 0) of the activation y."""
+    if dy.dtype == torch.bfloat16:          # the pool's output gradient in bf16 storage
+        _lib.check(_lib.load().ds_maxpool3_bwd_dy16(_p(dy), _p(argmax), _p(dx), int(accumulate), _p(y), act_dtype(y), N, H, W, C_,
+                                                    _p(partials), _stream()), "ds_maxpool3_bwd_dy16")
+        return
     _lib.check(_lib.load().ds_maxpool3_bwd_sums(_p(dy), _p(argmax), _p(dx), int(accumulate), _p(y), act_dtype(y), N, H, W, C_,
                                                 _p(partials), _stream()), "ds_maxpool3_bwd_sums")
 
