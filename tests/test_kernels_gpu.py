@@ -1079,6 +1079,52 @@ def test_max_pool_gradient_that_also_emits_the_batch_norm_sums(case):
         assert np.abs(q_got - q_ref).max() <= 2e-6 * scale_q, np.abs(q_got - q_ref).max() / scale_q
 
 
+@pytest.mark.parametrize("case", [(4, 14, 14, 480), (2, 28, 28, 192), (9, 7, 7, 832), (3, 6, 5, 12)])
+def test_max_pool_gradient_reading_bf16_storage_and_a_dgrad_writing_it(case):
+    """ds_maxpool3_bwd_dy16 + ds_conv_desc.z_dtype on a Conv2DBackpropInput launch (round 6, 16-bit labels, off in the engine:
+    no time gain): Branch_3's 1x1 dgrad writes its output rounded to bf16 and the 3x3 / 1 MaxPoolGrad reads that storage.  The
+    pool gradient (plain and accumulating, and with the BatchNorm sums) has the bits of ds_maxpool_bwd / ds_maxpool3_bwd_sums
+    on the same values in fp32; the dgrad's bf16 output is its fp32 output rounded to nearest even."""
+    ops = _ops()
+    N, H, W, Cc = case
+    rng = np.random.RandomState(N * 7 + Cc)
+    x = torch.from_numpy(rng.normal(size=(N, H, W, Cc)).astype(np.float32)).cuda()
+    pooled, am = torch.empty_like(x), torch.empty(N, H, W, Cc, dtype=torch.uint8, device="cuda")
+    ops.maxpool_fwd(x, pooled, am, N, H, W, Cc, 3, 1, "SAME")
+    dy16 = torch.from_numpy(rng.normal(size=(N, H, W, Cc)).astype(np.float32)).cuda().to(torch.bfloat16)
+    dy32 = dy16.float()
+    base = torch.from_numpy(rng.normal(size=(N, H, W, Cc)).astype(np.float32)).cuda()
+    y = torch.relu(torch.from_numpy(rng.normal(size=(N, H, W, Cc)).astype(np.float32)).cuda()).to(torch.bfloat16)
+    P = ops.maxpool3_bwd_sums_partials(N, W, Cc)
+    for acc in (True, False):
+        a, b = base.clone(), base.clone()
+        ops.maxpool_bwd(dy32, am, a, acc, N, H, W, Cc, 3, 1, "SAME")
+        ops.maxpool_bwd(dy16, am, b, acc, N, H, W, Cc, 3, 1, "SAME")
+        pa, pb = torch.zeros(2, Cc, P, device="cuda"), torch.zeros(2, Cc, P, device="cuda")
+        c, d = base.clone(), base.clone()
+        ops.maxpool3_bwd_sums(dy32, am, c, acc, y, N, H, W, Cc, pa)
+        ops.maxpool3_bwd_sums(dy16, am, d, acc, y, N, H, W, Cc, pb)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b) and torch.equal(c, d) and torch.equal(a, c) and torch.equal(pa, pb)
+    if Cc % 16 == 0:
+        Ci = 64          # a 1x1 dgrad [M, Ci] -> [M, Cc] on the register-direct bf16 kernel, fp32 and bf16 output
+        M = N * H * W
+        w = torch.from_numpy((rng.normal(size=(1, 1, Cc, Ci)) * 0.05).astype(np.float32)).cuda()
+        dz = torch.from_numpy(rng.normal(size=(M, Ci)).astype(np.float32)).cuda()
+        outs = []
+        for o16 in (False, True):
+            pl = ops.LayerPlan(ops.DS_CONV_DGRAD, ops.DS_ARITH_BF16, ops.DS_PLAN_ACT16, N, H, W, Cc, Ci, 1, 1, Ci, Cc, 0)
+            assert pl.family == ops.DS_FAM_BF16D
+            pl.alloc_weights(x.device)
+            pl.prepare(ops._p(w))
+            out = torch.zeros(M, Cc, device="cuda", dtype=torch.bfloat16 if o16 else torch.float32)
+            pl.d.z_dtype = ops.DS_DTYPE_BF16 if o16 else ops.DS_DTYPE_F32
+            pl.run(ops._p(dz), ops._p(w), ops._p(out))
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert torch.equal(outs[1], outs[0].to(torch.bfloat16)) and float(outs[0].abs().max()) > 0
+
+
 def _fp8_round(a, fmax, mant, emin):
     """saturating round-to-nearest-even to an OCP fp8 format (e4m3fn: 448, 3, -6; e5m2: 57344, 2, -14), as float64"""
     a = np.asarray(a, np.float64)
