@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: needs an ablation build of conv_igemm.hip (-DDS_BF16D_NOSTORE: the epilogue's output stores compiled out) that was
+# removed again with the experiment; kept as the record of how profiles/r06_notes.md's ablation numbers were taken.
 # ablation: the register-direct bf16 kernels WITHOUT their output stores (results wrong, timing only): what do the stores cost?
 R=$(cd $(dirname $0)/.. && pwd)
 T=$R/tumblr_emotions_amd/libds_kernels_tuning.so

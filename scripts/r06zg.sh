@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the LDS-transposed epilogue this A/B switched (DS_BF16D_TPOSE) was measured slower and removed again (profiles/r06_notes.md,
+# profiles/r06_bf16d_tpose_ab.txt); kept as the record of the measurement.
 # conv_bf16d: output through the LDS-transposed epilogue (16-byte stores) against the direct per-lane stores (DS_BF16D_TPOSE=0)
 R=$(cd $(dirname $0)/.. && pwd)
 export DS_LIB=$R/tumblr_emotions_amd/libds_kernels_tuning.so
