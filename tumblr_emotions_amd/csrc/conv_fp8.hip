@@ -205,10 +205,12 @@ __global__ __launch_bounds__(256, 2) void conv_fp8d_kernel(const Fp8Params p) {
     // (as gemm_wide_kernel) z / accumulate / activation accesses through buffer descriptors: 32-bit lane offset + row offset
     // in the vector offset, hardware range check for rows past M and columns past Cout (kOOB)
     const bool m16 = d.mask_dtype == DS_DTYPE_BF16;      // (uniform) BatchNorm-sums activation in bf16 storage
-    const __amdgpu_buffer_rsrc_t srd_z = make_srd(p.z, (unsigned)(((int64_t)(p.M - 1) * d.ldz + d.Cout) * 4));
+    const bool z16 = d.z_dtype == DS_DTYPE_BF16;         // (uniform) z stored as bf16(z - pivot): as conv_bf16d_kernel
+    const unsigned zeb = z16 ? 2u : 4u;
+    const __amdgpu_buffer_rsrc_t srd_z = make_srd(p.z, (unsigned)(((int64_t)(p.M - 1) * d.ldz + d.Cout) * zeb));
     const __amdgpu_buffer_rsrc_t srd_m = make_srd((flags & DS_EPI_BNSUMS) ? p.mask : (const void *)p.z,
                                                   (flags & DS_EPI_BNSUMS) ? (unsigned)(((int64_t)(p.M - 1) * d.ldmask + d.Cout) * (m16 ? 2 : 4)) : 0u);
-    const int rz = d.ldz * 4, rm = d.ldmask * (m16 ? 2 : 4);
+    const int rz = d.ldz * (int)zeb, rm = d.ldmask * (m16 ? 2 : 4);
     const int rbase = mrow0 + 4 * kh;
     auto roff = [](int r, int row_bytes) -> unsigned { return (unsigned)(((r & 3) + 8 * (r >> 2)) * row_bytes); };
     float pss[NB], pqq[NB];
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8d_kernel(const Fp8Params p) {
         const int col = n0 + 32 * b + li;
         const bool colok = item && col < d.Cout;
         const float pv = (p.pivot && colok) ? p.pivot[col] : 0.f;
-        const unsigned vz = colok ? (unsigned)(rbase * d.ldz + col) * 4u : kOOB;
+        const unsigned vz = colok ? (unsigned)(rbase * d.ldz + col) * zeb : kOOB;
         const unsigned vm = colok ? (unsigned)(rbase * d.ldmask + col) * (m16 ? 2u : 4u) : kOOB;
         float s = 0.f, q = 0.f;
         float zv[16];                                    // DS_EPI_ACCUM: the previous values
@@ -275,11 +277,20 @@ __global__ __launch_bounds__(256, 2) void conv_fp8d_kernel(const Fp8Params p) {
     for (int b = 0; b < NB; ++b) {
         const int col = n0 + 32 * b + li;
         const bool colok = item && col < d.Cout;
-        const unsigned vz = colok ? (unsigned)(rbase * d.ldz + col) * 4u : kOOB;
+        const unsigned vz = colok ? (unsigned)(rbase * d.ldz + col) * zeb : kOOB;
+        if (z16) {          // centred about the statistics pivot and rounded to nearest even (see conv_bf16d_kernel)
+            const float pvz = (p.pivot && colok) ? p.pivot[col] : 0.f;
 #pragma unroll
-        for (int r2 = 0; r2 < 16; ++r2) {
-            const float val = acc[b][r2];          // (bit_cast of a vector-element lvalue reads element 0: copy first)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_z, vz + roff(r2, rz), 0, 2 /* nt */);
+            for (int r2 = 0; r2 < 16; ++r2) {
+                const __bf16 hv = (__bf16)(acc[b][r2] - pvz);
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), srd_z, vz + roff(r2, rz), 0, 2 /* nt */);
+            }
+        } else {
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) {
+                const float val = acc[b][r2];          // (bit_cast of a vector-element lvalue reads element 0: copy first)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_z, vz + roff(r2, rz), 0, 2 /* nt */);
+            }
         }
         if ((flags & (DS_EPI_STATS | DS_EPI_BNSUMS)) && tid < 32 && item && n0 + 32 * b + tid < d.Cout) {
             p.stats[(int64_t)(n0 + 32 * b + tid) * p.row_tiles + trow] = pss[b];
@@ -435,6 +446,8 @@ extern "C" int ds_conv_fp8(const ds_conv_desc *d, const void *x, const float *x_
     DS_REQUIRE(fp8_ok(d), "ds_conv_fp8: needs a 1x1 or 3x3 conv, Cin %% 8 == 0, ldx %% 4 == 0, flags within DS_EPI_STATS, or "
                           "DS_EPI_ACCUM | DS_EPI_BNSUMS for a dgrad");
     DS_REQUIRE(a_format == DS_FP8_E4M3 || a_format == DS_FP8_E5M2, "ds_conv_fp8: a_format must be DS_FP8_E4M3 or DS_FP8_E5M2");
+    DS_REQUIRE(d->z_dtype == DS_DTYPE_F32 || (d->z_dtype == DS_DTYPE_BF16 && !(d->flags & (DS_EPI_ACCUM | DS_EPI_BNSUMS))),
+               "ds_conv_fp8: the output in bf16 storage excludes the accumulate / BatchNorm-sums epilogues");
     DS_REQUIRE(((((uintptr_t)x | (uintptr_t)wq) & 15) == 0) && fp8_M(d) < (1ll << 31), "ds_conv_fp8: operands must be 16-byte aligned");
     DS_REQUIRE(!(d->flags & DS_EPI_STATS) || stats, "ds_conv_fp8: DS_EPI_STATS without stats buffer");
     Fp8Params p = {};

@@ -348,7 +348,7 @@ class ConvBN:
             self.dgrad.d.ldx = self.cout
         # z16: z of such a layer itself in bf16 storage (ds_conv_desc.z_dtype; statistics from the fp32 accumulators) -- conv
         # write, apply read and backward read 2 B each
-        self.z16 = bool(eng.z16 and allow_z16 and self.dz16 is not None and self.fwd.family == ops.DS_FAM_BF16D
+        self.z16 = bool(eng.z16 and allow_z16 and self.dz16 is not None and self.fwd.family in (ops.DS_FAM_BF16D, ops.DS_FAM_FP8D)
                         and not self.skip_apply and not self.pool_inside)
         if self.z16:
             self.z = torch.empty(self.M, self.cout, device=eng.device, dtype=torch.bfloat16)
