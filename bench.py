@@ -332,7 +332,7 @@ def main():
     ap.add_argument("--stepwise-lstm", action="store_true",
                     help="A/B aid: one GEMM + one cell launch per LSTM step instead of the persistent ds_lstm_seq kernels")
     ap.add_argument("--lstm-rows", type=int, default=0,
-                    help="row groups per workgroup of the persistent LSTM kernels (1, 2, 4; default: the net's choice)")
+                    help="row groups per workgroup of the persistent LSTM kernels (1, 2, 4, 8; default: the net's choice)")
     ap.add_argument("--side-mode", type=int, default=-1,
                     help="A/B: 0 = Branch_2 and Branch_3 chains on a side stream each, 1 = both on one, 2 = only Branch_3 (default: 0 up to 32 samples per GPU, else 1)")
     ap.add_argument("--no-pool-first", action="store_true",

@@ -658,7 +658,7 @@ int ds_permute_rows(const void *src, int64_t lds, void *dst, int64_t ldd, const 
  *   gates  [T, B, 4H]   in: x_t Wx + bias for every step (the hoisted input projection); out: activations
  *   h, c   [T+1, B, H]  slot 0 = initial state (zeros in the reference), slot t+1 = state after step t with
  *                       dynamic_rnn's copy-through past seq_len, so h[T] is the last valid output
- *   rows   row groups (32 batch rows each) a workgroup walks per time step: 1, 2 or 4.  1 = the shortest
+ *   rows   row groups (32 batch rows each) a workgroup walks per time step: 1, 2, 4 or 8.  1 = the shortest
  *          sequence time (one workgroup per (16 units, 32 rows) pair); R > 1 = 1/R of the CUs for a longer time,
  *          one row group's hand-off wait covered by work on the others (beside a concurrent kernel that needs
  *          whole CUs).  Scheduling only: every cell's arithmetic and summation order are the same.  With rows = 1

@@ -1721,7 +1721,7 @@ def test_lstm_sequence_kernels_match_oracle(case):
     # rounding only where that one ran 16-row groups (small batches, H = 64 ... 512: the 16x16x4 MFMA sums the
     # reduction in another order than the 32x32x2 one).
     ref = None
-    for rows in (2, 4):
+    for rows in (2, 4, 8):
         g2, h2, c2 = dev(pre), torch.zeros_like(h), torch.zeros_like(c)
         ops.lstm_seq_fwd(g2, ops._p(whd), 4 * H, h2, c2, seqd, T, B, H, S.FORGET_BIAS, ws, rows=rows)
         dg3 = torch.empty_like(dg)
@@ -1737,7 +1737,7 @@ def test_lstm_sequence_kernels_match_oracle(case):
         assert float((dg3 - dg).abs().max()) <= 2e-6 * float(dg.abs().max()), rows
 
 
-@pytest.mark.parametrize("case", [(256, 32, 512, 1), (256, 32, 512, 4), (160, 32, 512, 4), (64, 12, 128, 1), (37, 9, 64, 2), (100, 20, 256, 1)])
+@pytest.mark.parametrize("case", [(256, 32, 512, 1), (256, 32, 512, 4), (256, 32, 512, 8), (200, 32, 512, 8), (160, 32, 512, 4), (64, 12, 128, 1), (37, 9, 64, 2), (100, 20, 256, 1)])
 def test_lstm_sequence_skips_masked_steps_to_the_bit_on_length_sorted_batches(case):
     """ds_seq_sort_desc + ds_permute_rows + DS_LSTM_SKIP_MASKED (round 6): the batch in descending order of length, every 32- /
     16-row group stopping after its longest row -- h at every step, c at every step, the last valid output and every per-step

@@ -633,6 +633,7 @@ bool seq_cfg(int H, SeqCfg *c, int rows = 1, int rb = 32) {
     switch (rows) {
         case 2: return seq_cfg_r<2, 32>(H, c);
         case 4: return seq_cfg_r<4, 32>(H, c);
+        case 8: return seq_cfg_r<8, 32>(H, c);
         default: return seq_cfg_r<1, 32>(H, c);
     }
 }
@@ -729,8 +730,10 @@ dim3 seq_grid(SeqParams &p, int H, int rows) {
 int common_checks(const char *who, const void *a, const void *b, const void *c, int T, int B, int H, int ldw, int rows,
                   void *ws, size_t ws_bytes) {
     DS_REQUIRE(a && b && c && ws, "%s: null argument", who);
-    // (eight row groups per workgroup existed through round 4, were never the measured choice and are no longer compiled)
-    DS_REQUIRE(rows == 1 || rows == 2 || rows == 4, "%s: rows (row groups per workgroup) must be 1, 2 or 4", who);
+    // (eight row groups per workgroup: dropped in round 5 as never the measured choice, back in round 6 -- with the batch sorted by
+    // length and the masked steps skipped a workgroup's eight groups thin out as the steps go, and ONE workgroup row on H / 16 CUs
+    // costs the image tower beside it less than two: joint step 13.30 -> 13.24 ms)
+    DS_REQUIRE(rows == 1 || rows == 2 || rows == 4 || rows == 8, "%s: rows (row groups per workgroup) must be 1, 2, 4 or 8", who);
     DS_REQUIRE(T > 0 && B > 0 && ds_lstm_seq_supported(B, H),
                "%s: unsupported size (H must be 32 ... 1024, a power of two, and H / 16 workgroups must fit the device's CUs)", who);
     DS_REQUIRE(ldw >= 4 * H && ldw % 4 == 0 && (((uintptr_t)b) & 15) == 0, "%s: Wh must be 16-byte aligned with ldw %% 4 == 0", who);

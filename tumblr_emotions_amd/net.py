@@ -71,8 +71,11 @@ class SentimentNet:
         if self.text_stream is not None:
             # beside the image tower the persistent LSTM runs four row groups per workgroup: a quarter of the CUs for a
             # longer time instead of a 256-register wave on every SIMD that mostly waits -- the Winograd conv needs
-            # whole SIMDs and could not run beside it (joint step 18.5 -> 17.9 ms; text-only keeps 1: shortest sequence)
-            self.text.seq_rows = 4
+            # whole SIMDs and could not run beside it (joint step 18.5 -> 17.9 ms; text-only keeps 1: shortest sequence).  Round 6:
+            # EIGHT -- with the batch sorted by length and the masked steps skipped a workgroup's groups thin out as the steps go,
+            # and one workgroup row on H / 16 CUs costs the image tower less than two (13.30 -> 13.24 ms; batches of fewer than
+            # eight 32-row groups use as many as they have)
+            self.text.seq_rows = 8
         self.reducer = GradientReducer(st.grad, st.n_bucket1, process_group, overlap_comm,
                                        force_buckets=force_dp_buckets)
         self.world = self.reducer.world

@@ -803,7 +803,7 @@ def lstm_seq_workspace(B, H):
 
 
 def lstm_seq_fwd(gates, wh_ptr, ldw, h, c, seq_len, T, B, H, forget_bias, ws, rows=1):
-    """rows: row groups per workgroup (1, 2, 4) -- scheduling only.  `ws` is zeroed once by its owner."""
+    """rows: row groups per workgroup (1, 2, 4, 8) -- scheduling only.  `ws` is zeroed once by its owner."""
     _lib.check(_lib.load().ds_lstm_seq_fwd(_p(gates), wh_ptr, ldw, _p(h), _p(c), _p(seq_len), T, B, H, forget_bias,
                                            int(rows), _p(ws), ws.numel() * ws.element_size(), _stream()),
                "ds_lstm_seq_fwd")
