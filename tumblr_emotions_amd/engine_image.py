@@ -1135,9 +1135,11 @@ class InceptionV1Engine:
         self.seed_dev = None         # device int64 added to the dropout seed (hipGraph replay draws fresh masks)
         # 1 (default): the Branch_3 chain, then the Branch_2 chain, on ONE side stream -- one cross-queue join per block (a join
         # costs ~17 us of idle GPU: 17.74 -> 17.58 ms/step against two side streams); 0: a side stream each; 2: Branch_3 only.
-        # side_mode None = by batch size (alloc): 0 up to 32 samples -- there every launch is a partial round of workgroups and
-        # three chains in flight fill more CUs than a join costs (B = 32: 4.27 -> 4.15 ms, B = 16: 3.87 -> 3.66; B = 64 / 128:
-        # no difference; B = 256: 14.43 -> 14.60, profiles/r05_notes.md) -- else 1
+        # side_mode None = by batch size (alloc).  Round 5: 0 up to 32 samples (three chains in flight filled more CUs than a join
+        # cost: B = 32 4.27 -> 4.15 ms).  Round 6, re-swept with split-K and the batched BatchNorm launches in: 2 (only the
+        # Branch_3 chain beside the main one) up to 128 samples -- B = 16 3.53 (0) / 3.41 (1) / 3.31 (2), B = 32 3.86 / 3.99 / 3.71,
+        # B = 64 a tie, B = 128 7.86 (1) / 7.82 (2) -- and 1 above (B = 256: 13.22 against 13.39 / 13.36; profiles/r06_notes.md).  The
+        # 16-bit labels: 1 at every batch size (bf16 B = 32 3.83 / 3.68 / 3.81, B = 64 4.28 / 4.11 / 4.47, B = 128 5.80 (1) / 5.96 (2))
         self.side_mode = None
         self.one_side_stream = 1
         self.pool_first = True       # Mixed backward: Branch_3's pool gradient written first, fused dgrad accumulates (False: the reverse)
@@ -1331,7 +1333,7 @@ class InceptionV1Engine:
         dev = self.device
         self.B = B
         self.alloc_gen = getattr(self, "alloc_gen", 0) + 1      # SentimentNet: a captured step is stale after this
-        self.one_side_stream = (0 if B <= 32 else 1) if self.side_mode is None else int(self.side_mode)
+        self.one_side_stream = (2 if (B <= 128 and self.dtype == "f32") else 1) if self.side_mode is None else int(self.side_mode)
         # fp8: device words that collect max|.| of the tensors the fp8 convs read (atomic max in the producing kernels,
         # zeroed at the start of every forward pass): the per-tensor scales without separate ds_absmax passes
         self.amax_pool = torch.zeros(AMAX_RECORDS * ops.AMAX_FLOATS, device=dev) if self.dtype == "fp8" else None

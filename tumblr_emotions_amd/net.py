@@ -371,7 +371,7 @@ class SentimentNet:
             # step keeps ONE side stream; release_graph() restores the eager setting
             if self._eager_side_streams is None:
                 self._eager_side_streams = self.image.one_side_stream
-            if self.image.one_side_stream == 0:
+            if self.image.one_side_stream != 1:      # (0: three joined side streams break hipStreamEndCapture; 2: slower as a graph, 3.95 vs 3.78 ms)
                 self.image.one_side_stream = 1
         # ... and of the BatchNorm pivots (each layer's previous batch mean), so that the first replayed step rounds
         # exactly like the eager step it replaces
