@@ -1042,12 +1042,13 @@ def test_batch_norm_finalize_and_apply_as_one_launch_are_bit_identical(case):
 
 
 @pytest.mark.parametrize("case", [(5, 14, 14, 480, "f32"), (3, 28, 28, 256, "bf16"), (9, 7, 7, 832, "f32"), (2, 9, 5, 12, "bf16"),
-                                  (300, 7, 7, 64, "bf16")])
+                                  (300, 7, 7, 64, "bf16"), (6, 14, 14, 528, "bf16"), (2, 5, 7, 1024, "f32"), (3, 4, 4, 68, "bf16")])
 def test_max_pool_gradient_that_also_emits_the_batch_norm_sums(case):
     """ds_maxpool3_bwd_sums (round 6): MaxPoolGrad of Branch_3's 3x3 / 1 pool (inception_v1.py:94 ... :246) added LAST onto the
     block-input gradient also leaves the previous block's BatchNorm-backward sums -- sum g and sum g*y with g = dx (y > 0),
     the DS_EPI_BNSUMS form -- so that block's ds_bn_bwd_reduce passes go.  dx is bit-identical to ds_maxpool_bwd (accumulating
-    and not); the partials add up to the fp64 sums; fp32 and bf16 activations; widths that leave threads idle (832, 12)."""
+    and not); the partials add up to the fp64 sums; fp32 and bf16 activations; widths the launch splits into channel chunks (528: 6 x 22
+    quads, 832: 13 x 16, 480: 2 x 60) and widths that leave threads idle (12, 68)."""
     ops = _ops()
     N, H, W, Cc, dt = case
     rng = np.random.RandomState(N + Cc)

@@ -366,24 +366,26 @@ __global__ __launch_bounds__(256) void maxpool3s1_bwd_rolling(const TD *dy, cons
 // g = dx (y > 0), what DS_EPI_BNSUMS leaves behind (ds_bn_bwd_finalize_segs kind 1) -- and the previous block's four
 // ds_bn_bwd_reduce passes over z and dy (8 B/element, two of them on the critical chain) disappear for 2 B/element of y here.
 // Layout as bn_bwd_reduce_kernel: thread = (channel quad cg, unit group rg) keeps its channels for the whole launch, a unit =
-// one image column (n, iw) walked down its H rows; workgroup b takes units [b * upb, (b + 1) * upb); partials [2][C][gridDim.x],
-// summed per thread in unit order and over the unit groups in a fixed order (deterministic).
+// one image column (n, iw) walked down its H rows.  A workgroup owns a CHUNK of CW channel quads (CW divides C / 4: pool_sums_shape
+// picks the divisor that fills the 256 threads -- 528 channels: 6 chunks of 22 quads x 11 unit groups instead of 132 of 256 threads,
+// 832: 13 chunks of 16 x 16 instead of 208) and the units [ub * upb, (ub + 1) * upb), ub = blockIdx.x / chunks; partials [2][C][P] with
+// P = gridDim.x / chunks, summed per thread in unit order and over the unit groups in a fixed order (deterministic).
 template <typename TY, typename TD = float>
 __global__ __launch_bounds__(256) void maxpool3s1_bwd_sums_kernel(const TD *dy, const uint8_t *am, float *dx, int accumulate,
                                                                   const TY *y, int N, int H, int W, int C, float *partials,
-                                                                  int upb) {
-    extern __shared__ __attribute__((aligned(16))) float sh[];   // [RG][C4][8]
-    const int C4 = C >> 2;
-    const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
+                                                                  int upb, int CW, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // [RG][CW][8]
+    const int RG = 256 / CW;
     const int tid = threadIdx.x;
-    const int cg = tid % C4, rg = tid / C4;
-    const bool active = tid < RG * C4;
+    const int cg = tid % CW, rg = tid / CW;
+    const bool active = tid < RG * CW;
     const int units = N * W;
-    const int u0 = blockIdx.x * upb;
+    const int ub = blockIdx.x / chunks, q0 = (blockIdx.x - ub * chunks) * CW;      // first channel quad of the chunk
+    const int u0 = ub * upb;
     const int u1 = u0 + upb < units ? u0 + upb : units;
     float sg[4] = {0.f, 0.f, 0.f, 0.f}, sy[4] = {0.f, 0.f, 0.f, 0.f};
     if (active) {
-        const int c = cg * 4;
+        const int c = (q0 + cg) * 4;
         for (int u = u0 + rg; u < u1; u += RG) {
             const int n = u / W, iw = u - n * W;
             const int64_t img = (int64_t)n * H;
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(256) void maxpool3s1_bwd_sums_kernel(const TD *dy, 
                 w1 = w2;
             }
         }
-        float *o = sh + ((int64_t)rg * C4 + cg) * 8;
+        float *o = sh + ((int64_t)rg * CW + cg) * 8;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             o[j] = sg[j];
@@ -433,28 +435,54 @@ __global__ __launch_bounds__(256) void maxpool3s1_bwd_sums_kernel(const TD *dy, 
         }
     }
     __syncthreads();
-    if (tid < C4) {
+    if (tid < CW) {
         float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int g = 0; g < RG; ++g)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] += sh[((int64_t)g * C4 + tid) * 8 + j];
-        const int P = gridDim.x;                       // partials laid out [2][C][P]
+            for (int j = 0; j < 8; ++j) a[j] += sh[((int64_t)g * CW + tid) * 8 + j];
+        const int P = gridDim.x / chunks;               // partials laid out [2][C][P]
+        const int ch = (q0 + tid) * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            partials[(int64_t)(tid * 4 + j) * P + blockIdx.x] = a[j];
-            partials[((int64_t)C + tid * 4 + j) * P + blockIdx.x] = a[4 + j];
+            partials[(int64_t)(ch + j) * P + ub] = a[j];
+            partials[((int64_t)C + ch + j) * P + ub] = a[4 + j];
         }
     }
 }
 
-// units (image columns) per workgroup: one per unit group of the workgroup (every thread walks ONE column, the parallelism of
-// maxpool3s1_bwd_rolling -- with four workgroups per CU and several columns per thread the launch was latency-bound: 119 us
-// against 79) unless that makes more than 2048 workgroups (partials)
-inline int pool_sums_upb(int N, int W, int C) {
+// The launch shape.  CW = channel quads per workgroup: the divisor of C / 4 in [16, 64] (256-byte to 1 KB runs of dy / dx per
+// pixel) that puts most of the 256 threads to work, the larger on ties; without one, all quads in one chunk.  Narrow chunks mean
+// MORE unit groups per workgroup, so fewer unit blocks and fewer of the scattered 4-byte partial stores (2 C per block), which is
+// what the launch paid for beside idle lanes (B = 256, 14x14x512: 92 -> 77 us with 64 quads x 4 groups instead of 128 x 2;
+// 14x14x528: 128 -> 90 with 22 x 11 instead of 132 x 1; 7x7x832: 65 -> 32 with 16 x 16; r06_notes).  DS_POOL_SUMS_CHUNKS=0
+// (tuning build): one chunk.  upb = units (image columns) per workgroup: one per unit group (every thread walks ONE column, the
+// parallelism of maxpool3s1_bwd_rolling -- with four workgroups per CU and several columns per thread the launch was
+// latency-bound: 119 us against 79) unless that makes more than 2048 unit blocks (partials).
+struct PoolSumsShape { int CW, chunks, RG, upb, P; };
+inline PoolSumsShape pool_sums_shape(int N, int W, int C) {
     const int units = N * W, C4 = C / 4;
-    const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
+    int cw = 0, act = 0;
+    const char *e = ds::tune_env("DS_POOL_SUMS_CHUNKS");
+    if (!(e && e[0] == '0'))
+        for (int d = C4 < 64 ? C4 : 64; d >= 16; --d) {
+            if (C4 % d) continue;
+            const int a = d * (256 / d);
+            if (a > act) { cw = d; act = a; }
+        }
+    if (cw == 0) cw = C4;      // C <= 1024: at most 256 quads
+    if (const char *f = ds::tune_env("DS_POOL_SUMS_CW")) {      // tuning build: the largest divisor of C / 4 not above the value
+        const int lim = atoi(f);
+        for (int d = lim < C4 ? lim : C4; d >= 1; --d)
+            if (C4 % d == 0) { cw = d; break; }
+    }
+    PoolSumsShape s;
+    s.CW = cw;
+    s.chunks = C4 / cw;
+    s.RG = 256 / cw;
     const int cap = (units + 2047) / 2048;
-    return RG > cap ? RG : cap;
+    s.upb = s.RG > cap ? s.RG : cap;
+    s.P = (units + s.upb - 1) / s.upb;
+    return s;
 }
 
 // MaxPoolGrad of the 3x3 stride-2 pools: a thread owns the 2x2 input patch
@@ -830,8 +858,7 @@ extern "C" int ds_maxpool_bwd(const float *dy, const uint8_t *argmax, float *dx,
 
 extern "C" int ds_maxpool3_bwd_sums_partials(int32_t N, int32_t W, int32_t C) {
     if (N <= 0 || W <= 0 || C < 4) return 0;
-    const int upb = pool_sums_upb(N, W, C);
-    return (N * W + upb - 1) / upb;
+    return pool_sums_shape(N, W, C).P;
 }
 
 // The 3x3 / 1 MaxPoolGrad reading its output gradient from bf16 storage (a Conv2DBackpropInput wrote it rounded:
@@ -848,17 +875,14 @@ extern "C" int ds_maxpool3_bwd_dy16(const void *dy16, const uint8_t *argmax, flo
         return ds::check_launch("ds_maxpool3_bwd_dy16");
     }
     DS_REQUIRE(y && C <= 1024 && (y_dtype == DS_DTYPE_F32 || y_dtype == DS_DTYPE_BF16), "ds_maxpool3_bwd_dy16: the sums need y (fp32 / bf16), C <= 1024");
-    const int upb = pool_sums_upb(N, W, C);
-    const int P = (N * W + upb - 1) / upb;
-    const int C4 = C / 4;
-    const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
-    const size_t shmem = (size_t)RG * C4 * 8 * sizeof(float);
+    const PoolSumsShape sh = pool_sums_shape(N, W, C);
+    const size_t shmem = (size_t)sh.RG * sh.CW * 8 * sizeof(float);
     if (y_dtype == DS_DTYPE_BF16)
-        hipLaunchKernelGGL((maxpool3s1_bwd_sums_kernel<__bf16, __bf16>), dim3(P), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
-                           accumulate, (const __bf16 *)y, N, H, W, C, partials, upb);
+        hipLaunchKernelGGL((maxpool3s1_bwd_sums_kernel<__bf16, __bf16>), dim3(sh.P * sh.chunks), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
+                           accumulate, (const __bf16 *)y, N, H, W, C, partials, sh.upb, sh.CW, sh.chunks);
     else
-        hipLaunchKernelGGL((maxpool3s1_bwd_sums_kernel<float, __bf16>), dim3(P), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
-                           accumulate, (const float *)y, N, H, W, C, partials, upb);
+        hipLaunchKernelGGL((maxpool3s1_bwd_sums_kernel<float, __bf16>), dim3(sh.P * sh.chunks), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
+                           accumulate, (const float *)y, N, H, W, C, partials, sh.upb, sh.CW, sh.chunks);
     return ds::check_launch("ds_maxpool3_bwd_dy16");
 }
 
@@ -869,17 +893,14 @@ extern "C" int ds_maxpool3_bwd_sums(const float *dy, const uint8_t *argmax, floa
                "ds_maxpool3_bwd_sums: bad argument (C %% 4 == 0, C <= 1024)");
     DS_REQUIRE(y_dtype == DS_DTYPE_F32 || y_dtype == DS_DTYPE_BF16, "ds_maxpool3_bwd_sums: y_dtype must be DS_DTYPE_F32 or DS_DTYPE_BF16");
     DS_REQUIRE((int64_t)N * H * W * C < (1ll << 40), "ds_maxpool3_bwd_sums: tensor too large");
-    const int upb = pool_sums_upb(N, W, C);
-    const int P = (N * W + upb - 1) / upb;
-    const int C4 = C / 4;
-    const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
-    const size_t shmem = (size_t)RG * C4 * 8 * sizeof(float);
+    const PoolSumsShape sh = pool_sums_shape(N, W, C);
+    const size_t shmem = (size_t)sh.RG * sh.CW * 8 * sizeof(float);
     if (y_dtype == DS_DTYPE_BF16)
-        hipLaunchKernelGGL((maxpool3s1_bwd_sums_kernel<__bf16, float>), dim3(P), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
-                           accumulate, (const __bf16 *)y, N, H, W, C, partials, upb);
+        hipLaunchKernelGGL((maxpool3s1_bwd_sums_kernel<__bf16, float>), dim3(sh.P * sh.chunks), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
+                           accumulate, (const __bf16 *)y, N, H, W, C, partials, sh.upb, sh.CW, sh.chunks);
     else
-        hipLaunchKernelGGL((maxpool3s1_bwd_sums_kernel<float, float>), dim3(P), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
-                           accumulate, (const float *)y, N, H, W, C, partials, upb);
+        hipLaunchKernelGGL((maxpool3s1_bwd_sums_kernel<float, float>), dim3(sh.P * sh.chunks), dim3(256), shmem, (hipStream_t)stream, dy, argmax, dx,
+                           accumulate, (const float *)y, N, H, W, C, partials, sh.upb, sh.CW, sh.chunks);
     return ds::check_launch("ds_maxpool3_bwd_sums");
 }
 
