@@ -239,6 +239,8 @@ WGRAD_DIRECT_CASES = [
     (3, 14, 14, 192, 384, 3, 1, 0),      # M = 588: waves with ragged quarters
     (8192, 1, 1, 300, 64, 1, 1, 0),      # the text tower's transposed MatMul (H = W = 1)
     (600, 1, 1, 52, 15, 1, 1, 0),        # Logits-like: 15 columns
+    (2048, 1, 1, 300, 1024, 1, 1, 0),    # wide outputs (the LSTM matrices' shape class)
+    (1024, 1, 1, 128, 1028, 1, 1, 0),    # ... with a ragged last column tile
 ]
 
 

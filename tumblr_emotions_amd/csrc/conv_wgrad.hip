@@ -486,7 +486,7 @@ WgradPlan plan_direct(const ds_conv_desc *d, int64_t M, int wx, int wz, int only
                 if (rounds * slots < per_xcd) rounds += 1.0;
                 const double steps = (double)M / slabs / 8.0;              // K steps per wave
                 // narrow blocks issue a load pair per few MFMAs: charge the address path too
-                const double step_cycles = nacc * 64.0 > 160.0 ? nacc * 64.0 : 160.0;
+                const double step_cycles = (nacc * 64.0 > 160.0 ? nacc * 64.0 : 160.0);
                 const double t_wg = steps * step_cycles + 1500.0 + nacc * 350.0;
                 const double t_red = slabs > 1 ? 6000.0 + slabs * wbytes / 1500.0 : 0.0;
                 const double cost = rounds * t_wg + t_red;
@@ -500,6 +500,10 @@ WgradPlan plan_direct(const ds_conv_desc *d, int64_t M, int wx, int wz, int only
     return best;
 }
 
+// (Round 6, measured and NOT kept: the two LSTM matrices -- 2048 output columns, every x row block the A operand of sixteen
+// column tiles -- run 168 -> 137 us and 222 -> 176 us on 64 x 128 / 128 x 128 tiles, the text-only step 1.06 -> 1.01 ms; but the
+// joint step, where these launches sit beside the image tower's backward chain, went 13.12 -> 13.15 ms and 7.80 -> 7.85 at B = 128:
+// one or two fat workgroups per CU hold the chain's launches off longer than three thin ones.  profiles/r06_notes.md.)
 WgradPlan plan_wgrad(const ds_conv_desc *d, int64_t M, const float *x, const float *dz, int lddz, const float *dw,
                      const void *ws) {
     if (direct_ok(d, M)) {
