@@ -486,7 +486,7 @@ WgradPlan plan_direct(const ds_conv_desc *d, int64_t M, int wx, int wz, int only
                 if (rounds * slots < per_xcd) rounds += 1.0;
                 const double steps = (double)M / slabs / 8.0;              // K steps per wave
                 // narrow blocks issue a load pair per few MFMAs: charge the address path too
-                const double step_cycles = (nacc * 64.0 > 160.0 ? nacc * 64.0 : 160.0);
+                const double step_cycles = nacc * 64.0 > 160.0 ? nacc * 64.0 : 160.0;
                 const double t_wg = steps * step_cycles + 1500.0 + nacc * 350.0;
                 const double t_red = slabs > 1 ? 6000.0 + slabs * wbytes / 1500.0 : 0.0;
                 const double cost = rounds * t_wg + t_red;
