@@ -165,6 +165,26 @@ def test_winograd_f4_launch_time_model_answers_without_a_device(lib):
     assert L.ds_conv_wino4_partials(2, 7, 7) == 1                    # 2 x 2 x 2 tiles -> one group of 32
 
 
+def test_pool_gradient_sums_launch_shape_answers_without_a_device(lib):
+    """ds_maxpool3_bwd_sums_partials is a pure host function: the number of unit blocks (= BatchNorm-sum partials per
+    channel) of the chunked launch -- a workgroup owns 16..64 channel quads x 256 / quads unit groups, one image column per
+    group, at most 2048 blocks.  The Branch_3 pools of the joint step at B = 256 and the degenerate widths."""
+    L = lib.load()
+    want = {(256, 28, 256): 1792,      # 64 quads x 4 groups: 7168 columns / 4
+            (256, 14, 480): 896,       # 60 x 4
+            (256, 14, 512): 896,       # 64 x 4
+            (256, 14, 528): 326,       # 22 x 11 (132 quads fill no workgroup; 44 x 5 and 33 x 7 use fewer threads)
+            (256, 7, 832): 112,        # 16 x 16
+            (2, 5, 12): 1,             # 3 quads x 85 groups: ten columns, one block
+            (3, 4, 68): 1}             # 17 quads (no divisor in 16..64): one chunk x 15 groups
+    for (n, w, c), p in want.items():
+        assert L.ds_maxpool3_bwd_sums_partials(n, w, c) == p, (n, w, c)
+    for n, w, c in ((1, 1, 4), (4096, 28, 192), (100000, 7, 1024), (7, 3, 1020)):
+        p = L.ds_maxpool3_bwd_sums_partials(n, w, c)
+        assert 1 <= p <= 2048 and p <= n * w, (n, w, c, p)
+    assert L.ds_maxpool3_bwd_sums_partials(0, 7, 64) == 0 and L.ds_maxpool3_bwd_sums_partials(4, 7, 0) == 0
+
+
 def test_conv_plan_picks_the_kernel_family_without_a_device(lib):
     """SURVEY 8(b) / VERDICT r03 weak #11: kernel-family selection lives BEHIND the ABI.  ds_conv_plan is host-only, so
     its choices for the tower's shapes can be pinned here: Winograd F(4x4) / F(2x2) / implicit GEMM for the 3x3 layers,
